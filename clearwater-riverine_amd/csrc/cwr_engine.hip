@@ -1,0 +1,763 @@
+// cwr_engine.hip -- host side of the transport engine: device memory, per-step orchestration, the
+// batched BiCGSTAB driver, the optional RCCL halo exchange, and the C ABI of include/cwr_transport.h.
+// Built for gfx950 only:  hipcc -O3 --offload-arch=gfx950 -munsafe-fp-atomics -shared -fPIC
+#include "../../include/cwr_transport.h"
+#include "cwr_kernels.hpp"
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace cwr;
+
+namespace {
+
+std::string g_create_error;
+
+// ---- RCCL, resolved lazily with dlopen so that a single-GPU engine has no RCCL dependency at all ----
+struct NcclUniqueId { char internal[128]; };
+typedef void* NcclComm;
+struct Rccl {
+  void* lib = nullptr;
+  int (*GetUniqueId)(NcclUniqueId*) = nullptr;
+  int (*CommInitRank)(NcclComm*, int, NcclUniqueId, int) = nullptr;
+  int (*CommDestroy)(NcclComm) = nullptr;
+  int (*Send)(const void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
+  int (*Recv)(void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool load(std::string& err) {
+    if (lib) return true;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) { lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (lib) break; }
+    if (!lib) { err = std::string("cannot dlopen librccl: ") + dlerror(); return false; }
+#define CWR_SYM(field, name) field = reinterpret_cast<decltype(field)>(dlsym(lib, name)); \
+    if (!field) { err = std::string("librccl lacks ") + name; return false; }
+    CWR_SYM(GetUniqueId, "ncclGetUniqueId") CWR_SYM(CommInitRank, "ncclCommInitRank")
+    CWR_SYM(CommDestroy, "ncclCommDestroy") CWR_SYM(Send, "ncclSend") CWR_SYM(Recv, "ncclRecv")
+    CWR_SYM(AllReduce, "ncclAllReduce") CWR_SYM(GroupStart, "ncclGroupStart")
+    CWR_SYM(GroupEnd, "ncclGroupEnd") CWR_SYM(GetErrorString, "ncclGetErrorString")
+#undef CWR_SYM
+    return true;
+  }
+};
+Rccl g_rccl;
+constexpr int NCCL_FLOAT64 = 8;   // ncclDataType_t::ncclFloat64
+constexpr int NCCL_SUM = 0;       // ncclRedOp_t::ncclSum
+
+}  // namespace
+
+struct cwr_engine {
+  int dev = 0;
+  hipStream_t stream = nullptr;
+  int n_owned = 0, n_halo = 0, n_real = 0, n_cells = 0, n_ghost = 0, E = 0, K = 0;
+  int VW = 1, G = 1, R = 1;
+  int nnz = 0, nblocks = 0, stage_cap = 0;
+  size_t apply_lds = 0;
+  // static topology
+  int32_t *d_f1 = nullptr, *d_f2 = nullptr, *d_ptr = nullptr, *d_ent_edge = nullptr, *d_ent_nb = nullptr;
+  // flow field, all levels resident in HBM
+  int T = 0, T_bc = 0;
+  float *d_adv = nullptr, *d_vel = nullptr, *d_vol = nullptr;
+  double* d_dif = nullptr;
+  std::vector<double> dt;
+  double D = 0.0;
+  double* d_bc = nullptr;
+  // per-step operator
+  FaceRec* d_rec = nullptr;
+  double* d_diag = nullptr;
+  int prepared_t = -1;
+  // vectors: c is the full state [owned | halo | ghost] x K and doubles as the solver's x
+  double *d_c = nullptr, *d_r = nullptr, *d_r0 = nullptr, *d_p = nullptr, *d_v = nullptr, *d_s = nullptr,
+         *d_t = nullptr, *d_b = nullptr;
+  double* d_scal = nullptr;      // acc[3][ACC_N][K] | rho[3][K] | bb[K]
+  int32_t* d_counters = nullptr; // 8 ints
+  double *d_fadv = nullptr, *d_fdif = nullptr, *d_ftot = nullptr;
+  bool flux_valid = false;
+  // communicator
+  NcclComm comm = nullptr;
+  int rank = 0, world = 1;
+  std::vector<int> peers, send_ptr, recv_ptr;
+  int32_t* d_send_cells = nullptr;
+  double* d_sendbuf = nullptr;
+  int n_send = 0;
+  // measurement
+  std::vector<hipEvent_t> ev;
+  size_t ev_used = 0;
+  bool profiling = false;
+  int64_t prof_launches = 0;
+  double prof_us = 0.0;
+  int last_iters = 0;
+  std::string err;
+
+  double* acc(int slot) const { return d_scal + (size_t)slot * ACC_N * K; }
+  double* rho(int slot) const { return d_scal + (size_t)3 * ACC_N * K + (size_t)slot * K; }
+  double* bb() const { return d_scal + (size_t)3 * ACC_N * K + (size_t)3 * K; }
+  size_t scal_count() const { return (size_t)3 * ACC_N * K + 3 * K + K; }
+};
+
+namespace {
+
+int fail(cwr_engine* e, int code, const std::string& msg) {
+  if (e) e->err = msg; else g_create_error = msg;
+  return code;
+}
+
+#define HIP_TRY(e, call)                                                                       \
+  do {                                                                                         \
+    hipError_t _st = (call);                                                                   \
+    if (_st != hipSuccess)                                                                     \
+      return fail((e), CWR_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_st));       \
+  } while (0)
+
+#define NCCL_TRY(e, call)                                                                      \
+  do {                                                                                         \
+    int _st = (call);                                                                          \
+    if (_st != 0)                                                                              \
+      return fail((e), CWR_ERR_RCCL, std::string(#call) + ": " + g_rccl.GetErrorString(_st)); \
+  } while (0)
+
+template <typename T> int dev_alloc(cwr_engine* e, T** p, size_t count) {
+  HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(count, 1) * sizeof(T)));
+  return CWR_OK;
+}
+template <typename T> int upload(cwr_engine* e, T* dst, const T* src, size_t count) {
+  if (count == 0) return CWR_OK;
+  HIP_TRY(e, hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return CWR_OK;
+}
+template <typename T> int download(cwr_engine* e, T* dst, const T* src, size_t count) {
+  if (count == 0) return CWR_OK;
+  HIP_TRY(e, hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return CWR_OK;
+}
+
+inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- launches ----------------------------------------------------------------------------------------
+int prep_step(cwr_engine* e, int t) {
+  if (e->prepared_t == t) return CWR_OK;
+  k_prep_step<<<cdiv(e->n_owned, BLOCK), BLOCK, 0, e->stream>>>(
+      e->n_owned, e->d_ptr, e->d_ent_edge, e->d_ent_nb, e->d_adv + (size_t)t * e->E,
+      e->d_dif + (size_t)t * e->E, e->d_vol + (size_t)(t + 1) * e->n_cells, e->dt[t], e->d_rec, e->d_diag);
+  HIP_TRY(e, hipGetLastError());
+  e->prepared_t = t;
+  return CWR_OK;
+}
+
+template <int MODE>
+int launch_apply(cwr_engine* e, const double* xin, double* yout, const double* r0, const double* bhat,
+                 double* r0_out, double* p_out, double* acc, double* bb) {
+  const int grid = cdiv(e->nblocks, N_XCD) * N_XCD;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (e->profiling && e->ev_used + 2 <= e->ev.size()) {
+    e0 = e->ev[e->ev_used++]; e1 = e->ev[e->ev_used++];
+    HIP_TRY(e, hipEventRecord(e0, e->stream));
+  }
+  if (e->VW == 2)
+    k_apply<2, MODE><<<grid, BLOCK, e->apply_lds, e->stream>>>(e->n_owned, e->K, e->G, e->nblocks, e->stage_cap,
+        e->d_ptr, e->d_rec, e->d_diag, xin, yout, r0, bhat, r0_out, p_out, acc, bb);
+  else
+    k_apply<1, MODE><<<grid, BLOCK, e->apply_lds, e->stream>>>(e->n_owned, e->K, e->G, e->nblocks, e->stage_cap,
+        e->d_ptr, e->d_rec, e->d_diag, xin, yout, r0, bhat, r0_out, p_out, acc, bb);
+  HIP_TRY(e, hipGetLastError());
+  if (e1) HIP_TRY(e, hipEventRecord(e1, e->stream));
+  return CWR_OK;
+}
+
+int vec_grid(const cwr_engine* e) {
+  // memory-bound streaming kernels: cap the grid at 8 blocks per CU and grid-stride the rest
+  return std::max(1, std::min(cdiv(e->n_owned, e->R), 256 * 8));
+}
+
+int exchange_halo(cwr_engine* e, double* vec) {
+  if (!e->comm || e->peers.empty()) return CWR_OK;
+  const int64_t total = (int64_t)e->n_send * e->K;
+  if (total > 0) {
+    k_pack_rows<<<cdiv(total, BLOCK), BLOCK, 0, e->stream>>>(total, e->K, e->d_send_cells, vec, e->d_sendbuf);
+    HIP_TRY(e, hipGetLastError());
+  }
+  NCCL_TRY(e, g_rccl.GroupStart());
+  for (size_t i = 0; i < e->peers.size(); ++i) {
+    const size_t ns = (size_t)(e->send_ptr[i + 1] - e->send_ptr[i]) * e->K;
+    const size_t nr = (size_t)(e->recv_ptr[i + 1] - e->recv_ptr[i]) * e->K;
+    if (ns) NCCL_TRY(e, g_rccl.Send(e->d_sendbuf + (size_t)e->send_ptr[i] * e->K, ns, NCCL_FLOAT64, e->peers[i], e->comm, e->stream));
+    if (nr) NCCL_TRY(e, g_rccl.Recv(vec + ((size_t)e->n_owned + e->recv_ptr[i]) * e->K, nr, NCCL_FLOAT64, e->peers[i], e->comm, e->stream));
+  }
+  NCCL_TRY(e, g_rccl.GroupEnd());
+  return CWR_OK;
+}
+
+int allreduce(cwr_engine* e, double* p, size_t count) {
+  if (!e->comm || e->world == 1) return CWR_OK;
+  NCCL_TRY(e, g_rccl.AllReduce(p, p, count, NCCL_FLOAT64, NCCL_SUM, e->comm, e->stream));
+  return CWR_OK;
+}
+
+#define TRY(call) do { int _rc = (call); if (_rc != CWR_OK) return _rc; } while (0)
+
+int launch_rhs(cwr_engine* e, int t, const double* x, double* b, bool scale) {
+  const int grid = cdiv(e->n_owned, e->R);
+  const size_t E = e->E;
+  const float* vol_t = e->d_vol + (size_t)t * e->n_cells;
+  const float* vel_n = e->d_vel + (size_t)(t + 1) * E;
+  const float* adv_n = e->d_adv + (size_t)(t + 1) * E;
+  const double* dif_n = e->d_dif + (size_t)(t + 1) * E;
+  const double* bc_n = e->d_bc + (size_t)(t + 1) * e->n_ghost * e->K;
+  const int used = (e->D != 0.0) ? 1 : 0;
+#define CWR_RHS(VWv, SC) k_rhs<VWv, SC><<<grid, BLOCK, 0, e->stream>>>(e->n_owned, e->K, e->G, e->d_ptr, e->d_ent_edge, \
+    e->d_ent_nb, vol_t, e->dt[t], vel_n, adv_n, dif_n, used, bc_n, x, e->d_diag, b, e->d_counters)
+  if (e->VW == 2) { if (scale) CWR_RHS(2, true); else CWR_RHS(2, false); }
+  else            { if (scale) CWR_RHS(1, true); else CWR_RHS(1, false); }
+#undef CWR_RHS
+  HIP_TRY(e, hipGetLastError());
+  return CWR_OK;
+}
+
+int one_iteration(cwr_engine* e, int it, double tol2) {
+  const int K = e->K;
+  const int slot = it % 3, prev = (it + 2) % 3, next = (it + 1) % 3;
+  double* acc_cur = e->acc(slot);
+  const double* rho_ptr = (it == 0) ? e->acc(2) + ACC_RR * K : e->rho(slot);
+  const double* rr_prev = e->acc(prev) + ACC_RR * K;
+  const int vg = vec_grid(e);
+  TRY(exchange_halo(e, e->d_p));
+  TRY(launch_apply<1>(e, e->d_p, e->d_v, e->d_r0, nullptr, nullptr, nullptr, acc_cur, nullptr));
+  TRY(allreduce(e, acc_cur + ACC_R0V * K, K));
+  if (e->VW == 2) k_vec_s<2><<<vg, BLOCK, 0, e->stream>>>(e->n_owned, K, e->G, e->d_r, e->d_v, e->d_s, rho_ptr, acc_cur, rr_prev, e->bb(), tol2);
+  else            k_vec_s<1><<<vg, BLOCK, 0, e->stream>>>(e->n_owned, K, e->G, e->d_r, e->d_v, e->d_s, rho_ptr, acc_cur, rr_prev, e->bb(), tol2);
+  HIP_TRY(e, hipGetLastError());
+  TRY(exchange_halo(e, e->d_s));
+  TRY(launch_apply<2>(e, e->d_s, e->d_t, e->d_r0, nullptr, nullptr, nullptr, acc_cur, nullptr));
+  TRY(allreduce(e, acc_cur + ACC_TS * K, 3 * (size_t)K));
+  if (e->VW == 2) k_vec_x<2><<<vg, BLOCK, 0, e->stream>>>(e->n_owned, K, e->G, e->d_c, e->d_r, e->d_p, e->d_s, e->d_t, e->d_v, rho_ptr, e->rho(next), acc_cur, e->acc(next), rr_prev, e->bb(), tol2, e->d_counters);
+  else            k_vec_x<1><<<vg, BLOCK, 0, e->stream>>>(e->n_owned, K, e->G, e->d_c, e->d_r, e->d_p, e->d_s, e->d_t, e->d_v, rho_ptr, e->rho(next), acc_cur, e->acc(next), rr_prev, e->bb(), tol2, e->d_counters);
+  HIP_TRY(e, hipGetLastError());
+  TRY(allreduce(e, acc_cur + ACC_RR * K, K));
+  return CWR_OK;
+}
+
+int check_level(cwr_engine* e, int t, bool need_next) {
+  if (e->T <= 0) return fail(e, CWR_ERR_STATE, "no flow field loaded (cwr_load_flow_field / cwr_load_coefficients)");
+  if (t < 0 || t + (need_next ? 1 : 0) >= e->T)
+    return fail(e, CWR_ERR_STATE, "time level " + std::to_string(t) + " out of range for " + std::to_string(e->T) + " levels");
+  return CWR_OK;
+}
+
+void collect_profile(cwr_engine* e) {
+  for (size_t i = 0; i + 1 < e->ev_used; i += 2) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e->ev[i], e->ev[i + 1]) == hipSuccess) { e->prof_us += 1000.0 * ms; e->prof_launches += 1; }
+  }
+  e->ev_used = 0;
+}
+
+int alloc_flow(cwr_engine* e, int T) {
+  if (e->T != T) {
+    hipFree(e->d_adv); hipFree(e->d_dif); hipFree(e->d_vel); hipFree(e->d_vol);
+    e->d_adv = nullptr; e->d_dif = nullptr; e->d_vel = nullptr; e->d_vol = nullptr; e->T = 0;
+    TRY(dev_alloc(e, &e->d_adv, (size_t)T * e->E));
+    TRY(dev_alloc(e, &e->d_dif, (size_t)T * e->E));
+    TRY(dev_alloc(e, &e->d_vel, (size_t)T * e->E));
+    TRY(dev_alloc(e, &e->d_vol, (size_t)T * e->n_cells));
+  }
+  e->T = T;
+  e->prepared_t = -1;
+  return CWR_OK;
+}
+
+}  // namespace
+
+// ====================================================================================================
+extern "C" {
+
+int32_t cwr_abi_version(void) { return 1; }
+
+const char* cwr_last_error(const cwr_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+
+int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_edges, int32_t K,
+                   const int32_t* face1, const int32_t* face2, int32_t device, cwr_engine** out) {
+  if (!out) return fail(nullptr, CWR_ERR_BAD_ARG, "out is NULL");
+  *out = nullptr;
+  if (n_owned <= 0 || n_halo < 0 || n_edges < 0 || K <= 0 || K > 256 || !face1 || !face2 ||
+      n_cells < n_owned + n_halo)
+    return fail(nullptr, CWR_ERR_BAD_ARG, "cwr_create: bad sizes or NULL topology");
+  const int n_real = n_owned + n_halo;
+  std::vector<int32_t> cnt((size_t)n_owned + 1, 0);
+  for (int e = 0; e < n_edges; ++e) {
+    const int P = face1[e], N = face2[e];
+    if (P < 0 || P >= n_real || N < 0 || N >= n_cells)
+      return fail(nullptr, CWR_ERR_BAD_ARG, "cwr_create: face " + std::to_string(e) +
+                  " has face1 outside the real cells or face2 outside the mesh (face1 must be a real cell, io/hdf.py:268)");
+    if (P < n_owned) cnt[P + 1]++;
+    if (N < n_owned) cnt[N + 1]++;
+  }
+  for (int c = 0; c < n_owned; ++c) cnt[c + 1] += cnt[c];
+  const int nnz = cnt[n_owned];
+  std::vector<int32_t> ent_edge((size_t)std::max(nnz, 1)), ent_nb((size_t)std::max(nnz, 1)), fill(cnt.begin(), cnt.end() - 1);
+  for (int e = 0; e < n_edges; ++e) {           // ascending face id inside every cell (last-write-wins order)
+    const int P = face1[e], N = face2[e];
+    if (P < n_owned) { const int j = fill[P]++; ent_edge[j] = (e << 1); ent_nb[j] = (N < n_real) ? N : -1 - (N - n_real); }
+    if (N < n_owned) { const int j = fill[N]++; ent_edge[j] = (e << 1) | 1; ent_nb[j] = P; }
+  }
+
+  cwr_engine* eng = new cwr_engine();
+  eng->dev = device;
+  eng->n_owned = n_owned; eng->n_halo = n_halo; eng->n_real = n_real; eng->n_cells = n_cells;
+  eng->n_ghost = n_cells - n_real; eng->E = n_edges; eng->K = K; eng->nnz = nnz;
+  eng->VW = (K % 2 == 0) ? 2 : 1;
+  eng->G = K / eng->VW;
+  eng->R = BLOCK / eng->G;
+  eng->nblocks = cdiv(n_owned, eng->R);
+  int cap = 0;
+  for (int b = 0; b < eng->nblocks; ++b) {
+    const int c0 = b * eng->R, c1 = std::min(c0 + eng->R, n_owned);
+    cap = std::max(cap, cnt[c1] - cnt[c0]);
+  }
+  eng->stage_cap = std::min(std::max(cap, 1), 6144);              // <= 96 KiB of records per block
+  eng->apply_lds = (size_t)eng->stage_cap * sizeof(FaceRec) + RED_DOUBLES * sizeof(double);
+
+#define CREATE_TRY(call) do { int _rc = (call); if (_rc != CWR_OK) { g_create_error = eng->err; cwr_destroy(eng); return _rc; } } while (0)
+#define CREATE_HIP(call) do { hipError_t _st = (call); if (_st != hipSuccess) { g_create_error = std::string(#call) + ": " + hipGetErrorString(_st); cwr_destroy(eng); return CWR_ERR_HIP; } } while (0)
+  CREATE_HIP(hipSetDevice(device));
+  CREATE_HIP(hipStreamCreateWithFlags(&eng->stream, hipStreamNonBlocking));
+  if (eng->apply_lds > 48 * 1024) {
+    CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_apply<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)eng->apply_lds));
+    CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_apply<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)eng->apply_lds));
+    CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_apply<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)eng->apply_lds));
+    CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_apply<1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)eng->apply_lds));
+    CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_apply<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)eng->apply_lds));
+    CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_apply<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)eng->apply_lds));
+    CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_apply<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)eng->apply_lds));
+    CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_apply<2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)eng->apply_lds));
+  }
+  const size_t nK = (size_t)n_real * K;
+  CREATE_TRY(dev_alloc(eng, &eng->d_f1, (size_t)n_edges));
+  CREATE_TRY(dev_alloc(eng, &eng->d_f2, (size_t)n_edges));
+  CREATE_TRY(dev_alloc(eng, &eng->d_ptr, (size_t)n_owned + 1));
+  CREATE_TRY(dev_alloc(eng, &eng->d_ent_edge, (size_t)nnz));
+  CREATE_TRY(dev_alloc(eng, &eng->d_ent_nb, (size_t)nnz));
+  CREATE_TRY(dev_alloc(eng, &eng->d_rec, (size_t)nnz));
+  CREATE_TRY(dev_alloc(eng, &eng->d_diag, (size_t)n_owned));
+  CREATE_TRY(dev_alloc(eng, &eng->d_c, (size_t)n_cells * K));
+  CREATE_TRY(dev_alloc(eng, &eng->d_r, nK));
+  CREATE_TRY(dev_alloc(eng, &eng->d_r0, nK));
+  CREATE_TRY(dev_alloc(eng, &eng->d_p, nK));
+  CREATE_TRY(dev_alloc(eng, &eng->d_v, nK));
+  CREATE_TRY(dev_alloc(eng, &eng->d_s, nK));
+  CREATE_TRY(dev_alloc(eng, &eng->d_t, nK));
+  CREATE_TRY(dev_alloc(eng, &eng->d_b, nK));
+  CREATE_TRY(dev_alloc(eng, &eng->d_scal, eng->scal_count()));
+  CREATE_TRY(dev_alloc(eng, &eng->d_counters, (size_t)8));
+  CREATE_TRY(upload(eng, eng->d_f1, face1, (size_t)n_edges));
+  CREATE_TRY(upload(eng, eng->d_f2, face2, (size_t)n_edges));
+  CREATE_TRY(upload(eng, eng->d_ptr, cnt.data(), (size_t)n_owned + 1));
+  CREATE_TRY(upload(eng, eng->d_ent_edge, ent_edge.data(), (size_t)nnz));
+  CREATE_TRY(upload(eng, eng->d_ent_nb, ent_nb.data(), (size_t)nnz));
+  CREATE_HIP(hipMemsetAsync(eng->d_c, 0, (size_t)n_cells * K * sizeof(double), eng->stream));
+  for (double* v : {eng->d_r, eng->d_r0, eng->d_p, eng->d_v, eng->d_s, eng->d_t, eng->d_b})
+    CREATE_HIP(hipMemsetAsync(v, 0, nK * sizeof(double), eng->stream));
+  CREATE_HIP(hipMemsetAsync(eng->d_scal, 0, eng->scal_count() * sizeof(double), eng->stream));
+  CREATE_HIP(hipMemsetAsync(eng->d_counters, 0, 8 * sizeof(int32_t), eng->stream));
+  CREATE_HIP(hipStreamSynchronize(eng->stream));
+#undef CREATE_TRY
+#undef CREATE_HIP
+  *out = eng;
+  return CWR_OK;
+}
+
+void cwr_destroy(cwr_engine* e) {
+  if (!e) return;
+  hipSetDevice(e->dev);
+  if (e->stream) hipStreamSynchronize(e->stream);
+  if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
+  for (hipEvent_t ev : e->ev) hipEventDestroy(ev);
+  void* ptrs[] = {e->d_f1, e->d_f2, e->d_ptr, e->d_ent_edge, e->d_ent_nb, e->d_adv, e->d_vel, e->d_vol, e->d_dif,
+                  e->d_bc, e->d_rec, e->d_diag, e->d_c, e->d_r, e->d_r0, e->d_p, e->d_v, e->d_s, e->d_t, e->d_b,
+                  e->d_scal, e->d_counters, e->d_fadv, e->d_fdif, e->d_ftot, e->d_send_cells, e->d_sendbuf};
+  for (void* p : ptrs) if (p) hipFree(p);
+  if (e->stream) hipStreamDestroy(e->stream);
+  delete e;
+}
+
+int32_t cwr_load_flow_field(cwr_engine* e, int32_t T, const float* face_flow, const float* edge_velocity,
+                            const float* volume, const double* dt, const double* dist, double D) {
+  if (!e) return CWR_ERR_BAD_ARG;
+  if (T < 2 || !face_flow || !edge_velocity || !volume || !dt || !dist)
+    return fail(e, CWR_ERR_BAD_ARG, "cwr_load_flow_field: need >= 2 time levels and non-NULL arrays");
+  HIP_TRY(e, hipSetDevice(e->dev));
+  TRY(alloc_flow(e, T));
+  const size_t TE = (size_t)T * e->E;
+  // raw flow goes through d_adv's storage; a temporary holds the distances
+  float* d_flow = nullptr; double* d_dist = nullptr;
+  TRY(dev_alloc(e, &d_flow, TE));
+  TRY(dev_alloc(e, &d_dist, (size_t)e->E));
+  int rc = upload(e, d_flow, face_flow, TE);
+  if (rc == CWR_OK) rc = upload(e, e->d_vel, edge_velocity, TE);
+  if (rc == CWR_OK) rc = upload(e, e->d_vol, volume, (size_t)T * e->n_cells);
+  if (rc == CWR_OK) rc = upload(e, d_dist, dist, (size_t)e->E);
+  if (rc == CWR_OK && TE > 0) {
+    const int grid = std::min(cdiv((int64_t)TE, BLOCK), 256 * 16);
+    k_derive_coeff<<<grid, BLOCK, 0, e->stream>>>((int64_t)TE, e->E, d_flow, e->d_vel, d_dist, (float)D, e->d_adv, e->d_dif);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess)
+      rc = fail(e, CWR_ERR_HIP, "k_derive_coeff failed");
+  }
+  hipFree(d_flow); hipFree(d_dist);
+  if (rc != CWR_OK) { e->T = 0; return rc; }
+  e->dt.assign(dt, dt + T);
+  e->D = D;
+  return CWR_OK;
+}
+
+int32_t cwr_load_coefficients(cwr_engine* e, int32_t T, const float* adv, const double* dif, const float* vel,
+                              const float* volume, const double* dt, double D) {
+  if (!e) return CWR_ERR_BAD_ARG;
+  if (T < 2 || !adv || !dif || !vel || !volume || !dt)
+    return fail(e, CWR_ERR_BAD_ARG, "cwr_load_coefficients: need >= 2 time levels and non-NULL arrays");
+  HIP_TRY(e, hipSetDevice(e->dev));
+  TRY(alloc_flow(e, T));
+  const size_t TE = (size_t)T * e->E;
+  TRY(upload(e, e->d_adv, adv, TE));
+  TRY(upload(e, e->d_dif, dif, TE));
+  TRY(upload(e, e->d_vel, vel, TE));
+  TRY(upload(e, e->d_vol, volume, (size_t)T * e->n_cells));
+  e->dt.assign(dt, dt + T);
+  e->D = D;
+  return CWR_OK;
+}
+
+int32_t cwr_get_coefficients(cwr_engine* e, int32_t t, float* adv, double* dif) {
+  if (!e) return CWR_ERR_BAD_ARG;
+  TRY(check_level(e, t, false));
+  HIP_TRY(e, hipSetDevice(e->dev));
+  if (adv) TRY(download(e, adv, e->d_adv + (size_t)t * e->E, (size_t)e->E));
+  if (dif) TRY(download(e, dif, e->d_dif + (size_t)t * e->E, (size_t)e->E));
+  return CWR_OK;
+}
+
+int32_t cwr_load_boundary(cwr_engine* e, int32_t T, const double* ghost_conc) {
+  if (!e) return CWR_ERR_BAD_ARG;
+  if (T < 1 || (!ghost_conc && e->n_ghost > 0)) return fail(e, CWR_ERR_BAD_ARG, "cwr_load_boundary: bad arguments");
+  HIP_TRY(e, hipSetDevice(e->dev));
+  const size_t cnt = (size_t)T * e->n_ghost * e->K;
+  if (e->T_bc != T) {
+    hipFree(e->d_bc); e->d_bc = nullptr; e->T_bc = 0;
+    TRY(dev_alloc(e, &e->d_bc, cnt));
+    e->T_bc = T;
+  }
+  TRY(upload(e, e->d_bc, ghost_conc, cnt));
+  return CWR_OK;
+}
+
+int32_t cwr_set_boundary_level(cwr_engine* e, int32_t t, const double* level) {
+  if (!e) return CWR_ERR_BAD_ARG;
+  if (t < 0 || t >= e->T_bc) return fail(e, CWR_ERR_STATE, "cwr_set_boundary_level: level outside the loaded boundary array");
+  HIP_TRY(e, hipSetDevice(e->dev));
+  TRY(upload(e, e->d_bc + (size_t)t * e->n_ghost * e->K, level, (size_t)e->n_ghost * e->K));
+  return CWR_OK;
+}
+
+int32_t cwr_set_state(cwr_engine* e, const double* conc_owned) {
+  if (!e || !conc_owned) return e ? fail(e, CWR_ERR_BAD_ARG, "cwr_set_state: NULL") : CWR_ERR_BAD_ARG;
+  HIP_TRY(e, hipSetDevice(e->dev));
+  TRY(upload(e, e->d_c, conc_owned, (size_t)e->n_owned * e->K));
+  return CWR_OK;
+}
+
+int32_t cwr_get_state(cwr_engine* e, double* conc_all) {
+  if (!e || !conc_all) return e ? fail(e, CWR_ERR_BAD_ARG, "cwr_get_state: NULL") : CWR_ERR_BAD_ARG;
+  HIP_TRY(e, hipSetDevice(e->dev));
+  TRY(download(e, conc_all, e->d_c, (size_t)e->n_cells * e->K));
+  return CWR_OK;
+}
+
+int32_t cwr_apply(cwr_engine* e, int32_t t, const double* x, double* y) {
+  if (!e || !x || !y) return e ? fail(e, CWR_ERR_BAD_ARG, "cwr_apply: NULL") : CWR_ERR_BAD_ARG;
+  TRY(check_level(e, t, true));
+  HIP_TRY(e, hipSetDevice(e->dev));
+  TRY(upload(e, e->d_p, x, (size_t)e->n_real * e->K));
+  TRY(prep_step(e, t));
+  TRY(launch_apply<0>(e, e->d_p, e->d_v, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
+  TRY(download(e, y, e->d_v, (size_t)e->n_owned * e->K));
+  return CWR_OK;
+}
+
+int32_t cwr_rhs(cwr_engine* e, int32_t t, const double* x_t, double* b) {
+  if (!e || !x_t || !b) return e ? fail(e, CWR_ERR_BAD_ARG, "cwr_rhs: NULL") : CWR_ERR_BAD_ARG;
+  TRY(check_level(e, t, true));
+  if (e->T_bc < t + 2) return fail(e, CWR_ERR_STATE, "cwr_rhs: boundary values of level t+1 not loaded");
+  HIP_TRY(e, hipSetDevice(e->dev));
+  TRY(upload(e, e->d_s, x_t, (size_t)e->n_owned * e->K));
+  HIP_TRY(e, hipMemsetAsync(e->d_counters, 0, 8 * sizeof(int32_t), e->stream));
+  TRY(launch_rhs(e, t, e->d_s, e->d_t, false));
+  int32_t cnt[8];
+  TRY(download(e, cnt, e->d_counters, (size_t)8));
+  if (cnt[2]) return fail(e, CWR_ERR_GHOST_COEFF, "active ghost face with a zero advection/diffusion coefficient at level t+1 "
+                          "(the reference raises a shape-mismatch ValueError, linalg.py:349-351)");
+  TRY(download(e, b, e->d_t, (size_t)e->n_owned * e->K));
+  return CWR_OK;
+}
+
+int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t flags, cwr_step_info* info) {
+  if (!e) return CWR_ERR_BAD_ARG;
+  const auto w0 = std::chrono::steady_clock::now();
+  cwr_step_info local; std::memset(&local, 0, sizeof(local));
+  if (info) *info = local;
+  TRY(check_level(e, t, true));
+  if (e->T_bc < t + 2) return fail(e, CWR_ERR_STATE, "cwr_step: boundary values of level t+1 not loaded (cwr_load_boundary)");
+  if (!(tol > 0.0) || max_iter < 1) return fail(e, CWR_ERR_BAD_ARG, "cwr_step: tol must be > 0 and max_iter >= 1");
+  HIP_TRY(e, hipSetDevice(e->dev));
+  const int K = e->K;
+  const double tol2 = tol * tol;
+  e->profiling = (flags & CWR_STEP_PROFILE) != 0;
+  if (e->profiling && e->ev.empty()) {
+    e->ev.resize(1024);
+    for (auto& ev : e->ev) HIP_TRY(e, hipEventCreate(&ev));
+  }
+  e->ev_used = 0;
+  e->flux_valid = false;
+
+  TRY(prep_step(e, t));
+  HIP_TRY(e, hipMemsetAsync(e->d_counters, 0, 8 * sizeof(int32_t), e->stream));
+  HIP_TRY(e, hipMemsetAsync(e->d_scal, 0, e->scal_count() * sizeof(double), e->stream));
+  TRY(launch_rhs(e, t, e->d_c, e->d_b, true));
+
+  std::vector<double> h_scal(e->scal_count());
+  int32_t h_cnt[8];
+  int total_it = 0, restarts = 0, launches = 0, status = CWR_OK;
+  double max_rel = 0.0;
+  bool converged = false;
+  for (int round = 0; !converged; ++round) {
+    // (re)start: true residual of the current x; r0 = p = r
+    if (round > 0) HIP_TRY(e, hipMemsetAsync(e->d_scal, 0, (size_t)3 * ACC_N * K * sizeof(double) + (size_t)3 * K * sizeof(double), e->stream));
+    TRY(exchange_halo(e, e->d_c));
+    TRY(launch_apply<3>(e, e->d_c, e->d_r, nullptr, e->d_b, e->d_r0, e->d_p, e->acc(2), round == 0 ? e->bb() : nullptr));
+    ++launches;
+    TRY(allreduce(e, e->acc(2) + ACC_RR * K, K));
+    if (round == 0) TRY(allreduce(e, e->bb(), K));
+    if (round > 0) {
+      TRY(download(e, h_scal.data(), e->d_scal, e->scal_count()));
+      const double* rr = h_scal.data() + (size_t)2 * ACC_N * K + ACC_RR * K;
+      const double* bbh = h_scal.data() + (size_t)3 * ACC_N * K + 3 * K;
+      bool ok = true, loose = true;
+      max_rel = 0.0;
+      for (int k = 0; k < K; ++k) {
+        if (!std::isfinite(rr[k])) { status = CWR_ERR_NONFINITE; break; }
+        const double rel = (bbh[k] > 0.0) ? std::sqrt(rr[k] / bbh[k]) : (rr[k] > 0.0 ? INFINITY : 0.0);
+        max_rel = std::max(max_rel, rel);
+        if (rr[k] > tol2 * bbh[k]) ok = false;
+        if (rr[k] > 1.0e4 * tol2 * bbh[k]) loose = false;
+      }
+      if (status != CWR_OK) break;
+      if (ok) { converged = true; break; }
+      if (total_it >= max_iter || round > 6) { if (loose && round > 6) { converged = true; break; } status = CWR_ERR_NOT_CONVERGED; break; }
+      ++restarts;
+    }
+    // iterate until the recurrence residual says converged, a breakdown is flagged, or max_iter
+    int it = 0;
+    int batch = (round == 0) ? std::max(2, e->last_iters) : 2;
+    bool inner_done = false;
+    while (!inner_done) {
+      batch = std::min(batch, std::max(1, max_iter - total_it));
+      for (int b = 0; b < batch; ++b) { TRY(one_iteration(e, it, tol2)); ++it; ++total_it; launches += 2; }
+      TRY(download(e, h_scal.data(), e->d_scal, e->scal_count()));
+      TRY(download(e, h_cnt, e->d_counters, (size_t)8));
+      const double* rr = h_scal.data() + (size_t)((it - 1) % 3) * ACC_N * K + ACC_RR * K;
+      const double* bbh = h_scal.data() + (size_t)3 * ACC_N * K + 3 * K;
+      bool ok = true;
+      for (int k = 0; k < K; ++k) {
+        if (!std::isfinite(rr[k])) { status = CWR_ERR_NONFINITE; }
+        if (rr[k] > tol2 * bbh[k]) ok = false;
+      }
+      if (h_cnt[2]) status = CWR_ERR_GHOST_COEFF;
+      if (h_cnt[3] && status == CWR_OK) status = CWR_ERR_NONFINITE;
+      if (status != CWR_OK) break;
+      if (ok || h_cnt[1] || total_it >= max_iter) inner_done = true;
+      if (h_cnt[1]) HIP_TRY(e, hipMemsetAsync(e->d_counters + 1, 0, sizeof(int32_t), e->stream));
+      batch = 2;
+    }
+    if (status != CWR_OK) break;
+  }
+  if (e->profiling) { hipStreamSynchronize(e->stream); collect_profile(e); }
+  e->profiling = false;
+  local.iterations = total_it; local.restarts = restarts; local.operator_launches = launches;
+  local.max_rel_residual = max_rel; local.status = status;
+  if (status != CWR_OK) {
+    if (info) *info = local;
+    switch (status) {
+      case CWR_ERR_GHOST_COEFF: return fail(e, status, "active ghost face with a zero advection/diffusion coefficient at level t+1 "
+                                                        "(the reference raises a shape-mismatch ValueError, linalg.py:349-351)");
+      case CWR_ERR_NONFINITE: return fail(e, status, "non-finite value met in the implicit solve (NaN/Inf in state, flow field or boundary values)");
+      default: return fail(e, status, "BiCGSTAB did not reach tol = " + std::to_string(tol) + " in " + std::to_string(total_it) +
+                                      " iterations (max relative residual " + std::to_string(max_rel) + ")");
+    }
+  }
+  e->last_iters = std::max(1, total_it - 1);
+
+  // write-back: real cells are already in place (x lives in the state vector); ghost rows from input_array[t+1]
+  const int64_t gk = (int64_t)e->n_ghost * K;
+  if (gk > 0) {
+    k_ghost_writeback<<<cdiv(gk, BLOCK), BLOCK, 0, e->stream>>>(gk, e->d_bc + (size_t)(t + 1) * gk, e->d_c + (size_t)e->n_real * K);
+    HIP_TRY(e, hipGetLastError());
+  }
+  if (flags & CWR_STEP_MASS_FLUX) {
+    TRY(exchange_halo(e, e->d_c));
+    if (!e->d_fadv) {
+      const size_t cnt = (size_t)e->E * K;
+      TRY(dev_alloc(e, &e->d_fadv, cnt)); TRY(dev_alloc(e, &e->d_fdif, cnt)); TRY(dev_alloc(e, &e->d_ftot, cnt));
+    }
+    const int grid = std::max(1, std::min(cdiv(e->E, e->R), 256 * 8));
+    const float* adv_t = e->d_adv + (size_t)t * e->E;
+    const double* dif_t = e->d_dif + (size_t)t * e->E;
+    if (e->VW == 2) k_mass_flux<2><<<grid, BLOCK, 0, e->stream>>>(e->E, e->n_owned, K, e->G, e->d_f1, e->d_f2, adv_t, dif_t, e->dt[t], e->d_c, e->d_fadv, e->d_fdif, e->d_ftot);
+    else            k_mass_flux<1><<<grid, BLOCK, 0, e->stream>>>(e->E, e->n_owned, K, e->G, e->d_f1, e->d_f2, adv_t, dif_t, e->dt[t], e->d_c, e->d_fadv, e->d_fdif, e->d_ftot);
+    HIP_TRY(e, hipGetLastError());
+    e->flux_valid = true;
+  }
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  local.solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+  if (info) *info = local;
+  return CWR_OK;
+}
+
+int32_t cwr_get_mass_flux(cwr_engine* e, double* adv, double* dif, double* tot) {
+  if (!e) return CWR_ERR_BAD_ARG;
+  if (!e->flux_valid) return fail(e, CWR_ERR_STATE, "cwr_get_mass_flux: the last step was not taken with CWR_STEP_MASS_FLUX");
+  HIP_TRY(e, hipSetDevice(e->dev));
+  const size_t cnt = (size_t)e->E * e->K;
+  if (adv) TRY(download(e, adv, e->d_fadv, cnt));
+  if (dif) TRY(download(e, dif, e->d_fdif, cnt));
+  if (tot) TRY(download(e, tot, e->d_ftot, cnt));
+  return CWR_OK;
+}
+
+int32_t cwr_time_apply(cwr_engine* e, int32_t t, int32_t variant, int32_t reps, double* avg_us) {
+  if (!e || !avg_us || reps < 1) return e ? fail(e, CWR_ERR_BAD_ARG, "cwr_time_apply: bad arguments") : CWR_ERR_BAD_ARG;
+  TRY(check_level(e, t, true));
+  HIP_TRY(e, hipSetDevice(e->dev));
+  TRY(prep_step(e, t));
+  const size_t nK = (size_t)e->n_real * e->K;
+  // operands: the current state and its image, so the numbers are those of a real step
+  HIP_TRY(e, hipMemcpyAsync(e->d_p, e->d_c, nK * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(e->d_s, e->d_c, nK * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(e->d_r0, e->d_c, nK * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+  hipEvent_t e0, e1;
+  HIP_TRY(e, hipEventCreate(&e0)); HIP_TRY(e, hipEventCreate(&e1));
+  const bool was = e->profiling; e->profiling = false;
+  int rc = CWR_OK;
+  auto body = [&](int i) -> int {
+    if (variant == 0) {
+      return (i & 1) ? launch_apply<1>(e, e->d_s, e->d_t, e->d_r0, nullptr, nullptr, nullptr, e->acc(1), nullptr)
+                     : launch_apply<1>(e, e->d_p, e->d_v, e->d_r0, nullptr, nullptr, nullptr, e->acc(1), nullptr);
+    }
+    const double* xin = (i & 1) ? e->d_s : e->d_p;
+    double* yo = (i & 1) ? e->d_t : e->d_v;
+    const int g1 = cdiv(e->n_owned, e->R), g2 = cdiv(e->E, e->R);
+    const float* adv_t = e->d_adv + (size_t)t * e->E;
+    const double* dif_t = e->d_dif + (size_t)t * e->E;
+    if (e->VW == 2) {
+      k_scatter_diag<2><<<g1, BLOCK, 0, e->stream>>>(e->n_owned, e->K, e->G, e->d_diag, xin, yo);
+      k_scatter_faces<2><<<g2, BLOCK, 0, e->stream>>>(e->E, e->n_owned, e->n_real, e->K, e->G, e->d_f1, e->d_f2, adv_t, dif_t, xin, yo);
+    } else {
+      k_scatter_diag<1><<<g1, BLOCK, 0, e->stream>>>(e->n_owned, e->K, e->G, e->d_diag, xin, yo);
+      k_scatter_faces<1><<<g2, BLOCK, 0, e->stream>>>(e->E, e->n_owned, e->n_real, e->K, e->G, e->d_f1, e->d_f2, adv_t, dif_t, xin, yo);
+    }
+    return hipGetLastError() == hipSuccess ? CWR_OK : fail(e, CWR_ERR_HIP, "scatter variant launch failed");
+  };
+  for (int i = 0; i < 2 && rc == CWR_OK; ++i) rc = body(i);          // warm-up
+  if (rc == CWR_OK) {
+    hipEventRecord(e0, e->stream);
+    for (int i = 0; i < reps && rc == CWR_OK; ++i) rc = body(i);
+    hipEventRecord(e1, e->stream);
+    if (hipEventSynchronize(e1) != hipSuccess) rc = fail(e, CWR_ERR_HIP, "cwr_time_apply: event synchronize failed");
+    float ms = 0.f;
+    if (rc == CWR_OK && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) *avg_us = 1000.0 * ms / reps;
+  }
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  e->profiling = was;
+  // the timing loop used the solver's work vectors and accumulators: leave them clean
+  hipMemsetAsync(e->d_scal, 0, e->scal_count() * sizeof(double), e->stream);
+  hipStreamSynchronize(e->stream);
+  return rc;
+}
+
+int32_t cwr_profile_read(cwr_engine* e, int64_t* launches, double* total_us) {
+  if (!e) return CWR_ERR_BAD_ARG;
+  if (launches) *launches = e->prof_launches;
+  if (total_us) *total_us = e->prof_us;
+  e->prof_launches = 0; e->prof_us = 0.0;
+  return CWR_OK;
+}
+
+int32_t cwr_synchronize(cwr_engine* e) {
+  if (!e) return CWR_ERR_BAD_ARG;
+  HIP_TRY(e, hipSetDevice(e->dev));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return CWR_OK;
+}
+
+int32_t cwr_apply_bytes(const cwr_engine* e, int64_t* bytes_read, int64_t* bytes_written) {
+  if (!e) return CWR_ERR_BAD_ARG;
+  // the solver's first-product launch k_apply<VW,1>: face records, CSR row pointers, diagonal, the
+  // input vector (every real row once), r0 for the fused inner product; one output row per owned cell
+  const int64_t K = e->K;
+  if (bytes_read) *bytes_read = 16LL * e->nnz + 4LL * (e->n_owned + 1) + 8LL * e->n_owned +
+                                8LL * K * e->n_real + 8LL * K * e->n_owned;
+  if (bytes_written) *bytes_written = 8LL * K * e->n_owned;
+  return CWR_OK;
+}
+
+int32_t cwr_comm_unique_id(uint8_t id_out[128]) {
+  std::string err;
+  if (!id_out) return CWR_ERR_BAD_ARG;
+  if (!g_rccl.load(err)) return fail(nullptr, CWR_ERR_RCCL, err);
+  NcclUniqueId id;
+  const int st = g_rccl.GetUniqueId(&id);
+  if (st != 0) return fail(nullptr, CWR_ERR_RCCL, std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(st));
+  std::memcpy(id_out, id.internal, 128);
+  return CWR_OK;
+}
+
+int32_t cwr_attach_comm(cwr_engine* e, int32_t rank, int32_t world, const uint8_t unique_id[128], int32_t n_peers,
+                        const int32_t* peers, const int32_t* send_ptr, const int32_t* send_cells, const int32_t* recv_ptr) {
+  if (!e) return CWR_ERR_BAD_ARG;
+  if (world < 1 || rank < 0 || rank >= world || !unique_id || n_peers < 0 ||
+      (n_peers > 0 && (!peers || !send_ptr || !recv_ptr)))
+    return fail(e, CWR_ERR_BAD_ARG, "cwr_attach_comm: bad arguments");
+  for (int i = 0; i < n_peers; ++i) {
+    if (peers[i] < 0 || peers[i] >= world || peers[i] == rank || send_ptr[i + 1] < send_ptr[i] || recv_ptr[i + 1] < recv_ptr[i])
+      return fail(e, CWR_ERR_BAD_ARG, "cwr_attach_comm: malformed peer lists");
+  }
+  const int n_send = n_peers ? send_ptr[n_peers] : 0;
+  const int n_recv = n_peers ? recv_ptr[n_peers] : 0;
+  if (n_recv != e->n_halo) return fail(e, CWR_ERR_BAD_ARG, "cwr_attach_comm: receive lists must cover the halo block exactly");
+  for (int i = 0; i < n_send; ++i)
+    if (!send_cells || send_cells[i] < 0 || send_cells[i] >= e->n_owned)
+      return fail(e, CWR_ERR_BAD_ARG, "cwr_attach_comm: send cell outside the owned block");
+  std::string err;
+  if (!g_rccl.load(err)) return fail(e, CWR_ERR_RCCL, err);
+  HIP_TRY(e, hipSetDevice(e->dev));
+  NcclUniqueId id; std::memcpy(id.internal, unique_id, 128);
+  NCCL_TRY(e, g_rccl.CommInitRank(&e->comm, world, id, rank));
+  e->rank = rank; e->world = world;
+  e->peers.assign(peers, peers + n_peers);
+  e->send_ptr.assign(send_ptr, send_ptr + (n_peers ? n_peers + 1 : 0));
+  e->recv_ptr.assign(recv_ptr, recv_ptr + (n_peers ? n_peers + 1 : 0));
+  e->n_send = n_send;
+  TRY(dev_alloc(e, &e->d_send_cells, (size_t)n_send));
+  TRY(dev_alloc(e, &e->d_sendbuf, (size_t)n_send * e->K));
+  TRY(upload(e, e->d_send_cells, send_cells, (size_t)n_send));
+  return CWR_OK;
+}
+
+}  // extern "C"

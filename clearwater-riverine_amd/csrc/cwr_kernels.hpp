@@ -1,0 +1,526 @@
+// cwr_kernels.hpp -- hand-written HIP kernels (gfx950 / CDNA4, wave64) of the transport engine.
+//
+// Reference semantics implemented here (paths relative to /root/reference/src/clearwater_riverine/):
+//   k_derive_coeff   utilities.py:513-535      advection_coeff / edge_vertical_area / coeff_to_diffusion
+//   k_prep_step      linalg.py:34-156          the per-step operator coefficients, regrouped per cell
+//   k_rhs            linalg.py:177-201,227-275,354-406   right-hand side incl. ghost (boundary) terms
+//   k_apply          transport.py:215-218 (A = csr(coo)) applied matrix-free: y = A x
+//   k_vec_s/k_vec_x  the BiCGSTAB recurrences standing in for transport.py:249 (spsolve)
+//   k_ghost_writeback transport.py:258-264, constituents.py:39-48
+//   k_mass_flux      transport.py:406-429
+//
+// Data layout (all device resident):
+//   x[cell*K + k]  float64, constituents inner.  A thread owns VW (1 or 2) consecutive constituents
+//   of one cell; G = K / VW consecutive lanes own one cell row, so a wave touches whole 128-B rows
+//   at K = 16 and every global access of a vector is fully coalesced.
+//   FaceRec rec[j]  one 16-byte record per (cell, face) adjacency entry, entries of a cell contiguous
+//   (CSR over ptr[]), faces of a cell in ascending face id: {neighbour cell or -1-ghost, signed
+//   outflow a_c (float32, as HEC-RAS stores it), diffusion coefficient d (float64)}.
+//   No MFMA anywhere: this is a bandwidth-bound sparse gather, ~0.1 flop/byte.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cwr {
+
+constexpr int BLOCK = 256;          // 4 waves of 64
+constexpr int N_XCD = 8;            // MI355X: 8 XCDs, workgroups dealt round-robin over them
+constexpr int ACC_R0V = 0, ACC_TS = 1, ACC_TT = 2, ACC_R0T = 3, ACC_RR = 4, ACC_N = 5;
+
+struct __attribute__((aligned(16))) FaceRec {
+  int32_t nb;      // >= 0: local real cell id (owned or halo); < 0: ghost cell -1-nb (boundary, not in A)
+  float a_c;       // flow leaving THIS cell through the face (advection_coeff with the cell's sign)
+  double d;        // coeff_to_diffusion of the face
+};
+
+// Scalars of the batched BiCGSTAB (K independent systems sharing A), all on device so that a whole
+// batch of iterations can be enqueued without a host round trip.  acc is a ring of 3 slots:
+// iteration `it` accumulates into slot it%3, reads ||r||^2 of iteration it-1 from slot (it-1)%3,
+// and its last kernel clears slot (it+1)%3.
+struct SolverScalars {
+  double* acc;       // [3][ACC_N][K]
+  double* rho;       // [3][K]
+  double* bb;        // [K]   ||D^-1 b||^2
+  int32_t* counters; // [0] iterations with an active column, [1] breakdown flag, [2] ghost-coefficient
+                     // precondition violated, [3] non-finite seen
+};
+
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+  // Workgroups are dealt round-robin over the 8 XCDs (observed, speed only): give each XCD one
+  // contiguous range of cell blocks so a face's two visits and a cell row's ~5 gathers hit one L2.
+  const int per = (nblocks + N_XCD - 1) / N_XCD;
+  return (bid % N_XCD) * per + bid / N_XCD;
+}
+
+template <int VW> struct VecT;
+template <> struct VecT<1> { using type = double; };
+template <> struct VecT<2> { using type = double2; };
+
+template <int VW> __device__ __forceinline__ void ldv(const double* p, double (&v)[VW]) {
+  if constexpr (VW == 2) { const double2 t = *reinterpret_cast<const double2*>(p); v[0] = t.x; v[1] = t.y; }
+  else { v[0] = *p; }
+}
+template <int VW> __device__ __forceinline__ void stv(double* p, const double (&v)[VW]) {
+  if constexpr (VW == 2) { *reinterpret_cast<double2*>(p) = make_double2(v[0], v[1]); }
+  else { *p = v[0]; }
+}
+
+// Column-wise block reduction of NV = ND*VW per-thread partial sums into out[d*K + g*VW + w] with one
+// float64 atomic per column, dot and block.  Threads are laid out tid = r*G + g (row-in-block, lane
+// group); when G divides 64 the rows of a wave are folded with xor-shuffles (ds_bpermute-free DPP
+// path), otherwise through LDS.
+template <int NV, int VW>
+__device__ __forceinline__ void block_reduce_cols(double (&val)[NV], int G, int K, double* out, double* lds) {
+  const int tid = threadIdx.x;
+  constexpr int ND = NV / VW;
+  if ((64 % G) == 0) {
+    for (int off = 32; off >= G; off >>= 1) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) val[i] += __shfl_xor(val[i], off, 64);
+    }
+    const int lane = tid & 63, wave = tid >> 6;
+    if (lane < G) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) lds[(wave * 64 + lane) * NV + i] = val[i];
+    }
+    __syncthreads();
+    if (tid < G) {
+#pragma unroll
+      for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int w = 0; w < VW; ++w) {
+          const int i = d * VW + w;
+          double s = 0.0;
+          for (int wv = 0; wv < BLOCK / 64; ++wv) s += lds[(wv * 64 + tid) * NV + i];
+          atomicAdd(&out[d * K + tid * VW + w], s);
+        }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) lds[tid * NV + i] = val[i];
+    __syncthreads();
+    if (tid < G) {
+      const int R = BLOCK / G;
+#pragma unroll
+      for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int w = 0; w < VW; ++w) {
+          const int i = d * VW + w;
+          double s = 0.0;
+          for (int r = 0; r < R; ++r) s += lds[(r * G + tid) * NV + i];
+          atomicAdd(&out[d * K + tid * VW + w], s);
+        }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ a-1
+// utilities.py:514-535, one thread per (time level, face).
+__global__ void __launch_bounds__(BLOCK) k_derive_coeff(
+    int64_t total, int E, const float* __restrict__ flow, const float* __restrict__ vel,
+    const double* __restrict__ dist, float Df, float* __restrict__ adv, double* __restrict__ dif) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * BLOCK) {
+    const int e = (int)(i % E);
+    const float f = flow[i], v = vel[i];
+    // np.sign(abs(v)): NaN -> NaN, 0 -> 0, else 1
+    const float sg = (v != v) ? v : (fabsf(v) > 0.0f ? 1.0f : 0.0f);
+    const float a = f * sg;
+    float area = a / v;                     // float32 division, correctly rounded (hipcc default)
+    if (area != area) area = 0.0f;          // .fillna(0)
+    const float ad = area * Df;             // float32 array * python float stays float32
+    adv[i] = a;
+    dif[i] = (double)ad / dist[e];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ a-2
+// Regroup the coefficients of level t per (cell, face) entry and form the diagonal
+//   diag[c] = V[t+1,c]/dt + [V[t+1,c]==0] + sum_faces ( d + max(a_c, 0) )
+// (linalg.py:76-103 dry dummy, V/dt, diffusion diagonals; :113-115 outflow incl. ghost faces;
+//  :139-141 inflow seen from the neighbour).  One thread per owned cell.
+__global__ void __launch_bounds__(BLOCK) k_prep_step(
+    int n_owned, const int32_t* __restrict__ ptr, const int32_t* __restrict__ ent_edge,
+    const int32_t* __restrict__ ent_nb, const float* __restrict__ adv_t, const double* __restrict__ dif_t,
+    const float* __restrict__ vol_next, double dt, FaceRec* __restrict__ rec, double* __restrict__ diag) {
+  const int c = blockIdx.x * BLOCK + threadIdx.x;
+  if (c >= n_owned) return;
+  const double vn = (double)vol_next[c];
+  double dg = vn / dt + (vn == 0.0 ? 1.0 : 0.0);
+  const int j1 = ptr[c + 1];
+  for (int j = ptr[c]; j < j1; ++j) {
+    const int code = ent_edge[j];
+    const int e = code >> 1;
+    const float a = adv_t[e];
+    const double d = dif_t[e];
+    const float a_c = (code & 1) ? -a : a;
+    dg += d + fmax((double)a_c, 0.0);
+    FaceRec r; r.nb = ent_nb[j]; r.a_c = a_c; r.d = d;
+    rec[j] = r;
+  }
+  diag[c] = dg;
+}
+
+// ------------------------------------------------------------------------------------------------ a-3
+// b[c,k] = V[t,c]*x[c,k]/dt + G_in[c,k] + G_out[c,k]; boundary terms from level t+1, selected by the
+// sign of edge_velocity[t+1]; the highest active ghost-face id of a cell wins in each set
+// (linalg.py:349-351,378: assignment, not accumulation).  SCALE: divide by diag (Jacobi row scaling).
+template <int VW, bool SCALE>
+__global__ void __launch_bounds__(BLOCK) k_rhs(
+    int n_owned, int K, int G, const int32_t* __restrict__ ptr, const int32_t* __restrict__ ent_edge,
+    const int32_t* __restrict__ ent_nb, const float* __restrict__ vol_t, double dt,
+    const float* __restrict__ vel_n, const float* __restrict__ adv_n, const double* __restrict__ dif_n,
+    int use_diffusion, const double* __restrict__ bc_n, const double* __restrict__ x,
+    const double* __restrict__ diag, double* __restrict__ b, int32_t* __restrict__ counters) {
+  const int R = BLOCK / G;
+  const int r = threadIdx.x / G, g = threadIdx.x - r * G;
+  if (r >= R) return;
+  const int c = blockIdx.x * R + r;
+  if (c >= n_owned) return;
+  const int col = g * VW;
+  double xv[VW], gin[VW], gout[VW];
+  ldv<VW>(x + (size_t)c * K + col, xv);
+#pragma unroll
+  for (int w = 0; w < VW; ++w) { gin[w] = 0.0; gout[w] = 0.0; }
+  const int j1 = ptr[c + 1];
+  for (int j = ptr[c]; j < j1; ++j) {
+    const int nb = ent_nb[j];
+    if (nb >= 0) continue;
+    const int e = ent_edge[j] >> 1;
+    const float v1 = vel_n[e];
+    if (!(v1 < 0.0f) && !(v1 > 0.0f)) continue;
+    const double a = fabs((double)adv_n[e]);
+    const double d = use_diffusion ? fabs(dif_n[e]) : 0.0;
+    double cg[VW];
+    ldv<VW>(bc_n + (size_t)(-1 - nb) * K + col, cg);
+    if (v1 < 0.0f) {
+      if (a == 0.0 || (use_diffusion && d == 0.0)) counters[2] = 1;
+#pragma unroll
+      for (int w = 0; w < VW; ++w) gin[w] = (a + d) * cg[w];
+    } else {
+      if (use_diffusion && d == 0.0) counters[2] = 1;
+#pragma unroll
+      for (int w = 0; w < VW; ++w) gout[w] = d * cg[w];
+    }
+  }
+  const double vt = (double)vol_t[c];
+  double out[VW];
+#pragma unroll
+  for (int w = 0; w < VW; ++w) {
+    out[w] = (vt * xv[w] / dt + gin[w]) + gout[w];
+    if (SCALE) out[w] /= diag[c];
+  }
+  stv<VW>(b + (size_t)c * K + col, out);
+}
+
+// ------------------------------------------------------------------------------------------------ the operator
+// y[c,:] = diag[c]*x[c,:] + sum over the faces of c with a real neighbour of ( -d + min(a_c,0) ) * x[nb,:]
+// MODE 0  y = A x                                   (cwr_apply; parity against the oracle's csr @ x)
+// MODE 1  v = D^-1 A p ;            acc[R0V] += (r0, v)                       (BiCGSTAB, first product)
+// MODE 2  t = D^-1 A s ;            acc[TS,TT,R0T] += (t,s), (t,t), (r0,t)    (second product)
+// MODE 3  r = bhat - D^-1 A x ; r0 = p = r ; acc[RR] += (r,r) ; bb += (bhat,bhat)   (start / verify)
+// The face records of the block's cells are staged through LDS with one coalesced 16-B load per lane,
+// then every lane group walks its own cell's records from LDS (broadcast reads) and gathers the
+// neighbour rows from L2.
+// Dynamic LDS: [stage_cap FaceRec][reduction scratch]; stage_cap = the largest number of records any
+// block owns (computed on the host at create time), so blocks/CU is set by the real footprint.
+constexpr int RED_DOUBLES = BLOCK * 3 * 2;
+
+template <int VW, int MODE>
+__global__ void __launch_bounds__(BLOCK) k_apply(
+    int n_owned, int K, int G, int nblocks, int stage_cap, const int32_t* __restrict__ ptr,
+    const FaceRec* __restrict__ rec, const double* __restrict__ diag, const double* __restrict__ xin,
+    double* __restrict__ yout, const double* __restrict__ r0, const double* __restrict__ bhat,
+    double* __restrict__ r0_out, double* __restrict__ p_out, double* __restrict__ acc,
+    double* __restrict__ bb) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+  FaceRec* s_rec = reinterpret_cast<FaceRec*>(s_dyn);
+  double* s_red = reinterpret_cast<double*>(s_dyn + (size_t)stage_cap * sizeof(FaceRec));
+  const int blk = xcd_remap(blockIdx.x, nblocks);
+  if (blk >= nblocks) return;                       // uniform per block: no barrier is skipped by part of a block
+  const int R = BLOCK / G;
+  const int tid = threadIdx.x;
+  const int c0 = blk * R;
+  const int c1 = min(c0 + R, n_owned);
+  const int jb = ptr[c0], je = ptr[c1];
+  const bool staged = (je - jb) <= stage_cap;
+  if (staged) {
+    for (int j = jb + tid; j < je; j += BLOCK) s_rec[j - jb] = rec[j];
+  }
+  __syncthreads();
+  const int r = tid / G, g = tid - r * G;
+  const int c = c0 + r;
+  const bool live = (r < R) && (c < c1);
+  constexpr int ND = (MODE == 1) ? 1 : (MODE == 2 ? 3 : (MODE == 3 ? 2 : 0));
+  double part[(ND > 0 ? ND : 1) * VW];
+#pragma unroll
+  for (int i = 0; i < (ND > 0 ? ND : 1) * VW; ++i) part[i] = 0.0;
+  if (live) {
+    const int col = g * VW;
+    const size_t o = (size_t)c * K + col;
+    double xc[VW], sum[VW];
+    ldv<VW>(xin + o, xc);
+    const double dg = diag[c];
+#pragma unroll
+    for (int w = 0; w < VW; ++w) sum[w] = 0.0;
+    const int j0 = ptr[c], j1 = ptr[c + 1];
+    for (int j = j0; j < j1; ++j) {
+      const FaceRec fr = staged ? s_rec[j - jb] : rec[j];
+      if (fr.nb >= 0) {
+        const double off = fmin((double)fr.a_c, 0.0) - fr.d;
+        double xn[VW];
+        ldv<VW>(xin + (size_t)fr.nb * K + col, xn);
+#pragma unroll
+        for (int w = 0; w < VW; ++w) sum[w] += off * xn[w];
+      }
+    }
+    double y[VW];
+    if constexpr (MODE == 0) {
+#pragma unroll
+      for (int w = 0; w < VW; ++w) y[w] = dg * xc[w] + sum[w];
+      stv<VW>(yout + o, y);
+    } else {
+#pragma unroll
+      for (int w = 0; w < VW; ++w) y[w] = xc[w] + sum[w] / dg;
+      if constexpr (MODE == 1) {
+        double q[VW]; ldv<VW>(r0 + o, q);
+        stv<VW>(yout + o, y);
+#pragma unroll
+        for (int w = 0; w < VW; ++w) part[w] = q[w] * y[w];
+      } else if constexpr (MODE == 2) {
+        double q[VW]; ldv<VW>(r0 + o, q);
+        stv<VW>(yout + o, y);
+#pragma unroll
+        for (int w = 0; w < VW; ++w) {
+          part[0 * VW + w] = y[w] * xc[w];
+          part[1 * VW + w] = y[w] * y[w];
+          part[2 * VW + w] = q[w] * y[w];
+        }
+      } else {  // MODE 3
+        double bh[VW]; ldv<VW>(bhat + o, bh);
+        double res[VW];
+#pragma unroll
+        for (int w = 0; w < VW; ++w) res[w] = bh[w] - y[w];
+        stv<VW>(yout + o, res);
+        stv<VW>(r0_out + o, res);
+        stv<VW>(p_out + o, res);
+#pragma unroll
+        for (int w = 0; w < VW; ++w) { part[0 * VW + w] = res[w] * res[w]; part[1 * VW + w] = bh[w] * bh[w]; }
+      }
+    }
+  }
+  if constexpr (MODE == 1) {
+    block_reduce_cols<1 * VW, VW>(part, G, K, acc + ACC_R0V * K, s_red);
+  } else if constexpr (MODE == 2) {
+    // TS, TT, R0T are consecutive slots
+    block_reduce_cols<3 * VW, VW>(part, G, K, acc + ACC_TS * K, s_red);
+  } else if constexpr (MODE == 3) {
+    double p1[VW], p2[VW];
+#pragma unroll
+    for (int w = 0; w < VW; ++w) { p1[w] = part[w]; p2[w] = part[VW + w]; }
+    block_reduce_cols<VW, VW>(p1, G, K, acc + ACC_RR * K, s_red);
+    if (bb != nullptr) {                 // first residual of a step only; restarts / verification keep bb
+      __syncthreads();
+      block_reduce_cols<VW, VW>(p2, G, K, bb, s_red);
+    }
+  }
+}
+
+// A/B variant of the operator (north star: "ds_bpermute vs global atomicAdd chosen by rocprof"):
+// face-parallel scatter with float64 global atomics.  k_scatter_diag writes y = diag*x, then
+// k_scatter_faces adds both sides' off-diagonal terms of every internal face.
+template <int VW>
+__global__ void __launch_bounds__(BLOCK) k_scatter_diag(int n_owned, int K, int G, const double* __restrict__ diag,
+                                                      const double* __restrict__ x, double* __restrict__ y) {
+  const int R = BLOCK / G;
+  const int r = threadIdx.x / G, g = threadIdx.x - r * G;
+  const int c = blockIdx.x * R + r;
+  if (r >= R || c >= n_owned) return;
+  double xv[VW]; ldv<VW>(x + (size_t)c * K + g * VW, xv);
+  const double dg = diag[c];
+#pragma unroll
+  for (int w = 0; w < VW; ++w) xv[w] *= dg;
+  stv<VW>(y + (size_t)c * K + g * VW, xv);
+}
+template <int VW>
+__global__ void __launch_bounds__(BLOCK) k_scatter_faces(int E, int n_owned, int n_real, int K, int G,
+                                                       const int32_t* __restrict__ f1, const int32_t* __restrict__ f2,
+                                                       const float* __restrict__ adv_t, const double* __restrict__ dif_t,
+                                                       const double* __restrict__ x, double* __restrict__ y) {
+  const int R = BLOCK / G;
+  const int r = threadIdx.x / G, g = threadIdx.x - r * G;
+  const int e = blockIdx.x * R + r;
+  if (r >= R || e >= E) return;
+  const int P = f1[e], N = f2[e];
+  if (N >= n_real) return;                          // ghost face: diagonal only (already in diag)
+  const double a = (double)adv_t[e], d = dif_t[e];
+  double xp[VW], xn[VW];
+  ldv<VW>(x + (size_t)P * K + g * VW, xp);
+  ldv<VW>(x + (size_t)N * K + g * VW, xn);
+  const double offP = fmin(a, 0.0) - d;             // row P, column N
+  const double offN = fmin(-a, 0.0) - d;            // row N, column P
+#pragma unroll
+  for (int w = 0; w < VW; ++w) {
+    if (P < n_owned) atomicAdd(&y[(size_t)P * K + g * VW + w], offP * xn[w]);
+    if (N < n_owned) atomicAdd(&y[(size_t)N * K + g * VW + w], offN * xp[w]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ BiCGSTAB vector kernels
+// rr_prev = the ||r||^2 row of slot (it-1)%3; a column is frozen once it is below tol^2 ||bhat||^2.
+__device__ __forceinline__ bool col_active(const double* rr_prev, const double* bb, double tol2, int k) {
+  return rr_prev[k] > tol2 * bb[k];
+}
+
+// s = r - alpha v,  alpha = rho / (r0, v) on active columns, 0 on converged ones.
+template <int VW>
+__global__ void __launch_bounds__(BLOCK) k_vec_s(
+    int n_owned, int K, int G, const double* __restrict__ r, const double* __restrict__ v,
+    double* __restrict__ s, const double* __restrict__ rho, const double* __restrict__ acc_cur,
+    const double* __restrict__ rr_prev, const double* __restrict__ bb, double tol2) {
+  const int R = BLOCK / G;
+  const int rr_ = threadIdx.x / G, g = threadIdx.x - rr_ * G;
+  if (rr_ >= R) return;
+  double alpha[VW];
+#pragma unroll
+  for (int w = 0; w < VW; ++w) {
+    const int k = g * VW + w;
+    const double den = acc_cur[ACC_R0V * K + k];
+    alpha[w] = (col_active(rr_prev, bb, tol2, k) && den != 0.0) ? rho[k] / den : 0.0;
+  }
+  for (int c = blockIdx.x * R + rr_; c < n_owned; c += gridDim.x * R) {
+    const size_t o = (size_t)c * K + g * VW;
+    double a[VW], b[VW];
+    ldv<VW>(r + o, a); ldv<VW>(v + o, b);
+#pragma unroll
+    for (int w = 0; w < VW; ++w) a[w] -= alpha[w] * b[w];
+    stv<VW>(s + o, a);
+  }
+}
+
+// omega = (t,s)/(t,t); x += alpha p + omega s; r = s - omega t;
+// rho' = rho - alpha (r0,v) - omega (r0,t)   [= (r0, r') by linearity, no extra reduction];
+// beta = (rho'/rho)(alpha/omega); p = r + beta (p - omega v); acc[RR] += (r', r').
+// Block 0 also publishes rho', clears the next accumulator slot and keeps the counters.
+template <int VW>
+__global__ void __launch_bounds__(BLOCK) k_vec_x(
+    int n_owned, int K, int G, double* __restrict__ x, double* __restrict__ r, double* __restrict__ p,
+    const double* __restrict__ s, const double* __restrict__ t, const double* __restrict__ v,
+    const double* __restrict__ rho, double* __restrict__ rho_next, double* __restrict__ acc_cur,
+    double* __restrict__ acc_next, const double* __restrict__ rr_prev, const double* __restrict__ bb,
+    double tol2, int32_t* __restrict__ counters) {
+  __shared__ double s_red[BLOCK * 2];
+  const int R = BLOCK / G;
+  const int rr_ = threadIdx.x / G, g = threadIdx.x - rr_ * G;
+  double alpha[VW], omega[VW], beta[VW], part[VW];
+#pragma unroll
+  for (int w = 0; w < VW; ++w) { alpha[w] = omega[w] = beta[w] = part[w] = 0.0; }
+  if (rr_ < R) {
+#pragma unroll
+    for (int w = 0; w < VW; ++w) {
+      const int k = g * VW + w;
+      const bool act = col_active(rr_prev, bb, tol2, k);
+      const double r0v = acc_cur[ACC_R0V * K + k], ts = acc_cur[ACC_TS * K + k];
+      const double tt = acc_cur[ACC_TT * K + k], r0t = acc_cur[ACC_R0T * K + k];
+      const double rh = rho[k];
+      const double al = (act && r0v != 0.0) ? rh / r0v : 0.0;
+      const double om = (act && tt > 0.0) ? ts / tt : 0.0;
+      const double rh2 = rh - al * r0v - om * r0t;
+      alpha[w] = al; omega[w] = om;
+      beta[w] = (act && om != 0.0 && rh != 0.0) ? (rh2 / rh) * (al / om) : 0.0;
+    }
+    for (int c = blockIdx.x * R + rr_; c < n_owned; c += gridDim.x * R) {
+      const size_t o = (size_t)c * K + g * VW;
+      double xv[VW], pv[VW], sv[VW], tv[VW], vv[VW], rv[VW];
+      ldv<VW>(x + o, xv); ldv<VW>(p + o, pv); ldv<VW>(s + o, sv); ldv<VW>(t + o, tv); ldv<VW>(v + o, vv);
+#pragma unroll
+      for (int w = 0; w < VW; ++w) {
+        xv[w] += alpha[w] * pv[w] + omega[w] * sv[w];
+        rv[w] = sv[w] - omega[w] * tv[w];
+        pv[w] = rv[w] + beta[w] * (pv[w] - omega[w] * vv[w]);
+        part[w] += rv[w] * rv[w];
+      }
+      stv<VW>(x + o, xv); stv<VW>(r + o, rv); stv<VW>(p + o, pv);
+    }
+  }
+  block_reduce_cols<VW, VW>(part, G, K, acc_cur + ACC_RR * K, s_red);
+  if (blockIdx.x == 0) {
+    const int tid = threadIdx.x;
+    if (tid < K) {
+      const int k = tid;
+      const bool act = col_active(rr_prev, bb, tol2, k);
+      const double r0v = acc_cur[ACC_R0V * K + k], ts = acc_cur[ACC_TS * K + k];
+      const double tt = acc_cur[ACC_TT * K + k], r0t = acc_cur[ACC_R0T * K + k];
+      const double rh = rho[k];
+      const double al = (act && r0v != 0.0) ? rh / r0v : 0.0;
+      const double om = (act && tt > 0.0) ? ts / tt : 0.0;
+      const double rh2 = rh - al * r0v - om * r0t;
+      rho_next[k] = rh2;
+      if (act && (r0v == 0.0 || om == 0.0 || rh2 == 0.0)) counters[1] = 1;        // (near-)breakdown: host restarts
+      if (act && !(fabs(rh2) < 1.0e300 && fabs(al) < 1.0e300)) counters[3] = 1;  // NaN / Inf
+    }
+    if (tid == 0) {                       // single writer: iterations in which some column still worked
+      bool any = false;
+      for (int k = 0; k < K; ++k) any = any || col_active(rr_prev, bb, tol2, k);
+      if (any) counters[0] += 1;
+    }
+    for (int i = tid; i < ACC_N * K; i += BLOCK) acc_next[i] = 0.0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ a-5
+// mesh[name][t+1, ghost] = input_array[t+1, ghost] where non-zero, NaN otherwise
+// (transport.py:258-264 over the NaN-initialised array of constituents.py:39-48).
+__global__ void __launch_bounds__(BLOCK) k_ghost_writeback(int64_t total, const double* __restrict__ bc_n,
+                                                         double* __restrict__ ghost_rows) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= total) return;
+  const double v = bc_n[i];
+  ghost_rows[i] = (v != 0.0) ? v : __builtin_nan("");
+}
+
+// ------------------------------------------------------------------------------------------------ a-6
+// transport.py:414-429 with c = concentrations of level t+1 (ghost rows included, NaN = no value).
+template <int VW>
+__global__ void __launch_bounds__(BLOCK) k_mass_flux(
+    int E, int n_owned, int K, int G, const int32_t* __restrict__ f1, const int32_t* __restrict__ f2,
+    const float* __restrict__ adv_t, const double* __restrict__ dif_t, double dt,
+    const double* __restrict__ c, double* __restrict__ fadv, double* __restrict__ fdif,
+    double* __restrict__ ftot) {
+  const int R = BLOCK / G;
+  const int r = threadIdx.x / G, g = threadIdx.x - r * G;
+  if (r >= R) return;
+  for (int e = blockIdx.x * R + r; e < E; e += gridDim.x * R) {
+    const int P = f1[e], N = f2[e];
+    const size_t o = (size_t)e * K + g * VW;
+    double oa[VW], od[VW], ot[VW];
+    if (P >= n_owned) {                 // face owned by another rank
+#pragma unroll
+      for (int w = 0; w < VW; ++w) oa[w] = od[w] = ot[w] = 0.0;
+    } else {
+      const float a = adv_t[e];
+      const double d = dif_t[e];
+      double cp[VW], cn[VW];
+      ldv<VW>(c + (size_t)P * K + g * VW, cp);
+      ldv<VW>(c + (size_t)N * K + g * VW, cn);
+#pragma unroll
+      for (int w = 0; w < VW; ++w) {
+        oa[w] = ((a < 0.0f) ? (double)a * cn[w] : (double)a * cp[w]) * dt;
+        od[w] = d * (cn[w] - cp[w]) * dt;
+        ot[w] = oa[w] + od[w];
+      }
+    }
+    stv<VW>(fadv + o, oa); stv<VW>(fdif + o, od); stv<VW>(ftot + o, ot);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ halo
+__global__ void __launch_bounds__(BLOCK) k_pack_rows(int64_t total, int K, const int32_t* __restrict__ cells,
+                                                   const double* __restrict__ vec, double* __restrict__ buf) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= total) return;
+  const int64_t row = i / K;
+  const int k = (int)(i - row * K);
+  buf[i] = vec[(size_t)cells[row] * K + k];
+}
+
+}  // namespace cwr

@@ -1,0 +1,305 @@
+"""ctypes binding of the C ABI in include/cwr_transport.h (libcwr_transport.so).
+
+This is the only place that talks to the HIP engine.  There is NO CPU fallback: if the
+shared library is missing, or no GPU is visible, the product path raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_NAME = 'libcwr_transport.so'
+LIB_PATH = os.path.join(_HERE, LIB_NAME)
+
+CWR_OK = 0
+CWR_ERR_BAD_ARG = -1
+CWR_ERR_HIP = -2
+CWR_ERR_NOT_CONVERGED = -3
+CWR_ERR_GHOST_COEFF = -4
+CWR_ERR_RCCL = -5
+CWR_ERR_STATE = -6
+CWR_ERR_NONFINITE = -7
+
+STEP_MASS_FLUX = 1
+STEP_PROFILE = 2
+
+# every symbol include/cwr_transport.h declares (tests check that the library exports them all)
+ABI_SYMBOLS = (
+    'cwr_abi_version', 'cwr_create', 'cwr_destroy', 'cwr_last_error', 'cwr_load_flow_field',
+    'cwr_load_coefficients', 'cwr_get_coefficients', 'cwr_load_boundary', 'cwr_set_boundary_level',
+    'cwr_set_state', 'cwr_get_state', 'cwr_apply', 'cwr_rhs', 'cwr_step', 'cwr_get_mass_flux',
+    'cwr_time_apply', 'cwr_profile_read', 'cwr_synchronize', 'cwr_apply_bytes',
+    'cwr_comm_unique_id', 'cwr_attach_comm',
+)
+
+
+class SolverNotConverged(RuntimeError):
+    """The implicit solve did not reach the tolerance (scipy's direct solve has no such outcome)."""
+
+
+class StepInfo(C.Structure):
+    _fields_ = [('iterations', C.c_int32), ('restarts', C.c_int32), ('status', C.c_int32),
+                ('operator_launches', C.c_int32), ('max_rel_residual', C.c_double),
+                ('solve_ms', C.c_double)]
+
+
+@dataclass
+class StepResult:
+    iterations: int
+    restarts: int
+    operator_launches: int
+    max_rel_residual: float
+    solve_ms: float
+
+
+_lib = None
+
+
+def load_library(path: str | None = None) -> C.CDLL:
+    """Load libcwr_transport.so and declare the prototypes.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(
+            f'{p} not found: build the HIP extension first (python -c "import __graft_entry__ as g; g.build()"); '
+            'there is no CPU fallback')
+    lib = C.CDLL(p)
+    vp, i32, f64 = C.c_void_p, C.c_int32, C.c_double
+    P = C.POINTER
+    lib.cwr_abi_version.restype = i32
+    lib.cwr_abi_version.argtypes = []
+    lib.cwr_last_error.restype = C.c_char_p
+    lib.cwr_last_error.argtypes = [vp]
+    lib.cwr_destroy.restype = None
+    lib.cwr_destroy.argtypes = [vp]
+    protos = {
+        'cwr_create': [i32, i32, i32, i32, i32, vp, vp, i32, P(vp)],
+        'cwr_load_flow_field': [vp, i32, vp, vp, vp, vp, vp, f64],
+        'cwr_load_coefficients': [vp, i32, vp, vp, vp, vp, vp, f64],
+        'cwr_get_coefficients': [vp, i32, vp, vp],
+        'cwr_load_boundary': [vp, i32, vp],
+        'cwr_set_boundary_level': [vp, i32, vp],
+        'cwr_set_state': [vp, vp],
+        'cwr_get_state': [vp, vp],
+        'cwr_apply': [vp, i32, vp, vp],
+        'cwr_rhs': [vp, i32, vp, vp],
+        'cwr_step': [vp, i32, f64, i32, i32, P(StepInfo)],
+        'cwr_get_mass_flux': [vp, vp, vp, vp],
+        'cwr_time_apply': [vp, i32, i32, i32, P(f64)],
+        'cwr_profile_read': [vp, P(C.c_int64), P(f64)],
+        'cwr_synchronize': [vp],
+        'cwr_apply_bytes': [vp, P(C.c_int64), P(C.c_int64)],
+        'cwr_comm_unique_id': [vp],
+        'cwr_attach_comm': [vp, i32, i32, vp, i32, vp, vp, vp, vp],
+    }
+    for name, args in protos.items():
+        fn = getattr(lib, name)
+        fn.restype = i32
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _arr(a, dtype, shape=None, name='array'):
+    """C-contiguous view/copy of the right dtype, shape-checked (the wrapper validates, the ABI trusts)."""
+    out = np.ascontiguousarray(a, dtype=dtype)
+    if shape is not None and tuple(out.shape) != tuple(shape):
+        raise ValueError(f'{name}: expected shape {tuple(shape)}, got {tuple(out.shape)}')
+    return out
+
+
+def _ptr(a: np.ndarray | None):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class TransportEngine:
+    """One GPU's transport engine: the MI355X-native replacement of the LHS/RHS assembly +
+    scipy.sparse solve of ``ClearwaterRiverine.update()``
+    (/root/reference/src/clearwater_riverine/transport.py:201-276).
+
+    Local cell numbering: [0, n_owned) owned real cells, [n_owned, n_owned+n_halo) real cells of
+    other ranks, then ghost (boundary) cells.  On one GPU this is the reference's numbering.
+    """
+
+    def __init__(self, face1, face2, n_cells: int, n_constituents: int, *, n_owned: int | None = None,
+                 n_halo: int = 0, device: int = 0):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        f1 = _arr(face1, np.int32)
+        f2 = _arr(face2, np.int32, f1.shape, 'edges_face2')
+        if f1.ndim != 1:
+            raise ValueError('edges_face1 must be one-dimensional')
+        if n_owned is None:
+            n_owned = int(f1.max()) + 1 if len(f1) else 0     # nreal + 1 (io/hdf.py:268)
+        self.n_owned, self.n_halo, self.n_cells = int(n_owned), int(n_halo), int(n_cells)
+        self.n_real = self.n_owned + self.n_halo
+        self.n_ghost = self.n_cells - self.n_real
+        self.n_edges = int(len(f1))
+        self.K = int(n_constituents)
+        self.n_times = 0
+        rc = self._lib.cwr_create(self.n_owned, self.n_halo, self.n_cells, self.n_edges, self.K,
+                                  _ptr(f1), _ptr(f2), int(device), C.byref(self._h))
+        if rc != CWR_OK:
+            msg = self._lib.cwr_last_error(None).decode()
+            self._h = C.c_void_p()
+            self._raise(rc, msg)
+
+    # ------------------------------------------------------------------ errors
+    def _raise(self, rc: int, msg: str | None = None):
+        if msg is None:
+            msg = self._lib.cwr_last_error(self._h).decode()
+        if rc in (CWR_ERR_BAD_ARG, CWR_ERR_GHOST_COEFF):
+            raise ValueError(msg)
+        if rc == CWR_ERR_NOT_CONVERGED:
+            raise SolverNotConverged(msg)
+        if rc == CWR_ERR_NONFINITE:
+            raise FloatingPointError(msg)
+        if rc == CWR_ERR_STATE:
+            raise IndexError(msg)
+        raise RuntimeError(f'cwr error {rc}: {msg}')
+
+    def _check(self, rc: int):
+        if rc != CWR_OK:
+            self._raise(rc)
+
+    # ------------------------------------------------------------------ inputs
+    def load_flow_field(self, face_flow, edge_velocity, volume, dt, face_to_face_dist, diffusion_coefficient):
+        ff = _arr(face_flow, np.float32)
+        T = ff.shape[0]
+        ff = _arr(ff, np.float32, (T, self.n_edges), 'face_flow')
+        ev = _arr(edge_velocity, np.float32, (T, self.n_edges), 'edge_velocity')
+        vol = _arr(volume, np.float32, (T, self.n_cells), 'volume')
+        dtv = _arr(dt, np.float64, (T,), 'dt')
+        dist = _arr(face_to_face_dist, np.float64, (self.n_edges,), 'face_to_face_dist')
+        self._check(self._lib.cwr_load_flow_field(self._h, T, _ptr(ff), _ptr(ev), _ptr(vol), _ptr(dtv),
+                                                  _ptr(dist), float(diffusion_coefficient)))
+        self.n_times = T
+
+    def load_coefficients(self, advection_coeff, coeff_to_diffusion, edge_velocity, volume, dt,
+                          diffusion_coefficient):
+        adv = _arr(advection_coeff, np.float32)
+        T = adv.shape[0]
+        adv = _arr(adv, np.float32, (T, self.n_edges), 'advection_coeff')
+        dif = _arr(coeff_to_diffusion, np.float64, (T, self.n_edges), 'coeff_to_diffusion')
+        ev = _arr(edge_velocity, np.float32, (T, self.n_edges), 'edge_velocity')
+        vol = _arr(volume, np.float32, (T, self.n_cells), 'volume')
+        dtv = _arr(dt, np.float64, (T,), 'dt')
+        self._check(self._lib.cwr_load_coefficients(self._h, T, _ptr(adv), _ptr(dif), _ptr(ev), _ptr(vol),
+                                                    _ptr(dtv), float(diffusion_coefficient)))
+        self.n_times = T
+
+    def get_coefficients(self, t: int):
+        adv = np.empty(self.n_edges, np.float32)
+        dif = np.empty(self.n_edges, np.float64)
+        self._check(self._lib.cwr_get_coefficients(self._h, int(t), _ptr(adv), _ptr(dif)))
+        return adv, dif
+
+    def load_boundary(self, ghost_conc):
+        g = _arr(ghost_conc, np.float64)
+        T = g.shape[0]
+        g = _arr(g.reshape(T, self.n_ghost, -1), np.float64, (T, self.n_ghost, self.K), 'ghost_conc')
+        self._check(self._lib.cwr_load_boundary(self._h, T, _ptr(g)))
+
+    def set_boundary_level(self, t: int, ghost_conc_level):
+        g = _arr(ghost_conc_level, np.float64).reshape(self.n_ghost, -1)
+        g = _arr(g, np.float64, (self.n_ghost, self.K), 'ghost_conc_level')
+        self._check(self._lib.cwr_set_boundary_level(self._h, int(t), _ptr(g)))
+
+    # ------------------------------------------------------------------ state
+    def set_state(self, conc_owned):
+        x = _arr(np.asarray(conc_owned, dtype=np.float64).reshape(self.n_owned, -1), np.float64,
+                 (self.n_owned, self.K), 'conc_owned')
+        self._check(self._lib.cwr_set_state(self._h, _ptr(x)))
+
+    def get_state(self) -> np.ndarray:
+        out = np.empty((self.n_cells, self.K), np.float64)
+        self._check(self._lib.cwr_get_state(self._h, _ptr(out)))
+        return out
+
+    # ------------------------------------------------------------------ operator / rhs / step
+    def apply(self, t: int, x) -> np.ndarray:
+        xv = _arr(np.asarray(x, dtype=np.float64).reshape(self.n_real, -1), np.float64, (self.n_real, self.K), 'x')
+        y = np.empty((self.n_owned, self.K), np.float64)
+        self._check(self._lib.cwr_apply(self._h, int(t), _ptr(xv), _ptr(y)))
+        return y
+
+    def rhs(self, t: int, x_t) -> np.ndarray:
+        xv = _arr(np.asarray(x_t, dtype=np.float64).reshape(self.n_owned, -1), np.float64, (self.n_owned, self.K), 'x_t')
+        b = np.empty((self.n_owned, self.K), np.float64)
+        self._check(self._lib.cwr_rhs(self._h, int(t), _ptr(xv), _ptr(b)))
+        return b
+
+    def step(self, t: int, *, tol: float = 1e-12, max_iter: int = 2000, mass_flux: bool = True,
+             profile: bool = False) -> StepResult:
+        info = StepInfo()
+        flags = (STEP_MASS_FLUX if mass_flux else 0) | (STEP_PROFILE if profile else 0)
+        self._check(self._lib.cwr_step(self._h, int(t), float(tol), int(max_iter), flags, C.byref(info)))
+        return StepResult(info.iterations, info.restarts, info.operator_launches, info.max_rel_residual,
+                          info.solve_ms)
+
+    def get_mass_flux(self):
+        shape = (self.n_edges, self.K)
+        adv, dif, tot = (np.empty(shape, np.float64) for _ in range(3))
+        self._check(self._lib.cwr_get_mass_flux(self._h, _ptr(adv), _ptr(dif), _ptr(tot)))
+        return adv, dif, tot
+
+    # ------------------------------------------------------------------ measurement
+    def time_apply(self, t: int, reps: int = 50, variant: int = 0) -> float:
+        us = C.c_double(0.0)
+        self._check(self._lib.cwr_time_apply(self._h, int(t), int(variant), int(reps), C.byref(us)))
+        return us.value
+
+    def profile_read(self):
+        n = C.c_int64(0)
+        us = C.c_double(0.0)
+        self._check(self._lib.cwr_profile_read(self._h, C.byref(n), C.byref(us)))
+        return n.value, us.value
+
+    def apply_bytes(self):
+        r = C.c_int64(0)
+        w = C.c_int64(0)
+        self._check(self._lib.cwr_apply_bytes(self._h, C.byref(r), C.byref(w)))
+        return r.value, w.value
+
+    def synchronize(self):
+        self._check(self._lib.cwr_synchronize(self._h))
+
+    # ------------------------------------------------------------------ domain decomposition
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        lib = load_library()
+        buf = (C.c_uint8 * 128)()
+        rc = lib.cwr_comm_unique_id(C.cast(buf, C.c_void_p))
+        if rc != CWR_OK:
+            raise RuntimeError(f'cwr_comm_unique_id failed ({rc}): {lib.cwr_last_error(None).decode()}')
+        return bytes(buf)
+
+    def attach_comm(self, rank: int, world: int, unique_id: bytes, peers, send_ptr, send_cells, recv_ptr):
+        if len(unique_id) != 128:
+            raise ValueError('unique_id must be 128 bytes')
+        uid = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        pe = _arr(peers, np.int32)
+        sp = _arr(send_ptr, np.int32)
+        sc = _arr(send_cells, np.int32)
+        rp = _arr(recv_ptr, np.int32)
+        self._check(self._lib.cwr_attach_comm(self._h, int(rank), int(world), C.cast(uid, C.c_void_p), int(len(pe)),
+                                              _ptr(pe), _ptr(sp), _ptr(sc), _ptr(rp)))
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h:
+            self._lib.cwr_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,294 @@
+"""Host-side mirror of the reference's model facade for the transport path.
+
+``ClearwaterRiverine`` here keeps the constructor keywords, attributes and ``update()`` semantics of
+/root/reference/src/clearwater_riverine/transport.py:68-276 for the per-step transport path, with the
+LHS/RHS assembly + scipy.sparse solve replaced by the HIP engine (``engine.TransportEngine``).
+
+The Dataset surface is a plain mapping of numpy arrays keyed by the reference's variable names
+(variables.py:1-37) because xarray is not installed in this image; when the reference runs with its
+own xarray mesh, INTEGRATION.md shows the few lines that hand ``mesh[var].values`` to the same engine.
+Out of scope here: plotting, zarr/netCDF output, unit conversion, YAML config.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, Optional
+
+import numpy as np
+
+from .engine import TransportEngine, StepResult
+
+# variables.py names used on the path
+EDGES_FACE1 = 'edges_face1'
+EDGES_FACE2 = 'edges_face2'
+NUMBER_OF_REAL_CELLS = 'nreal'
+VOLUME = 'volume'
+EDGE_VELOCITY = 'edge_velocity'
+CHANGE_IN_TIME = 'dt'
+FLOW_ACROSS_FACE = 'face_flow'
+ADVECTION_COEFFICIENT = 'advection_coeff'
+FACE_TO_FACE_DISTANCE = 'face_to_face_dist'
+COEFFICIENT_TO_DIFFUSION_TERM = 'coeff_to_diffusion'
+
+
+class Mesh(dict):
+    """Minimal stand-in for the reference's xr.Dataset: variables by name + ``attrs`` +
+    the attribute shortcuts the transport path uses (``mesh.nreal``, ``mesh.diffusion_coefficient``)."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.attrs: Dict[str, Any] = {}
+
+    def __getattr__(self, name):
+        attrs = self.__dict__.get('attrs', {})
+        if name in attrs:
+            return attrs[name]
+        if name in self:
+            return self[name]
+        raise AttributeError(name)
+
+
+def face_to_face_distance(mesh) -> np.ndarray:
+    """utilities.py:261-278 (_calc_distances_cell_centroids), float64."""
+    f1 = np.asarray(mesh[EDGES_FACE1])
+    f2 = np.asarray(mesh[EDGES_FACE2])
+    fx = np.asarray(mesh['face_x'], dtype=np.float64)
+    fy = np.asarray(mesh['face_y'], dtype=np.float64)
+    return np.sqrt((fx[f1] - fx[f2]) ** 2 + (fy[f1] - fy[f2]) ** 2)
+
+
+def change_in_time(time) -> np.ndarray:
+    """utilities.py:537-541: seconds between stamps with a trailing NaN.  ``time`` is datetime64 or seconds."""
+    t = np.asarray(time)
+    if np.issubdtype(t.dtype, np.datetime64):
+        d = np.ediff1d(t) / np.timedelta64(1, 's')
+    else:
+        d = np.ediff1d(t.astype(np.float64))
+    return np.append(d.astype(np.float64), np.nan)
+
+
+class Constituent:
+    """constituents.py:17-75 over arrays: NaN-initialised (T, ncell) state, input_array with the
+    initial condition in row 0 and boundary values in ghost-cell columns, three (T, E) flux arrays."""
+
+    def __init__(self, name: str, mesh: Mesh, input_array: np.ndarray, units: str = 'Unknown',
+                 store_history: bool = True):
+        T = len(mesh['time'])
+        E = len(mesh[EDGES_FACE1])
+        ncell = len(mesh['face_x'])
+        self.name = name
+        self.units = units
+        self.input_array = np.ascontiguousarray(input_array, dtype=np.float64)
+        if self.input_array.shape != (T, ncell):
+            raise ValueError(f'input_array of {name}: expected {(T, ncell)}, got {self.input_array.shape}')
+        if store_history:
+            self.advection_mass_flux = np.zeros((T, E))
+            self.diffusion_mass_flux = np.zeros((T, E))
+            self.total_mass_flux = np.zeros((T, E))
+            state = np.full((T, ncell), np.nan)
+        else:
+            self.advection_mass_flux = self.diffusion_mass_flux = self.total_mass_flux = None
+            state = np.full((2, ncell), np.nan)      # rolling pair of levels
+        state[0] = self.input_array[0]               # constituents.py:94-98
+        mesh[name] = state
+        self.max_value = None
+        self.min_value = None
+
+
+def input_array_from_tables(mesh: Mesh, ic_cell_index, ic_concentration, bc_by_ghost_cell: Optional[dict] = None):
+    """constituents.py:78-98 and :153-164 given already time-aligned boundary series:
+    ``bc_by_ghost_cell`` maps ghost-cell id -> (T,) concentrations."""
+    T = len(mesh['time'])
+    ncell = len(mesh['face_x'])
+    arr = np.zeros((T, ncell))
+    arr[0, np.asarray(ic_cell_index, dtype=np.int64)] = np.asarray(ic_concentration, dtype=np.float64)
+    for g, series in (bc_by_ghost_cell or {}).items():
+        arr[:, int(g)] = np.asarray(series, dtype=np.float64)
+    return arr
+
+
+def input_array_from_csv(mesh: Mesh, initial_conditions_csv: str, boundary_conditions_csv: str,
+                        boundary_faces: Dict[str, list]) -> np.ndarray:
+    """constituents.py:78-164 with pandas: IC CSV (Cell_Index, Concentration) -> row 0; BC CSV
+    (RAS2D_TS_Name, Datetime, Concentration) merged backward onto the model stamps
+    (merge_asof), linearly interpolated, written at [time index, ghost cell of each face of the
+    named boundary line].  ``boundary_faces`` is the Name -> Face Index table of
+    mesh.attrs['boundary_data'] (io/hdf.py:355-436)."""
+    import pandas as pd
+    T = len(mesh['time'])
+    ncell = len(mesh['face_x'])
+    arr = np.zeros((T, ncell))
+    ic = pd.read_csv(initial_conditions_csv)
+    arr[0, ic['Cell_Index'].astype(int).to_numpy()] = ic['Concentration'].to_numpy(dtype=np.float64)
+    bc = pd.read_csv(boundary_conditions_csv, parse_dates=['Datetime']).dropna(how='all')
+    model_df = pd.DataFrame({'Datetime': pd.DatetimeIndex(np.asarray(mesh['time'])), 'Time Index': range(T)})
+    f2 = np.asarray(mesh[EDGES_FACE2])
+    for boundary, group in bc.groupby('RAS2D_TS_Name'):
+        merged = pd.merge_asof(model_df, group.sort_values('Datetime'), on='Datetime')
+        merged['Concentration'] = merged['Concentration'].interpolate(method='linear')
+        for face in boundary_faces.get(boundary, []):
+            vals = merged['Concentration'].to_numpy(dtype=np.float64)
+            arr[merged['Time Index'].to_numpy(), f2[int(face)]] = vals      # NaN stays NaN, as in the reference
+    return arr
+
+
+class ClearwaterRiverine:
+    """Drop-in for the transport path of the reference class of the same name
+    (transport.py:68-276).  Construct either from arrays (``mesh=`` + ``input_arrays=``) or, when h5py
+    is importable, from a HEC-RAS HDF path exactly as the reference does."""
+
+    def __init__(self, flow_field_file_path: Optional[str] = None,
+                 diffusion_coefficient_input: Optional[float] = None,
+                 constituent_dict: Optional[Dict[str, Dict[str, Any]]] = None,
+                 config_filepath: Optional[str] = None, verbose: Optional[bool] = False,
+                 datetime_range=None, mesh_file_path: Optional[str] = None, *,
+                 mesh: Optional[dict] = None, input_arrays: Optional[Dict[str, np.ndarray]] = None,
+                 device: int = 0, tol: float = 1e-12, max_iter: int = 5000, store_history: bool = True):
+        self.gdf = None
+        self.time_step = 0                                       # transport.py:102
+        self.verbose = bool(verbose)
+        self.tol = float(tol)
+        self.max_iter = int(max_iter)
+        self.store_history = bool(store_history)
+        if mesh is None:
+            if mesh_file_path:
+                raise NotImplementedError('loading a saved zarr/netCDF mesh is post-processing only in the '
+                                          'reference (transport.py:126-139) and outside the transport path')
+            if config_filepath or flow_field_file_path:
+                from .hdf_reader import read_ras_hdf              # needs h5py; gated
+                if config_filepath:
+                    import yaml
+                    with open(config_filepath) as fh:
+                        cfg = yaml.safe_load(fh)
+                    if diffusion_coefficient_input is None:
+                        diffusion_coefficient_input = cfg['diffusion_coefficient']
+                    flow_field_file_path = flow_field_file_path or cfg['flow_field_filepath']
+                    constituent_dict = cfg['constituents']
+                mesh = read_ras_hdf(flow_field_file_path, datetime_range=datetime_range)
+            else:
+                raise TypeError('Missing a `config_filepath` or a `constituent_dict` and '
+                                '`flow_field_file_path` to run the model.')      # transport.py:121-123
+        m = mesh if isinstance(mesh, Mesh) else Mesh(mesh)
+        if diffusion_coefficient_input is not None:
+            m.attrs['diffusion_coefficient'] = float(diffusion_coefficient_input)
+        elif 'diffusion_coefficient' in m:
+            m.attrs['diffusion_coefficient'] = float(m['diffusion_coefficient'])
+        if 'diffusion_coefficient' not in m.attrs:
+            raise TypeError('diffusion_coefficient_input is required')
+        if 'time' not in m:
+            m['time'] = np.asarray(m['time_seconds'], dtype=np.float64)
+        f1 = np.ascontiguousarray(m[EDGES_FACE1], dtype=np.int32)
+        f2 = np.ascontiguousarray(m[EDGES_FACE2], dtype=np.int32)
+        m.attrs[NUMBER_OF_REAL_CELLS] = int(f1.max())            # io/hdf.py:268-269
+        m.attrs.setdefault('boundary_data', m.get('boundary_data'))
+        self.mesh = m
+        self.boundary_data = m.attrs['boundary_data']
+        n = m.attrs[NUMBER_OF_REAL_CELLS] + 1
+        ncell = len(m['face_x'])
+        T = len(m['time'])
+        self._n, self._ncell, self._T = n, ncell, T
+
+        # a-1 host part: centroid distances and dt; the rest is derived on the GPU
+        m[FACE_TO_FACE_DISTANCE] = face_to_face_distance(m)
+        m[CHANGE_IN_TIME] = change_in_time(m['time'])
+
+        # constituents (transport.py:158-199)
+        if input_arrays is None:
+            if not isinstance(constituent_dict, dict):
+                raise TypeError('Missing a `config_filepath` or a `constituent_dict` and '
+                                '`flow_field_file_path` to run the model.')
+            bfaces = m.attrs.get('boundary_faces') or {}
+            input_arrays = {
+                name: input_array_from_csv(m, cfg['initial_conditions'], cfg['boundary_conditions'], bfaces)
+                for name, cfg in constituent_dict.items()}
+        self.constituents = list(input_arrays.keys())
+        self.constituent_dict: Dict[str, Constituent] = {}
+        for name in self.constituents:
+            units = (constituent_dict or {}).get(name, {}).get('units', 'Unknown') if constituent_dict else 'Unknown'
+            self.constituent_dict[name] = Constituent(name, m, input_arrays[name], units, self.store_history)
+        K = len(self.constituents)
+
+        # engine: topology, flow field and boundary values resident in HBM
+        self.engine = TransportEngine(f1, f2, ncell, K, device=device)
+        self.engine.load_flow_field(m[FLOW_ACROSS_FACE], m[EDGE_VELOCITY], m[VOLUME], m[CHANGE_IN_TIME],
+                                    m[FACE_TO_FACE_DISTANCE], m.attrs['diffusion_coefficient'])
+        ghost = np.stack([self.constituent_dict[c].input_array[:, n:] for c in self.constituents], axis=2)
+        self.engine.load_boundary(ghost)
+        # rows of input_array that carry non-zero values in REAL cells (the IC row, normally only t = 0):
+        # RHS.update_values overwrites the solution with them (linalg.py:199-200)
+        self._real_input_rows = set()
+        for c in self.constituents:
+            rows = np.nonzero(np.any(self.constituent_dict[c].input_array[:, :n] != 0, axis=1))[0]
+            self._real_input_rows.update(int(r) for r in rows)
+        self._device_level = -1
+        self.last_step: Optional[StepResult] = None
+
+    # ------------------------------------------------------------------ helpers
+    def _row(self, name: str, t: int) -> np.ndarray:
+        st = self.mesh[name]
+        return st[t] if self.store_history else st[t % 2]
+
+    def coefficients(self, t: int):
+        """advection_coeff[t] (f32) and coeff_to_diffusion[t] (f64) as derived on the device."""
+        return self.engine.get_coefficients(t)
+
+    # ------------------------------------------------------------------ the hot path
+    def update(self, update_concentration: Optional[dict] = None):
+        """Update a single timestep (transport.py:201-276)."""
+        t = self.time_step
+        n = self._n
+        if t + 1 >= self._T:
+            raise IndexError(f'time step {t} is the last level of the flow field')
+        overridden = False
+        if isinstance(update_concentration, dict):
+            for cname in update_concentration:
+                if cname not in self.constituent_dict:           # transport.py:223-229
+                    print(f'WARNING: {cname} is not being used in the model.')
+                    print('Please review the constituent names in the update dictionary')
+            for cname in self.constituents:
+                if cname in update_concentration:                # transport.py:233-236
+                    vals = update_concentration[cname]
+                    vals = np.asarray(getattr(vals, 'values', vals), dtype=np.float64)
+                    self._row(cname, t)[0:n] = vals[0:n]
+                    overridden = True
+        if overridden or self._device_level != t or t in self._real_input_rows:
+            x = np.stack([self._row(c, t)[0:n] for c in self.constituents], axis=1)
+            if t in self._real_input_rows:                       # linalg.py:199-200
+                inp = np.stack([self.constituent_dict[c].input_array[t, :n] for c in self.constituents], axis=1)
+                x = np.where(inp != 0, inp, x)
+            self.engine.set_state(x)
+        self.last_step = self.engine.step(t, tol=self.tol, max_iter=self.max_iter, mass_flux=self.store_history)
+        self._device_level = t + 1
+        c_all = self.engine.get_state()                          # (ncell, K): transport.py:252-264
+        for k, cname in enumerate(self.constituents):
+            self._row(cname, t + 1)[:] = c_all[:, k]
+        if self.store_history:                                   # transport.py:267-273
+            adv, dif, tot = self.engine.get_mass_flux()
+            for k, cname in enumerate(self.constituents):
+                con = self.constituent_dict[cname]
+                con.advection_mass_flux[t] = adv[:, k]
+                con.diffusion_mass_flux[t] = dif[:, k]
+                con.total_mass_flux[t] = tot[:, k]
+        self.time_step += 1                                      # transport.py:276
+
+    def simulate_wq(self, *a, **kw):
+        """Deprecated and unrunnable in the reference at HEAD (transport.py:279-372 reads ``x`` before
+        assignment); kept as the loop the docstring promises: update() over every remaining level."""
+        import warnings
+        warnings.warn('Use `update` method instead.', DeprecationWarning)
+        while self.time_step + 1 < self._T:
+            self.update()
+
+    def set_value_range(self, constituent_name: Optional[str] = None):
+        """constituents.py:167-172."""
+        names = [constituent_name] if constituent_name is not None else self.constituents
+        for nme in names:
+            real = self.mesh[nme][:, : self._n]
+            self.constituent_dict[nme].max_value = int(np.nanmax(real))
+            self.constituent_dict[nme].min_value = int(np.nanmin(real))
+
+    def finalize(self, save: bool = False, output_filepath: Optional[str] = None):
+        """transport.py:385-395 without the zarr/netCDF writer (out of scope): sets value ranges."""
+        self.set_value_range()
+        if save:
+            np.savez_compressed(output_filepath, **{k: np.asarray(v) for k, v in self.mesh.items()
+                                                    if isinstance(v, np.ndarray)})

@@ -1,0 +1,241 @@
+"""Synthetic HEC-RAS-2D-like meshes and flow fields (host side, numpy only).
+
+The Ohio River / Sumwere HDF files of the reference are missing blobs, and the
+1 M / 4 M-cell benchmark meshes never existed, so the workloads of BASELINE.json are
+generated here with the array surface the reference's HDF reader yields
+(/root/reference/src/clearwater_riverine/io/hdf.py:246-310):
+
+    edges_face1, edges_face2  (E,) int32   face1 always a real cell, ghost cells only as face2,
+                                           one ghost cell per perimeter face, ids > nreal
+    face_x, face_y            (ncell,) f64
+    face_flow, edge_velocity  (T, E) f32   signed: > 0 flows face1 -> face2
+    volume                    (T, ncell) f32
+    time_seconds              (T,) f64
+
+Construction: an nx x ny quad band with jittered nodes; optionally
+`n_merge` horizontally adjacent cell pairs are fused into 6-sided cells (mixed cell
+degrees, duplicate faces between the same two cells); cells and faces are renumbered
+row-major with a random shuffle inside windows of `shuffle_window` ids and random face
+orientation (HEC-RAS numbering is not monotone).  The flow is a node stream function
+(exactly divergence-free per cell: uniform through-flow + wall-bounded eddies, with a
+sinusoidal unsteadiness) plus a small potential component whose divergence is integrated
+into the cell volumes, so the float64 field satisfies discrete continuity
+V[t+1] - V[t] = -dt * sum(signed outflow) before it is rounded to float32.
+Walls carry exactly zero flow and zero velocity (so, as in the reference, no diffusion).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def make_mesh(nx: int, ny: int, n_steps: int, *, seed: int = 0, n_merge: int = 0,
+              shuffle_window: int = 32, dx: float = 10.0, dy: float = 10.0, depth: float = 2.0,
+              dt: float = 10.0, velocity: float = 0.5, unsteady: float = 0.1, period_steps: int = 24,
+              eddy: float = 0.3, breathing: float = 0.02, jitter: float = 0.2,
+              diffusion_coefficient: float = 0.1, n_dry: int = 0, steady: bool = False) -> dict:
+    """Return a mesh dict (reference variable names) with T = n_steps + 1 time levels.
+    steady=True freezes the field in time (then the reference scheme is exactly conservative)."""
+    rng = np.random.default_rng(seed)
+    if steady:
+        unsteady = 0.0
+        breathing = 0.0
+    T = n_steps + 1
+
+    # ---- base grid: cell (i, j) -> base id j*nx + i ; optional pair merges ------------
+    nb = nx * ny
+    base_to_cell = np.arange(nb, dtype=np.int64)
+    if n_merge > 0:
+        # candidate pairs ((2m, j), (2m+1, j)) never overlap
+        ii, jj = np.meshgrid(np.arange(0, nx - 1, 2), np.arange(ny), indexing='xy')
+        cand = (jj * nx + ii).ravel()
+        if n_merge > len(cand):
+            raise ValueError('n_merge too large for this grid')
+        pick = rng.choice(cand, size=n_merge, replace=False)
+        base_to_cell[pick + 1] = pick                      # right cell joins the left one
+    # compact + locally shuffled numbering of the surviving cells
+    reps = np.unique(base_to_cell)
+    n = len(reps)
+    order = np.arange(n)
+    if shuffle_window > 1:
+        keys = (order // shuffle_window).astype(np.float64) + rng.random(n)
+        order = np.argsort(keys, kind='stable')            # position -> old compact id
+    newid = np.empty(n, dtype=np.int64)
+    newid[order] = np.arange(n)
+    compact = np.full(nb, -1, dtype=np.int64)
+    compact[reps] = newid
+    cell_of_base = compact[base_to_cell]                   # (nb,) final real-cell id
+
+    # ---- nodes (jittered) and the two families of faces --------------------------------
+    xn = np.arange(nx + 1, dtype=np.float64)[None, :] * dx + np.zeros((ny + 1, 1))
+    yn = np.arange(ny + 1, dtype=np.float64)[:, None] * dy + np.zeros((1, nx + 1))
+    if jitter > 0:
+        jx = (rng.random((ny + 1, nx + 1)) - 0.5) * 2 * jitter * dx
+        jy = (rng.random((ny + 1, nx + 1)) - 0.5) * 2 * jitter * dy
+        jx[:, 0] = jx[:, -1] = 0.0
+        jy[0, :] = jy[-1, :] = 0.0
+        jx[0, :] = jx[-1, :] = 0.0
+        jy[:, 0] = jy[:, -1] = 0.0
+        xn = xn + jx
+        yn = yn + jy
+
+    def base_id(i, j):
+        return j * nx + i
+
+    # vertical faces: between base cells (i-1, j) and (i, j), i = 0..nx ; node (i, j)-(i, j+1)
+    iv, jv = np.meshgrid(np.arange(nx + 1), np.arange(ny), indexing='xy')
+    iv = iv.ravel(); jv = jv.ravel()
+    v_left = np.where(iv > 0, base_id(np.maximum(iv - 1, 0), jv), -1)
+    v_right = np.where(iv < nx, base_id(np.minimum(iv, nx - 1), jv), -1)
+    v_len = np.hypot(xn[jv + 1, iv] - xn[jv, iv], yn[jv + 1, iv] - yn[jv, iv])
+    # horizontal faces: between base cells (i, j-1) and (i, j), j = 0..ny ; node (i, j)-(i+1, j)
+    ih, jh = np.meshgrid(np.arange(nx), np.arange(ny + 1), indexing='xy')
+    ih = ih.ravel(); jh = jh.ravel()
+    h_lo = np.where(jh > 0, base_id(ih, np.maximum(jh - 1, 0)), -1)
+    h_hi = np.where(jh < ny, base_id(ih, np.minimum(jh, ny - 1)), -1)
+    h_len = np.hypot(xn[jh, ih + 1] - xn[jh, ih], yn[jh, ih + 1] - yn[jh, ih])
+
+    # positive direction: vertical faces left -> right, horizontal faces low -> high
+    side_a = np.concatenate([v_left, h_lo])                 # upstream side of the + direction
+    side_b = np.concatenate([v_right, h_hi])
+    flen = np.concatenate([v_len, h_len])
+    is_vert = np.concatenate([np.ones(len(v_left), bool), np.zeros(len(h_lo), bool)])
+    node_i = np.concatenate([iv, ih]); node_j = np.concatenate([jv, jh])
+
+    ca = np.where(side_a >= 0, cell_of_base[np.maximum(side_a, 0)], -1)
+    cb = np.where(side_b >= 0, cell_of_base[np.maximum(side_b, 0)], -1)
+    keep = ca != cb                                         # drop faces swallowed by a merge
+    ca, cb, flen, is_vert = ca[keep], cb[keep], flen[keep], is_vert[keep]
+    node_i, node_j = node_i[keep], node_j[keep]
+    E = len(ca)
+
+    # ---- face numbering: spatial order with a windowed shuffle --------------------------
+    pos_key = np.where(ca >= 0, ca, cb).astype(np.float64)  # near the owning cells' ids
+    eorder = np.argsort(pos_key + rng.random(E) * max(shuffle_window, 1), kind='stable')
+    ca, cb, flen, is_vert = ca[eorder], cb[eorder], flen[eorder], is_vert[eorder]
+    node_i, node_j = node_i[eorder], node_j[eorder]
+
+    # ---- orientation: face1 real; perimeter faces get their own ghost cell as face2 ------
+    boundary = (ca < 0) | (cb < 0)
+    flip = np.where(boundary, ca < 0, rng.random(E) < 0.5)  # True: face1 = b side, + dir is face2->face1
+    face1 = np.where(flip, cb, ca)
+    face2 = np.where(flip, ca, cb)
+    n_ghost = int(boundary.sum())
+    face2 = face2.copy()
+    face2[boundary] = n + np.arange(n_ghost)
+    sign = np.where(flip, -1.0, 1.0)                        # flow(face1->face2) = sign * flow(+dir)
+    ncell = n + n_ghost
+
+    # ---- cell centres and volumes --------------------------------------------------------
+    bi, bj = np.meshgrid(np.arange(nx), np.arange(ny), indexing='xy')
+    bcx = 0.25 * (xn[:-1, :-1] + xn[:-1, 1:] + xn[1:, :-1] + xn[1:, 1:]).ravel()
+    bcy = 0.25 * (yn[:-1, :-1] + yn[:-1, 1:] + yn[1:, :-1] + yn[1:, 1:]).ravel()
+    cnt = np.bincount(cell_of_base, minlength=n).astype(np.float64)
+    face_x = np.empty(ncell); face_y = np.empty(ncell)
+    face_x[:n] = np.bincount(cell_of_base, weights=bcx, minlength=n) / cnt
+    face_y[:n] = np.bincount(cell_of_base, weights=bcy, minlength=n) / cnt
+    # ghost centre: mirror of the real centre through the face midpoint (outside the band)
+    gi, gj = node_i[boundary], node_j[boundary]
+    gv = is_vert[boundary]
+    mx = np.where(gv, xn[gj, gi], 0.5 * (xn[gj, gi] + xn[gj, np.minimum(gi + 1, nx)]))
+    my = np.where(gv, 0.5 * (yn[gj, gi] + yn[np.minimum(gj + 1, ny), gi]), yn[gj, gi])
+    rp = face1[boundary]
+    face_x[n:] = mx + 0.5 * (mx - face_x[rp])
+    face_y[n:] = my + 0.5 * (my - face_y[rp])
+    area0 = cnt * dx * dy * (1.0 + 0.1 * (rng.random(n) - 0.5))
+    vol0 = area0 * depth
+
+    # ---- flow field ------------------------------------------------------------------------
+    # stream function at nodes (ny+1, nx+1): through-flow Q per unit row + eddies vanishing on walls
+    q_row = velocity * depth * dy                           # flow through one vertical face
+    jn = np.arange(ny + 1, dtype=np.float64)[:, None]
+    inn = np.arange(nx + 1, dtype=np.float64)[None, :]
+    psi_uniform = q_row * jn + np.zeros((1, nx + 1))
+    mx_modes = max(1, nx // 12)
+    psi_eddy = eddy * q_row * min(ny, 8) / np.pi * \
+        np.sin(np.pi * inn / nx * mx_modes) * np.sin(np.pi * jn / ny)
+    # + direction flux: vertical face psi(i, j+1) - psi(i, j); horizontal face -(psi(i+1, j) - psi(i, j))
+    def plus_flux(psi):
+        fv = psi[node_j + 1 * is_vert, node_i] - psi[node_j, node_i]
+        fh = -(psi[node_j, np.minimum(node_i + 1, nx)] - psi[node_j, node_i])
+        return np.where(is_vert, fv, fh)
+    f_uniform = plus_flux(psi_uniform)
+    f_eddy = plus_flux(psi_eddy)
+    # potential ("breathing") component on internal faces only
+    internal = ~boundary
+    kappa = flen * depth / np.where(is_vert, dx, dy)
+    phase = 2 * np.pi * (face_x[:n] / max(nx * dx, 1.0))
+    p1 = np.where(internal, face1, 0); p2 = np.where(internal, np.minimum(face2, n - 1), 0)
+
+    steps = np.arange(T, dtype=np.float64)
+    amp_t = 1.0 + unsteady * np.sin(2 * np.pi * steps / period_steps)
+    flow = np.empty((T, E), dtype=np.float64)
+    vol = np.empty((T, n), dtype=np.float64)
+    vol[0] = vol0
+    breath_scale = breathing * vol0.mean() / dt / 4.0
+    for t in range(T):
+        phi = breath_scale * np.sin(2 * np.pi * steps[t] / (period_steps * 0.75) + phase)
+        pot = np.where(internal, 0.25 * (phi[p1] - phi[p2]) * kappa / kappa.mean(), 0.0)
+        eddy_t = 1.0 if steady else np.cos(2 * np.pi * steps[t] / (2 * period_steps))
+        f12 = sign * (amp_t[t] * f_uniform + eddy_t * f_eddy) + pot
+        flow[t] = f12
+        if t + 1 < T:
+            div = np.bincount(face1, weights=f12, minlength=n) - \
+                np.bincount(np.where(internal, face2, 0), weights=np.where(internal, f12, 0.0), minlength=n)
+            vol[t + 1] = vol[t] - dt * div
+    if vol.min() <= 0:
+        raise ValueError('synthetic volumes went non-positive; lower dt/velocity/breathing')
+    flow[np.abs(flow) < 1e-12 * q_row] = 0.0                # walls: exactly zero
+    vel = flow / (flen * depth)[None, :]
+
+    volume = np.zeros((T, ncell), dtype=np.float32)
+    volume[:, :n] = vol
+    flow32 = flow.astype(np.float32)
+    vel32 = vel.astype(np.float32)
+    vel32[flow32 == 0] = 0.0
+
+    if n_dry > 0:                                           # permanently dry cells: V = 0, no flow on their faces
+        dry = rng.choice(n, size=n_dry, replace=False)
+        volume[:, dry] = 0.0
+        isdry = np.zeros(ncell, bool); isdry[dry] = True
+        touch = isdry[face1] | isdry[np.minimum(face2, ncell - 1)]
+        flow32[:, touch] = 0.0
+        vel32[:, touch] = 0.0
+
+    inlet = boundary & is_vert & (node_i == 0)
+    outlet = boundary & is_vert & (node_i == nx)
+    return {
+        'edges_face1': face1.astype(np.int32), 'edges_face2': face2.astype(np.int32),
+        'nreal': int(n - 1),
+        'face_x': face_x, 'face_y': face_y,
+        'face_flow': flow32, 'edge_velocity': vel32, 'volume': volume,
+        'time_seconds': steps * dt,
+        'diffusion_coefficient': float(diffusion_coefficient),
+        'inlet_ghost_cells': face2[inlet].astype(np.int64),
+        'outlet_ghost_cells': face2[outlet].astype(np.int64),
+        'wall_ghost_cells': face2[boundary & ~inlet & ~outlet].astype(np.int64),
+        'grid': (nx, ny),
+    }
+
+
+def boundary_input_array(mesh: dict, n_const: int, *, ic: float | np.ndarray = 1.0,
+                         inlet_base: float = 60.0, inlet_amp: float = 40.0,
+                         inlet_period_s: float = 600.0, outlet_value: float = 5.0) -> np.ndarray:
+    """(T, ncell, K) input array in the reference's convention
+    (/root/reference/src/clearwater_riverine/constituents.py:78-164): row 0 carries the
+    initial condition of the real cells, ghost-cell columns carry boundary values, zero
+    means "no boundary value".  Constituent k is scaled by (k + 1)."""
+    T = len(mesh['time_seconds'])
+    ncell = len(mesh['face_x'])
+    n = mesh['nreal'] + 1
+    arr = np.zeros((T, ncell, n_const))
+    scale = (np.arange(n_const) + 1.0)[None, :]
+    ic_arr = np.broadcast_to(np.asarray(ic, dtype=np.float64).reshape(-1, 1) if np.ndim(ic) else
+                             np.full((n, 1), float(ic)), (n, 1))
+    arr[0, :n, :] = ic_arr * scale
+    tsec = np.asarray(mesh['time_seconds'])
+    series = inlet_base + inlet_amp * np.sin(2 * np.pi * tsec / inlet_period_s)
+    arr[:, mesh['inlet_ghost_cells'], :] = series[:, None, None] * scale[None]
+    if outlet_value:
+        out = mesh['outlet_ghost_cells']
+        arr[:, out[::2], :] = outlet_value * scale[None]   # every other outlet ghost: the rest have "no BC"
+    return arr

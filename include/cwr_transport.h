@@ -1,0 +1,167 @@
+/*
+ * cwr_transport.h -- C ABI of the MI355X-native transport engine that drops in behind
+ * clearwater_riverine's ClearwaterRiverine.update() time-step loop.
+ *
+ * The reference has no FFI: the seam is the Python method
+ *   ClearwaterRiverine.update(update_concentration)      src/clearwater_riverine/transport.py:201-276
+ * whose per-step work is LHS.update_values (linalg.py:34-156) -> csr_matrix (transport.py:215-218)
+ * -> per constituent RHS.update_values (linalg.py:177-201) -> scipy spsolve (transport.py:249)
+ * -> write-back (transport.py:252-264) -> _mass_flux (transport.py:406-429).
+ * Each entry point below names the reference interface it replaces; INTEGRATION.md shows the
+ * ctypes binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C, no C++ types, no exceptions across the boundary; every call returns an int status
+ *     (0 = CWR_OK, < 0 = error; message via cwr_last_error()).
+ *   - all array arguments are HOST pointers to C-contiguous buffers owned by the caller; the engine
+ *     owns all device memory.  One engine = one GPU = one host thread at a time.
+ *   - cell ids and face ("edge") ids are the reference's ids: real cells 0..nreal, ghost cells
+ *     > nreal (io/hdf.py:257-269), faces in HDF order.  Concentration layout is x[cell * K + k]
+ *     (constituents are the inner, coalesced dimension), float64.
+ *   - time level t uses advection_coeff[t], coeff_to_diffusion[t], volume[t+1] on the left-hand
+ *     side and volume[t], boundary terms of level t+1 on the right-hand side, exactly as
+ *     linalg.py:61-66,84-89 and linalg.py:238-240,274 do.
+ */
+#ifndef CWR_TRANSPORT_H
+#define CWR_TRANSPORT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cwr_engine cwr_engine;
+
+enum {
+  CWR_OK = 0,
+  CWR_ERR_BAD_ARG = -1,        /* python: TypeError / ValueError raised by the wrapper's own checks   */
+  CWR_ERR_HIP = -2,            /* a HIP runtime call failed                                          */
+  CWR_ERR_NOT_CONVERGED = -3,  /* iterative solve did not reach tol in max_iter (spsolve has no such) */
+  CWR_ERR_GHOST_COEFF = -4,    /* active ghost face with a zero coefficient: the reference raises a
+                                  shape-mismatch ValueError at linalg.py:349-351                      */
+  CWR_ERR_RCCL = -5,           /* an RCCL call failed (partitioned engines only)                     */
+  CWR_ERR_STATE = -6,          /* call out of order (no flow field loaded, t out of range, ...)      */
+  CWR_ERR_NONFINITE = -7       /* NaN/Inf met in the solve (spsolve would return NaNs silently)      */
+};
+
+/* flags for cwr_step() */
+enum {
+  CWR_STEP_MASS_FLUX = 1,      /* also evaluate the three per-face mass-flux arrays (transport.py:406-429) */
+  CWR_STEP_PROFILE = 2         /* bracket every operator launch with HIP events (see cwr_profile_read)     */
+};
+
+typedef struct cwr_step_info {
+  int32_t iterations;          /* BiCGSTAB iterations in which at least one constituent was still active */
+  int32_t restarts;
+  int32_t status;              /* CWR_OK or the error code also returned */
+  int32_t operator_launches;   /* face-flux operator launches in this step */
+  double max_rel_residual;     /* max over constituents of ||D^-1 (b - A x)||_2 / ||D^-1 b||_2 */
+  double solve_ms;             /* host wall time of the step, for information only */
+} cwr_step_info;
+
+int32_t cwr_abi_version(void);
+
+/* ---- construction -------------------------------------------------------------------------------
+ * Replaces LHS.__init__ (linalg.py:18-32: internal / real face index sets) and RHS.__init__
+ * (linalg.py:159-175: ghost face set).  Local cell numbering:
+ *   [0, n_owned)                      real cells whose rows this engine solves
+ *   [n_owned, n_owned + n_halo)       real cells owned by other ranks (n_halo = 0 on one GPU)
+ *   [n_owned + n_halo, n_cells)       ghost (boundary) cells
+ * On one GPU n_owned = nreal + 1 and the numbering is the reference's own.
+ * face1/face2: (n_edges) int32, face1 must be a real cell (as in every HEC-RAS file the reference reads).
+ */
+int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_edges,
+                   int32_t n_constituents, const int32_t* face1, const int32_t* face2,
+                   int32_t device, cwr_engine** out);
+void cwr_destroy(cwr_engine* e);
+const char* cwr_last_error(const cwr_engine* e);   /* e may be NULL: last error of a failed cwr_create */
+
+/* ---- flow field (inputs of the path) ----------------------------------------------------------
+ * cwr_load_flow_field derives the coefficients ON DEVICE, replacing
+ * WQVariableCalculator.calculate else-branch (utilities.py:513-541):
+ *   advection_coeff = face_flow * sign(|edge_velocity|)            (float32)
+ *   edge_vertical_area = advection_coeff / edge_velocity, NaN -> 0  (float32)
+ *   coeff_to_diffusion = float32(area * D) / face_to_face_dist       (float64)
+ * face_flow, edge_velocity: (T, n_edges) float32; volume: (T, n_cells) float32;
+ * dt: (T) float64 (seconds, last entry unused); face_to_face_dist: (n_edges) float64
+ * (utilities.py:261-278, computed by the host wrapper); D = mesh.attrs['diffusion_coefficient'].
+ */
+int32_t cwr_load_flow_field(cwr_engine* e, int32_t n_times, const float* face_flow,
+                            const float* edge_velocity, const float* volume, const double* dt,
+                            const double* face_to_face_dist, double diffusion_coefficient);
+/* Same, from the reference's already-derived Dataset variables 'advection_coeff' (T,E) f32 and
+ * 'coeff_to_diffusion' (T,E) f64 (variables.py:30-33): the drop-in route from an existing xarray mesh. */
+int32_t cwr_load_coefficients(cwr_engine* e, int32_t n_times, const float* advection_coeff,
+                              const double* coeff_to_diffusion, const float* edge_velocity,
+                              const float* volume, const double* dt, double diffusion_coefficient);
+/* Read back the device-resident coefficients of level t (parity check of the on-device derivation). */
+int32_t cwr_get_coefficients(cwr_engine* e, int32_t t, float* advection_coeff, double* coeff_to_diffusion);
+
+/* ---- boundary values ----------------------------------------------------------------------------
+ * Ghost-cell columns of Constituent.input_array (constituents.py:31,153-164), all time levels:
+ * ghost_conc is (T, n_ghost, K) float64 with n_ghost = n_cells - n_owned - n_halo; 0 = "no boundary
+ * value" (the reference's sentinel, transport.py:258-264). */
+int32_t cwr_load_boundary(cwr_engine* e, int32_t n_times, const double* ghost_conc);
+/* One level only (streaming alternative). */
+int32_t cwr_set_boundary_level(cwr_engine* e, int32_t t, const double* ghost_conc_level);
+
+/* ---- state --------------------------------------------------------------------------------------
+ * cwr_set_state: concentrations of the owned real cells at the current level, (n_owned, K).  Used for
+ * the initial condition (constituents.py:94-98) and for the per-step override of update()'s
+ * `update_concentration` argument (transport.py:233-236).
+ * cwr_get_state: full (n_cells, K) row of mesh[name][t+1] after a step: solved real cells, ghost cells
+ * = boundary value where non-zero, NaN elsewhere (transport.py:252-264, constituents.py:39-48);
+ * halo rows hold the neighbours' values of the last exchange. */
+int32_t cwr_set_state(cwr_engine* e, const double* conc_owned);
+int32_t cwr_get_state(cwr_engine* e, double* conc_all_cells);
+
+/* ---- the face-flux operator (exported for parity tests and roofline timing) ---------------------
+ * y = A x with A the matrix LHS.update_values(mesh, t) + csr_matrix build (linalg.py:34-156,
+ * transport.py:215-218), evaluated matrix-free per cell over the CSR face adjacency.
+ * x: (n_owned + n_halo, K), y: (n_owned, K). */
+int32_t cwr_apply(cwr_engine* e, int32_t t, const double* x, double* y);
+/* b of RHS.update_values(solution=x_t, mesh, t) (linalg.py:177-201,262-275,354-406). x_t, b: (n_owned, K). */
+int32_t cwr_rhs(cwr_engine* e, int32_t t, const double* x_t, double* b);
+
+/* ---- one time step ------------------------------------------------------------------------------
+ * Replaces the body of ClearwaterRiverine.update() for all constituents at once
+ * (transport.py:209-273): operator set-up for level t, right-hand side, implicit solve
+ * (Jacobi-scaled BiCGSTAB converging to the spsolve solution; K systems share A), write-back of the
+ * real cells and of the ghost cells, optional mass flux.  State advances from level t to t+1.
+ * tol: relative residual target (e.g. 1e-12).  info may be NULL. */
+int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t flags,
+                 cwr_step_info* info);
+/* The three (n_edges, K) arrays of the last step taken with CWR_STEP_MASS_FLUX
+ * (advection, diffusion, total: transport.py:419-429).  Any pointer may be NULL. */
+int32_t cwr_get_mass_flux(cwr_engine* e, double* advection, double* diffusion, double* total);
+
+/* ---- measurement --------------------------------------------------------------------------------
+ * cwr_time_apply: `reps` back-to-back launches of the operator of level t on device-resident vectors,
+ * timed with HIP events on the engine's own stream; variant 0 = gather kernel (the solver's),
+ * 1 = scatter kernel with global float64 atomics (A/B only).  avg_us = mean launch duration.
+ * cwr_profile_read: event-timed totals of the operator launches made by steps run with
+ * CWR_STEP_PROFILE since the last call: number of launches and their summed duration. */
+int32_t cwr_time_apply(cwr_engine* e, int32_t t, int32_t variant, int32_t reps, double* avg_us);
+int32_t cwr_profile_read(cwr_engine* e, int64_t* launches, double* total_us);
+int32_t cwr_synchronize(cwr_engine* e);
+/* Algorithmic bytes of one operator launch (read, written), as DESIGN.md defines them. */
+int32_t cwr_apply_bytes(const cwr_engine* e, int64_t* bytes_read, int64_t* bytes_written);
+
+/* ---- domain decomposition (one process per GPU, RCCL over xGMI) --------------------------------
+ * cwr_comm_unique_id: rank 0 creates the 128-byte RCCL unique id, the host broadcasts it.
+ * cwr_attach_comm: joins the communicator and installs the halo exchange of this rank:
+ *   peers[i]                      rank of the i-th neighbour
+ *   send_ptr[i] .. send_ptr[i+1]  slice of send_cells (local owned ids) packed for peers[i]
+ *   recv_ptr[i] .. recv_ptr[i+1]  slice of the halo block [n_owned, n_owned+n_halo) filled by peers[i]
+ * Every operator input is exchanged before the launch (ncclGroupStart/Send/Recv/End on the engine
+ * stream) and every inner product is completed with ncclAllReduce. */
+int32_t cwr_comm_unique_id(uint8_t id_out[128]);
+int32_t cwr_attach_comm(cwr_engine* e, int32_t rank, int32_t world, const uint8_t unique_id[128],
+                        int32_t n_peers, const int32_t* peers, const int32_t* send_ptr,
+                        const int32_t* send_cells, const int32_t* recv_ptr);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CWR_TRANSPORT_H */
