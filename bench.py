@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the transport path: Mcell-updates/s on the synthetic 1 M-cell mesh.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+            --master-port P bench.py --gpus N --steps K --warmup W)
+
+A "step" is one ClearwaterRiverine.update()-equivalent pass (transport.py:201-276) over all cells and
+constituents: operator set-up, right-hand side, implicit solve, write-back, per-face mass flux.
+Workload: BASELINE.json's 1 M-cell synthetic floodplain mesh (1000 x 1000 cells, 2 002 000 faces,
+4 000 ghost cells, CFL ~ 2.5, D = 0.5) with 16 constituents (the north-star roofline target case);
+--constituents 1 gives configs[3] literally.  The whole flow field, boundary values and state are
+resident in HBM before the timed region; nothing is copied to the host inside it.
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+HBM_MEASURED_GBS = 6290.0      # measured float4 copy, same guide
+
+
+def cpu_baseline(nx: int, steps: int, dt: float, D: float, seed: int):
+    """The oracle (numpy COO assembly + scipy spsolve per constituent, the reference algorithm) timed on
+    this host, single process, on a bounded sample of the same generator."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import cwr_oracle as oracle
+    from clearwater_riverine_amd import synthetic
+    mesh = synthetic.make_mesh(nx, nx, steps + 1, seed=seed, dt=dt, diffusion_coefficient=D)
+    oracle.derive_coefficients(mesh)
+    inp = synthetic.boundary_input_array(mesh, 1)[:, :, 0]
+    model = oracle.OracleModel(mesh, {'c': inp})
+    model.update()                                    # warm-up step (imports, allocator)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        model.update()
+    el = time.perf_counter() - t0
+    n = mesh['nreal'] + 1
+    return n * steps / el / 1e6, el, n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--nx', type=int, default=1000)
+    ap.add_argument('--ny', type=int, default=1000)
+    ap.add_argument('--constituents', type=int, default=16)
+    ap.add_argument('--tol', type=float, default=1e-12)
+    ap.add_argument('--dt', type=float, default=40.0)
+    ap.add_argument('--diffusion', type=float, default=0.5)
+    ap.add_argument('--seed', type=int, default=4)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample-nx', type=int, default=640)
+    ap.add_argument('--cpu-sample-steps', type=int, default=3)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if args.gpus > 1:
+            sys.exit(f'--gpus {args.gpus} needs one process per GPU: launch with torch.distributed.run '
+                     f'--nproc-per-node {args.gpus} (WORLD_SIZE is {world})')
+    import torch                                       # device plumbing + control plane only
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        sys.exit('bench.py needs a GPU: the transport path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='gloo', rank=rank, world_size=world)
+
+    from clearwater_riverine_amd import synthetic
+    from clearwater_riverine_amd.distributed import PartitionedTransport, broadcast_bytes
+    from clearwater_riverine_amd.engine import TransportEngine
+
+    K = args.constituents
+    n_levels = args.warmup + args.steps + 1
+    mesh = synthetic.make_mesh(args.nx, args.ny, n_levels, seed=args.seed, dt=args.dt,
+                               diffusion_coefficient=args.diffusion)
+    inputs3 = synthetic.boundary_input_array(mesh, K)
+    n = mesh['nreal'] + 1
+
+    uid = None
+    if world > 1:
+        uid = broadcast_bytes(TransportEngine.comm_unique_id() if rank == 0 else None, 128, src=0)
+    pt = PartitionedTransport(mesh, inputs3, rank, world, device=local_rank, unique_id=uid)
+    eng = pt.engine
+
+    def barrier():
+        eng.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    iters = []
+    for t in range(args.warmup):
+        pt.step(t, tol=args.tol, mass_flux=True)
+    saved = eng.get_state()[: pt.local.n_owned].copy()       # state at the start of the timed region
+    barrier()
+    t0 = time.perf_counter()
+    for t in range(args.warmup, args.warmup + args.steps):
+        r = pt.step(t, tol=args.tol, mass_flux=True)
+        iters.append(r.iterations)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    max_resid = r.max_rel_residual
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- roofline of the dominant kernel (the face-flux operator), HIP events on the engine's stream ----
+    roofline = None
+    eng.set_state(saved)                                 # every rank replays the timed steps, event-timed
+    eng.profile_read()
+    for t in range(args.warmup, args.warmup + args.steps):
+        pt.step(t, tol=args.tol, mass_flux=True, profile=True)
+    launches, total_us = eng.profile_read()
+    if rank == 0:
+        b_r, b_w = eng.apply_bytes()
+        back_to_back_us = eng.time_apply(args.warmup, reps=50) if world == 1 else None
+        if launches > 0:
+            avg_us = total_us / launches
+            achieved = b_r / (avg_us * 1e-6) / 1e9
+            roofline = {
+                'bound': 'hbm', 'kernel': 'k_apply (face-flux operator, gather form)',
+                'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+                'bytes_read': b_r, 'bytes_written': b_w, 'avg_launch_us': round(avg_us, 2),
+                'launches_timed': launches,
+                'achieved_read_plus_write': round((b_r + b_w) / (avg_us * 1e-6) / 1e9, 1),
+                'frac_rw_of_measured_stream_peak': round((b_r + b_w) / (avg_us * 1e-6) / 1e9 / HBM_MEASURED_GBS, 4),
+                'back_to_back_launch_us': None if back_to_back_us is None else round(back_to_back_us, 2),
+            }
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        v, el, nn = cpu_baseline(args.cpu_sample_nx, args.cpu_sample_steps, args.dt, args.diffusion, args.seed)
+        cpu = {'value': round(v, 5), 'unit': 'Mcell-updates/s', 'cores': 1, 'kind': 'port',
+               'sample': f'{args.cpu_sample_nx}x{args.cpu_sample_nx}-cell mesh of the same generator ({nn} cells), '
+                         f'1 constituent, {args.cpu_sample_steps} steps after 1 warm-up, {el:.1f} s; numpy COO '
+                         f'assembly + scipy.sparse.linalg.spsolve per constituent (single-threaded SuperLU); '
+                         f'host has {os.cpu_count()} cores',
+               'host_cores': os.cpu_count()}
+
+    if rank == 0:
+        value = n * K * args.steps / elapsed / 1e6
+        line = {
+            'metric': 'Mcell-updates/s', 'value': round(value, 2), 'unit': 'Mcell-updates/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(1000.0 * elapsed / args.steps, 3), 'higher_is_better': True,
+            'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': f'synthetic {args.nx}x{args.ny} floodplain mesh ({n} cells, '
+                                   f'{len(mesh["edges_face1"])} faces), {K} constituents, implicit upwind '
+                                   f'advection-diffusion step, dt={args.dt} s, D={args.diffusion}',
+                       'cells': n, 'faces': int(len(mesh['edges_face1'])), 'constituents': K,
+                       'partition': f'contiguous cell ranges x{world}', 'tol': args.tol},
+            'solver': {'method': 'Jacobi-scaled BiCGSTAB, K systems batched', 'iterations_per_step': iters,
+                       'max_rel_residual': max_resid},
+            'roofline': roofline, 'cpu_baseline': cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

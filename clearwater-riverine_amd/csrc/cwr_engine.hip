@@ -10,6 +10,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -60,7 +61,8 @@ struct cwr_engine {
   hipStream_t stream = nullptr;
   int n_owned = 0, n_halo = 0, n_real = 0, n_cells = 0, n_ghost = 0, E = 0, K = 0;
   int VW = 1, G = 1, R = 1;
-  int nnz = 0, nblocks = 0, stage_cap = 0;
+  int nnz = 0, U = 1, ntiles = 0, apply_grid = 0, stage_cap = 0, cu_cap = 8;
+  double* d_partial = nullptr;   // [max grid][4][K] per-block inner-product partials
   size_t apply_lds = 0;
   // static topology
   int32_t *d_f1 = nullptr, *d_f2 = nullptr, *d_ptr = nullptr, *d_ent_edge = nullptr, *d_ent_nb = nullptr;
@@ -155,21 +157,28 @@ int prep_step(cwr_engine* e, int t) {
   return CWR_OK;
 }
 
+int reduce_partials(cwr_engine* e, int nslots, int ND, double* o0, double* o1 = nullptr, double* o2 = nullptr, double* o3 = nullptr) {
+  ReduceOuts outs; outs.p[0] = o0; outs.p[1] = o1; outs.p[2] = o2; outs.p[3] = o3;
+  k_reduce_partials<<<ND, RBLOCK, 0, e->stream>>>(nslots, ND, e->K, e->d_partial, outs);
+  HIP_TRY(e, hipGetLastError());
+  return CWR_OK;
+}
+
 template <int MODE>
 int launch_apply(cwr_engine* e, const double* xin, double* yout, const double* r0, const double* bhat,
-                 double* r0_out, double* p_out, double* acc, double* bb) {
-  const int grid = cdiv(e->nblocks, N_XCD) * N_XCD;
+                 double* r0_out, double* p_out) {
+  const int grid = e->apply_grid;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (e->profiling && e->ev_used + 2 <= e->ev.size()) {
     e0 = e->ev[e->ev_used++]; e1 = e->ev[e->ev_used++];
     HIP_TRY(e, hipEventRecord(e0, e->stream));
   }
   if (e->VW == 2)
-    k_apply<2, MODE><<<grid, BLOCK, e->apply_lds, e->stream>>>(e->n_owned, e->K, e->G, e->nblocks, e->stage_cap,
-        e->d_ptr, e->d_rec, e->d_diag, xin, yout, r0, bhat, r0_out, p_out, acc, bb);
+    k_apply<2, MODE><<<grid, BLOCK, e->apply_lds, e->stream>>>(e->n_owned, e->K, e->G, e->U, e->ntiles, e->stage_cap,
+        e->d_ptr, e->d_rec, e->d_diag, xin, yout, r0, bhat, r0_out, p_out, e->d_partial);
   else
-    k_apply<1, MODE><<<grid, BLOCK, e->apply_lds, e->stream>>>(e->n_owned, e->K, e->G, e->nblocks, e->stage_cap,
-        e->d_ptr, e->d_rec, e->d_diag, xin, yout, r0, bhat, r0_out, p_out, acc, bb);
+    k_apply<1, MODE><<<grid, BLOCK, e->apply_lds, e->stream>>>(e->n_owned, e->K, e->G, e->U, e->ntiles, e->stage_cap,
+        e->d_ptr, e->d_rec, e->d_diag, xin, yout, r0, bhat, r0_out, p_out, e->d_partial);
   HIP_TRY(e, hipGetLastError());
   if (e1) HIP_TRY(e, hipEventRecord(e1, e->stream));
   return CWR_OK;
@@ -177,7 +186,7 @@ int launch_apply(cwr_engine* e, const double* xin, double* yout, const double* r
 
 int vec_grid(const cwr_engine* e) {
   // memory-bound streaming kernels: cap the grid at 8 blocks per CU and grid-stride the rest
-  return std::max(1, std::min(cdiv(e->n_owned, e->R), 256 * 8));
+  return std::max(1, std::min(cdiv(e->n_owned, e->R), 256 * 4));
 }
 
 int exchange_halo(cwr_engine* e, double* vec) {
@@ -232,17 +241,20 @@ int one_iteration(cwr_engine* e, int it, double tol2) {
   const double* rr_prev = e->acc(prev) + ACC_RR * K;
   const int vg = vec_grid(e);
   TRY(exchange_halo(e, e->d_p));
-  TRY(launch_apply<1>(e, e->d_p, e->d_v, e->d_r0, nullptr, nullptr, nullptr, acc_cur, nullptr));
+  TRY(launch_apply<1>(e, e->d_p, e->d_v, e->d_r0, nullptr, nullptr, nullptr));
+  TRY(reduce_partials(e, e->apply_grid, 1, acc_cur + ACC_R0V * K));
   TRY(allreduce(e, acc_cur + ACC_R0V * K, K));
   if (e->VW == 2) k_vec_s<2><<<vg, BLOCK, 0, e->stream>>>(e->n_owned, K, e->G, e->d_r, e->d_v, e->d_s, rho_ptr, acc_cur, rr_prev, e->bb(), tol2);
   else            k_vec_s<1><<<vg, BLOCK, 0, e->stream>>>(e->n_owned, K, e->G, e->d_r, e->d_v, e->d_s, rho_ptr, acc_cur, rr_prev, e->bb(), tol2);
   HIP_TRY(e, hipGetLastError());
   TRY(exchange_halo(e, e->d_s));
-  TRY(launch_apply<2>(e, e->d_s, e->d_t, e->d_r0, nullptr, nullptr, nullptr, acc_cur, nullptr));
-  TRY(allreduce(e, acc_cur + ACC_TS * K, 3 * (size_t)K));
-  if (e->VW == 2) k_vec_x<2><<<vg, BLOCK, 0, e->stream>>>(e->n_owned, K, e->G, e->d_c, e->d_r, e->d_p, e->d_s, e->d_t, e->d_v, rho_ptr, e->rho(next), acc_cur, e->acc(next), rr_prev, e->bb(), tol2, e->d_counters);
-  else            k_vec_x<1><<<vg, BLOCK, 0, e->stream>>>(e->n_owned, K, e->G, e->d_c, e->d_r, e->d_p, e->d_s, e->d_t, e->d_v, rho_ptr, e->rho(next), acc_cur, e->acc(next), rr_prev, e->bb(), tol2, e->d_counters);
+  TRY(launch_apply<2>(e, e->d_s, e->d_t, e->d_r0, nullptr, nullptr, nullptr));
+  TRY(reduce_partials(e, e->apply_grid, 4, acc_cur + ACC_TS * K, acc_cur + ACC_TT * K, acc_cur + ACC_R0T * K, acc_cur + ACC_R0S * K));
+  TRY(allreduce(e, acc_cur + ACC_TS * K, 4 * (size_t)K));
+  if (e->VW == 2) k_vec_x<2><<<vg, BLOCK, 0, e->stream>>>(e->n_owned, K, e->G, e->d_c, e->d_r, e->d_p, e->d_s, e->d_t, e->d_v, rho_ptr, e->rho(next), acc_cur, e->d_partial, rr_prev, e->bb(), tol2, e->d_counters);
+  else            k_vec_x<1><<<vg, BLOCK, 0, e->stream>>>(e->n_owned, K, e->G, e->d_c, e->d_r, e->d_p, e->d_s, e->d_t, e->d_v, rho_ptr, e->rho(next), acc_cur, e->d_partial, rr_prev, e->bb(), tol2, e->d_counters);
   HIP_TRY(e, hipGetLastError());
+  TRY(reduce_partials(e, vg, 1, acc_cur + ACC_RR * K));
   TRY(allreduce(e, acc_cur + ACC_RR * K, K));
   return CWR_OK;
 }
@@ -318,14 +330,22 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   eng->VW = (K % 2 == 0) ? 2 : 1;
   eng->G = K / eng->VW;
   eng->R = BLOCK / eng->G;
-  eng->nblocks = cdiv(n_owned, eng->R);
+  int tile_rows = 256, cu_cap = 8;                               // tunables (measured defaults; env overrides for sweeps)
+  if (const char* v = getenv("CWR_TILE_ROWS")) tile_rows = std::max(1, atoi(v));
+  if (const char* v = getenv("CWR_BLOCKS_PER_CU")) cu_cap = std::max(1, atoi(v));
+  eng->U = std::max(1, tile_rows / eng->R);
+  const int TR = eng->R * eng->U;
+  eng->ntiles = cdiv(n_owned, TR);
   int cap = 0;
-  for (int b = 0; b < eng->nblocks; ++b) {
-    const int c0 = b * eng->R, c1 = std::min(c0 + eng->R, n_owned);
+  for (int b = 0; b < eng->ntiles; ++b) {
+    const int c0 = b * TR, c1 = std::min(c0 + TR, n_owned);
     cap = std::max(cap, cnt[c1] - cnt[c0]);
   }
-  eng->stage_cap = std::min(std::max(cap, 1), 6144);              // <= 96 KiB of records per block
-  eng->apply_lds = (size_t)eng->stage_cap * sizeof(FaceRec) + RED_DOUBLES * sizeof(double);
+  eng->stage_cap = std::min(std::max(cap, 1), 6144);              // <= 96 KiB of records per tile
+  eng->apply_lds = (size_t)eng->stage_cap * sizeof(FaceRec) + (size_t)red_doubles(eng->G, eng->VW) * sizeof(double) +
+                   (size_t)(TR + 1) * sizeof(int32_t);
+  eng->apply_lds = (eng->apply_lds + 15) & ~(size_t)15;
+  eng->cu_cap = cu_cap;
 
 #define CREATE_TRY(call) do { int _rc = (call); if (_rc != CWR_OK) { g_create_error = eng->err; cwr_destroy(eng); return _rc; } } while (0)
 #define CREATE_HIP(call) do { hipError_t _st = (call); if (_st != hipSuccess) { g_create_error = std::string(#call) + ": " + hipGetErrorString(_st); cwr_destroy(eng); return CWR_ERR_HIP; } } while (0)
@@ -340,6 +360,18 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
     CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_apply<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)eng->apply_lds));
     CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_apply<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)eng->apply_lds));
     CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_apply<2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)eng->apply_lds));
+  }
+  {
+    // persistent grid = what is really co-resident: blocks/CU from the occupancy query (LDS, registers, waves),
+    // times the CU count, rounded down to a multiple of 8 (one share per XCD); a block that had to wait for a
+    // free CU slot would run its whole tile range as a tail
+    int per_cu = 1, n_cu = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+    const void* fn = (eng->VW == 2) ? reinterpret_cast<const void*>(&k_apply<2, 2>) : reinterpret_cast<const void*>(&k_apply<1, 2>);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, BLOCK, eng->apply_lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    per_cu = std::min(per_cu, eng->cu_cap);
+    eng->apply_grid = std::max(N_XCD, std::min(cdiv(eng->ntiles, N_XCD) * N_XCD, (n_cu * per_cu / N_XCD) * N_XCD));
   }
   const size_t nK = (size_t)n_real * K;
   CREATE_TRY(dev_alloc(eng, &eng->d_f1, (size_t)n_edges));
@@ -359,6 +391,8 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   CREATE_TRY(dev_alloc(eng, &eng->d_b, nK));
   CREATE_TRY(dev_alloc(eng, &eng->d_scal, eng->scal_count()));
   CREATE_TRY(dev_alloc(eng, &eng->d_counters, (size_t)8));
+  CREATE_TRY(dev_alloc(eng, &eng->d_partial, (size_t)std::max(eng->apply_grid, 256 * 8) * 4 * K));
+  if (getenv("CWR_VERBOSE")) fprintf(stderr, "[cwr] K=%d VW=%d G=%d U=%d tiles=%d stage_cap=%d lds=%zu grid=%d\n", K, eng->VW, eng->G, eng->U, eng->ntiles, eng->stage_cap, eng->apply_lds, eng->apply_grid);
   CREATE_TRY(upload(eng, eng->d_f1, face1, (size_t)n_edges));
   CREATE_TRY(upload(eng, eng->d_f2, face2, (size_t)n_edges));
   CREATE_TRY(upload(eng, eng->d_ptr, cnt.data(), (size_t)n_owned + 1));
@@ -384,7 +418,7 @@ void cwr_destroy(cwr_engine* e) {
   for (hipEvent_t ev : e->ev) hipEventDestroy(ev);
   void* ptrs[] = {e->d_f1, e->d_f2, e->d_ptr, e->d_ent_edge, e->d_ent_nb, e->d_adv, e->d_vel, e->d_vol, e->d_dif,
                   e->d_bc, e->d_rec, e->d_diag, e->d_c, e->d_r, e->d_r0, e->d_p, e->d_v, e->d_s, e->d_t, e->d_b,
-                  e->d_scal, e->d_counters, e->d_fadv, e->d_fdif, e->d_ftot, e->d_send_cells, e->d_sendbuf};
+                  e->d_scal, e->d_counters, e->d_partial, e->d_fadv, e->d_fdif, e->d_ftot, e->d_send_cells, e->d_sendbuf};
   for (void* p : ptrs) if (p) hipFree(p);
   if (e->stream) hipStreamDestroy(e->stream);
   delete e;
@@ -487,7 +521,7 @@ int32_t cwr_apply(cwr_engine* e, int32_t t, const double* x, double* y) {
   HIP_TRY(e, hipSetDevice(e->dev));
   TRY(upload(e, e->d_p, x, (size_t)e->n_real * e->K));
   TRY(prep_step(e, t));
-  TRY(launch_apply<0>(e, e->d_p, e->d_v, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
+  TRY(launch_apply<0>(e, e->d_p, e->d_v, nullptr, nullptr, nullptr, nullptr));
   TRY(download(e, y, e->d_v, (size_t)e->n_owned * e->K));
   return CWR_OK;
 }
@@ -541,7 +575,8 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
     // (re)start: true residual of the current x; r0 = p = r
     if (round > 0) HIP_TRY(e, hipMemsetAsync(e->d_scal, 0, (size_t)3 * ACC_N * K * sizeof(double) + (size_t)3 * K * sizeof(double), e->stream));
     TRY(exchange_halo(e, e->d_c));
-    TRY(launch_apply<3>(e, e->d_c, e->d_r, nullptr, e->d_b, e->d_r0, e->d_p, e->acc(2), round == 0 ? e->bb() : nullptr));
+    TRY(launch_apply<3>(e, e->d_c, e->d_r, nullptr, e->d_b, e->d_r0, e->d_p));
+    TRY(reduce_partials(e, e->apply_grid, 2, e->acc(2) + ACC_RR * K, round == 0 ? e->bb() : nullptr));
     ++launches;
     TRY(allreduce(e, e->acc(2) + ACC_RR * K, K));
     if (round == 0) TRY(allreduce(e, e->bb(), K));
@@ -657,8 +692,8 @@ int32_t cwr_time_apply(cwr_engine* e, int32_t t, int32_t variant, int32_t reps, 
   int rc = CWR_OK;
   auto body = [&](int i) -> int {
     if (variant == 0) {
-      return (i & 1) ? launch_apply<1>(e, e->d_s, e->d_t, e->d_r0, nullptr, nullptr, nullptr, e->acc(1), nullptr)
-                     : launch_apply<1>(e, e->d_p, e->d_v, e->d_r0, nullptr, nullptr, nullptr, e->acc(1), nullptr);
+      return (i & 1) ? launch_apply<1>(e, e->d_s, e->d_t, e->d_r0, nullptr, nullptr, nullptr)
+                     : launch_apply<1>(e, e->d_p, e->d_v, e->d_r0, nullptr, nullptr, nullptr);
     }
     const double* xin = (i & 1) ? e->d_s : e->d_p;
     double* yo = (i & 1) ? e->d_t : e->d_v;

@@ -25,7 +25,7 @@ namespace cwr {
 
 constexpr int BLOCK = 256;          // 4 waves of 64
 constexpr int N_XCD = 8;            // MI355X: 8 XCDs, workgroups dealt round-robin over them
-constexpr int ACC_R0V = 0, ACC_TS = 1, ACC_TT = 2, ACC_R0T = 3, ACC_RR = 4, ACC_N = 5;
+constexpr int ACC_R0V = 0, ACC_TS = 1, ACC_TT = 2, ACC_R0T = 3, ACC_R0S = 4, ACC_RR = 5, ACC_N = 6;
 
 struct __attribute__((aligned(16))) FaceRec {
   int32_t nb;      // >= 0: local real cell id (owned or halo); < 0: ghost cell -1-nb (boundary, not in A)
@@ -35,8 +35,8 @@ struct __attribute__((aligned(16))) FaceRec {
 
 // Scalars of the batched BiCGSTAB (K independent systems sharing A), all on device so that a whole
 // batch of iterations can be enqueued without a host round trip.  acc is a ring of 3 slots:
-// iteration `it` accumulates into slot it%3, reads ||r||^2 of iteration it-1 from slot (it-1)%3,
-// and its last kernel clears slot (it+1)%3.
+// iteration `it` writes its inner products into slot it%3 and reads ||r||^2 of iteration it-1 from
+// slot (it-1)%3, so no kernel ever reads a row another kernel of the same iteration rewrites.
 struct SolverScalars {
   double* acc;       // [3][ACC_N][K]
   double* rho;       // [3][K]
@@ -65,10 +65,11 @@ template <int VW> __device__ __forceinline__ void stv(double* p, const double (&
   else { *p = v[0]; }
 }
 
-// Column-wise block reduction of NV = ND*VW per-thread partial sums into out[d*K + g*VW + w] with one
-// float64 atomic per column, dot and block.  Threads are laid out tid = r*G + g (row-in-block, lane
-// group); when G divides 64 the rows of a wave are folded with xor-shuffles (ds_bpermute-free DPP
-// path), otherwise through LDS.
+// Column-wise block reduction of NV = ND*VW per-thread partial sums.  The block's totals are STORED to
+// out[d*K + g*VW + w] (this block's private slot of a partials buffer): no atomics, so inner products
+// are bitwise reproducible; k_reduce_partials folds the slots in a fixed order afterwards.  Threads
+// are laid out tid = r*G + g (row-in-tile, lane group); when G divides 64 the rows of a wave are
+// folded with xor-shuffles (DPP / ds_bpermute class cross-lane ops), otherwise through LDS.
 template <int NV, int VW>
 __device__ __forceinline__ void block_reduce_cols(double (&val)[NV], int G, int K, double* out, double* lds) {
   const int tid = threadIdx.x;
@@ -81,7 +82,7 @@ __device__ __forceinline__ void block_reduce_cols(double (&val)[NV], int G, int 
     const int lane = tid & 63, wave = tid >> 6;
     if (lane < G) {
 #pragma unroll
-      for (int i = 0; i < NV; ++i) lds[(wave * 64 + lane) * NV + i] = val[i];
+      for (int i = 0; i < NV; ++i) lds[(wave * G + lane) * NV + i] = val[i];
     }
     __syncthreads();
     if (tid < G) {
@@ -91,8 +92,8 @@ __device__ __forceinline__ void block_reduce_cols(double (&val)[NV], int G, int 
         for (int w = 0; w < VW; ++w) {
           const int i = d * VW + w;
           double s = 0.0;
-          for (int wv = 0; wv < BLOCK / 64; ++wv) s += lds[(wv * 64 + tid) * NV + i];
-          atomicAdd(&out[d * K + tid * VW + w], s);
+          for (int wv = 0; wv < BLOCK / 64; ++wv) s += lds[(wv * G + tid) * NV + i];
+          out[d * K + tid * VW + w] = s;
         }
     }
   } else {
@@ -108,9 +109,45 @@ __device__ __forceinline__ void block_reduce_cols(double (&val)[NV], int G, int 
           const int i = d * VW + w;
           double s = 0.0;
           for (int r = 0; r < R; ++r) s += lds[(r * G + tid) * NV + i];
-          atomicAdd(&out[d * K + tid * VW + w], s);
+          out[d * K + tid * VW + w] = s;
         }
     }
+  }
+}
+
+// Second stage of every inner product: out[d][k] = sum over slots of partial[slot][d][k], slots folded in a
+// fixed order (strided per thread, then an LDS tree), one block per dot d.  `outs` holds the destination
+// row of each dot (they are not contiguous for the start-up residual: ||r||^2 and ||bhat||^2).
+struct ReduceOuts { double* p[4]; };
+constexpr int RBLOCK = 1024;
+__global__ void __launch_bounds__(RBLOCK) k_reduce_partials(int nslots, int ND, int K, const double* __restrict__ partial,
+                                                          ReduceOuts outs) {
+  __shared__ double sm[RBLOCK];
+  const int d = blockIdx.x;
+  double* out = outs.p[d];
+  if (out == nullptr) return;                   // uniform per block
+  const int S = RBLOCK / K;                     // slot lanes per column
+  const int tid = threadIdx.x;
+  const int k = tid % K, l = tid / K;
+  const size_t stride = (size_t)ND * K;
+  const double* base = partial + (size_t)d * K + k;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;   // four independent chains keep four loads in flight
+  if (l < S) {
+    int slot = l;
+    for (; slot + 3 * S < nslots; slot += 4 * S) {
+      s0 += base[(size_t)slot * stride];
+      s1 += base[(size_t)(slot + S) * stride];
+      s2 += base[(size_t)(slot + 2 * S) * stride];
+      s3 += base[(size_t)(slot + 3 * S) * stride];
+    }
+    for (; slot < nslots; slot += S) s0 += base[(size_t)slot * stride];
+  }
+  sm[tid] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (tid < K) {
+    double tot = 0.0;
+    for (int i = 0; i < S; ++i) tot += sm[i * K + tid];
+    out[tid] = tot;
   }
 }
 
@@ -215,113 +252,129 @@ __global__ void __launch_bounds__(BLOCK) k_rhs(
 // ------------------------------------------------------------------------------------------------ the operator
 // y[c,:] = diag[c]*x[c,:] + sum over the faces of c with a real neighbour of ( -d + min(a_c,0) ) * x[nb,:]
 // MODE 0  y = A x                                   (cwr_apply; parity against the oracle's csr @ x)
-// MODE 1  v = D^-1 A p ;            acc[R0V] += (r0, v)                       (BiCGSTAB, first product)
-// MODE 2  t = D^-1 A s ;            acc[TS,TT,R0T] += (t,s), (t,t), (r0,t)    (second product)
-// MODE 3  r = bhat - D^-1 A x ; r0 = p = r ; acc[RR] += (r,r) ; bb += (bhat,bhat)   (start / verify)
-// The face records of the block's cells are staged through LDS with one coalesced 16-B load per lane,
-// then every lane group walks its own cell's records from LDS (broadcast reads) and gathers the
-// neighbour rows from L2.
-// Dynamic LDS: [stage_cap FaceRec][reduction scratch]; stage_cap = the largest number of records any
-// block owns (computed on the host at create time), so blocks/CU is set by the real footprint.
-constexpr int RED_DOUBLES = BLOCK * 3 * 2;
+// MODE 1  v = D^-1 A p ;            partial[R0V] = (r0, v)                     (BiCGSTAB, first product)
+// MODE 2  t = D^-1 A s ;            partial[TS,TT,R0T,R0S] = (t,s), (t,t), (r0,t), (r0,s)   (second product)
+// MODE 3  r = bhat - D^-1 A x ; r0 = p = r ; partial = (r,r), (bhat,bhat)      (start / verify)
+//
+// Persistent grid, XCD-aware: the row tiles (TR = U*R rows each) are split into 8 contiguous ranges, one
+// per XCD (blockIdx % 8 names the XCD group under round-robin dispatch -- speed only), and the blocks of
+// an XCD sweep their range together, so the ~5 gathers of a cell row and the two visits of a face meet
+// in that XCD's L2.  Per tile the face records are staged through LDS with one coalesced 16-B load per
+// lane; each lane group then walks its rows' records from LDS (broadcast reads) and gathers the
+// neighbour rows.  Inner-product partials stay in registers across tiles and leave the block once.
+// Dynamic LDS: [stage_cap FaceRec][reduction scratch][TR + 1 row pointers].
+__host__ __device__ inline int red_doubles(int G, int VW) {     // scratch of block_reduce_cols for <= 4 dots
+  return ((64 % G) == 0 ? (BLOCK / 64) * G : BLOCK) * 4 * VW;
+}
 
 template <int VW, int MODE>
 __global__ void __launch_bounds__(BLOCK) k_apply(
-    int n_owned, int K, int G, int nblocks, int stage_cap, const int32_t* __restrict__ ptr,
+    int n_owned, int K, int G, int U, int ntiles, int stage_cap, const int32_t* __restrict__ ptr,
     const FaceRec* __restrict__ rec, const double* __restrict__ diag, const double* __restrict__ xin,
     double* __restrict__ yout, const double* __restrict__ r0, const double* __restrict__ bhat,
-    double* __restrict__ r0_out, double* __restrict__ p_out, double* __restrict__ acc,
-    double* __restrict__ bb) {
+    double* __restrict__ r0_out, double* __restrict__ p_out, double* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
   FaceRec* s_rec = reinterpret_cast<FaceRec*>(s_dyn);
   double* s_red = reinterpret_cast<double*>(s_dyn + (size_t)stage_cap * sizeof(FaceRec));
-  const int blk = xcd_remap(blockIdx.x, nblocks);
-  if (blk >= nblocks) return;                       // uniform per block: no barrier is skipped by part of a block
+  int32_t* s_ptr = reinterpret_cast<int32_t*>(s_red + red_doubles(G, VW));
   const int R = BLOCK / G;
+  const int TR = R * U;
   const int tid = threadIdx.x;
-  const int c0 = blk * R;
-  const int c1 = min(c0 + R, n_owned);
-  const int jb = ptr[c0], je = ptr[c1];
-  const bool staged = (je - jb) <= stage_cap;
-  if (staged) {
-    for (int j = jb + tid; j < je; j += BLOCK) s_rec[j - jb] = rec[j];
-  }
-  __syncthreads();
   const int r = tid / G, g = tid - r * G;
-  const int c = c0 + r;
-  const bool live = (r < R) && (c < c1);
-  constexpr int ND = (MODE == 1) ? 1 : (MODE == 2 ? 3 : (MODE == 3 ? 2 : 0));
-  double part[(ND > 0 ? ND : 1) * VW];
+  const int col = g * VW;
+  constexpr int ND = (MODE == 1) ? 1 : (MODE == 2 ? 4 : (MODE == 3 ? 2 : 0));
+  constexpr int NP = (ND > 0 ? ND : 1) * VW;
+  double part[NP];
 #pragma unroll
-  for (int i = 0; i < (ND > 0 ? ND : 1) * VW; ++i) part[i] = 0.0;
-  if (live) {
-    const int col = g * VW;
-    const size_t o = (size_t)c * K + col;
-    double xc[VW], sum[VW];
-    ldv<VW>(xin + o, xc);
-    const double dg = diag[c];
-#pragma unroll
-    for (int w = 0; w < VW; ++w) sum[w] = 0.0;
-    const int j0 = ptr[c], j1 = ptr[c + 1];
-    for (int j = j0; j < j1; ++j) {
-      const FaceRec fr = staged ? s_rec[j - jb] : rec[j];
-      if (fr.nb >= 0) {
-        const double off = fmin((double)fr.a_c, 0.0) - fr.d;
-        double xn[VW];
-        ldv<VW>(xin + (size_t)fr.nb * K + col, xn);
-#pragma unroll
-        for (int w = 0; w < VW; ++w) sum[w] += off * xn[w];
-      }
+  for (int i = 0; i < NP; ++i) part[i] = 0.0;
+
+  const int xcd = blockIdx.x % N_XCD, lidx = blockIdx.x / N_XCD, bpx = gridDim.x / N_XCD;
+  const int tpx = (ntiles + N_XCD - 1) / N_XCD;
+  for (int i = lidx; i < tpx; i += bpx) {
+    const int tile = xcd * tpx + i;
+    if (tile >= ntiles) break;                      // uniform per block
+    const int c0 = tile * TR;
+    const int c1 = min(c0 + TR, n_owned);
+    __syncthreads();                                // previous tile's readers are done with the LDS images
+    for (int q = tid; q <= c1 - c0; q += BLOCK) s_ptr[q] = ptr[c0 + q];
+    __syncthreads();
+    const int jb = s_ptr[0], je = s_ptr[c1 - c0];
+    const bool staged = (je - jb) <= stage_cap;
+    if (staged) {
+      for (int j = jb + tid; j < je; j += BLOCK) s_rec[j - jb] = rec[j];
     }
-    double y[VW];
-    if constexpr (MODE == 0) {
+    __syncthreads();
+    if (r < R) {
+      for (int c = c0 + r; c < c1; c += R) {
+        const size_t o = (size_t)c * K + col;
+        double xc[VW], sum[VW], q0[VW];
+        ldv<VW>(xin + o, xc);
+        const double dg = diag[c];
+        if constexpr (MODE == 1 || MODE == 2) ldv<VW>(r0 + o, q0);
+        if constexpr (MODE == 3) ldv<VW>(bhat + o, q0);
 #pragma unroll
-      for (int w = 0; w < VW; ++w) y[w] = dg * xc[w] + sum[w];
-      stv<VW>(yout + o, y);
-    } else {
+        for (int w = 0; w < VW; ++w) sum[w] = 0.0;
+        const int j0 = s_ptr[c - c0], j1 = s_ptr[c - c0 + 1];
+        for (int j = j0; j < j1; j += 4) {
+          // up to four faces at a time: all neighbour-row gathers are issued before the first is consumed
+          FaceRec fr[4];
+          double xn[4][VW];
 #pragma unroll
-      for (int w = 0; w < VW; ++w) y[w] = xc[w] + sum[w] / dg;
-      if constexpr (MODE == 1) {
-        double q[VW]; ldv<VW>(r0 + o, q);
-        stv<VW>(yout + o, y);
+          for (int u = 0; u < 4; ++u) {
+            if (j + u < j1) fr[u] = staged ? s_rec[j + u - jb] : rec[j + u];
+            else fr[u].nb = -1;
+          }
 #pragma unroll
-        for (int w = 0; w < VW; ++w) part[w] = q[w] * y[w];
-      } else if constexpr (MODE == 2) {
-        double q[VW]; ldv<VW>(r0 + o, q);
-        stv<VW>(yout + o, y);
+          for (int u = 0; u < 4; ++u) {
+            if (fr[u].nb >= 0) ldv<VW>(xin + (size_t)fr[u].nb * K + col, xn[u]);
+          }
 #pragma unroll
-        for (int w = 0; w < VW; ++w) {
-          part[0 * VW + w] = y[w] * xc[w];
-          part[1 * VW + w] = y[w] * y[w];
-          part[2 * VW + w] = q[w] * y[w];
+          for (int u = 0; u < 4; ++u) {
+            if (fr[u].nb >= 0) {
+              const double off = fmin((double)fr[u].a_c, 0.0) - fr[u].d;
+#pragma unroll
+              for (int w = 0; w < VW; ++w) sum[w] += off * xn[u][w];
+            }
+          }
         }
-      } else {  // MODE 3
-        double bh[VW]; ldv<VW>(bhat + o, bh);
-        double res[VW];
+        double y[VW];
+        if constexpr (MODE == 0) {
 #pragma unroll
-        for (int w = 0; w < VW; ++w) res[w] = bh[w] - y[w];
-        stv<VW>(yout + o, res);
-        stv<VW>(r0_out + o, res);
-        stv<VW>(p_out + o, res);
+          for (int w = 0; w < VW; ++w) y[w] = dg * xc[w] + sum[w];
+          stv<VW>(yout + o, y);
+        } else {
 #pragma unroll
-        for (int w = 0; w < VW; ++w) { part[0 * VW + w] = res[w] * res[w]; part[1 * VW + w] = bh[w] * bh[w]; }
+          for (int w = 0; w < VW; ++w) y[w] = xc[w] + sum[w] / dg;
+          if constexpr (MODE == 1) {
+            stv<VW>(yout + o, y);
+#pragma unroll
+            for (int w = 0; w < VW; ++w) part[w] += q0[w] * y[w];
+          } else if constexpr (MODE == 2) {
+            stv<VW>(yout + o, y);
+#pragma unroll
+            for (int w = 0; w < VW; ++w) {
+              part[0 * VW + w] += y[w] * xc[w];
+              part[1 * VW + w] += y[w] * y[w];
+              part[2 * VW + w] += q0[w] * y[w];
+              part[3 * VW + w] += q0[w] * xc[w];
+            }
+          } else {  // MODE 3
+            double res[VW];
+#pragma unroll
+            for (int w = 0; w < VW; ++w) res[w] = q0[w] - y[w];
+            stv<VW>(yout + o, res);
+            stv<VW>(r0_out + o, res);
+            stv<VW>(p_out + o, res);
+#pragma unroll
+            for (int w = 0; w < VW; ++w) { part[0 * VW + w] += res[w] * res[w]; part[1 * VW + w] += q0[w] * q0[w]; }
+          }
+        }
       }
     }
   }
-  if constexpr (MODE == 1) {
-    block_reduce_cols<1 * VW, VW>(part, G, K, acc + ACC_R0V * K, s_red);
-  } else if constexpr (MODE == 2) {
-    // TS, TT, R0T are consecutive slots
-    block_reduce_cols<3 * VW, VW>(part, G, K, acc + ACC_TS * K, s_red);
-  } else if constexpr (MODE == 3) {
-    double p1[VW], p2[VW];
-#pragma unroll
-    for (int w = 0; w < VW; ++w) { p1[w] = part[w]; p2[w] = part[VW + w]; }
-    block_reduce_cols<VW, VW>(p1, G, K, acc + ACC_RR * K, s_red);
-    if (bb != nullptr) {                 // first residual of a step only; restarts / verification keep bb
-      __syncthreads();
-      block_reduce_cols<VW, VW>(p2, G, K, bb, s_red);
-    }
+  if constexpr (ND > 0) {
+    __syncthreads();
+    block_reduce_cols<NP, VW>(part, G, K, partial + (size_t)blockIdx.x * ND * K, s_red);
   }
 }
 
@@ -398,15 +451,17 @@ __global__ void __launch_bounds__(BLOCK) k_vec_s(
 }
 
 // omega = (t,s)/(t,t); x += alpha p + omega s; r = s - omega t;
-// rho' = rho - alpha (r0,v) - omega (r0,t)   [= (r0, r') by linearity, no extra reduction];
+// rho' = (r0,s) - omega (r0,t)   [= (r0, r') by linearity, from two TRUE inner products of the second
+// product's launch: the textbook shortcut rho - alpha (r0,v) - omega (r0,t) accumulates the rounding of
+// every earlier rho and stalls the iteration once r is nearly orthogonal to r0];
 // beta = (rho'/rho)(alpha/omega); p = r + beta (p - omega v); acc[RR] += (r', r').
-// Block 0 also publishes rho', clears the next accumulator slot and keeps the counters.
+// Block 0 also publishes rho' and keeps the counters.
 template <int VW>
 __global__ void __launch_bounds__(BLOCK) k_vec_x(
     int n_owned, int K, int G, double* __restrict__ x, double* __restrict__ r, double* __restrict__ p,
     const double* __restrict__ s, const double* __restrict__ t, const double* __restrict__ v,
-    const double* __restrict__ rho, double* __restrict__ rho_next, double* __restrict__ acc_cur,
-    double* __restrict__ acc_next, const double* __restrict__ rr_prev, const double* __restrict__ bb,
+    const double* __restrict__ rho, double* __restrict__ rho_next, const double* __restrict__ acc_cur,
+    double* __restrict__ partial, const double* __restrict__ rr_prev, const double* __restrict__ bb,
     double tol2, int32_t* __restrict__ counters) {
   __shared__ double s_red[BLOCK * 2];
   const int R = BLOCK / G;
@@ -421,10 +476,11 @@ __global__ void __launch_bounds__(BLOCK) k_vec_x(
       const bool act = col_active(rr_prev, bb, tol2, k);
       const double r0v = acc_cur[ACC_R0V * K + k], ts = acc_cur[ACC_TS * K + k];
       const double tt = acc_cur[ACC_TT * K + k], r0t = acc_cur[ACC_R0T * K + k];
+      const double r0s = acc_cur[ACC_R0S * K + k];
       const double rh = rho[k];
       const double al = (act && r0v != 0.0) ? rh / r0v : 0.0;
       const double om = (act && tt > 0.0) ? ts / tt : 0.0;
-      const double rh2 = rh - al * r0v - om * r0t;
+      const double rh2 = r0s - om * r0t;
       alpha[w] = al; omega[w] = om;
       beta[w] = (act && om != 0.0 && rh != 0.0) ? (rh2 / rh) * (al / om) : 0.0;
     }
@@ -442,7 +498,7 @@ __global__ void __launch_bounds__(BLOCK) k_vec_x(
       stv<VW>(x + o, xv); stv<VW>(r + o, rv); stv<VW>(p + o, pv);
     }
   }
-  block_reduce_cols<VW, VW>(part, G, K, acc_cur + ACC_RR * K, s_red);
+  block_reduce_cols<VW, VW>(part, G, K, partial + (size_t)blockIdx.x * K, s_red);
   if (blockIdx.x == 0) {
     const int tid = threadIdx.x;
     if (tid < K) {
@@ -450,11 +506,12 @@ __global__ void __launch_bounds__(BLOCK) k_vec_x(
       const bool act = col_active(rr_prev, bb, tol2, k);
       const double r0v = acc_cur[ACC_R0V * K + k], ts = acc_cur[ACC_TS * K + k];
       const double tt = acc_cur[ACC_TT * K + k], r0t = acc_cur[ACC_R0T * K + k];
+      const double r0s = acc_cur[ACC_R0S * K + k];
       const double rh = rho[k];
       const double al = (act && r0v != 0.0) ? rh / r0v : 0.0;
       const double om = (act && tt > 0.0) ? ts / tt : 0.0;
-      const double rh2 = rh - al * r0v - om * r0t;
-      rho_next[k] = rh2;
+      const double rh2 = r0s - om * r0t;
+      rho_next[k] = act ? rh2 : rh;
       if (act && (r0v == 0.0 || om == 0.0 || rh2 == 0.0)) counters[1] = 1;        // (near-)breakdown: host restarts
       if (act && !(fabs(rh2) < 1.0e300 && fabs(al) < 1.0e300)) counters[3] = 1;  // NaN / Inf
     }
@@ -463,7 +520,6 @@ __global__ void __launch_bounds__(BLOCK) k_vec_x(
       for (int k = 0; k < K; ++k) any = any || col_active(rr_prev, bb, tol2, k);
       if (any) counters[0] += 1;
     }
-    for (int i = tid; i < ACC_N * K; i += BLOCK) acc_next[i] = 0.0;
   }
 }
 

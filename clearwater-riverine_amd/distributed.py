@@ -1,0 +1,84 @@
+"""One process per GPU: the partitioned transport engine and its control plane.
+
+Data path: every rank owns a contiguous range of real cells (partition.py); operator inputs are
+completed by a neighbour halo exchange (RCCL ncclSend/ncclRecv grouped on the engine's stream, over the
+direct xGMI links) and inner products by ncclAllReduce -- both issued from the C++ solver loop
+(csrc/cwr_engine.hip), never from Python.  Control plane (rendezvous, broadcast of the RCCL unique id,
+barriers, gathering results): torch.distributed, any backend.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from .engine import TransportEngine
+from .model import face_to_face_distance, change_in_time
+from .partition import LocalMesh, partition_mesh, slice_fields
+
+
+def env_rank_world():
+    return int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('LOCAL_RANK', '0'))
+
+
+def broadcast_bytes(payload: bytes | None, nbytes: int, src: int = 0) -> bytes:
+    """Broadcast a small byte string over the default torch.distributed group (CPU or GPU backend)."""
+    import torch
+    import torch.distributed as dist
+    dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+    t = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    if dist.get_rank() == src:
+        t.copy_(torch.frombuffer(bytearray(payload), dtype=torch.uint8))
+    dist.broadcast(t, src=src)
+    return bytes(t.cpu().numpy().tobytes())
+
+
+class PartitionedTransport:
+    """The transport engine of one rank of a domain-decomposed run.  With world == 1 it is exactly the
+    single-GPU engine (no halo, no communicator)."""
+
+    def __init__(self, mesh: dict, inputs3: np.ndarray, rank: int, world: int, device: int = 0,
+                 unique_id: bytes | None = None):
+        f1 = np.asarray(mesh['edges_face1'])
+        f2 = np.asarray(mesh['edges_face2'])
+        n = int(f1.max()) + 1
+        self.n_global = n
+        self.K = int(inputs3.shape[2])
+        self.local: LocalMesh = partition_mesh(f1, f2, n, world, rank)
+        lm = self.local
+        dist_e = mesh.get('face_to_face_dist')
+        if dist_e is None:
+            dist_e = face_to_face_distance(mesh)
+        dt = mesh.get('dt')
+        if dt is None:
+            dt = change_in_time(mesh['time_seconds'] if 'time_seconds' in mesh else mesh['time'])
+        fields = slice_fields(lm, mesh, np.asarray(dist_e))
+        self.engine = TransportEngine(lm.face1, lm.face2, lm.n_cells, self.K, n_owned=lm.n_owned,
+                                      n_halo=lm.n_halo, device=device)
+        self.engine.load_flow_field(fields['face_flow'], fields['edge_velocity'], fields['volume'], dt,
+                                    fields['face_to_face_dist'], float(mesh['diffusion_coefficient']))
+        ghost_global = lm.cell_global[lm.n_real:]
+        self.engine.load_boundary(np.ascontiguousarray(inputs3[:, ghost_global, :]))
+        if world > 1:
+            if unique_id is None:
+                raise ValueError('world > 1 needs the RCCL unique id broadcast from rank 0')
+            self.engine.attach_comm(rank, world, unique_id, lm.peers, lm.send_ptr, lm.send_cells, lm.recv_ptr)
+        # initial condition of the owned cells (row 0 of input_array, constituents.py:94-98)
+        self.engine.set_state(np.ascontiguousarray(inputs3[0, lm.lo:lm.hi, :]))
+
+    def step(self, t: int, **kw):
+        return self.engine.step(t, **kw)
+
+    def owned_state(self) -> np.ndarray:
+        return self.engine.get_state()[: self.local.n_owned]
+
+    def gather_state(self) -> np.ndarray:
+        """(n_global, K) concentrations of all real cells on every rank (control-plane all_gather)."""
+        mine = self.owned_state()
+        if self.local.world == 1:
+            return mine
+        import torch
+        import torch.distributed as dist
+        parts = [None] * self.local.world
+        dist.all_gather_object(parts, mine)
+        return np.concatenate(parts, axis=0)
