@@ -1,0 +1,159 @@
+"""GPU tests (through the C ABI): committed golden outputs, error behaviour mirroring the reference,
+size-independent properties at large sizes, run-to-run reproducibility."""
+import os
+
+import numpy as np
+import pytest
+
+import cwr_oracle as oracle
+from util import GOLDEN, load_plan, rel_err
+from test_gpu_parity import make_engine, synthetic_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('plan', ['plan01', 'plan02', 'plan03'])
+def test_against_committed_golden_outputs(gpu_lib, plan):
+    """HIP path vs tests/golden/*_expected.npz (oracle outputs on the reference's HDF fixtures)."""
+    import clearwater_riverine_amd as cw
+    exp = np.load(os.path.join(GOLDEN, f'{plan}_expected.npz'))
+    D, steps = float(exp['diffusion_coefficient']), int(exp['steps'])
+    mesh, inp, _ = load_plan(plan, D)
+    model = cw.ClearwaterRiverine(mesh=dict(mesh), diffusion_coefficient_input=D, input_arrays={'c': inp.copy()})
+    for _ in range(steps):
+        model.update()
+    assert rel_err(model.mesh['c'][:steps + 1], exp['state']) <= 1e-9
+    assert rel_err(model.constituent_dict['c'].advection_mass_flux[:steps], exp['advection_mass_flux']) <= 1e-8
+    assert rel_err(model.constituent_dict['c'].diffusion_mass_flux[:steps], exp['diffusion_mass_flux']) <= 1e-8
+    adv, dif = model.coefficients(3)
+    assert np.array_equal(adv, exp['advection_coeff'][3]) and np.array_equal(dif, exp['coeff_to_diffusion'][3])
+
+
+def test_zero_coefficient_on_active_ghost_face_raises_value_error(gpu_lib):
+    """Mirrors the reference's shape-mismatch ValueError (linalg.py:349-351) for rhs() and step()."""
+    import clearwater_riverine_amd as cw
+    mesh, inputs3 = synthetic_case(1, nx=8, ny=5, n_steps=3, seed=1)
+    f2 = mesh['edges_face2']
+    inlet_faces = np.nonzero(np.isin(f2, mesh['inlet_ghost_cells']))[0]
+    flow = mesh['face_flow'].copy()
+    flow[2, inlet_faces[:2]] = 0.0                       # advection_coeff becomes 0 while velocity stays < 0
+    n = mesh['nreal'] + 1
+    eng = cw.TransportEngine(mesh['edges_face1'], f2, len(mesh['face_x']), 1)
+    eng.load_flow_field(flow, mesh['edge_velocity'], mesh['volume'], mesh['dt'], mesh['face_to_face_dist'], 0.1)
+    eng.load_boundary(inputs3[:, n:, :])
+    eng.set_state(np.ones((n, 1)))
+    with pytest.raises(ValueError, match='ghost face'):
+        eng.rhs(1, np.ones((n, 1)))
+    with pytest.raises(ValueError, match='ghost face'):
+        eng.step(1)
+    eng.step(0)                                           # level 1 boundary terms are fine
+
+
+def test_call_order_and_range_errors(gpu_lib):
+    import clearwater_riverine_amd as cw
+    mesh, inputs3 = synthetic_case(2, nx=6, ny=4, n_steps=2, seed=0)
+    n = mesh['nreal'] + 1
+    eng = cw.TransportEngine(mesh['edges_face1'], mesh['edges_face2'], len(mesh['face_x']), 2)
+    with pytest.raises(IndexError, match='no flow field'):
+        eng.step(0)
+    eng.load_flow_field(mesh['face_flow'], mesh['edge_velocity'], mesh['volume'], mesh['dt'], mesh['face_to_face_dist'], 0.1)
+    with pytest.raises(IndexError, match='boundary'):
+        eng.step(0)
+    eng.load_boundary(inputs3[:, n:, :])
+    with pytest.raises(IndexError, match='out of range'):
+        eng.step(2)                                       # needs level 3
+    with pytest.raises(ValueError):
+        eng.set_state(np.ones((n + 1, 2)))                # wrapper shape check
+    with pytest.raises(ValueError):
+        eng.step(0, tol=0.0)
+
+
+def test_not_converged_is_reported(gpu_lib):
+    import clearwater_riverine_amd as cw
+    mesh, inputs3 = synthetic_case(1, nx=40, ny=20, n_steps=2, seed=2)
+    eng = make_engine(mesh, inputs3)
+    eng.set_state(inputs3[0, :mesh['nreal'] + 1, :])
+    with pytest.raises(cw.SolverNotConverged):
+        eng.step(0, tol=1e-14, max_iter=3)
+
+
+def test_nan_state_is_reported_not_looped(gpu_lib):
+    mesh, inputs3 = synthetic_case(1, nx=10, ny=6, n_steps=2, seed=2)
+    eng = make_engine(mesh, inputs3)
+    x = inputs3[0, :mesh['nreal'] + 1, :].copy()
+    x[3] = np.nan
+    eng.set_state(x)
+    with pytest.raises(FloatingPointError):
+        eng.step(0)
+
+
+def test_load_coefficients_route_equals_device_derivation(gpu_lib):
+    """cwr_load_coefficients (the reference's already-derived Dataset variables) == cwr_load_flow_field."""
+    import clearwater_riverine_amd as cw
+    mesh, inputs3 = synthetic_case(3, nx=16, ny=9, n_steps=4, seed=8, n_merge=10)
+    n = mesh['nreal'] + 1
+    a = make_engine(mesh, inputs3)
+    b = cw.TransportEngine(mesh['edges_face1'], mesh['edges_face2'], len(mesh['face_x']), 3)
+    b.load_coefficients(mesh['advection_coeff'], mesh['coeff_to_diffusion'], mesh['edge_velocity'], mesh['volume'],
+                        mesh['dt'], mesh['diffusion_coefficient'])
+    b.load_boundary(inputs3[:, n:, :])
+    for e in (a, b):
+        e.set_state(inputs3[0, :n, :])
+        for t in range(3):
+            e.step(t)
+    assert np.array_equal(a.get_state(), b.get_state(), equal_nan=True)
+
+
+def test_run_to_run_bitwise_reproducible(gpu_lib):
+    """Inner products are reduced in a fixed order (no float atomics): two runs agree bit for bit."""
+    mesh, inputs3 = synthetic_case(4, nx=120, ny=50, n_steps=3, seed=6, n_merge=200)
+    n = mesh['nreal'] + 1
+    outs = []
+    for _ in range(2):
+        eng = make_engine(mesh, inputs3)
+        eng.set_state(inputs3[0, :n, :])
+        for t in range(3):
+            eng.step(t)
+        outs.append(eng.get_state())
+        eng.close()
+    assert np.array_equal(outs[0], outs[1], equal_nan=True)
+
+
+@pytest.mark.parametrize('K', [1, 16])
+def test_full_size_properties_1m_cells(gpu_lib, K):
+    """BASELINE.json's 1 M-cell mesh: size-independent properties instead of a direct solve.
+    (i) linearity of the operator, (ii) the solve's true residual, (iii) constant-state preservation rows:
+    A.1 = V[t+1]/dt + net outflow, (iv) scaling invariance across constituents."""
+    import clearwater_riverine_amd as cw
+    mesh = cw.synthetic.make_mesh(1000, 1000, 2, seed=4, dt=40.0, diffusion_coefficient=0.5)
+    inputs3 = cw.synthetic.boundary_input_array(mesh, K)
+    n = mesh['nreal'] + 1
+    from clearwater_riverine_amd.model import face_to_face_distance, change_in_time
+    mesh['face_to_face_dist'] = face_to_face_distance(mesh)
+    mesh['dt'] = change_in_time(mesh['time_seconds'])
+    eng = make_engine(mesh, inputs3)
+    rng = np.random.default_rng(0)
+    x1, x2 = rng.standard_normal((n, K)), rng.standard_normal((n, K))
+    y1, y2, y12 = eng.apply(0, x1), eng.apply(0, x2), eng.apply(0, 2.0 * x1 - 3.0 * x2)
+    assert np.max(np.abs(y12 - (2.0 * y1 - 3.0 * y2))) <= 1e-12 * np.max(np.abs(y1))
+    # row sums against an independent numpy evaluation from the raw fields
+    adv, dif = eng.get_coefficients(0)
+    f1, f2 = mesh['edges_face1'].astype(np.int64), mesh['edges_face2'].astype(np.int64)
+    a = adv.astype(np.float64)
+    internal = f2 < n
+    rows = mesh['volume'][1, :n].astype(np.float64) / mesh['dt'][0]
+    rows += np.bincount(f1, weights=np.where(internal, a, np.maximum(a, 0.0) + dif), minlength=n)
+    rows -= np.bincount(f2[internal], weights=a[internal], minlength=n)
+    ones = eng.apply(0, np.ones((n, K)))
+    assert np.max(np.abs(ones[:, 0] - rows)) <= 1e-11 * np.max(np.abs(rows))
+    # one implicit step: residual of the returned state, through the exported operator and right-hand side
+    x0 = inputs3[0, :n, :]
+    eng.set_state(x0)
+    b = eng.rhs(0, x0)
+    res = eng.step(0, tol=1e-12)
+    xs = eng.get_state()[:n]
+    r = b - eng.apply(0, xs)
+    assert np.max(np.linalg.norm(r, axis=0) / np.linalg.norm(b, axis=0)) <= 1e-10
+    assert res.iterations < 100
+    if K > 1:                                              # constituent k is (k+1) x constituent 0
+        assert np.max(np.abs(xs[:, K - 1] - K * xs[:, 0])) <= 1e-9 * np.max(np.abs(xs[:, K - 1]))

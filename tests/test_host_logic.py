@@ -1,0 +1,89 @@
+"""CPU tests of the host-side logic around the C ABI (no GPU compute)."""
+import os
+
+import numpy as np
+import pandas as pd
+
+import cwr_oracle as oracle
+from util import GOLDEN, load_plan
+
+
+def test_host_part_of_coefficient_derivation_matches_oracle():
+    from clearwater_riverine_amd.model import face_to_face_distance, change_in_time
+    mesh, _, _ = load_plan('plan01', 0.01)
+    assert np.array_equal(face_to_face_distance(mesh), mesh['face_to_face_dist'])
+    dt = change_in_time(mesh['time_seconds'])
+    assert np.array_equal(dt[:-1], mesh['dt'][:-1]) and np.isnan(dt[-1])
+    stamps = np.array(['2023-01-01T12:00:00', '2023-01-01T12:05:00', '2023-01-01T12:10:00'], dtype='datetime64[ns]')
+    assert np.array_equal(change_in_time(stamps)[:2], [300.0, 300.0])
+
+
+def test_input_array_from_the_reference_csv_data(tmp_path):
+    """constituents.py:78-164 on the reference's own CSV data (plan02): IC row 0, BC in ghost cells 4 and 6."""
+    from clearwater_riverine_amd.model import Mesh, input_array_from_csv
+    z = np.load(os.path.join(GOLDEN, 'plan02_inputs.npz'))
+    ic = tmp_path / 'ic.csv'
+    bc = tmp_path / 'bc.csv'
+    pd.DataFrame({'Cell_Index': z['ic_cell_index'], 'Concentration': z['ic_concentration']}).to_csv(ic, index=False)
+    pd.DataFrame({'RAS2D_TS_Name': z['bc_csv_name'], 'Datetime': z['bc_csv_datetime'],
+                  'Concentration': z['bc_csv_concentration']}).to_csv(bc, index=False)
+    secs = oracle.parse_ras_stamps(z['time_stamps'])
+    time = np.datetime64('2023-01-01T12:00:00') + (secs * 1e9).astype('timedelta64[ns]')
+    mesh = Mesh({'time': time, 'face_x': z['face_x'], 'edges_face2': z['edges_face2']})
+    faces = {str(nm): [int(f) for f, l in zip(z['bc_face_index'], z['bc_face_line']) if l == i]
+             for i, nm in enumerate(z['bc_line_names'])}
+    arr = input_array_from_csv(mesh, str(ic), str(bc), faces)
+    assert arr.shape == (25, 8)
+    assert np.all(arr[0, :2] == 100.0)
+    assert np.all(arr[:, 4] == 100.0) and np.all(arr[:, 6] == 100.0)
+    assert np.all(arr[1:, [0, 1, 2, 3, 5, 7]] == 0.0)
+    _, want, _ = load_plan('plan02', 0.01)
+    assert np.array_equal(arr, want)
+
+
+def test_synthetic_mesh_has_the_reference_surface_and_discrete_continuity():
+    import clearwater_riverine_amd as cw
+    m = cw.synthetic.make_mesh(30, 12, 10, seed=2, n_merge=40, n_dry=3)
+    n = m['nreal'] + 1
+    f1, f2 = m['edges_face1'], m['edges_face2']
+    assert f1.dtype == np.int32 and m['face_flow'].dtype == np.float32 and m['volume'].dtype == np.float32
+    assert f1.max() == m['nreal'] and f1.min() >= 0                     # face1 always real (io/hdf.py:268)
+    ghosts = f2[f2 > m['nreal']]
+    assert len(np.unique(ghosts)) == len(ghosts)                        # one ghost cell per perimeter face
+    assert len(m['face_x']) == n + len(ghosts)
+    assert n == 30 * 12 - 40
+    deg = np.bincount(np.concatenate([f1, f2[f2 <= m['nreal']]]), minlength=n)
+    assert set(np.unique(deg)) >= {4, 6}                                # mixed cell degrees
+    assert np.count_nonzero(m['volume'][0, :n] == 0) == 3               # the dry cells (dummy-diagonal rows)
+    # discrete continuity of the float32 field to float32 rounding (mesh without dry cells)
+    m = cw.synthetic.make_mesh(30, 12, 10, seed=2, n_merge=40)
+    f1, f2 = m['edges_face1'], m['edges_face2']
+    dt = np.diff(m['time_seconds'])[0]
+    wet = m['volume'][0, :n] > 0
+    for t in (0, 5):
+        a = m['face_flow'][t].astype(np.float64)
+        div = np.bincount(f1, weights=a, minlength=n)
+        internal = f2 <= m['nreal']
+        div -= np.bincount(f2[internal], weights=a[internal], minlength=n)
+        dv = m['volume'][t + 1, :n].astype(np.float64) - m['volume'][t, :n].astype(np.float64)
+        assert np.max(np.abs(dv + dt * div)[wet]) <= 2e-4 * np.max(m['volume'][t, :n])
+    assert np.all(m['edge_velocity'][m['face_flow'] == 0] == 0)         # walls: zero flow, zero velocity
+
+
+def test_boundary_input_array_convention():
+    import clearwater_riverine_amd as cw
+    m = cw.synthetic.make_mesh(10, 6, 4, seed=0)
+    arr = cw.synthetic.boundary_input_array(m, 3)
+    n = m['nreal'] + 1
+    assert arr.shape == (5, len(m['face_x']), 3)
+    assert np.all(arr[0, :n, 1] == 2.0) and np.all(arr[1:, :n] == 0.0)
+    assert np.all(arr[:, m['inlet_ghost_cells'], 0] > 0)
+    assert np.all(arr[:, m['wall_ghost_cells']] == 0)                    # zero = "no boundary value"
+
+
+def test_mesh_attribute_surface():
+    from clearwater_riverine_amd.model import Mesh
+    m = Mesh({'volume': np.zeros(3)})
+    m.attrs['nreal'] = 2
+    m.attrs['diffusion_coefficient'] = 0.1
+    assert m.nreal == 2 and m.diffusion_coefficient == 0.1 and m.volume.shape == (3,)
