@@ -97,7 +97,7 @@ struct cwr_engine {
   bool profiling = false;
   int64_t prof_launches = 0;
   double prof_us = 0.0;
-  int last_iters = 0;
+  int last_iters = 0, last_sweeps = 0, jacobi_limit = 400;
   std::string err;
 
   double* acc(int slot) const { return d_scal + (size_t)slot * ACC_N * K; }
@@ -288,6 +288,136 @@ int alloc_flow(cwr_engine* e, int T) {
   return CWR_OK;
 }
 
+struct SolveStats {
+  int iterations = 0, sweeps = 0, restarts = 0, launches = 0, status = CWR_OK;
+  double max_rel = 0.0;
+};
+
+// Fully fused Jacobi sweeps x <- x + (bhat - D^-1 A x): one operator launch (and, partitioned, one halo
+// exchange) per sweep, no inner products between checks.  ||x' - x|| of a sweep is the scaled residual of
+// its input, so the check after a batch is exact.  The measured contraction predicts the sweeps still
+// needed; when that exceeds what BiCGSTAB would cost (stiff steps: large CFL), or the residual grows,
+// the caller switches to BiCGSTAB from the current iterate.
+int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveStats& st, bool& need_bicg) {
+  const int K = e->K;
+  need_bicg = false;
+  std::vector<double> h(2 * (size_t)K);
+  double* d_rr = e->acc(0) + ACC_RR * K;      // device rows for the two reduced inner products
+  double* d_bb = e->bb();
+  double prev_worst = -1.0;
+  int prev_sweeps = 0;
+  int batch = (e->last_sweeps > 0) ? std::max(2, (e->last_sweeps - 1) & ~1) : 8;
+  const int sweep_limit = forced ? max_iter : std::min(max_iter, e->jacobi_limit);
+  for (;;) {
+    batch = std::max(2, std::min(batch, 64)) & ~1;                     // even: the result lands in the state vector
+    for (int i = 0; i < batch; ++i) {
+      double* src = (i & 1) ? e->d_p : e->d_c;
+      double* dst = (i & 1) ? e->d_c : e->d_p;
+      TRY(exchange_halo(e, src));
+      TRY(launch_apply<4>(e, src, dst, nullptr, e->d_b, nullptr, nullptr));
+    }
+    st.sweeps += batch; st.launches += batch;
+    TRY(reduce_partials(e, e->apply_grid, 2, d_rr, d_bb));
+    TRY(allreduce(e, d_rr, K));
+    TRY(allreduce(e, d_bb, K));
+    TRY(download(e, h.data(), d_rr, (size_t)K));
+    TRY(download(e, h.data() + K, d_bb, (size_t)K));
+    bool ok = true;
+    double worst = 0.0;                                                   // max over columns of rr / (tol^2 bb)
+    st.max_rel = 0.0;
+    for (int k = 0; k < K; ++k) {
+      const double rr = h[k], bb = h[K + k];
+      if (!std::isfinite(rr) || !std::isfinite(bb)) { st.status = CWR_ERR_NONFINITE; return CWR_ERR_NONFINITE; }
+      st.max_rel = std::max(st.max_rel, bb > 0.0 ? std::sqrt(rr / bb) : (rr > 0.0 ? (double)INFINITY : 0.0));
+      if (rr > tol2 * bb) ok = false;
+      worst = std::max(worst, bb > 0.0 ? rr / (tol2 * bb) : (rr > 0.0 ? (double)INFINITY : 0.0));
+    }
+    if (ok) { e->last_sweeps = st.sweeps; return CWR_OK; }
+    if (st.sweeps >= sweep_limit) {
+      if (forced || sweep_limit >= max_iter) { st.status = CWR_ERR_NOT_CONVERGED; return CWR_ERR_NOT_CONVERGED; }
+      need_bicg = true; e->last_sweeps = 0; return CWR_OK;
+    }
+    // contraction per sweep from the last two checks (worst is a squared, normalised residual)
+    int predicted = 16;
+    if (prev_worst > 0.0 && std::isfinite(worst)) {
+      const double rate = std::pow(worst / prev_worst, 0.5 / (st.sweeps - prev_sweeps));
+      if (!(rate < 1.0)) {                                               // stalled or diverging
+        if (forced) { predicted = 64; } else { need_bicg = true; e->last_sweeps = 0; return CWR_OK; }
+      } else {
+        predicted = (int)std::ceil(0.5 * std::log(worst) / -std::log(rate)) + 1;
+        if (!forced && st.sweeps + predicted > e->jacobi_limit) { need_bicg = true; e->last_sweeps = 0; return CWR_OK; }
+      }
+    }
+    prev_worst = worst; prev_sweeps = st.sweeps;
+    batch = std::min(predicted + (predicted & 1), std::max(2, sweep_limit - st.sweeps));
+  }
+}
+
+int solve_bicgstab(cwr_engine* e, double tol2, int max_iter, SolveStats& st) {
+  const int K = e->K;
+  std::vector<double> h_scal(e->scal_count());
+  int32_t h_cnt[8];
+  int total_it = 0, restarts = 0, launches = 0, status = CWR_OK;
+  double max_rel = st.max_rel;
+  bool converged = false;
+  HIP_TRY(e, hipMemsetAsync(e->d_scal, 0, e->scal_count() * sizeof(double), e->stream));
+  for (int round = 0; !converged; ++round) {
+    // (re)start: true residual of the current x; r0 = p = r
+    if (round > 0) HIP_TRY(e, hipMemsetAsync(e->d_scal, 0, (size_t)3 * ACC_N * K * sizeof(double) + (size_t)3 * K * sizeof(double), e->stream));
+    TRY(exchange_halo(e, e->d_c));
+    TRY(launch_apply<3>(e, e->d_c, e->d_r, nullptr, e->d_b, e->d_r0, e->d_p));
+    TRY(reduce_partials(e, e->apply_grid, 2, e->acc(2) + ACC_RR * K, round == 0 ? e->bb() : nullptr));
+    ++launches;
+    TRY(allreduce(e, e->acc(2) + ACC_RR * K, K));
+    if (round == 0) TRY(allreduce(e, e->bb(), K));
+    if (round > 0) {
+      TRY(download(e, h_scal.data(), e->d_scal, e->scal_count()));
+      const double* rr = h_scal.data() + (size_t)2 * ACC_N * K + ACC_RR * K;
+      const double* bbh = h_scal.data() + (size_t)3 * ACC_N * K + 3 * K;
+      bool ok = true, loose = true;
+      max_rel = 0.0;
+      for (int k = 0; k < K; ++k) {
+        if (!std::isfinite(rr[k])) { status = CWR_ERR_NONFINITE; break; }
+        const double rel = (bbh[k] > 0.0) ? std::sqrt(rr[k] / bbh[k]) : (rr[k] > 0.0 ? INFINITY : 0.0);
+        max_rel = std::max(max_rel, rel);
+        if (rr[k] > tol2 * bbh[k]) ok = false;
+        if (rr[k] > 1.0e4 * tol2 * bbh[k]) loose = false;
+      }
+      if (status != CWR_OK) break;
+      if (ok) { converged = true; break; }
+      if (total_it >= max_iter || round > 6) { if (loose && round > 6) { converged = true; break; } status = CWR_ERR_NOT_CONVERGED; break; }
+      ++restarts;
+    }
+    // iterate until the recurrence residual says converged, a breakdown is flagged, or max_iter
+    int it = 0;
+    int batch = (round == 0) ? std::max(2, e->last_iters) : 2;
+    bool inner_done = false;
+    while (!inner_done) {
+      batch = std::min(batch, std::max(1, max_iter - total_it));
+      for (int b = 0; b < batch; ++b) { TRY(one_iteration(e, it, tol2)); ++it; ++total_it; launches += 2; }
+      TRY(download(e, h_scal.data(), e->d_scal, e->scal_count()));
+      TRY(download(e, h_cnt, e->d_counters, (size_t)8));
+      const double* rr = h_scal.data() + (size_t)((it - 1) % 3) * ACC_N * K + ACC_RR * K;
+      const double* bbh = h_scal.data() + (size_t)3 * ACC_N * K + 3 * K;
+      bool ok = true;
+      for (int k = 0; k < K; ++k) {
+        if (!std::isfinite(rr[k])) { status = CWR_ERR_NONFINITE; }
+        if (rr[k] > tol2 * bbh[k]) ok = false;
+      }
+      if (h_cnt[2]) status = CWR_ERR_GHOST_COEFF;
+      if (h_cnt[3] && status == CWR_OK) status = CWR_ERR_NONFINITE;
+      if (status != CWR_OK) break;
+      if (ok || h_cnt[1] || total_it >= max_iter) inner_done = true;
+      if (h_cnt[1]) HIP_TRY(e, hipMemsetAsync(e->d_counters + 1, 0, sizeof(int32_t), e->stream));
+      batch = 2;
+    }
+    if (status != CWR_OK) break;
+  }
+  st.iterations += total_it; st.restarts += restarts; st.launches += launches; st.max_rel = max_rel; st.status = status;
+  if (status == CWR_OK) e->last_iters = std::max(1, total_it - 1);
+  return status;
+}
+
 }  // namespace
 
 // ====================================================================================================
@@ -333,6 +463,7 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   int tile_rows = 256, cu_cap = 8;                               // tunables (measured defaults; env overrides for sweeps)
   if (const char* v = getenv("CWR_TILE_ROWS")) tile_rows = std::max(1, atoi(v));
   if (const char* v = getenv("CWR_BLOCKS_PER_CU")) cu_cap = std::max(1, atoi(v));
+  if (const char* v = getenv("CWR_JACOBI_LIMIT")) eng->jacobi_limit = std::max(2, atoi(v));
   eng->U = std::max(1, tile_rows / eng->R);
   const int TR = eng->R * eng->U;
   eng->ntiles = cdiv(n_owned, TR);
@@ -566,78 +697,47 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
   HIP_TRY(e, hipMemsetAsync(e->d_scal, 0, e->scal_count() * sizeof(double), e->stream));
   TRY(launch_rhs(e, t, e->d_c, e->d_b, true));
 
-  std::vector<double> h_scal(e->scal_count());
-  int32_t h_cnt[8];
-  int total_it = 0, restarts = 0, launches = 0, status = CWR_OK;
-  double max_rel = 0.0;
-  bool converged = false;
-  for (int round = 0; !converged; ++round) {
-    // (re)start: true residual of the current x; r0 = p = r
-    if (round > 0) HIP_TRY(e, hipMemsetAsync(e->d_scal, 0, (size_t)3 * ACC_N * K * sizeof(double) + (size_t)3 * K * sizeof(double), e->stream));
-    TRY(exchange_halo(e, e->d_c));
-    TRY(launch_apply<3>(e, e->d_c, e->d_r, nullptr, e->d_b, e->d_r0, e->d_p));
-    TRY(reduce_partials(e, e->apply_grid, 2, e->acc(2) + ACC_RR * K, round == 0 ? e->bb() : nullptr));
-    ++launches;
-    TRY(allreduce(e, e->acc(2) + ACC_RR * K, K));
-    if (round == 0) TRY(allreduce(e, e->bb(), K));
-    if (round > 0) {
-      TRY(download(e, h_scal.data(), e->d_scal, e->scal_count()));
-      const double* rr = h_scal.data() + (size_t)2 * ACC_N * K + ACC_RR * K;
-      const double* bbh = h_scal.data() + (size_t)3 * ACC_N * K + 3 * K;
-      bool ok = true, loose = true;
-      max_rel = 0.0;
-      for (int k = 0; k < K; ++k) {
-        if (!std::isfinite(rr[k])) { status = CWR_ERR_NONFINITE; break; }
-        const double rel = (bbh[k] > 0.0) ? std::sqrt(rr[k] / bbh[k]) : (rr[k] > 0.0 ? INFINITY : 0.0);
-        max_rel = std::max(max_rel, rel);
-        if (rr[k] > tol2 * bbh[k]) ok = false;
-        if (rr[k] > 1.0e4 * tol2 * bbh[k]) loose = false;
-      }
-      if (status != CWR_OK) break;
-      if (ok) { converged = true; break; }
-      if (total_it >= max_iter || round > 6) { if (loose && round > 6) { converged = true; break; } status = CWR_ERR_NOT_CONVERGED; break; }
-      ++restarts;
-    }
-    // iterate until the recurrence residual says converged, a breakdown is flagged, or max_iter
-    int it = 0;
-    int batch = (round == 0) ? std::max(2, e->last_iters) : 2;
-    bool inner_done = false;
-    while (!inner_done) {
-      batch = std::min(batch, std::max(1, max_iter - total_it));
-      for (int b = 0; b < batch; ++b) { TRY(one_iteration(e, it, tol2)); ++it; ++total_it; launches += 2; }
-      TRY(download(e, h_scal.data(), e->d_scal, e->scal_count()));
-      TRY(download(e, h_cnt, e->d_counters, (size_t)8));
-      const double* rr = h_scal.data() + (size_t)((it - 1) % 3) * ACC_N * K + ACC_RR * K;
-      const double* bbh = h_scal.data() + (size_t)3 * ACC_N * K + 3 * K;
-      bool ok = true;
-      for (int k = 0; k < K; ++k) {
-        if (!std::isfinite(rr[k])) { status = CWR_ERR_NONFINITE; }
-        if (rr[k] > tol2 * bbh[k]) ok = false;
-      }
-      if (h_cnt[2]) status = CWR_ERR_GHOST_COEFF;
-      if (h_cnt[3] && status == CWR_OK) status = CWR_ERR_NONFINITE;
-      if (status != CWR_OK) break;
-      if (ok || h_cnt[1] || total_it >= max_iter) inner_done = true;
-      if (h_cnt[1]) HIP_TRY(e, hipMemsetAsync(e->d_counters + 1, 0, sizeof(int32_t), e->stream));
-      batch = 2;
-    }
-    if (status != CWR_OK) break;
+  SolveStats st;
+  int rc_solve = CWR_OK;
+  const bool force_bicg = (flags & CWR_STEP_FORCE_BICGSTAB) != 0;
+  const bool force_jac = (flags & CWR_STEP_FORCE_JACOBI) != 0;
+  bool need_bicg = force_bicg;
+  if (!force_bicg) {
+    rc_solve = solve_jacobi(e, tol2, max_iter, force_jac, st, need_bicg);
+    if (rc_solve != CWR_OK && st.status == CWR_OK) return rc_solve;       // HIP / RCCL failure
+  }
+  if (need_bicg && st.status == CWR_OK) {
+    rc_solve = solve_bicgstab(e, tol2, max_iter, st);
+    if (rc_solve != CWR_OK && st.status == CWR_OK) return rc_solve;
+  }
+  const int status = st.status;
+  const int total_it = st.iterations + st.sweeps;
+  const double max_rel = st.max_rel;
+  {
+    int32_t h_cnt[8];
+    TRY(download(e, h_cnt, e->d_counters, (size_t)8));
+    if (h_cnt[2] && st.status == CWR_OK) st.status = CWR_ERR_GHOST_COEFF;
   }
   if (e->profiling) { hipStreamSynchronize(e->stream); collect_profile(e); }
   e->profiling = false;
-  local.iterations = total_it; local.restarts = restarts; local.operator_launches = launches;
-  local.max_rel_residual = max_rel; local.status = status;
-  if (status != CWR_OK) {
+  local.iterations = st.iterations; local.sweeps = st.sweeps; local.restarts = st.restarts; local.operator_launches = st.launches;
+  local.max_rel_residual = max_rel; local.status = st.status;
+  local.solver = (st.iterations == 0 && !force_bicg) ? 0 : (st.sweeps == 0 ? 1 : 2);
+  if (st.status != CWR_OK) {
     if (info) *info = local;
-    switch (status) {
-      case CWR_ERR_GHOST_COEFF: return fail(e, status, "active ghost face with a zero advection/diffusion coefficient at level t+1 "
+    switch (st.status) {
+      case CWR_ERR_GHOST_COEFF: return fail(e, st.status, "active ghost face with a zero advection/diffusion coefficient at level t+1 "
                                                         "(the reference raises a shape-mismatch ValueError, linalg.py:349-351)");
-      case CWR_ERR_NONFINITE: return fail(e, status, "non-finite value met in the implicit solve (NaN/Inf in state, flow field or boundary values)");
-      default: return fail(e, status, "BiCGSTAB did not reach tol = " + std::to_string(tol) + " in " + std::to_string(total_it) +
-                                      " iterations (max relative residual " + std::to_string(max_rel) + ")");
+      case CWR_ERR_NONFINITE: return fail(e, st.status, "non-finite value met in the implicit solve (NaN/Inf in state, flow field or boundary values)");
+      default: {
+        char buf[256];
+        snprintf(buf, sizeof(buf), "implicit solve did not reach tol = %.3e in %d Jacobi sweeps + %d BiCGSTAB iterations "
+                 "(max relative residual %.3e)", tol, st.sweeps, st.iterations, max_rel);
+        return fail(e, st.status, buf);
+      }
     }
   }
-  e->last_iters = std::max(1, total_it - 1);
+  (void)status; (void)total_it;
 
   // write-back: real cells are already in place (x lives in the state vector); ghost rows from input_array[t+1]
   const int64_t gk = (int64_t)e->n_ghost * K;

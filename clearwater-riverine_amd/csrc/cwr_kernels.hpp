@@ -255,6 +255,9 @@ __global__ void __launch_bounds__(BLOCK) k_rhs(
 // MODE 1  v = D^-1 A p ;            partial[R0V] = (r0, v)                     (BiCGSTAB, first product)
 // MODE 2  t = D^-1 A s ;            partial[TS,TT,R0T,R0S] = (t,s), (t,t), (r0,t), (r0,s)   (second product)
 // MODE 3  r = bhat - D^-1 A x ; r0 = p = r ; partial = (r,r), (bhat,bhat)      (start / verify)
+// MODE 4  x' = x + (bhat - D^-1 A x) = bhat - (sum offd x[nb]) / diag ;  partial = (x'-x, x'-x), (bhat,bhat)
+//         one fully fused Jacobi sweep: ||x'-x|| IS the scaled residual of x, so convergence needs no
+//         second pass, no recurrence and (between checks) no reduction at all
 //
 // Persistent grid, XCD-aware: the row tiles (TR = U*R rows each) are split into 8 contiguous ranges, one
 // per XCD (blockIdx % 8 names the XCD group under round-robin dispatch -- speed only), and the blocks of
@@ -282,7 +285,7 @@ __global__ void __launch_bounds__(BLOCK) k_apply(
   const int tid = threadIdx.x;
   const int r = tid / G, g = tid - r * G;
   const int col = g * VW;
-  constexpr int ND = (MODE == 1) ? 1 : (MODE == 2 ? 4 : (MODE == 3 ? 2 : 0));
+  constexpr int ND = (MODE == 1) ? 1 : (MODE == 2 ? 4 : ((MODE == 3 || MODE == 4) ? 2 : 0));
   constexpr int NP = (ND > 0 ? ND : 1) * VW;
   double part[NP];
 #pragma unroll
@@ -311,7 +314,7 @@ __global__ void __launch_bounds__(BLOCK) k_apply(
         ldv<VW>(xin + o, xc);
         const double dg = diag[c];
         if constexpr (MODE == 1 || MODE == 2) ldv<VW>(r0 + o, q0);
-        if constexpr (MODE == 3) ldv<VW>(bhat + o, q0);
+        if constexpr (MODE == 3 || MODE == 4) ldv<VW>(bhat + o, q0);
 #pragma unroll
         for (int w = 0; w < VW; ++w) sum[w] = 0.0;
         const int j0 = s_ptr[c - c0], j1 = s_ptr[c - c0 + 1];
@@ -341,6 +344,15 @@ __global__ void __launch_bounds__(BLOCK) k_apply(
         if constexpr (MODE == 0) {
 #pragma unroll
           for (int w = 0; w < VW; ++w) y[w] = dg * xc[w] + sum[w];
+          stv<VW>(yout + o, y);
+        } else if constexpr (MODE == 4) {
+#pragma unroll
+          for (int w = 0; w < VW; ++w) {
+            y[w] = q0[w] - sum[w] / dg;
+            const double dx = y[w] - xc[w];
+            part[0 * VW + w] += dx * dx;
+            part[1 * VW + w] += q0[w] * q0[w];
+          }
           stv<VW>(yout + o, y);
         } else {
 #pragma unroll

@@ -26,6 +26,8 @@ CWR_ERR_NONFINITE = -7
 
 STEP_MASS_FLUX = 1
 STEP_PROFILE = 2
+STEP_FORCE_BICGSTAB = 4
+STEP_FORCE_JACOBI = 8
 
 # every symbol include/cwr_transport.h declares (tests check that the library exports them all)
 ABI_SYMBOLS = (
@@ -42,16 +44,18 @@ class SolverNotConverged(RuntimeError):
 
 
 class StepInfo(C.Structure):
-    _fields_ = [('iterations', C.c_int32), ('restarts', C.c_int32), ('status', C.c_int32),
-                ('operator_launches', C.c_int32), ('max_rel_residual', C.c_double),
+    _fields_ = [('iterations', C.c_int32), ('sweeps', C.c_int32), ('restarts', C.c_int32), ('status', C.c_int32),
+                ('operator_launches', C.c_int32), ('solver', C.c_int32), ('max_rel_residual', C.c_double),
                 ('solve_ms', C.c_double)]
 
 
 @dataclass
 class StepResult:
-    iterations: int
+    iterations: int          # BiCGSTAB iterations
+    sweeps: int              # fused Jacobi sweeps
     restarts: int
     operator_launches: int
+    solver: int              # 0 Jacobi only, 1 BiCGSTAB only, 2 both
     max_rel_residual: float
     solve_ms: float
 
@@ -237,12 +241,14 @@ class TransportEngine:
         return b
 
     def step(self, t: int, *, tol: float = 1e-12, max_iter: int = 2000, mass_flux: bool = True,
-             profile: bool = False) -> StepResult:
+             profile: bool = False, solver: str = 'auto') -> StepResult:
+        """solver: 'auto' (Jacobi sweeps, switching to BiCGSTAB on stiff steps), 'jacobi', 'bicgstab'."""
         info = StepInfo()
         flags = (STEP_MASS_FLUX if mass_flux else 0) | (STEP_PROFILE if profile else 0)
+        flags |= {'auto': 0, 'jacobi': STEP_FORCE_JACOBI, 'bicgstab': STEP_FORCE_BICGSTAB}[solver]
         self._check(self._lib.cwr_step(self._h, int(t), float(tol), int(max_iter), flags, C.byref(info)))
-        return StepResult(info.iterations, info.restarts, info.operator_launches, info.max_rel_residual,
-                          info.solve_ms)
+        return StepResult(info.iterations, info.sweeps, info.restarts, info.operator_launches, info.solver,
+                          info.max_rel_residual, info.solve_ms)
 
     def get_mass_flux(self):
         shape = (self.n_edges, self.K)

@@ -142,13 +142,15 @@ class ClearwaterRiverine:
                  config_filepath: Optional[str] = None, verbose: Optional[bool] = False,
                  datetime_range=None, mesh_file_path: Optional[str] = None, *,
                  mesh: Optional[dict] = None, input_arrays: Optional[Dict[str, np.ndarray]] = None,
-                 device: int = 0, tol: float = 1e-12, max_iter: int = 5000, store_history: bool = True):
+                 device: int = 0, tol: float = 1e-12, max_iter: int = 5000, store_history: bool = True,
+                 solver: str = 'auto'):
         self.gdf = None
         self.time_step = 0                                       # transport.py:102
         self.verbose = bool(verbose)
         self.tol = float(tol)
         self.max_iter = int(max_iter)
         self.store_history = bool(store_history)
+        self.solver = solver
         if mesh is None:
             if mesh_file_path:
                 raise NotImplementedError('loading a saved zarr/netCDF mesh is post-processing only in the '
@@ -256,7 +258,8 @@ class ClearwaterRiverine:
                 inp = np.stack([self.constituent_dict[c].input_array[t, :n] for c in self.constituents], axis=1)
                 x = np.where(inp != 0, inp, x)
             self.engine.set_state(x)
-        self.last_step = self.engine.step(t, tol=self.tol, max_iter=self.max_iter, mass_flux=self.store_history)
+        self.last_step = self.engine.step(t, tol=self.tol, max_iter=self.max_iter, mass_flux=self.store_history,
+                                          solver=self.solver)
         self._device_level = t + 1
         c_all = self.engine.get_state()                          # (ncell, K): transport.py:252-264
         for k, cname in enumerate(self.constituents):

@@ -48,14 +48,18 @@ enum {
 /* flags for cwr_step() */
 enum {
   CWR_STEP_MASS_FLUX = 1,      /* also evaluate the three per-face mass-flux arrays (transport.py:406-429) */
-  CWR_STEP_PROFILE = 2         /* bracket every operator launch with HIP events (see cwr_profile_read)     */
+  CWR_STEP_PROFILE = 2,        /* bracket every operator launch with HIP events (see cwr_profile_read)     */
+  CWR_STEP_FORCE_BICGSTAB = 4, /* skip the Jacobi fast path                                                */
+  CWR_STEP_FORCE_JACOBI = 8    /* never switch to BiCGSTAB (fails with CWR_ERR_NOT_CONVERGED instead)      */
 };
 
 typedef struct cwr_step_info {
-  int32_t iterations;          /* BiCGSTAB iterations in which at least one constituent was still active */
-  int32_t restarts;
+  int32_t iterations;          /* BiCGSTAB iterations (0 when the Jacobi sweeps alone converged) */
+  int32_t sweeps;              /* fused Jacobi sweeps */
+  int32_t restarts;            /* BiCGSTAB restarts (true-residual verification rounds that went on iterating) */
   int32_t status;              /* CWR_OK or the error code also returned */
   int32_t operator_launches;   /* face-flux operator launches in this step */
+  int32_t solver;              /* 0 = Jacobi sweeps only, 1 = BiCGSTAB only, 2 = sweeps then BiCGSTAB */
   double max_rel_residual;     /* max over constituents of ||D^-1 (b - A x)||_2 / ||D^-1 b||_2 */
   double solve_ms;             /* host wall time of the step, for information only */
 } cwr_step_info;
@@ -126,10 +130,12 @@ int32_t cwr_rhs(cwr_engine* e, int32_t t, const double* x_t, double* b);
 
 /* ---- one time step ------------------------------------------------------------------------------
  * Replaces the body of ClearwaterRiverine.update() for all constituents at once
- * (transport.py:209-273): operator set-up for level t, right-hand side, implicit solve
- * (Jacobi-scaled BiCGSTAB converging to the spsolve solution; K systems share A), write-back of the
- * real cells and of the ghost cells, optional mass flux.  State advances from level t to t+1.
- * tol: relative residual target (e.g. 1e-12).  info may be NULL. */
+ * (transport.py:209-273): operator set-up for level t, right-hand side, implicit solve converging to the
+ * spsolve solution (fully fused Jacobi sweeps while their measured contraction is fast enough, otherwise
+ * Jacobi-scaled BiCGSTAB; the K systems share A), write-back of the real cells and of the ghost cells,
+ * optional mass flux.  State advances from level t to t+1.
+ * tol: target for ||D^-1 (b - A x)||_2 / ||D^-1 b||_2 per constituent (e.g. 1e-12); max_iter bounds
+ * sweeps and BiCGSTAB iterations each.  info may be NULL. */
 int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t flags,
                  cwr_step_info* info);
 /* The three (n_edges, K) arrays of the last step taken with CWR_STEP_MASS_FLUX

@@ -11,6 +11,6 @@ for nx, K in [(100,1),(100,16),(300,1),(300,16),(1000,1),(1000,16)]:
         pt.engine.set_state(inputs3[0,:mesh['nreal']+1,:])
         try:
             t0=time.time(); r = pt.step(0, tol=tol, max_iter=300, mass_flux=False); el=time.time()-t0
-            print(nx, K, tol, 'iters', r.iterations, 'restarts', r.restarts, 'resid', r.max_rel_residual, 'ms', el*1e3, flush=True)
+            print(nx, K, tol, 'sweeps', r.sweeps, 'iters', r.iterations, 'restarts', r.restarts, 'resid', r.max_rel_residual, 'ms', el*1e3, flush=True)
         except Exception as e:
             print(nx, K, tol, 'FAIL', e, flush=True)

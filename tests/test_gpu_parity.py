@@ -98,15 +98,17 @@ def test_rhs_matches_reference_assembly(gpu_lib, K):
             assert np.max(np.abs(b[:, k] - r.vals)) <= TOL_OP * np.max(np.abs(r.vals))
 
 
+@pytest.mark.parametrize('solver', ['auto', 'bicgstab'])
 @pytest.mark.parametrize('plan,D,steps', [('plan01', 0.01, 30), ('plan02', 0.01, 24), ('plan03', 0.001, 30),
                                           ('plan01', 0.0, 10)])
-def test_facade_update_matches_oracle_on_reference_fixtures(gpu_lib, plan, D, steps):
+def test_facade_update_matches_oracle_on_reference_fixtures(gpu_lib, plan, D, steps, solver):
     """ClearwaterRiverine.update() loop == oracle (spsolve) on the reference's HDF fixtures:
     concentrations incl. ghost-cell NaN pattern, and the three mass-flux arrays."""
     import clearwater_riverine_amd as cw
     mesh, inp, _ = load_plan(plan, D)
     ref = oracle_run(mesh, inp[:, :, None], steps)
-    model = cw.ClearwaterRiverine(mesh=dict(mesh), diffusion_coefficient_input=D, input_arrays={'c0': inp.copy()})
+    model = cw.ClearwaterRiverine(mesh=dict(mesh), diffusion_coefficient_input=D, input_arrays={'c0': inp.copy()},
+                                  solver=solver)
     for _ in range(steps):
         model.update()
     assert model.time_step == steps
@@ -118,8 +120,9 @@ def test_facade_update_matches_oracle_on_reference_fixtures(gpu_lib, plan, D, st
         assert rel_err(got[:steps], want[:steps]) <= 1e-8
 
 
+@pytest.mark.parametrize('solver', ['auto', 'jacobi', 'bicgstab'])
 @pytest.mark.parametrize('K', [1, 3, 12, 16])
-def test_facade_multi_constituent_and_override(gpu_lib, K):
+def test_facade_multi_constituent_and_override(gpu_lib, K, solver):
     """K batched constituents + the update_concentration override of transport.py:233-236."""
     import clearwater_riverine_amd as cw
     mesh, inputs3 = synthetic_case(K, nx=30, ny=11, n_steps=12, seed=11, n_merge=25, n_dry=2)
@@ -128,7 +131,8 @@ def test_facade_multi_constituent_and_override(gpu_lib, K):
     rng = np.random.default_rng(4)
     overrides = {5: {names[0]: 2.0 + rng.random(n)}, 8: {names[-1]: 3.0 + rng.random(n), 'not_a_constituent': np.zeros(n)}}
     ref = oracle_run(mesh, inputs3, 12, overrides)
-    model = cw.ClearwaterRiverine(mesh=dict(mesh), input_arrays={nm: inputs3[:, :, k].copy() for k, nm in enumerate(names)})
+    model = cw.ClearwaterRiverine(mesh=dict(mesh), input_arrays={nm: inputs3[:, :, k].copy() for k, nm in enumerate(names)},
+                                  solver=solver)
     for s in range(12):
         model.update(overrides.get(s))
     for nm in names:
