@@ -133,13 +133,19 @@ def main():
     if rank == 0:
         b_r, b_w = eng.apply_bytes()
         back_to_back_us = eng.time_apply(args.warmup, reps=50) if world == 1 else None
+        traffic = None
+        try:                                             # PMC-measured HBM bytes per launch of this exact config, if profiled
+            with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as fh:
+                traffic = json.load(fh).get(f'{args.nx}x{args.ny}', {}).get(str(K)) if world == 1 else None
+        except OSError:
+            pass
         if launches > 0:
             avg_us = total_us / launches
             achieved = b_r / (avg_us * 1e-6) / 1e9
             roofline = {
                 'bound': 'hbm', 'kernel': 'k_apply (face-flux operator, gather form)',
                 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+                'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
                 'bytes_read': b_r, 'bytes_written': b_w, 'avg_launch_us': round(avg_us, 2),
                 'launches_timed': launches,
                 'achieved_read_plus_write': round((b_r + b_w) / (avg_us * 1e-6) / 1e9, 1),

@@ -87,6 +87,7 @@ struct cwr_engine {
   // communicator
   NcclComm comm = nullptr;
   int rank = 0, world = 1;
+  bool force_coll = false;      // CWR_FORCE_COLLECTIVES=1: issue the all-reduces even with one rank (test hook)
   std::vector<int> peers, send_ptr, recv_ptr;
   int32_t* d_send_cells = nullptr;
   double* d_sendbuf = nullptr;
@@ -208,7 +209,7 @@ int exchange_halo(cwr_engine* e, double* vec) {
 }
 
 int allreduce(cwr_engine* e, double* p, size_t count) {
-  if (!e->comm || e->world == 1) return CWR_OK;
+  if (!e->comm || (e->world == 1 && !e->force_coll)) return CWR_OK;
   NCCL_TRY(e, g_rccl.AllReduce(p, p, count, NCCL_FLOAT64, NCCL_SUM, e->comm, e->stream));
   return CWR_OK;
 }
@@ -460,7 +461,7 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   eng->VW = (K % 2 == 0) ? 2 : 1;
   eng->G = K / eng->VW;
   eng->R = BLOCK / eng->G;
-  int tile_rows = 256, cu_cap = 8;                               // tunables (measured defaults; env overrides for sweeps)
+  int tile_rows = 128, cu_cap = 8;                               // tunables (measured defaults; env overrides for sweeps)
   if (const char* v = getenv("CWR_TILE_ROWS")) tile_rows = std::max(1, atoi(v));
   if (const char* v = getenv("CWR_BLOCKS_PER_CU")) cu_cap = std::max(1, atoi(v));
   if (const char* v = getenv("CWR_JACOBI_LIMIT")) eng->jacobi_limit = std::max(2, atoi(v));
@@ -885,6 +886,7 @@ int32_t cwr_attach_comm(cwr_engine* e, int32_t rank, int32_t world, const uint8_
   NcclUniqueId id; std::memcpy(id.internal, unique_id, 128);
   NCCL_TRY(e, g_rccl.CommInitRank(&e->comm, world, id, rank));
   e->rank = rank; e->world = world;
+  if (const char* v = getenv("CWR_FORCE_COLLECTIVES")) e->force_coll = atoi(v) != 0;
   e->peers.assign(peers, peers + n_peers);
   e->send_ptr.assign(send_ptr, send_ptr + (n_peers ? n_peers + 1 : 0));
   e->recv_ptr.assign(recv_ptr, recv_ptr + (n_peers ? n_peers + 1 : 0));

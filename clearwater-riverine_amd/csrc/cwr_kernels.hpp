@@ -60,6 +60,32 @@ template <int VW> __device__ __forceinline__ void ldv(const double* p, double (&
   if constexpr (VW == 2) { const double2 t = *reinterpret_cast<const double2*>(p); v[0] = t.x; v[1] = t.y; }
   else { v[0] = *p; }
 }
+// streamed-once operands (face records, bhat / r0, outputs) bypass cache retention with `nt` loads/stores so the
+// gathered x rows keep the L2 (compile-time A/B knob; measured neutral-to-slightly-negative on MI355X, so off)
+#ifndef CWR_NT
+#define CWR_NT 0
+#endif
+template <int VW> __device__ __forceinline__ void ldv_nt(const double* p, double (&v)[VW]) {
+#if CWR_NT
+  if constexpr (VW == 2) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const d2 t = __builtin_nontemporal_load(reinterpret_cast<const d2*>(p)); v[0] = t.x; v[1] = t.y;
+  } else { v[0] = __builtin_nontemporal_load(p); }
+#else
+  ldv<VW>(p, v);
+#endif
+}
+template <int VW> __device__ __forceinline__ void stv_nt(double* p, const double (&v)[VW]) {
+#if CWR_NT
+  if constexpr (VW == 2) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    d2 t; t.x = v[0]; t.y = v[1];
+    __builtin_nontemporal_store(t, reinterpret_cast<d2*>(p));
+  } else { __builtin_nontemporal_store(v[0], p); }
+#else
+  if constexpr (VW == 2) { *reinterpret_cast<double2*>(p) = make_double2(v[0], v[1]); } else { *p = v[0]; }
+#endif
+}
 template <int VW> __device__ __forceinline__ void stv(double* p, const double (&v)[VW]) {
   if constexpr (VW == 2) { *reinterpret_cast<double2*>(p) = make_double2(v[0], v[1]); }
   else { *p = v[0]; }
@@ -313,8 +339,8 @@ __global__ void __launch_bounds__(BLOCK) k_apply(
         double xc[VW], sum[VW], q0[VW];
         ldv<VW>(xin + o, xc);
         const double dg = diag[c];
-        if constexpr (MODE == 1 || MODE == 2) ldv<VW>(r0 + o, q0);
-        if constexpr (MODE == 3 || MODE == 4) ldv<VW>(bhat + o, q0);
+        if constexpr (MODE == 1 || MODE == 2) ldv_nt<VW>(r0 + o, q0);
+        if constexpr (MODE == 3 || MODE == 4) ldv_nt<VW>(bhat + o, q0);
 #pragma unroll
         for (int w = 0; w < VW; ++w) sum[w] = 0.0;
         const int j0 = s_ptr[c - c0], j1 = s_ptr[c - c0 + 1];

@@ -183,3 +183,26 @@ def test_full_size_properties_1m_cells(gpu_lib, K):
     assert np.max(np.abs(eng.get_state()[:n] - xs)) <= 1e-9 * np.max(np.abs(xs))
     if K > 1:                                              # constituent k is (k+1) x constituent 0
         assert np.max(np.abs(xs[:, K - 1] - K * xs[:, 0])) <= 1e-9 * np.max(np.abs(xs[:, K - 1]))
+
+
+def test_single_rank_rccl_communicator(gpu_lib, monkeypatch):
+    """The RCCL plumbing that can run on one GPU: dlopen of librccl, unique id, ncclCommInitRank with one rank,
+    and (CWR_FORCE_COLLECTIVES=1) the all-reduce call sites inside both solver loops.  Results must equal the
+    communicator-free engine bit for bit (an all-reduce over one rank is the identity)."""
+    import clearwater_riverine_amd as cw
+    monkeypatch.setenv('CWR_FORCE_COLLECTIVES', '1')
+    mesh, inputs3 = synthetic_case(3, nx=30, ny=14, n_steps=3, seed=12, n_merge=15)
+    n = mesh['nreal'] + 1
+    outs = []
+    for with_comm in (False, True):
+        eng = make_engine(mesh, inputs3)
+        if with_comm:
+            uid = cw.TransportEngine.comm_unique_id()
+            assert len(uid) == 128
+            eng.attach_comm(0, 1, uid, [], [0], [], [0])
+        eng.set_state(inputs3[0, :n, :])
+        eng.step(0, solver='jacobi')
+        eng.step(1, solver='bicgstab')
+        outs.append(eng.get_state())
+        eng.close()
+    assert np.array_equal(outs[0], outs[1], equal_nan=True)
