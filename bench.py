@@ -80,7 +80,10 @@ def main():
         sys.exit('bench.py needs a GPU: the transport path has no CPU fallback')
     torch.cuda.set_device(local_rank)
     if world > 1:
+        import signal
+        signal.alarm(1500)                              # a lost rank must not leave the others waiting forever
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('GLOO_SOCKET_IFNAME', 'lo')  # one node: the control plane runs over loopback
         dist.init_process_group(backend='gloo', rank=rank, world_size=world)
 
     from clearwater_riverine_amd import synthetic

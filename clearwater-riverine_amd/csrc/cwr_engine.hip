@@ -697,6 +697,14 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
   HIP_TRY(e, hipMemsetAsync(e->d_counters, 0, 8 * sizeof(int32_t), e->stream));
   HIP_TRY(e, hipMemsetAsync(e->d_scal, 0, e->scal_count() * sizeof(double), e->stream));
   TRY(launch_rhs(e, t, e->d_c, e->d_b, true));
+  if (!e->comm) {
+    // one GPU: stop before the solve touches the state.  Partitioned runs keep going instead -- the violating
+    // rank's right-hand side is NaN-poisoned, so every rank leaves the solve together (no rank is left in a collective)
+    int32_t h_cnt[8];
+    TRY(download(e, h_cnt, e->d_counters, (size_t)8));
+    if (h_cnt[2]) return fail(e, CWR_ERR_GHOST_COEFF, "active ghost face with a zero advection/diffusion coefficient at level t+1 "
+                              "(the reference raises a shape-mismatch ValueError, linalg.py:349-351)");
+  }
 
   SolveStats st;
   int rc_solve = CWR_OK;
@@ -717,7 +725,7 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
   {
     int32_t h_cnt[8];
     TRY(download(e, h_cnt, e->d_counters, (size_t)8));
-    if (h_cnt[2] && st.status == CWR_OK) st.status = CWR_ERR_GHOST_COEFF;
+    if (h_cnt[2]) st.status = CWR_ERR_GHOST_COEFF;                         // takes precedence over the NaN it caused
   }
   if (e->profiling) { hipStreamSynchronize(e->stream); collect_profile(e); }
   e->profiling = false;

@@ -241,6 +241,7 @@ __global__ void __launch_bounds__(BLOCK) k_rhs(
   if (c >= n_owned) return;
   const int col = g * VW;
   double xv[VW], gin[VW], gout[VW];
+  bool bad = false;
   ldv<VW>(x + (size_t)c * K + col, xv);
 #pragma unroll
   for (int w = 0; w < VW; ++w) { gin[w] = 0.0; gout[w] = 0.0; }
@@ -256,11 +257,11 @@ __global__ void __launch_bounds__(BLOCK) k_rhs(
     double cg[VW];
     ldv<VW>(bc_n + (size_t)(-1 - nb) * K + col, cg);
     if (v1 < 0.0f) {
-      if (a == 0.0 || (use_diffusion && d == 0.0)) counters[2] = 1;
+      if (a == 0.0 || (use_diffusion && d == 0.0)) { counters[2] = 1; bad = true; }
 #pragma unroll
       for (int w = 0; w < VW; ++w) gin[w] = (a + d) * cg[w];
     } else {
-      if (use_diffusion && d == 0.0) counters[2] = 1;
+      if (use_diffusion && d == 0.0) { counters[2] = 1; bad = true; }
 #pragma unroll
       for (int w = 0; w < VW; ++w) gout[w] = d * cg[w];
     }
@@ -271,6 +272,9 @@ __global__ void __launch_bounds__(BLOCK) k_rhs(
   for (int w = 0; w < VW; ++w) {
     out[w] = (vt * xv[w] / dt + gin[w]) + gout[w];
     if (SCALE) out[w] /= diag[c];
+    // a violated precondition poisons the row: the residual turns NaN on EVERY rank after the all-reduce, so a
+    // partitioned run stops everywhere instead of leaving the other ranks waiting in a collective
+    if (bad) out[w] = __builtin_nan("");
   }
   stv<VW>(b + (size_t)c * K + col, out);
 }
