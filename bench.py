@@ -78,6 +78,8 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         sys.exit('bench.py needs a GPU: the transport path has no CPU fallback')
+    if 'CWR_BENCH_DEVICE' in os.environ:                # rehearsal of the N > 1 path on a one-GPU box (with CWR_RCCL_LIB)
+        local_rank = int(os.environ['CWR_BENCH_DEVICE'])
     torch.cuda.set_device(local_rank)
     if world > 1:
         import signal

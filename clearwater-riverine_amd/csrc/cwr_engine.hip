@@ -37,8 +37,11 @@ struct Rccl {
   const char* (*GetErrorString)(int) = nullptr;
   bool load(std::string& err) {
     if (lib) return true;
+    // CWR_RCCL_LIB: explicit library path (the tests point it at a shared-memory stand-in so that several ranks
+    // can share ONE GPU, which RCCL itself refuses)
+    if (const char* over = getenv("CWR_RCCL_LIB")) lib = dlopen(over, RTLD_NOW | RTLD_LOCAL);
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* n : names) { lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (lib) break; }
+    for (const char* n : names) { if (lib) break; lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); }
     if (!lib) { err = std::string("cannot dlopen librccl: ") + dlerror(); return false; }
 #define CWR_SYM(field, name) field = reinterpret_cast<decltype(field)>(dlsym(lib, name)); \
     if (!field) { err = std::string("librccl lacks ") + name; return false; }
