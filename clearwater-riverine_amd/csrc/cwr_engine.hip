@@ -102,6 +102,12 @@ struct cwr_engine {
   int64_t prof_launches = 0;
   double prof_us = 0.0;
   int last_iters = 0, last_sweeps = 0, jacobi_limit = 400;
+  // a batch of fused sweeps captured once as a hipGraph (kernel arguments never change between steps: only the
+  // contents of the buffers do), replayed to keep small meshes from being host-launch-bound
+  static constexpr int GRAPH_SWEEPS = 8;
+  hipGraph_t sweep_graph = nullptr;
+  hipGraphExec_t sweep_exec = nullptr;
+  bool graph_tried = false, use_graphs = true;
   std::string err;
 
   double* acc(int slot) const { return d_scal + (size_t)slot * ACC_N * K; }
@@ -314,7 +320,31 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
   const int sweep_limit = forced ? max_iter : std::min(max_iter, e->jacobi_limit);
   for (;;) {
     batch = std::max(2, std::min(batch, 64)) & ~1;                     // even: the result lands in the state vector
-    for (int i = 0; i < batch; ++i) {
+    int todo = batch;
+    if (!e->comm && !e->profiling && e->use_graphs) {
+      if (!e->graph_tried) {                               // capture GRAPH_SWEEPS sweeps once
+        e->graph_tried = true;
+        if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+          int rc = CWR_OK;
+          for (int i = 0; i < cwr_engine::GRAPH_SWEEPS && rc == CWR_OK; ++i)
+            rc = launch_apply<4>(e, (i & 1) ? e->d_p : e->d_c, (i & 1) ? e->d_c : e->d_p, nullptr, e->d_b, nullptr, nullptr);
+          hipGraph_t g = nullptr;
+          const hipError_t ec = hipStreamEndCapture(e->stream, &g);
+          if (rc == CWR_OK && ec == hipSuccess && g && hipGraphInstantiate(&e->sweep_exec, g, nullptr, nullptr, 0) == hipSuccess) {
+            e->sweep_graph = g;
+          } else {
+            if (g) hipGraphDestroy(g);
+            e->sweep_exec = nullptr;
+            (void)hipGetLastError();
+          }
+        }
+      }
+      while (e->sweep_exec && todo >= cwr_engine::GRAPH_SWEEPS) {
+        HIP_TRY(e, hipGraphLaunch(e->sweep_exec, e->stream));
+        todo -= cwr_engine::GRAPH_SWEEPS;
+      }
+    }
+    for (int i = 0; i < todo; ++i) {                        // remainder (even), partitioned or profiled runs
       double* src = (i & 1) ? e->d_p : e->d_c;
       double* dst = (i & 1) ? e->d_c : e->d_p;
       TRY(exchange_halo(e, src));
@@ -468,6 +498,7 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   if (const char* v = getenv("CWR_TILE_ROWS")) tile_rows = std::max(1, atoi(v));
   if (const char* v = getenv("CWR_BLOCKS_PER_CU")) cu_cap = std::max(1, atoi(v));
   if (const char* v = getenv("CWR_JACOBI_LIMIT")) eng->jacobi_limit = std::max(2, atoi(v));
+  if (const char* v = getenv("CWR_NO_GRAPHS")) eng->use_graphs = atoi(v) == 0;
   eng->U = std::max(1, tile_rows / eng->R);
   const int TR = eng->R * eng->U;
   eng->ntiles = cdiv(n_owned, TR);
@@ -550,6 +581,8 @@ void cwr_destroy(cwr_engine* e) {
   hipSetDevice(e->dev);
   if (e->stream) hipStreamSynchronize(e->stream);
   if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
+  if (e->sweep_exec) hipGraphExecDestroy(e->sweep_exec);
+  if (e->sweep_graph) hipGraphDestroy(e->sweep_graph);
   for (hipEvent_t ev : e->ev) hipEventDestroy(ev);
   void* ptrs[] = {e->d_f1, e->d_f2, e->d_ptr, e->d_ent_edge, e->d_ent_nb, e->d_adv, e->d_vel, e->d_vol, e->d_dif,
                   e->d_bc, e->d_rec, e->d_diag, e->d_c, e->d_r, e->d_r0, e->d_p, e->d_v, e->d_s, e->d_t, e->d_b,

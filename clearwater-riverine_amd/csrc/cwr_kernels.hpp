@@ -300,8 +300,14 @@ __host__ __device__ inline int red_doubles(int G, int VW) {     // scratch of bl
   return ((64 % G) == 0 ? (BLOCK / 64) * G : BLOCK) * 4 * VW;
 }
 
+#ifndef CWR_FACE_BATCH
+#define CWR_FACE_BATCH 4          // faces whose neighbour gathers are in flight together (tuning knob)
+#endif
+#ifndef CWR_APPLY_MIN_WAVES
+#define CWR_APPLY_MIN_WAVES 1     // __launch_bounds__ second argument: waves per SIMD the allocator must allow
+#endif
 template <int VW, int MODE>
-__global__ void __launch_bounds__(BLOCK) k_apply(
+__global__ void __launch_bounds__(BLOCK, CWR_APPLY_MIN_WAVES) k_apply(
     int n_owned, int K, int G, int U, int ntiles, int stage_cap, const int32_t* __restrict__ ptr,
     const FaceRec* __restrict__ rec, const double* __restrict__ diag, const double* __restrict__ xin,
     double* __restrict__ yout, const double* __restrict__ r0, const double* __restrict__ bhat,
@@ -348,21 +354,22 @@ __global__ void __launch_bounds__(BLOCK) k_apply(
 #pragma unroll
         for (int w = 0; w < VW; ++w) sum[w] = 0.0;
         const int j0 = s_ptr[c - c0], j1 = s_ptr[c - c0 + 1];
-        for (int j = j0; j < j1; j += 4) {
-          // up to four faces at a time: all neighbour-row gathers are issued before the first is consumed
-          FaceRec fr[4];
-          double xn[4][VW];
+        constexpr int FB = CWR_FACE_BATCH;
+        for (int j = j0; j < j1; j += FB) {
+          // up to FB faces at a time: all neighbour-row gathers are issued before the first is consumed
+          FaceRec fr[FB];
+          double xn[FB][VW];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
+          for (int u = 0; u < FB; ++u) {
             if (j + u < j1) fr[u] = staged ? s_rec[j + u - jb] : rec[j + u];
             else fr[u].nb = -1;
           }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
+          for (int u = 0; u < FB; ++u) {
             if (fr[u].nb >= 0) ldv<VW>(xin + (size_t)fr[u].nb * K + col, xn[u]);
           }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
+          for (int u = 0; u < FB; ++u) {
             if (fr[u].nb >= 0) {
               const double off = fmin((double)fr[u].a_c, 0.0) - fr[u].d;
 #pragma unroll

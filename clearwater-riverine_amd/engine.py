@@ -68,7 +68,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get('CWR_TRANSPORT_LIB') or LIB_PATH       # env override: A/B builds of the kernels
     if not os.path.exists(p):
         raise RuntimeError(
             f'{p} not found: build the HIP extension first (python -c "import __graft_entry__ as g; g.build()"); '
