@@ -62,6 +62,7 @@ def main():
     ap.add_argument('--diffusion', type=float, default=0.5)
     ap.add_argument('--seed', type=int, default=4)
     ap.add_argument('--solver', default='auto', choices=['auto', 'jacobi', 'bicgstab'])
+    ap.add_argument('--halo-depth', type=int, default=8, help='N > 1: halo layers = Jacobi sweeps between two exchanges')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-nx', type=int, default=640)
     ap.add_argument('--cpu-sample-steps', type=int, default=3)
@@ -102,7 +103,7 @@ def main():
     uid = None
     if world > 1:
         uid = broadcast_bytes(TransportEngine.comm_unique_id() if rank == 0 else None, 128, src=0)
-    pt = PartitionedTransport(mesh, inputs3, rank, world, device=local_rank, unique_id=uid)
+    pt = PartitionedTransport(mesh, inputs3, rank, world, device=local_rank, unique_id=uid, halo_depth=args.halo_depth)
     eng = pt.engine
 
     def barrier():
@@ -114,7 +115,7 @@ def main():
     iters = []
     for t in range(args.warmup):
         pt.step(t, tol=args.tol, mass_flux=True, solver=args.solver)
-    saved = eng.get_state()[: pt.local.n_owned].copy()       # state at the start of the timed region
+    saved = eng.get_state()[: pt.local.n_core].copy()       # state at the start of the timed region
     barrier()
     t0 = time.perf_counter()
     for t in range(args.warmup, args.warmup + args.steps):
@@ -179,7 +180,8 @@ def main():
                                    f'{len(mesh["edges_face1"])} faces), {K} constituents, implicit upwind '
                                    f'advection-diffusion step, dt={args.dt} s, D={args.diffusion}',
                        'cells': n, 'faces': int(len(mesh['edges_face1'])), 'constituents': K,
-                       'partition': f'contiguous cell ranges x{world}', 'tol': args.tol},
+                       'partition': f'contiguous cell ranges x{world}' + (f', halo depth {pt.local.depth}' if world > 1 else ''),
+                       'tol': args.tol},
             'solver': {'method': 'fused Jacobi sweeps, BiCGSTAB on stiff steps; K systems batched', 'iterations_per_step': iters,
                        'max_rel_residual': max_resid},
             'roofline': roofline, 'cpu_baseline': cpu,

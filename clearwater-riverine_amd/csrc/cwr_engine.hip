@@ -63,8 +63,10 @@ struct cwr_engine {
   int dev = 0;
   hipStream_t stream = nullptr;
   int n_owned = 0, n_halo = 0, n_real = 0, n_cells = 0, n_ghost = 0, E = 0, K = 0;
+  int n_core = 0;               // rows this rank owns (<= n_owned = rows it computes); inner products, results
+  int exch_every = 1;           // Jacobi sweeps between two halo exchanges (= halo depth)
   int VW = 1, G = 1, R = 1;
-  int nnz = 0, U = 1, ntiles = 0, apply_grid = 0, stage_cap = 0, cu_cap = 8;
+  int nnz = 0, U = 1, ntiles = 0, apply_grid = 0, last_apply_grid = 0, stage_cap = 0, cu_cap = 8;
   double* d_partial = nullptr;   // [max grid][4][K] per-block inner-product partials
   size_t apply_lds = 0;
   // static topology
@@ -92,9 +94,9 @@ struct cwr_engine {
   int rank = 0, world = 1;
   bool force_coll = false;      // CWR_FORCE_COLLECTIVES=1: issue the all-reduces even with one rank (test hook)
   std::vector<int> peers, send_ptr, recv_ptr;
-  int32_t* d_send_cells = nullptr;
-  double* d_sendbuf = nullptr;
-  int n_send = 0;
+  int32_t *d_send_cells = nullptr, *d_recv_cells = nullptr;
+  double *d_sendbuf = nullptr, *d_recvbuf = nullptr;
+  int n_send = 0, n_recv = 0;
   // measurement
   std::vector<hipEvent_t> ev;
   size_t ev_used = 0;
@@ -176,27 +178,30 @@ int reduce_partials(cwr_engine* e, int nslots, int ND, double* o0, double* o1 = 
 
 template <int MODE>
 int launch_apply(cwr_engine* e, const double* xin, double* yout, const double* r0, const double* bhat,
-                 double* r0_out, double* p_out) {
-  const int grid = e->apply_grid;
+                 double* r0_out, double* p_out, int rows = -1) {
+  if (rows < 0) rows = e->n_owned;
+  const int ntiles = cdiv(rows, e->R * e->U);
+  const int grid = std::max(N_XCD, std::min(e->apply_grid, cdiv(ntiles, N_XCD) * N_XCD));
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (e->profiling && e->ev_used + 2 <= e->ev.size()) {
     e0 = e->ev[e->ev_used++]; e1 = e->ev[e->ev_used++];
     HIP_TRY(e, hipEventRecord(e0, e->stream));
   }
   if (e->VW == 2)
-    k_apply<2, MODE><<<grid, BLOCK, e->apply_lds, e->stream>>>(e->n_owned, e->K, e->G, e->U, e->ntiles, e->stage_cap,
+    k_apply<2, MODE><<<grid, BLOCK, e->apply_lds, e->stream>>>(rows, e->n_core, e->K, e->G, e->U, ntiles, e->stage_cap,
         e->d_ptr, e->d_rec, e->d_diag, xin, yout, r0, bhat, r0_out, p_out, e->d_partial);
   else
-    k_apply<1, MODE><<<grid, BLOCK, e->apply_lds, e->stream>>>(e->n_owned, e->K, e->G, e->U, e->ntiles, e->stage_cap,
+    k_apply<1, MODE><<<grid, BLOCK, e->apply_lds, e->stream>>>(rows, e->n_core, e->K, e->G, e->U, ntiles, e->stage_cap,
         e->d_ptr, e->d_rec, e->d_diag, xin, yout, r0, bhat, r0_out, p_out, e->d_partial);
+  e->last_apply_grid = grid;
   HIP_TRY(e, hipGetLastError());
   if (e1) HIP_TRY(e, hipEventRecord(e1, e->stream));
   return CWR_OK;
 }
 
 int vec_grid(const cwr_engine* e) {
-  // memory-bound streaming kernels: cap the grid at 8 blocks per CU and grid-stride the rest
-  return std::max(1, std::min(cdiv(e->n_owned, e->R), 256 * 4));
+  // memory-bound streaming kernels: cap the grid and grid-stride the rest
+  return std::max(1, std::min(cdiv(e->n_core, e->R), 256 * 4));
 }
 
 int exchange_halo(cwr_engine* e, double* vec) {
@@ -211,9 +216,14 @@ int exchange_halo(cwr_engine* e, double* vec) {
     const size_t ns = (size_t)(e->send_ptr[i + 1] - e->send_ptr[i]) * e->K;
     const size_t nr = (size_t)(e->recv_ptr[i + 1] - e->recv_ptr[i]) * e->K;
     if (ns) NCCL_TRY(e, g_rccl.Send(e->d_sendbuf + (size_t)e->send_ptr[i] * e->K, ns, NCCL_FLOAT64, e->peers[i], e->comm, e->stream));
-    if (nr) NCCL_TRY(e, g_rccl.Recv(vec + ((size_t)e->n_owned + e->recv_ptr[i]) * e->K, nr, NCCL_FLOAT64, e->peers[i], e->comm, e->stream));
+    if (nr) NCCL_TRY(e, g_rccl.Recv(e->d_recvbuf + (size_t)e->recv_ptr[i] * e->K, nr, NCCL_FLOAT64, e->peers[i], e->comm, e->stream));
   }
   NCCL_TRY(e, g_rccl.GroupEnd());
+  const int64_t rtotal = (int64_t)e->n_recv * e->K;
+  if (rtotal > 0) {
+    k_unpack_rows<<<cdiv(rtotal, BLOCK), BLOCK, 0, e->stream>>>(rtotal, e->K, e->d_recv_cells, e->d_recvbuf, vec);
+    HIP_TRY(e, hipGetLastError());
+  }
   return CWR_OK;
 }
 
@@ -251,18 +261,18 @@ int one_iteration(cwr_engine* e, int it, double tol2) {
   const double* rr_prev = e->acc(prev) + ACC_RR * K;
   const int vg = vec_grid(e);
   TRY(exchange_halo(e, e->d_p));
-  TRY(launch_apply<1>(e, e->d_p, e->d_v, e->d_r0, nullptr, nullptr, nullptr));
-  TRY(reduce_partials(e, e->apply_grid, 1, acc_cur + ACC_R0V * K));
+  TRY(launch_apply<1>(e, e->d_p, e->d_v, e->d_r0, nullptr, nullptr, nullptr, e->n_core));
+  TRY(reduce_partials(e, e->last_apply_grid, 1, acc_cur + ACC_R0V * K));
   TRY(allreduce(e, acc_cur + ACC_R0V * K, K));
-  if (e->VW == 2) k_vec_s<2><<<vg, BLOCK, 0, e->stream>>>(e->n_owned, K, e->G, e->d_r, e->d_v, e->d_s, rho_ptr, acc_cur, rr_prev, e->bb(), tol2);
-  else            k_vec_s<1><<<vg, BLOCK, 0, e->stream>>>(e->n_owned, K, e->G, e->d_r, e->d_v, e->d_s, rho_ptr, acc_cur, rr_prev, e->bb(), tol2);
+  if (e->VW == 2) k_vec_s<2><<<vg, BLOCK, 0, e->stream>>>(e->n_core, K, e->G, e->d_r, e->d_v, e->d_s, rho_ptr, acc_cur, rr_prev, e->bb(), tol2);
+  else            k_vec_s<1><<<vg, BLOCK, 0, e->stream>>>(e->n_core, K, e->G, e->d_r, e->d_v, e->d_s, rho_ptr, acc_cur, rr_prev, e->bb(), tol2);
   HIP_TRY(e, hipGetLastError());
   TRY(exchange_halo(e, e->d_s));
-  TRY(launch_apply<2>(e, e->d_s, e->d_t, e->d_r0, nullptr, nullptr, nullptr));
-  TRY(reduce_partials(e, e->apply_grid, 4, acc_cur + ACC_TS * K, acc_cur + ACC_TT * K, acc_cur + ACC_R0T * K, acc_cur + ACC_R0S * K));
+  TRY(launch_apply<2>(e, e->d_s, e->d_t, e->d_r0, nullptr, nullptr, nullptr, e->n_core));
+  TRY(reduce_partials(e, e->last_apply_grid, 4, acc_cur + ACC_TS * K, acc_cur + ACC_TT * K, acc_cur + ACC_R0T * K, acc_cur + ACC_R0S * K));
   TRY(allreduce(e, acc_cur + ACC_TS * K, 4 * (size_t)K));
-  if (e->VW == 2) k_vec_x<2><<<vg, BLOCK, 0, e->stream>>>(e->n_owned, K, e->G, e->d_c, e->d_r, e->d_p, e->d_s, e->d_t, e->d_v, rho_ptr, e->rho(next), acc_cur, e->d_partial, rr_prev, e->bb(), tol2, e->d_counters);
-  else            k_vec_x<1><<<vg, BLOCK, 0, e->stream>>>(e->n_owned, K, e->G, e->d_c, e->d_r, e->d_p, e->d_s, e->d_t, e->d_v, rho_ptr, e->rho(next), acc_cur, e->d_partial, rr_prev, e->bb(), tol2, e->d_counters);
+  if (e->VW == 2) k_vec_x<2><<<vg, BLOCK, 0, e->stream>>>(e->n_core, K, e->G, e->d_c, e->d_r, e->d_p, e->d_s, e->d_t, e->d_v, rho_ptr, e->rho(next), acc_cur, e->d_partial, rr_prev, e->bb(), tol2, e->d_counters);
+  else            k_vec_x<1><<<vg, BLOCK, 0, e->stream>>>(e->n_core, K, e->G, e->d_c, e->d_r, e->d_p, e->d_s, e->d_t, e->d_v, rho_ptr, e->rho(next), acc_cur, e->d_partial, rr_prev, e->bb(), tol2, e->d_counters);
   HIP_TRY(e, hipGetLastError());
   TRY(reduce_partials(e, vg, 1, acc_cur + ACC_RR * K));
   TRY(allreduce(e, acc_cur + ACC_RR * K, K));
@@ -316,6 +326,7 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
   double* d_bb = e->bb();
   double prev_worst = -1.0;
   int prev_sweeps = 0;
+  int since_exchange = 0;                     // the caller exchanged the state's halo just before the right-hand side
   int batch = (e->last_sweeps > 0) ? std::max(2, (e->last_sweeps - 1) & ~1) : 8;
   const int sweep_limit = forced ? max_iter : std::min(max_iter, e->jacobi_limit);
   for (;;) {
@@ -347,11 +358,12 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
     for (int i = 0; i < todo; ++i) {                        // remainder (even), partitioned or profiled runs
       double* src = (i & 1) ? e->d_p : e->d_c;
       double* dst = (i & 1) ? e->d_c : e->d_p;
-      TRY(exchange_halo(e, src));
+      if (since_exchange >= e->exch_every) { TRY(exchange_halo(e, src)); since_exchange = 0; }
       TRY(launch_apply<4>(e, src, dst, nullptr, e->d_b, nullptr, nullptr));
+      ++since_exchange;
     }
     st.sweeps += batch; st.launches += batch;
-    TRY(reduce_partials(e, e->apply_grid, 2, d_rr, d_bb));
+    TRY(reduce_partials(e, e->last_apply_grid, 2, d_rr, d_bb));
     TRY(allreduce(e, d_rr, K));
     TRY(allreduce(e, d_bb, K));
     TRY(download(e, h.data(), d_rr, (size_t)K));
@@ -399,8 +411,8 @@ int solve_bicgstab(cwr_engine* e, double tol2, int max_iter, SolveStats& st) {
     // (re)start: true residual of the current x; r0 = p = r
     if (round > 0) HIP_TRY(e, hipMemsetAsync(e->d_scal, 0, (size_t)3 * ACC_N * K * sizeof(double) + (size_t)3 * K * sizeof(double), e->stream));
     TRY(exchange_halo(e, e->d_c));
-    TRY(launch_apply<3>(e, e->d_c, e->d_r, nullptr, e->d_b, e->d_r0, e->d_p));
-    TRY(reduce_partials(e, e->apply_grid, 2, e->acc(2) + ACC_RR * K, round == 0 ? e->bb() : nullptr));
+    TRY(launch_apply<3>(e, e->d_c, e->d_r, nullptr, e->d_b, e->d_r0, e->d_p, e->n_core));
+    TRY(reduce_partials(e, e->last_apply_grid, 2, e->acc(2) + ACC_RR * K, round == 0 ? e->bb() : nullptr));
     ++launches;
     TRY(allreduce(e, e->acc(2) + ACC_RR * K, K));
     if (round == 0) TRY(allreduce(e, e->bb(), K));
@@ -489,6 +501,7 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
 
   cwr_engine* eng = new cwr_engine();
   eng->dev = device;
+  eng->n_core = n_owned;
   eng->n_owned = n_owned; eng->n_halo = n_halo; eng->n_real = n_real; eng->n_cells = n_cells;
   eng->n_ghost = n_cells - n_real; eng->E = n_edges; eng->K = K; eng->nnz = nnz;
   eng->VW = (K % 2 == 0) ? 2 : 1;
@@ -586,7 +599,7 @@ void cwr_destroy(cwr_engine* e) {
   for (hipEvent_t ev : e->ev) hipEventDestroy(ev);
   void* ptrs[] = {e->d_f1, e->d_f2, e->d_ptr, e->d_ent_edge, e->d_ent_nb, e->d_adv, e->d_vel, e->d_vol, e->d_dif,
                   e->d_bc, e->d_rec, e->d_diag, e->d_c, e->d_r, e->d_r0, e->d_p, e->d_v, e->d_s, e->d_t, e->d_b,
-                  e->d_scal, e->d_counters, e->d_partial, e->d_fadv, e->d_fdif, e->d_ftot, e->d_send_cells, e->d_sendbuf};
+                  e->d_scal, e->d_counters, e->d_partial, e->d_fadv, e->d_fdif, e->d_ftot, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf};
   for (void* p : ptrs) if (p) hipFree(p);
   if (e->stream) hipStreamDestroy(e->stream);
   delete e;
@@ -672,7 +685,7 @@ int32_t cwr_set_boundary_level(cwr_engine* e, int32_t t, const double* level) {
 int32_t cwr_set_state(cwr_engine* e, const double* conc_owned) {
   if (!e || !conc_owned) return e ? fail(e, CWR_ERR_BAD_ARG, "cwr_set_state: NULL") : CWR_ERR_BAD_ARG;
   HIP_TRY(e, hipSetDevice(e->dev));
-  TRY(upload(e, e->d_c, conc_owned, (size_t)e->n_owned * e->K));
+  TRY(upload(e, e->d_c, conc_owned, (size_t)e->n_core * e->K));
   return CWR_OK;
 }
 
@@ -732,6 +745,7 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
   TRY(prep_step(e, t));
   HIP_TRY(e, hipMemsetAsync(e->d_counters, 0, 8 * sizeof(int32_t), e->stream));
   HIP_TRY(e, hipMemsetAsync(e->d_scal, 0, e->scal_count() * sizeof(double), e->stream));
+  TRY(exchange_halo(e, e->d_c));                      // the inner halo layers need x_t for their right-hand sides
   TRY(launch_rhs(e, t, e->d_c, e->d_b, true));
   if (!e->comm) {
     // one GPU: stop before the solve touches the state.  Partitioned runs keep going instead -- the violating
@@ -799,8 +813,8 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
     const int grid = std::max(1, std::min(cdiv(e->E, e->R), 256 * 8));
     const float* adv_t = e->d_adv + (size_t)t * e->E;
     const double* dif_t = e->d_dif + (size_t)t * e->E;
-    if (e->VW == 2) k_mass_flux<2><<<grid, BLOCK, 0, e->stream>>>(e->E, e->n_owned, K, e->G, e->d_f1, e->d_f2, adv_t, dif_t, e->dt[t], e->d_c, e->d_fadv, e->d_fdif, e->d_ftot);
-    else            k_mass_flux<1><<<grid, BLOCK, 0, e->stream>>>(e->E, e->n_owned, K, e->G, e->d_f1, e->d_f2, adv_t, dif_t, e->dt[t], e->d_c, e->d_fadv, e->d_fdif, e->d_ftot);
+    if (e->VW == 2) k_mass_flux<2><<<grid, BLOCK, 0, e->stream>>>(e->E, e->n_core, K, e->G, e->d_f1, e->d_f2, adv_t, dif_t, e->dt[t], e->d_c, e->d_fadv, e->d_fdif, e->d_ftot);
+    else            k_mass_flux<1><<<grid, BLOCK, 0, e->stream>>>(e->E, e->n_core, K, e->G, e->d_f1, e->d_f2, adv_t, dif_t, e->dt[t], e->d_c, e->d_fadv, e->d_fdif, e->d_ftot);
     HIP_TRY(e, hipGetLastError());
     e->flux_valid = true;
   }
@@ -908,11 +922,12 @@ int32_t cwr_comm_unique_id(uint8_t id_out[128]) {
   return CWR_OK;
 }
 
-int32_t cwr_attach_comm(cwr_engine* e, int32_t rank, int32_t world, const uint8_t unique_id[128], int32_t n_peers,
-                        const int32_t* peers, const int32_t* send_ptr, const int32_t* send_cells, const int32_t* recv_ptr) {
+int32_t cwr_attach_comm(cwr_engine* e, int32_t rank, int32_t world, const uint8_t unique_id[128], int32_t n_core,
+                        int32_t exchange_every, int32_t n_peers, const int32_t* peers, const int32_t* send_ptr,
+                        const int32_t* send_cells, const int32_t* recv_ptr, const int32_t* recv_cells) {
   if (!e) return CWR_ERR_BAD_ARG;
-  if (world < 1 || rank < 0 || rank >= world || !unique_id || n_peers < 0 ||
-      (n_peers > 0 && (!peers || !send_ptr || !recv_ptr)))
+  if (world < 1 || rank < 0 || rank >= world || !unique_id || n_peers < 0 || n_core < 1 || n_core > e->n_owned ||
+      exchange_every < 1 || (n_peers > 0 && (!peers || !send_ptr || !recv_ptr)))
     return fail(e, CWR_ERR_BAD_ARG, "cwr_attach_comm: bad arguments");
   for (int i = 0; i < n_peers; ++i) {
     if (peers[i] < 0 || peers[i] >= world || peers[i] == rank || send_ptr[i + 1] < send_ptr[i] || recv_ptr[i + 1] < recv_ptr[i])
@@ -920,24 +935,37 @@ int32_t cwr_attach_comm(cwr_engine* e, int32_t rank, int32_t world, const uint8_
   }
   const int n_send = n_peers ? send_ptr[n_peers] : 0;
   const int n_recv = n_peers ? recv_ptr[n_peers] : 0;
-  if (n_recv != e->n_halo) return fail(e, CWR_ERR_BAD_ARG, "cwr_attach_comm: receive lists must cover the halo block exactly");
+  if (n_recv != e->n_real - n_core)
+    return fail(e, CWR_ERR_BAD_ARG, "cwr_attach_comm: receive lists must cover every real row outside the core exactly once");
   for (int i = 0; i < n_send; ++i)
-    if (!send_cells || send_cells[i] < 0 || send_cells[i] >= e->n_owned)
-      return fail(e, CWR_ERR_BAD_ARG, "cwr_attach_comm: send cell outside the owned block");
+    if (!send_cells || send_cells[i] < 0 || send_cells[i] >= n_core)
+      return fail(e, CWR_ERR_BAD_ARG, "cwr_attach_comm: send cell outside the core block");
+  {
+    std::vector<char> seen((size_t)e->n_real, 0);
+    for (int i = 0; i < n_recv; ++i) {
+      if (!recv_cells || recv_cells[i] < n_core || recv_cells[i] >= e->n_real || seen[recv_cells[i]])
+        return fail(e, CWR_ERR_BAD_ARG, "cwr_attach_comm: receive cell outside the halo rows or listed twice");
+      seen[recv_cells[i]] = 1;
+    }
+  }
   std::string err;
   if (!g_rccl.load(err)) return fail(e, CWR_ERR_RCCL, err);
   HIP_TRY(e, hipSetDevice(e->dev));
   NcclUniqueId id; std::memcpy(id.internal, unique_id, 128);
   NCCL_TRY(e, g_rccl.CommInitRank(&e->comm, world, id, rank));
   e->rank = rank; e->world = world;
+  e->n_core = n_core; e->exch_every = exchange_every;
   if (const char* v = getenv("CWR_FORCE_COLLECTIVES")) e->force_coll = atoi(v) != 0;
   e->peers.assign(peers, peers + n_peers);
   e->send_ptr.assign(send_ptr, send_ptr + (n_peers ? n_peers + 1 : 0));
   e->recv_ptr.assign(recv_ptr, recv_ptr + (n_peers ? n_peers + 1 : 0));
-  e->n_send = n_send;
+  e->n_send = n_send; e->n_recv = n_recv;
   TRY(dev_alloc(e, &e->d_send_cells, (size_t)n_send));
   TRY(dev_alloc(e, &e->d_sendbuf, (size_t)n_send * e->K));
+  TRY(dev_alloc(e, &e->d_recv_cells, (size_t)n_recv));
+  TRY(dev_alloc(e, &e->d_recvbuf, (size_t)n_recv * e->K));
   TRY(upload(e, e->d_send_cells, send_cells, (size_t)n_send));
+  TRY(upload(e, e->d_recv_cells, recv_cells, (size_t)n_recv));
   return CWR_OK;
 }
 

@@ -308,7 +308,7 @@ __host__ __device__ inline int red_doubles(int G, int VW) {     // scratch of bl
 #endif
 template <int VW, int MODE>
 __global__ void __launch_bounds__(BLOCK, CWR_APPLY_MIN_WAVES) k_apply(
-    int n_owned, int K, int G, int U, int ntiles, int stage_cap, const int32_t* __restrict__ ptr,
+    int n_owned, int n_dot, int K, int G, int U, int ntiles, int stage_cap, const int32_t* __restrict__ ptr,
     const FaceRec* __restrict__ rec, const double* __restrict__ diag, const double* __restrict__ xin,
     double* __restrict__ yout, const double* __restrict__ r0, const double* __restrict__ bhat,
     double* __restrict__ r0_out, double* __restrict__ p_out, double* __restrict__ partial) {
@@ -346,6 +346,7 @@ __global__ void __launch_bounds__(BLOCK, CWR_APPLY_MIN_WAVES) k_apply(
     if (r < R) {
       for (int c = c0 + r; c < c1; c += R) {
         const size_t o = (size_t)c * K + col;
+        const double wdot = (c < n_dot) ? 1.0 : 0.0;   // rows of the inner halo layers are computed but belong to a neighbour
         double xc[VW], sum[VW], q0[VW];
         ldv<VW>(xin + o, xc);
         const double dg = diag[c];
@@ -387,8 +388,8 @@ __global__ void __launch_bounds__(BLOCK, CWR_APPLY_MIN_WAVES) k_apply(
           for (int w = 0; w < VW; ++w) {
             y[w] = q0[w] - sum[w] / dg;
             const double dx = y[w] - xc[w];
-            part[0 * VW + w] += dx * dx;
-            part[1 * VW + w] += q0[w] * q0[w];
+            part[0 * VW + w] += wdot * dx * dx;
+            part[1 * VW + w] += wdot * q0[w] * q0[w];
           }
           stv<VW>(yout + o, y);
         } else {
@@ -397,15 +398,15 @@ __global__ void __launch_bounds__(BLOCK, CWR_APPLY_MIN_WAVES) k_apply(
           if constexpr (MODE == 1) {
             stv<VW>(yout + o, y);
 #pragma unroll
-            for (int w = 0; w < VW; ++w) part[w] += q0[w] * y[w];
+            for (int w = 0; w < VW; ++w) part[w] += wdot * q0[w] * y[w];
           } else if constexpr (MODE == 2) {
             stv<VW>(yout + o, y);
 #pragma unroll
             for (int w = 0; w < VW; ++w) {
-              part[0 * VW + w] += y[w] * xc[w];
-              part[1 * VW + w] += y[w] * y[w];
-              part[2 * VW + w] += q0[w] * y[w];
-              part[3 * VW + w] += q0[w] * xc[w];
+              part[0 * VW + w] += wdot * y[w] * xc[w];
+              part[1 * VW + w] += wdot * y[w] * y[w];
+              part[2 * VW + w] += wdot * q0[w] * y[w];
+              part[3 * VW + w] += wdot * q0[w] * xc[w];
             }
           } else {  // MODE 3
             double res[VW];
@@ -415,7 +416,7 @@ __global__ void __launch_bounds__(BLOCK, CWR_APPLY_MIN_WAVES) k_apply(
             stv<VW>(r0_out + o, res);
             stv<VW>(p_out + o, res);
 #pragma unroll
-            for (int w = 0; w < VW; ++w) { part[0 * VW + w] += res[w] * res[w]; part[1 * VW + w] += q0[w] * q0[w]; }
+            for (int w = 0; w < VW; ++w) { part[0 * VW + w] += wdot * res[w] * res[w]; part[1 * VW + w] += wdot * q0[w] * q0[w]; }
           }
         }
       }
@@ -626,6 +627,15 @@ __global__ void __launch_bounds__(BLOCK) k_pack_rows(int64_t total, int K, const
   const int64_t row = i / K;
   const int k = (int)(i - row * K);
   buf[i] = vec[(size_t)cells[row] * K + k];
+}
+
+__global__ void __launch_bounds__(BLOCK) k_unpack_rows(int64_t total, int K, const int32_t* __restrict__ cells,
+                                                     const double* __restrict__ buf, double* __restrict__ vec) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= total) return;
+  const int64_t row = i / K;
+  const int k = (int)(i - row * K);
+  vec[(size_t)cells[row] * K + k] = buf[i];
 }
 
 }  // namespace cwr

@@ -38,13 +38,13 @@ class PartitionedTransport:
     single-GPU engine (no halo, no communicator)."""
 
     def __init__(self, mesh: dict, inputs3: np.ndarray, rank: int, world: int, device: int = 0,
-                 unique_id: bytes | None = None):
+                 unique_id: bytes | None = None, halo_depth: int = 1):
         f1 = np.asarray(mesh['edges_face1'])
         f2 = np.asarray(mesh['edges_face2'])
         n = int(f1.max()) + 1
         self.n_global = n
         self.K = int(inputs3.shape[2])
-        self.local: LocalMesh = partition_mesh(f1, f2, n, world, rank)
+        self.local: LocalMesh = partition_mesh(f1, f2, n, world, rank, depth=halo_depth)
         lm = self.local
         dist_e = mesh.get('face_to_face_dist')
         if dist_e is None:
@@ -53,7 +53,7 @@ class PartitionedTransport:
         if dt is None:
             dt = change_in_time(mesh['time_seconds'] if 'time_seconds' in mesh else mesh['time'])
         fields = slice_fields(lm, mesh, np.asarray(dist_e))
-        self.engine = TransportEngine(lm.face1, lm.face2, lm.n_cells, self.K, n_owned=lm.n_owned,
+        self.engine = TransportEngine(lm.face1, lm.face2, lm.n_cells, self.K, n_owned=lm.n_rows,
                                       n_halo=lm.n_halo, device=device)
         self.engine.load_flow_field(fields['face_flow'], fields['edge_velocity'], fields['volume'], dt,
                                     fields['face_to_face_dist'], float(mesh['diffusion_coefficient']))
@@ -62,7 +62,8 @@ class PartitionedTransport:
         if world > 1:
             if unique_id is None:
                 raise ValueError('world > 1 needs the RCCL unique id broadcast from rank 0')
-            self.engine.attach_comm(rank, world, unique_id, lm.peers, lm.send_ptr, lm.send_cells, lm.recv_ptr)
+            self.engine.attach_comm(rank, world, unique_id, lm.peers, lm.send_ptr, lm.send_cells, lm.recv_ptr,
+                                    lm.recv_cells, n_core=lm.n_core, exchange_every=lm.depth)
         # initial condition of the owned cells (row 0 of input_array, constituents.py:94-98)
         self.engine.set_state(np.ascontiguousarray(inputs3[0, lm.lo:lm.hi, :]))
 
@@ -70,7 +71,7 @@ class PartitionedTransport:
         return self.engine.step(t, **kw)
 
     def owned_state(self) -> np.ndarray:
-        return self.engine.get_state()[: self.local.n_owned]
+        return self.engine.get_state()[: self.local.n_core]
 
     def gather_state(self) -> np.ndarray:
         """(n_global, K) concentrations of all real cells on every rank (control-plane all_gather)."""

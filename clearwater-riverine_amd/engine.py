@@ -100,7 +100,7 @@ def load_library(path: str | None = None) -> C.CDLL:
         'cwr_synchronize': [vp],
         'cwr_apply_bytes': [vp, P(C.c_int64), P(C.c_int64)],
         'cwr_comm_unique_id': [vp],
-        'cwr_attach_comm': [vp, i32, i32, vp, i32, vp, vp, vp, vp],
+        'cwr_attach_comm': [vp, i32, i32, vp, i32, i32, i32, vp, vp, vp, vp, vp],
     }
     for name, args in protos.items():
         fn = getattr(lib, name)
@@ -147,6 +147,7 @@ class TransportEngine:
         self.n_ghost = self.n_cells - self.n_real
         self.n_edges = int(len(f1))
         self.K = int(n_constituents)
+        self.n_core = self.n_owned                 # rows owned by this rank (== n_owned unless deep halos are attached)
         self.n_times = 0
         rc = self._lib.cwr_create(self.n_owned, self.n_halo, self.n_cells, self.n_edges, self.K,
                                   _ptr(f1), _ptr(f2), int(device), C.byref(self._h))
@@ -218,8 +219,8 @@ class TransportEngine:
 
     # ------------------------------------------------------------------ state
     def set_state(self, conc_owned):
-        x = _arr(np.asarray(conc_owned, dtype=np.float64).reshape(self.n_owned, -1), np.float64,
-                 (self.n_owned, self.K), 'conc_owned')
+        x = _arr(np.asarray(conc_owned, dtype=np.float64).reshape(self.n_core, -1), np.float64,
+                 (self.n_core, self.K), 'conc_owned')
         self._check(self._lib.cwr_set_state(self._h, _ptr(x)))
 
     def get_state(self) -> np.ndarray:
@@ -287,7 +288,8 @@ class TransportEngine:
             raise RuntimeError(f'cwr_comm_unique_id failed ({rc}): {lib.cwr_last_error(None).decode()}')
         return bytes(buf)
 
-    def attach_comm(self, rank: int, world: int, unique_id: bytes, peers, send_ptr, send_cells, recv_ptr):
+    def attach_comm(self, rank: int, world: int, unique_id: bytes, peers, send_ptr, send_cells, recv_ptr,
+                    recv_cells, n_core: int | None = None, exchange_every: int = 1):
         if len(unique_id) != 128:
             raise ValueError('unique_id must be 128 bytes')
         uid = (C.c_uint8 * 128).from_buffer_copy(unique_id)
@@ -295,8 +297,12 @@ class TransportEngine:
         sp = _arr(send_ptr, np.int32)
         sc = _arr(send_cells, np.int32)
         rp = _arr(recv_ptr, np.int32)
-        self._check(self._lib.cwr_attach_comm(self._h, int(rank), int(world), C.cast(uid, C.c_void_p), int(len(pe)),
-                                              _ptr(pe), _ptr(sp), _ptr(sc), _ptr(rp)))
+        rc = _arr(recv_cells, np.int32)
+        n_core = self.n_owned if n_core is None else int(n_core)
+        self._check(self._lib.cwr_attach_comm(self._h, int(rank), int(world), C.cast(uid, C.c_void_p), n_core,
+                                              int(exchange_every), int(len(pe)), _ptr(pe), _ptr(sp), _ptr(sc),
+                                              _ptr(rp), _ptr(rc)))
+        self.n_core = n_core
 
     # ------------------------------------------------------------------ lifetime
     def close(self):

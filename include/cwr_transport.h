@@ -155,17 +155,22 @@ int32_t cwr_synchronize(cwr_engine* e);
 int32_t cwr_apply_bytes(const cwr_engine* e, int64_t* bytes_read, int64_t* bytes_written);
 
 /* ---- domain decomposition (one process per GPU, RCCL over xGMI) --------------------------------
+ * A partitioned engine is created with n_owned = the rows it COMPUTES (its own core range plus, with deep
+ * halos, the inner halo layers it replays) and n_halo = the outermost, read-only halo layer.
  * cwr_comm_unique_id: rank 0 creates the 128-byte RCCL unique id, the host broadcasts it.
  * cwr_attach_comm: joins the communicator and installs the halo exchange of this rank:
+ *   n_core                        rows [0, n_core) are the rank's own cells: only they enter inner products,
+ *                                 are sent to neighbours, and own faces in the mass-flux output
+ *   exchange_every                Jacobi sweeps between two exchanges (= halo depth; 1 = before every sweep)
  *   peers[i]                      rank of the i-th neighbour
- *   send_ptr[i] .. send_ptr[i+1]  slice of send_cells (local owned ids) packed for peers[i]
- *   recv_ptr[i] .. recv_ptr[i+1]  slice of the halo block [n_owned, n_owned+n_halo) filled by peers[i]
- * Every operator input is exchanged before the launch (ncclGroupStart/Send/Recv/End on the engine
- * stream) and every inner product is completed with ncclAllReduce. */
+ *   send_ptr[i] .. send_ptr[i+1]  slice of send_cells (local core ids) packed for peers[i]
+ *   recv_ptr[i] .. recv_ptr[i+1]  slice of recv_cells (local ids in [n_core, n_owned + n_halo)) filled by peers[i]
+ * Exchanges are ncclGroupStart/Send/Recv/End on the engine stream between a pack and an unpack kernel;
+ * inner products are completed with ncclAllReduce.  BiCGSTAB exchanges before every operator launch. */
 int32_t cwr_comm_unique_id(uint8_t id_out[128]);
-int32_t cwr_attach_comm(cwr_engine* e, int32_t rank, int32_t world, const uint8_t unique_id[128],
-                        int32_t n_peers, const int32_t* peers, const int32_t* send_ptr,
-                        const int32_t* send_cells, const int32_t* recv_ptr);
+int32_t cwr_attach_comm(cwr_engine* e, int32_t rank, int32_t world, const uint8_t unique_id[128], int32_t n_core,
+                        int32_t exchange_every, int32_t n_peers, const int32_t* peers, const int32_t* send_ptr,
+                        const int32_t* send_cells, const int32_t* recv_ptr, const int32_t* recv_cells);
 
 #ifdef __cplusplus
 }

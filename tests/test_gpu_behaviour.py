@@ -199,7 +199,7 @@ def test_single_rank_rccl_communicator(gpu_lib, monkeypatch):
         if with_comm:
             uid = cw.TransportEngine.comm_unique_id()
             assert len(uid) == 128
-            eng.attach_comm(0, 1, uid, [], [0], [], [0])
+            eng.attach_comm(0, 1, uid, [], [0], [], [0], [])
         eng.set_state(inputs3[0, :n, :])
         eng.step(0, solver='jacobi')
         eng.step(1, solver='bicgstab')

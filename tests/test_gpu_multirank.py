@@ -37,7 +37,7 @@ def make_case(K):
     return mesh, inputs3
 
 
-def _rank_main(rank, world, K, solver, uid_pipe, out_queue):
+def _rank_main(rank, world, K, solver, depth, uid_pipe, out_queue):
     try:
         os.environ['CWR_RCCL_LIB'] = MOCK_LIB
         import clearwater_riverine_amd as cw
@@ -49,13 +49,13 @@ def _rank_main(rank, world, K, solver, uid_pipe, out_queue):
                 uid_pipe.put(uid)
         else:
             uid = uid_pipe.get(timeout=120)
-        pt = PartitionedTransport(mesh, inputs3, rank, world, device=0, unique_id=uid)
+        pt = PartitionedTransport(mesh, inputs3, rank, world, device=0, unique_id=uid, halo_depth=depth)
         infos = []
         for t in range(3):
             r = pt.step(t, tol=1e-12, mass_flux=True, solver=solver)
             infos.append((r.sweeps, r.iterations))
         adv, dif, tot = pt.engine.get_mass_flux()
-        owned_faces = pt.local.face1 < pt.local.n_owned
+        owned_faces = pt.local.face1 < pt.local.n_core
         out_queue.put((rank, pt.local.lo, pt.local.hi, pt.owned_state(), pt.local.edge_global[owned_faces],
                        tot[owned_faces], infos, None))
         pt.engine.close()
@@ -63,12 +63,13 @@ def _rank_main(rank, world, K, solver, uid_pipe, out_queue):
         out_queue.put((rank, 0, 0, None, None, None, None, repr(exc)))
 
 
-@pytest.mark.parametrize('world,K,solver', [(2, 3, 'jacobi'), (2, 3, 'bicgstab'), (3, 16, 'auto'), (4, 1, 'auto')])
-def test_partitioned_step_matches_single_rank_and_oracle(gpu_lib, world, K, solver):
+@pytest.mark.parametrize('world,K,solver,depth', [(2, 3, 'jacobi', 1), (2, 3, 'bicgstab', 1), (3, 16, 'auto', 1), (4, 1, 'auto', 1),
+                                                  (2, 3, 'jacobi', 4), (3, 2, 'bicgstab', 3), (4, 16, 'auto', 8), (3, 1, 'auto', 2)])
+def test_partitioned_step_matches_single_rank_and_oracle(gpu_lib, world, K, solver, depth):
     build_mock()
     ctx = mp.get_context('spawn')
     uid_pipe, out_queue = ctx.Queue(), ctx.Queue()
-    procs = [ctx.Process(target=_rank_main, args=(r, world, K, solver, uid_pipe, out_queue)) for r in range(world)]
+    procs = [ctx.Process(target=_rank_main, args=(r, world, K, solver, depth, uid_pipe, out_queue)) for r in range(world)]
     for p in procs:
         p.start()
     results = [out_queue.get(timeout=240) for _ in range(world)]
@@ -93,6 +94,8 @@ def test_partitioned_step_matches_single_rank_and_oracle(gpu_lib, world, K, solv
     for t in range(3):
         single.step(t, tol=1e-12, mass_flux=True, solver=solver)
     assert rel_err(state, single.owned_state()) <= 1e-10
+    if solver == 'jacobi':                                   # sweeps replay the owner's arithmetic: independent of world and depth
+        assert np.array_equal(state, single.owned_state())
     # oracle
     oracle.derive_coefficients(mesh)
     ref = oracle.OracleModel(mesh, {f'c{k}': inputs3[:, :, k].copy() for k in range(K)})

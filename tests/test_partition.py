@@ -29,13 +29,14 @@ def local_oracle_mesh(mesh, lm):
     }
 
 
+@pytest.mark.parametrize('depth', [1, 2, 4])
 @pytest.mark.parametrize('world', [1, 2, 3, 4, 8])
-def test_partition_invariants_and_local_operator(world):
+def test_partition_invariants_and_local_operator(world, depth):
     from clearwater_riverine_amd.partition import partition_mesh, range_bounds
     mesh, inputs3 = make_case()
     f1, f2 = mesh['edges_face1'], mesh['edges_face2']
     n = mesh['nreal'] + 1
-    parts = [partition_mesh(f1, f2, n, world, r) for r in range(world)]
+    parts = [partition_mesh(f1, f2, n, world, r, depth=depth) for r in range(world)]
     bounds = range_bounds(n, world)
     assert bounds[0] == 0 and bounds[-1] == n
     rng = np.random.default_rng(0)
@@ -45,37 +46,97 @@ def test_partition_invariants_and_local_operator(world):
     b_global = oracle.rhs_percell(mesh, t, x, inputs3[t + 1])
     owners_of_face1 = np.zeros(len(f1), dtype=int)
     for r, lm in enumerate(parts):
-        assert (lm.lo, lm.hi) == (bounds[r], bounds[r + 1]) and lm.n_owned == lm.hi - lm.lo
-        # numbering: owned | halo (sorted by global id == by owner) | ghost
-        assert np.array_equal(lm.cell_global[:lm.n_owned], np.arange(lm.lo, lm.hi))
-        halo = lm.cell_global[lm.n_owned:lm.n_real]
-        assert np.all(np.diff(halo) > 0) and np.all((halo < lm.lo) | (halo >= lm.hi)) and np.all(halo < n)
+        assert (lm.lo, lm.hi) == (bounds[r], bounds[r + 1]) and lm.n_core == lm.hi - lm.lo
+        assert lm.depth == (depth if world > 1 else 1)
+        # numbering: core | computed halo layers | last (read-only) layer | ghost
+        assert np.array_equal(lm.cell_global[:lm.n_core], np.arange(lm.lo, lm.hi))
+        halo = lm.cell_global[lm.n_core:lm.n_real]
+        assert len(np.unique(halo)) == len(halo) and np.all((halo < lm.lo) | (halo >= lm.hi)) and np.all(halo < n)
         assert np.all(lm.cell_global[lm.n_real:] >= n)
-        # faces: exactly those touching an owned cell, ascending global id, ids mapped back bit-exactly
-        touching = ((f1 >= lm.lo) & (f1 < lm.hi)) | ((f2 >= lm.lo) & (f2 < lm.hi))
+        if world == 1:
+            assert lm.n_rows == lm.n_core and lm.n_halo == 0
+        # faces: exactly those touching a computed row, ascending global id, ids mapped back bit-exactly
+        comp = np.zeros(len(mesh['face_x']), dtype=bool)
+        comp[lm.cell_global[:lm.n_rows]] = True
+        touching = comp[f1] | comp[f2]
         assert np.array_equal(lm.edge_global, np.nonzero(touching)[0])
         assert np.array_equal(lm.cell_global[lm.face1], f1[lm.edge_global])
         assert np.array_equal(lm.cell_global[lm.face2], f2[lm.edge_global])
         assert lm.face1.max() < lm.n_real                                  # face1 real in local numbering
         owners_of_face1[(f1 >= lm.lo) & (f1 < lm.hi)] += 1
-        # receive lists tile the halo block; peers never include self
-        assert lm.recv_ptr[0] == 0 and lm.recv_ptr[-1] == lm.n_halo and r not in lm.peers
-        # local operator and right-hand side rows == the global ones
+        # receive lists cover every halo row exactly once; peers never include self
+        assert lm.recv_ptr[0] == 0 and lm.recv_ptr[-1] == lm.n_real - lm.n_core and r not in lm.peers
+        assert sorted(lm.recv_cells) == list(range(lm.n_core, lm.n_real))
+        # EVERY computed row (core and replayed halo layers) reproduces the global operator / right-hand side row
         lmesh = local_oracle_mesh(mesh, lm)
         xl = x[lm.cell_global[:lm.n_real]]
-        assert np.allclose(oracle.apply_percell(lmesh, t, xl)[:lm.n_owned], y_global[lm.lo:lm.hi], rtol=1e-13, atol=1e-13)
+        rows_g = lm.cell_global[:lm.n_rows]
+        assert np.allclose(oracle.apply_percell(lmesh, t, xl)[:lm.n_rows], y_global[rows_g], rtol=1e-13, atol=1e-13)
         gl = inputs3[t + 1][lm.cell_global]
         bl = oracle.rhs_percell(lmesh, t, xl, gl)
-        assert np.allclose(bl[:lm.n_owned], b_global[lm.lo:lm.hi], rtol=1e-13, atol=1e-13)
+        assert np.allclose(bl[:lm.n_rows], b_global[rows_g], rtol=1e-13, atol=1e-13)
     assert np.all(owners_of_face1 == 1)                                    # every face has exactly one face1 owner
-    # send lists mirror receive lists
+    # send lists mirror receive lists, element for element
     for r, lm in enumerate(parts):
         for i, s in enumerate(lm.peers):
             sent = lm.cell_global[lm.send_cells[lm.send_ptr[i]:lm.send_ptr[i + 1]]]
             other = parts[s]
             j = list(other.peers).index(r)
-            got = other.cell_global[other.n_owned + other.recv_ptr[j]: other.n_owned + other.recv_ptr[j + 1]]
+            got = other.cell_global[other.recv_cells[other.recv_ptr[j]: other.recv_ptr[j + 1]]]
             assert np.array_equal(sent, got)
+            assert np.all((sent >= lm.lo) & (sent < lm.hi))
+
+
+def test_deep_halo_sweeps_reproduce_global_jacobi():
+    """s sweeps between exchanges: the core rows after every sweep equal the global Jacobi iterate and never read
+    a stale value (numpy stand-in for the kernel; the validity-shrinks-one-layer-per-sweep argument, executed
+    with NaN marking every stale row)."""
+    import scipy.sparse as sp
+    from clearwater_riverine_amd.partition import partition_mesh
+    mesh, inputs3 = make_case(K=1)
+    f1, f2 = mesh['edges_face1'], mesh['edges_face2']
+    n = mesh['nreal'] + 1
+    t, world, depth = 1, 3, 3
+    lhs = oracle.LHS(mesh)
+    lhs.update_values(mesh, t)
+    A = lhs.csr()
+    d = A.diagonal()
+    J = sp.eye(n) - sp.diags(1.0 / d) @ A
+    bh = oracle.rhs_percell(mesh, t, inputs3[t, :n, 0] + 1.0, inputs3[t + 1, :, 0]) / d
+    xg = np.ones(n)
+    parts = [partition_mesh(f1, f2, n, world, r, depth=depth) for r in range(world)]
+    loc = []
+    for lm in parts:
+        rows = lm.cell_global[:lm.n_rows]
+        Jl = J[rows][:, lm.cell_global[:lm.n_real]]
+        loc.append({'lm': lm, 'J': sp.csr_matrix(Jl), 'b': bh[rows], 'x': np.full(lm.n_real, np.nan)})
+    for L in loc:
+        L['x'][:L['lm'].n_core] = xg[L['lm'].lo:L['lm'].hi]
+    since = depth                                                          # forces the first exchange
+    for sweep in range(9):
+        if since >= depth:
+            for L in loc:                                                  # exchange: owners' core rows -> all halo layers
+                lm = L['lm']
+                L['x'][lm.n_core:] = np.nan
+            snapshot = np.concatenate([L['x'][:L['lm'].n_core] for L in loc])
+            for L in loc:
+                lm = L['lm']
+                L['x'][lm.recv_cells] = snapshot[lm.cell_global[lm.recv_cells]]
+            since = 0
+        xg = bh + J @ xg
+        for L in loc:
+            lm = L['lm']
+            new = np.full(lm.n_real, np.nan)
+            with np.errstate(invalid='ignore'):
+                new[:lm.n_rows] = L['b'] + L['J'] @ np.where(np.isnan(L['x']), 0.0, L['x'])
+                # a row is valid only if every input it read was valid
+                bad = (abs(L['J']) @ np.isnan(L['x']).astype(float)) > 0
+            new[:lm.n_rows][bad] = np.nan
+            L['x'] = new
+            core = new[:lm.n_core]                                         # core rows: never invalid, equal to the global iterate
+            assert not np.isnan(core).any()                                # (to rounding: scipy sums the sliced rows in another order)
+            assert np.allclose(core, xg[lm.lo:lm.hi], rtol=1e-13, atol=0)
+        since += 1
 
 
 def _free_port():
@@ -94,10 +155,10 @@ def _worker(rank, world, port, ok_flags):
         f1, f2 = mesh['edges_face1'], mesh['edges_face2']
         n = mesh['nreal'] + 1
         K = 2
-        lm = partition_mesh(f1, f2, n, world, rank)
+        lm = partition_mesh(f1, f2, n, world, rank, depth=2)
         x_global = np.random.default_rng(5).standard_normal((n, K))       # same on every rank (the check)
         vec = np.full((lm.n_real, K), np.nan)
-        vec[:lm.n_owned] = x_global[lm.lo:lm.hi]                           # a rank knows only its own rows
+        vec[:lm.n_core] = x_global[lm.lo:lm.hi]                            # a rank knows only its own rows
         # the engine's exchange pattern (csrc/cwr_engine.hip exchange_halo): pack rows per peer, grouped send/recv
         reqs, recv_bufs = [], []
         for i, peer in enumerate(lm.peers):
@@ -110,11 +171,11 @@ def _worker(rank, world, port, ok_flags):
         for q in reqs:
             q.wait()
         for i, rb in enumerate(recv_bufs):
-            vec[lm.n_owned + lm.recv_ptr[i]: lm.n_owned + lm.recv_ptr[i + 1]] = rb.numpy()
+            vec[lm.recv_cells[lm.recv_ptr[i]: lm.recv_ptr[i + 1]]] = rb.numpy()     # the engine's k_unpack_rows
         assert np.array_equal(vec, x_global[lm.cell_global[:lm.n_real]])   # halo rows bit-exact
         # operator rows of this rank, gathered over ranks == the global product
         from test_partition import local_oracle_mesh
-        y_local = oracle.apply_percell(local_oracle_mesh(mesh, lm), 2, vec)[:lm.n_owned]
+        y_local = oracle.apply_percell(local_oracle_mesh(mesh, lm), 2, vec)[:lm.n_core]
         parts = [None] * world
         dist.all_gather_object(parts, y_local)
         y = np.concatenate(parts, axis=0)
