@@ -138,18 +138,21 @@ def main():
     launches, total_us = eng.profile_read()
     if rank == 0:
         b_r, b_w = eng.apply_bytes()
+        double_sweep = bool(iters) and world == 1 and r.operator_launches < r.sweeps
+        kernel_name = ('k_apply<VW,5>: J^2 double sweep (two Jacobi iterations per launch)' if double_sweep
+                       else 'k_apply<VW,4>: fused Jacobi sweep of the face-flux operator')
         back_to_back_us = eng.time_apply(args.warmup, reps=50) if world == 1 else None
         traffic = None
         try:                                             # PMC-measured HBM bytes per launch of this exact config, if profiled
             with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as fh:
-                traffic = json.load(fh).get(f'{args.nx}x{args.ny}', {}).get(str(K)) if world == 1 else None
+                traffic = json.load(fh).get(f'{args.nx}x{args.ny}', {}).get(str(K)) if world == 1 and args.solver == 'auto' else None
         except OSError:
             pass
         if launches > 0:
             avg_us = total_us / launches
             achieved = b_r / (avg_us * 1e-6) / 1e9
             roofline = {
-                'bound': 'hbm', 'kernel': 'k_apply (face-flux operator, gather form)',
+                'bound': 'hbm', 'kernel': kernel_name,
                 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
                 'bytes_read': b_r, 'bytes_written': b_w, 'avg_launch_us': round(avg_us, 2),

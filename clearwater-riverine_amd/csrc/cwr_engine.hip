@@ -104,12 +104,26 @@ struct cwr_engine {
   int64_t prof_launches = 0;
   double prof_us = 0.0;
   int last_iters = 0, last_sweeps = 0, jacobi_limit = 400;
+  double last_rate = 0.0;       // contraction per sweep measured in the previous step (first-check prediction)
   // a batch of fused sweeps captured once as a hipGraph (kernel arguments never change between steps: only the
   // contents of the buffers do), replayed to keep small meshes from being host-launch-bound
   static constexpr int GRAPH_SWEEPS = 8;
   hipGraph_t sweep_graph = nullptr;
   hipGraphExec_t sweep_exec = nullptr;
   bool graph_tried = false, use_graphs = true;
+  // squared operator J^2 (two Jacobi sweeps per launch; single GPU, K >= sq_min_k)
+  std::vector<int32_t> h_ptr, h_nb;      // host copies of the adjacency for the symbolic J^2
+  bool use_sq = true, sq_pattern = false, sq_failed = false;
+  int sq_min_k = 8, nnz2 = 0, stage_cap2 = 0, apply_grid2 = 0;
+  size_t apply_lds2 = 0;
+  int32_t *d_ptr2 = nullptr, *d_col2 = nullptr, *d_row2 = nullptr;
+  FaceRec* d_rec2 = nullptr;
+  double* d_w = nullptr;
+  hipGraph_t sq_graph = nullptr;
+  hipGraphExec_t sq_exec = nullptr;
+  bool sq_graph_tried = false;
+  int dominant_mode = 4;
+  int nt_stream = 0;            // nt loads for the streamed operands (records, bhat/c2/r0): pays for wide rows only
   std::string err;
 
   double* acc(int slot) const { return d_scal + (size_t)slot * ACC_N * K; }
@@ -181,18 +195,24 @@ int launch_apply(cwr_engine* e, const double* xin, double* yout, const double* r
                  double* r0_out, double* p_out, int rows = -1) {
   if (rows < 0) rows = e->n_owned;
   const int ntiles = cdiv(rows, e->R * e->U);
-  const int grid = std::max(N_XCD, std::min(e->apply_grid, cdiv(ntiles, N_XCD) * N_XCD));
+  const bool sq = (MODE == 5);
+  const int max_grid = sq ? e->apply_grid2 : e->apply_grid;
+  const int grid = std::max(N_XCD, std::min(max_grid, cdiv(ntiles, N_XCD) * N_XCD));
+  const int32_t* ptr = sq ? e->d_ptr2 : e->d_ptr;
+  const FaceRec* rec = sq ? e->d_rec2 : e->d_rec;
+  const int cap = sq ? e->stage_cap2 : e->stage_cap;
+  const size_t lds = sq ? e->apply_lds2 : e->apply_lds;
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (e->profiling && e->ev_used + 2 <= e->ev.size()) {
+  if (e->profiling && MODE == e->dominant_mode && e->ev_used + 2 <= e->ev.size()) {
     e0 = e->ev[e->ev_used++]; e1 = e->ev[e->ev_used++];
     HIP_TRY(e, hipEventRecord(e0, e->stream));
   }
   if (e->VW == 2)
-    k_apply<2, MODE><<<grid, BLOCK, e->apply_lds, e->stream>>>(rows, e->n_core, e->K, e->G, e->U, ntiles, e->stage_cap,
-        e->d_ptr, e->d_rec, e->d_diag, xin, yout, r0, bhat, r0_out, p_out, e->d_partial);
+    k_apply<2, MODE><<<grid, BLOCK, lds, e->stream>>>(rows, e->n_core, e->K, e->G, e->U, ntiles, cap, e->nt_stream,
+        ptr, rec, e->d_diag, xin, yout, r0, bhat, r0_out, p_out, e->d_partial);
   else
-    k_apply<1, MODE><<<grid, BLOCK, e->apply_lds, e->stream>>>(rows, e->n_core, e->K, e->G, e->U, ntiles, e->stage_cap,
-        e->d_ptr, e->d_rec, e->d_diag, xin, yout, r0, bhat, r0_out, p_out, e->d_partial);
+    k_apply<1, MODE><<<grid, BLOCK, lds, e->stream>>>(rows, e->n_core, e->K, e->G, e->U, ntiles, cap, e->nt_stream,
+        ptr, rec, e->d_diag, xin, yout, r0, bhat, r0_out, p_out, e->d_partial);
   e->last_apply_grid = grid;
   HIP_TRY(e, hipGetLastError());
   if (e1) HIP_TRY(e, hipEventRecord(e1, e->stream));
@@ -308,6 +328,78 @@ int alloc_flow(cwr_engine* e, int T) {
   return CWR_OK;
 }
 
+// Symbolic J^2 (once): row c of J^2 has the columns reachable in two face steps.  Numeric values per step on
+// the device (k_entry_w, k_build_sq), then c2 = bhat + J bhat with one plain sweep of bhat.
+int ensure_sq_pattern(cwr_engine* e) {
+  if (e->sq_pattern || e->sq_failed) return CWR_OK;
+  const int n = e->n_owned;
+  std::vector<int32_t> ptr2((size_t)n + 1, 0), col2;
+  col2.reserve((size_t)e->nnz * 3 + 16);
+  std::vector<int32_t> tmp;
+  const int TR = e->R * e->U;
+  for (int c = 0; c < n; ++c) {
+    tmp.clear();
+    for (int j = e->h_ptr[c]; j < e->h_ptr[c + 1]; ++j) {
+      const int m = e->h_nb[j];
+      if (m < 0) continue;
+      if (m >= n) { e->sq_failed = true; return CWR_OK; }     // a neighbour without a row of its own (halo): no J^2
+      for (int i = e->h_ptr[m]; i < e->h_ptr[m + 1]; ++i) if (e->h_nb[i] >= 0) tmp.push_back(e->h_nb[i]);
+    }
+    std::sort(tmp.begin(), tmp.end());
+    tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+    col2.insert(col2.end(), tmp.begin(), tmp.end());
+    ptr2[c + 1] = (int32_t)col2.size();
+  }
+  e->nnz2 = (int)col2.size();
+  int cap = 1;
+  for (int b = 0; b * TR < n; ++b) cap = std::max(cap, ptr2[std::min((b + 1) * TR, n)] - ptr2[b * TR]);
+  if (cap > 8192) { e->sq_failed = true; return CWR_OK; }      // would not fit LDS staging: stay with plain sweeps
+  e->stage_cap2 = cap;
+  e->apply_lds2 = ((size_t)cap * sizeof(FaceRec) + (size_t)red_doubles(e->G, e->VW) * sizeof(double) + (size_t)(TR + 1) * sizeof(int32_t) + 15) & ~(size_t)15;
+  const void* fn = (e->VW == 2) ? reinterpret_cast<const void*>(&k_apply<2, 5>) : reinterpret_cast<const void*>(&k_apply<1, 5>);
+  if (e->apply_lds2 > 48 * 1024) HIP_TRY(e, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->apply_lds2));
+  int per_cu = 1, n_cu = 256;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, e->dev) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, BLOCK, e->apply_lds2) != hipSuccess || per_cu < 1) per_cu = 1;
+  per_cu = std::min(per_cu, e->cu_cap);
+  e->apply_grid2 = std::max(N_XCD, std::min(cdiv(e->ntiles, N_XCD) * N_XCD, (n_cu * per_cu / N_XCD) * N_XCD));
+  if (e->apply_grid2 > std::max(e->apply_grid, 256 * 8)) e->apply_grid2 = std::max(e->apply_grid, 256 * 8);   // partials buffer size
+  TRY(dev_alloc(e, &e->d_ptr2, (size_t)n + 1));
+  TRY(dev_alloc(e, &e->d_col2, (size_t)e->nnz2));
+  TRY(dev_alloc(e, &e->d_row2, (size_t)e->nnz2));
+  TRY(dev_alloc(e, &e->d_rec2, (size_t)e->nnz2));
+  TRY(dev_alloc(e, &e->d_w, (size_t)e->nnz));
+  TRY(upload(e, e->d_ptr2, ptr2.data(), (size_t)n + 1));
+  TRY(upload(e, e->d_col2, col2.data(), (size_t)e->nnz2));
+  {
+    std::vector<int32_t> row2((size_t)e->nnz2);
+    for (int c = 0; c < n; ++c) for (int q = ptr2[c]; q < ptr2[c + 1]; ++q) row2[q] = c;
+    TRY(upload(e, e->d_row2, row2.data(), (size_t)e->nnz2));
+  }
+  e->sq_pattern = true;
+  if (getenv("CWR_VERBOSE")) fprintf(stderr, "[cwr] J^2: nnz2=%d (%.1f per row) stage_cap2=%d lds2=%zu grid2=%d\n", e->nnz2, (double)e->nnz2 / n, e->stage_cap2, e->apply_lds2, e->apply_grid2);
+  return CWR_OK;
+}
+
+// numeric J^2 and c2 (into d_t) for the step whose operator is prepared; active = false -> plain sweeps only
+int prepare_sq(cwr_engine* e, bool& active) {
+  active = false;
+  if (e->comm || !e->use_sq || e->sq_failed || e->K < e->sq_min_k) return CWR_OK;
+  TRY(ensure_sq_pattern(e));
+  if (!e->sq_pattern) return CWR_OK;
+  const int n = e->n_owned;
+  k_entry_w<<<cdiv(n, BLOCK), BLOCK, 0, e->stream>>>(n, e->d_ptr, e->d_rec, e->d_diag, e->d_w);
+  k_build_sq<<<cdiv(e->nnz2, BLOCK), BLOCK, 0, e->stream>>>(e->nnz2, e->d_ptr, e->d_ent_nb, e->d_w, e->d_row2, e->d_col2, e->d_rec2);
+  HIP_TRY(e, hipGetLastError());
+  const int keep = e->dominant_mode; e->dominant_mode = -1;                    // this set-up launch is not a profiled sweep
+  const int rc = launch_apply<4>(e, e->d_b, e->d_t, nullptr, e->d_b, nullptr, nullptr);   // c2 = bhat + J bhat
+  e->dominant_mode = keep;
+  if (rc != CWR_OK) return rc;
+  active = true;
+  return CWR_OK;
+}
+
 struct SolveStats {
   int iterations = 0, sweeps = 0, restarts = 0, launches = 0, status = CWR_OK;
   double max_rel = 0.0;
@@ -327,12 +419,42 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
   double prev_worst = -1.0;
   int prev_sweeps = 0;
   int since_exchange = 0;                     // the caller exchanged the state's halo just before the right-hand side
-  int batch = (e->last_sweeps > 0) ? std::max(2, (e->last_sweeps - 1) & ~1) : 8;
+  int batch = (e->last_sweeps > 0) ? std::max(2, (e->last_sweeps + 1) & ~1) : 8;
   const int sweep_limit = forced ? max_iter : std::min(max_iter, e->jacobi_limit);
+  bool sq = false;
+  TRY(prepare_sq(e, sq));
+  e->dominant_mode = sq ? 5 : 4;
   for (;;) {
-    batch = std::max(2, std::min(batch, 64)) & ~1;                     // even: the result lands in the state vector
+    batch = std::max(2, std::min(batch, 128)) & ~1;                    // even: the result lands in the state vector
+    int launches = batch;
     int todo = batch;
-    if (!e->comm && !e->profiling && e->use_graphs) {
+    if (sq) {
+      // batch = 2*doubles + 2 with an even number of J^2 passes, then two plain sweeps: the last one's ||x'-x|| is the
+      // exact scaled residual of its input, so the convergence criterion is unchanged
+      batch += (6 - batch % 4) % 4;                                     // round up to 2 (mod 4)
+      int doubles = (batch - 2) / 2;
+      launches = doubles + 2;
+      todo = 0;
+      if (!e->profiling && e->use_graphs) {
+        if (!e->sq_graph_tried) {
+          e->sq_graph_tried = true;
+          if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            int rc = CWR_OK;
+            for (int i = 0; i < cwr_engine::GRAPH_SWEEPS && rc == CWR_OK; ++i)
+              rc = launch_apply<5>(e, (i & 1) ? e->d_p : e->d_c, (i & 1) ? e->d_c : e->d_p, nullptr, e->d_t, nullptr, nullptr);
+            hipGraph_t g = nullptr;
+            const hipError_t ec = hipStreamEndCapture(e->stream, &g);
+            if (rc == CWR_OK && ec == hipSuccess && g && hipGraphInstantiate(&e->sq_exec, g, nullptr, nullptr, 0) == hipSuccess) e->sq_graph = g;
+            else { if (g) hipGraphDestroy(g); e->sq_exec = nullptr; (void)hipGetLastError(); }
+          }
+        }
+        while (e->sq_exec && doubles >= cwr_engine::GRAPH_SWEEPS) { HIP_TRY(e, hipGraphLaunch(e->sq_exec, e->stream)); doubles -= cwr_engine::GRAPH_SWEEPS; }
+      }
+      for (int i = 0; i < doubles; ++i)
+        TRY(launch_apply<5>(e, (i & 1) ? e->d_p : e->d_c, (i & 1) ? e->d_c : e->d_p, nullptr, e->d_t, nullptr, nullptr));
+      TRY(launch_apply<4>(e, e->d_c, e->d_p, nullptr, e->d_b, nullptr, nullptr));
+      TRY(launch_apply<4>(e, e->d_p, e->d_c, nullptr, e->d_b, nullptr, nullptr));
+    } else if (!e->comm && !e->profiling && e->use_graphs) {
       if (!e->graph_tried) {                               // capture GRAPH_SWEEPS sweeps once
         e->graph_tried = true;
         if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
@@ -362,7 +484,7 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
       TRY(launch_apply<4>(e, src, dst, nullptr, e->d_b, nullptr, nullptr));
       ++since_exchange;
     }
-    st.sweeps += batch; st.launches += batch;
+    st.sweeps += batch; st.launches += launches;
     TRY(reduce_partials(e, e->last_apply_grid, 2, d_rr, d_bb));
     TRY(allreduce(e, d_rr, K));
     TRY(allreduce(e, d_bb, K));
@@ -378,15 +500,26 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
       if (rr > tol2 * bb) ok = false;
       worst = std::max(worst, bb > 0.0 ? rr / (tol2 * bb) : (rr > 0.0 ? (double)INFINITY : 0.0));
     }
-    if (ok) { e->last_sweeps = st.sweeps; return CWR_OK; }
+    if (ok) {
+      // remember the sweeps this step really needed (the margin below the tolerance, converted with the measured
+      // contraction), so that the next step's first batch neither overshoots nor needs a second check
+      int extra = 0;
+      if (worst > 0.0 && worst < 1.0 && e->last_rate > 0.0 && e->last_rate < 1.0)
+        extra = (int)std::floor(0.5 * std::log(1.0 / worst) / -std::log(e->last_rate));
+      e->last_sweeps = std::max(2, st.sweeps - extra);
+      return CWR_OK;
+    }
     if (st.sweeps >= sweep_limit) {
       if (forced || sweep_limit >= max_iter) { st.status = CWR_ERR_NOT_CONVERGED; return CWR_ERR_NOT_CONVERGED; }
       need_bicg = true; e->last_sweeps = 0; return CWR_OK;
     }
     // contraction per sweep from the last two checks (worst is a squared, normalised residual)
     int predicted = 16;
+    if (prev_worst <= 0.0 && e->last_rate > 0.0 && e->last_rate < 1.0 && std::isfinite(worst))
+      predicted = (int)std::ceil(0.5 * std::log(worst) / -std::log(e->last_rate)) + 1;
     if (prev_worst > 0.0 && std::isfinite(worst)) {
       const double rate = std::pow(worst / prev_worst, 0.5 / (st.sweeps - prev_sweeps));
+      if (rate > 0.0 && rate < 1.0) e->last_rate = rate;
       if (!(rate < 1.0)) {                                               // stalled or diverging
         if (forced) { predicted = 64; } else { need_bicg = true; e->last_sweeps = 0; return CWR_OK; }
       } else {
@@ -395,7 +528,7 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
       }
     }
     prev_worst = worst; prev_sweeps = st.sweeps;
-    batch = std::min(predicted + (predicted & 1), std::max(2, sweep_limit - st.sweeps));
+    batch = std::min(predicted + (predicted & 1), std::max(2, (sweep_limit - st.sweeps) & ~1));
   }
 }
 
@@ -406,6 +539,7 @@ int solve_bicgstab(cwr_engine* e, double tol2, int max_iter, SolveStats& st) {
   int total_it = 0, restarts = 0, launches = 0, status = CWR_OK;
   double max_rel = st.max_rel;
   bool converged = false;
+  e->dominant_mode = 1;                       // profile the first-product launches of BiCGSTAB steps
   HIP_TRY(e, hipMemsetAsync(e->d_scal, 0, e->scal_count() * sizeof(double), e->stream));
   for (int round = 0; !converged; ++round) {
     // (re)start: true residual of the current x; r0 = p = r
@@ -481,6 +615,8 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
       n_cells < n_owned + n_halo)
     return fail(nullptr, CWR_ERR_BAD_ARG, "cwr_create: bad sizes or NULL topology");
   const int n_real = n_owned + n_halo;
+  if ((double)n_cells * K * 8.0 >= 4294967296.0)
+    return fail(nullptr, CWR_ERR_BAD_ARG, "cwr_create: n_cells * K * 8 bytes must stay below 4 GiB per engine (32-bit row offsets); partition the mesh");
   std::vector<int32_t> cnt((size_t)n_owned + 1, 0);
   for (int e = 0; e < n_edges; ++e) {
     const int P = face1[e], N = face2[e];
@@ -501,6 +637,8 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
 
   cwr_engine* eng = new cwr_engine();
   eng->dev = device;
+  eng->h_ptr = cnt;
+  eng->h_nb.assign(ent_nb.begin(), ent_nb.begin() + nnz);
   eng->n_core = n_owned;
   eng->n_owned = n_owned; eng->n_halo = n_halo; eng->n_real = n_real; eng->n_cells = n_cells;
   eng->n_ghost = n_cells - n_real; eng->E = n_edges; eng->K = K; eng->nnz = nnz;
@@ -512,18 +650,31 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   if (const char* v = getenv("CWR_BLOCKS_PER_CU")) cu_cap = std::max(1, atoi(v));
   if (const char* v = getenv("CWR_JACOBI_LIMIT")) eng->jacobi_limit = std::max(2, atoi(v));
   if (const char* v = getenv("CWR_NO_GRAPHS")) eng->use_graphs = atoi(v) == 0;
-  eng->U = std::max(1, tile_rows / eng->R);
-  const int TR = eng->R * eng->U;
-  eng->ntiles = cdiv(n_owned, TR);
-  int cap = 0;
-  for (int b = 0; b < eng->ntiles; ++b) {
-    const int c0 = b * TR, c1 = std::min(c0 + TR, n_owned);
-    cap = std::max(cap, cnt[c1] - cnt[c0]);
+  if (const char* v = getenv("CWR_NO_SQ")) eng->use_sq = atoi(v) == 0;
+  eng->nt_stream = (K >= 8) ? 1 : 0;
+  if (const char* v = getenv("CWR_NT_STREAM")) eng->nt_stream = atoi(v) != 0;
+  if (const char* v = getenv("CWR_SQ_MIN_K")) eng->sq_min_k = std::max(1, atoi(v));
+  eng->U = std::max(1, std::min(4, tile_rows / eng->R));
+  int TR = 0;
+  for (;;) {                                                       // the records of one tile must fit the LDS staging area
+    TR = eng->R * eng->U;
+    eng->ntiles = cdiv(n_owned, TR);
+    int cap = 0;
+    for (int b = 0; b < eng->ntiles; ++b) {
+      const int c0 = b * TR, c1 = std::min(c0 + TR, n_owned);
+      cap = std::max(cap, cnt[c1] - cnt[c0]);
+    }
+    eng->stage_cap = std::max(cap, 1);
+    eng->apply_lds = (size_t)eng->stage_cap * sizeof(FaceRec) + (size_t)red_doubles(eng->G, eng->VW) * sizeof(double) +
+                     (size_t)(TR + 1) * sizeof(int32_t);
+    eng->apply_lds = (eng->apply_lds + 15) & ~(size_t)15;
+    if (eng->apply_lds <= 64 * 1024 || eng->U == 1) break;
+    eng->U /= 2;
   }
-  eng->stage_cap = std::min(std::max(cap, 1), 6144);              // <= 96 KiB of records per tile
-  eng->apply_lds = (size_t)eng->stage_cap * sizeof(FaceRec) + (size_t)red_doubles(eng->G, eng->VW) * sizeof(double) +
-                   (size_t)(TR + 1) * sizeof(int32_t);
-  eng->apply_lds = (eng->apply_lds + 15) & ~(size_t)15;
+  if (eng->apply_lds > 160 * 1024) {
+    delete eng;
+    return fail(nullptr, CWR_ERR_BAD_ARG, "cwr_create: a block of cells has too many faces for the LDS staging area");
+  }
   eng->cu_cap = cu_cap;
 
 #define CREATE_TRY(call) do { int _rc = (call); if (_rc != CWR_OK) { g_create_error = eng->err; cwr_destroy(eng); return _rc; } } while (0)
@@ -596,10 +747,12 @@ void cwr_destroy(cwr_engine* e) {
   if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
   if (e->sweep_exec) hipGraphExecDestroy(e->sweep_exec);
   if (e->sweep_graph) hipGraphDestroy(e->sweep_graph);
+  if (e->sq_exec) hipGraphExecDestroy(e->sq_exec);
+  if (e->sq_graph) hipGraphDestroy(e->sq_graph);
   for (hipEvent_t ev : e->ev) hipEventDestroy(ev);
   void* ptrs[] = {e->d_f1, e->d_f2, e->d_ptr, e->d_ent_edge, e->d_ent_nb, e->d_adv, e->d_vel, e->d_vol, e->d_dif,
                   e->d_bc, e->d_rec, e->d_diag, e->d_c, e->d_r, e->d_r0, e->d_p, e->d_v, e->d_s, e->d_t, e->d_b,
-                  e->d_scal, e->d_counters, e->d_partial, e->d_fadv, e->d_fdif, e->d_ftot, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf};
+                  e->d_scal, e->d_counters, e->d_partial, e->d_fadv, e->d_fdif, e->d_ftot, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf, e->d_ptr2, e->d_col2, e->d_row2, e->d_rec2, e->d_w};
   for (void* p : ptrs) if (p) hipFree(p);
   if (e->stream) hipStreamDestroy(e->stream);
   delete e;
@@ -850,7 +1003,14 @@ int32_t cwr_time_apply(cwr_engine* e, int32_t t, int32_t variant, int32_t reps, 
   const bool was = e->profiling; e->profiling = false;
   int rc = CWR_OK;
   auto body = [&](int i) -> int {
-    if (variant == 0) {
+    if (variant == 0) {                                        // the last step's dominant sweep kernel
+      if (e->dominant_mode == 5)
+        return (i & 1) ? launch_apply<5>(e, e->d_s, e->d_v, nullptr, e->d_t, nullptr, nullptr)
+                       : launch_apply<5>(e, e->d_p, e->d_v, nullptr, e->d_t, nullptr, nullptr);
+      return (i & 1) ? launch_apply<4>(e, e->d_s, e->d_v, nullptr, e->d_b, nullptr, nullptr)
+                     : launch_apply<4>(e, e->d_p, e->d_v, nullptr, e->d_b, nullptr, nullptr);
+    }
+    if (variant == 2) {                                        // BiCGSTAB's first product
       return (i & 1) ? launch_apply<1>(e, e->d_s, e->d_t, e->d_r0, nullptr, nullptr, nullptr)
                      : launch_apply<1>(e, e->d_p, e->d_v, e->d_r0, nullptr, nullptr, nullptr);
     }
@@ -902,10 +1062,13 @@ int32_t cwr_synchronize(cwr_engine* e) {
 
 int32_t cwr_apply_bytes(const cwr_engine* e, int64_t* bytes_read, int64_t* bytes_written) {
   if (!e) return CWR_ERR_BAD_ARG;
-  // the solver's first-product launch k_apply<VW,1>: face records, CSR row pointers, diagonal, the
-  // input vector (every real row once), r0 for the fused inner product; one output row per owned cell
+  // algorithmic bytes of one launch of the last step's dominant operator kernel: adjacency records (16 B each; of J^2
+  // when the double sweep is active), CSR row pointers, diagonal (plain sweep only), the input vector (every real row
+  // once), the bhat / c2 / r0 operand; one output row per computed row
   const int64_t K = e->K;
-  if (bytes_read) *bytes_read = 16LL * e->nnz + 4LL * (e->n_owned + 1) + 8LL * e->n_owned +
+  const bool sq = (e->dominant_mode == 5);
+  const int64_t entries = sq ? e->nnz2 : e->nnz;
+  if (bytes_read) *bytes_read = 16LL * entries + 4LL * (e->n_owned + 1) + (sq ? 0LL : 8LL * e->n_owned) +
                                 8LL * K * e->n_real + 8LL * K * e->n_owned;
   if (bytes_written) *bytes_written = 8LL * K * e->n_owned;
   return CWR_OK;

@@ -61,9 +61,9 @@ template <int VW> __device__ __forceinline__ void ldv(const double* p, double (&
   else { v[0] = *p; }
 }
 // streamed-once operands (face records, bhat / r0, outputs) bypass cache retention with `nt` loads/stores so the
-// gathered x rows keep the L2 (compile-time A/B knob; measured neutral-to-slightly-negative on MI355X, so off)
+// gathered x rows keep the L2 (measured on MI355X: -6 % per step at K = 16, +12 % at K = 1, so the host enables it per engine for wide rows only)
 #ifndef CWR_NT
-#define CWR_NT 0
+#define CWR_NT 1
 #endif
 template <int VW> __device__ __forceinline__ void ldv_nt(const double* p, double (&v)[VW]) {
 #if CWR_NT
@@ -73,6 +73,29 @@ template <int VW> __device__ __forceinline__ void ldv_nt(const double* p, double
   } else { v[0] = __builtin_nontemporal_load(p); }
 #else
   ldv<VW>(p, v);
+#endif
+}
+// CWR_STREAM_STORE: 0 plain, 1 nt, 2 sc1 (write-through, line not kept in this XCD's L2)
+#ifndef CWR_STREAM_STORE
+#define CWR_STREAM_STORE 0
+#endif
+template <int VW> __device__ __forceinline__ void stv_stream(double* p, const double (&v)[VW]) {
+#if CWR_STREAM_STORE == 2
+  if constexpr (VW == 2) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    d2 t; t.x = v[0]; t.y = v[1];
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(t) : "memory");
+  } else {
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v[0]) : "memory");
+  }
+#elif CWR_STREAM_STORE == 1
+  if constexpr (VW == 2) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    d2 t; t.x = v[0]; t.y = v[1];
+    __builtin_nontemporal_store(t, reinterpret_cast<d2*>(p));
+  } else { __builtin_nontemporal_store(v[0], p); }
+#else
+  if constexpr (VW == 2) { *reinterpret_cast<double2*>(p) = make_double2(v[0], v[1]); } else { *p = v[0]; }
 #endif
 }
 template <int VW> __device__ __forceinline__ void stv_nt(double* p, const double (&v)[VW]) {
@@ -288,6 +311,9 @@ __global__ void __launch_bounds__(BLOCK) k_rhs(
 // MODE 4  x' = x + (bhat - D^-1 A x) = bhat - (sum offd x[nb]) / diag ;  partial = (x'-x, x'-x), (bhat,bhat)
 //         one fully fused Jacobi sweep: ||x'-x|| IS the scaled residual of x, so convergence needs no
 //         second pass, no recurrence and (between checks) no reduction at all
+// MODE 5  x'' = c2 + J^2 x  with J = I - D^-1 A, c2 = bhat + J bhat: TWO Jacobi sweeps in one launch.  ptr/rec are
+//         the CSR of J^2 (built per step by k_build_sq; rec.d carries the coefficient, rec.nb the column), so the
+//         pass moves x, c2 and x'' once for two iterations; its gathers (13 rows per row on a quad mesh) are L2 hits
 //
 // Persistent grid, XCD-aware: the row tiles (TR = U*R rows each) are split into 8 contiguous ranges, one
 // per XCD (blockIdx % 8 names the XCD group under round-robin dispatch -- speed only), and the blocks of
@@ -308,7 +334,7 @@ __host__ __device__ inline int red_doubles(int G, int VW) {     // scratch of bl
 #endif
 template <int VW, int MODE>
 __global__ void __launch_bounds__(BLOCK, CWR_APPLY_MIN_WAVES) k_apply(
-    int n_owned, int n_dot, int K, int G, int U, int ntiles, int stage_cap, const int32_t* __restrict__ ptr,
+    int n_owned, int n_dot, int K, int G, int U, int ntiles, int stage_cap, int nt, const int32_t* __restrict__ ptr,
     const FaceRec* __restrict__ rec, const double* __restrict__ diag, const double* __restrict__ xin,
     double* __restrict__ yout, const double* __restrict__ r0, const double* __restrict__ bhat,
     double* __restrict__ r0_out, double* __restrict__ p_out, double* __restrict__ partial) {
@@ -321,7 +347,7 @@ __global__ void __launch_bounds__(BLOCK, CWR_APPLY_MIN_WAVES) k_apply(
   const int tid = threadIdx.x;
   const int r = tid / G, g = tid - r * G;
   const int col = g * VW;
-  constexpr int ND = (MODE == 1) ? 1 : (MODE == 2 ? 4 : ((MODE == 3 || MODE == 4) ? 2 : 0));
+  constexpr int ND = (MODE == 1) ? 1 : (MODE == 2 ? 4 : ((MODE == 3 || MODE == 4 || MODE == 5) ? 2 : 0));
   constexpr int NP = (ND > 0 ? ND : 1) * VW;
   double part[NP];
 #pragma unroll
@@ -337,45 +363,51 @@ __global__ void __launch_bounds__(BLOCK, CWR_APPLY_MIN_WAVES) k_apply(
     __syncthreads();                                // previous tile's readers are done with the LDS images
     for (int q = tid; q <= c1 - c0; q += BLOCK) s_ptr[q] = ptr[c0 + q];
     __syncthreads();
-    const int jb = s_ptr[0], je = s_ptr[c1 - c0];
-    const bool staged = (je - jb) <= stage_cap;
-    if (staged) {
-      for (int j = jb + tid; j < je; j += BLOCK) s_rec[j - jb] = rec[j];
+    const int jb = s_ptr[0], je = s_ptr[c1 - c0];      // the host sizes stage_cap to the largest tile: always fits
+    {
+      typedef int i4 __attribute__((ext_vector_type(4)));
+      if (nt) {
+        for (int j = jb + tid; j < je; j += BLOCK)
+          reinterpret_cast<i4*>(s_rec)[j - jb] = __builtin_nontemporal_load(reinterpret_cast<const i4*>(rec) + j);
+      } else {
+        for (int j = jb + tid; j < je; j += BLOCK) s_rec[j - jb] = rec[j];
+      }
     }
     __syncthreads();
     if (r < R) {
+      const char* xbase = reinterpret_cast<const char*>(xin);
+      const unsigned rowB = (unsigned)K * 8u, colB = (unsigned)col * 8u;   // byte offsets stay below 4 GiB (checked at create)
       for (int c = c0 + r; c < c1; c += R) {
         const size_t o = (size_t)c * K + col;
         const double wdot = (c < n_dot) ? 1.0 : 0.0;   // rows of the inner halo layers are computed but belong to a neighbour
         double xc[VW], sum[VW], q0[VW];
         ldv<VW>(xin + o, xc);
-        const double dg = diag[c];
-        if constexpr (MODE == 1 || MODE == 2) ldv_nt<VW>(r0 + o, q0);
-        if constexpr (MODE == 3 || MODE == 4) ldv_nt<VW>(bhat + o, q0);
+        double dg = 1.0;
+        if constexpr (MODE != 5) dg = diag[c];
+        if constexpr (MODE == 1 || MODE == 2) { if (nt) ldv_nt<VW>(r0 + o, q0); else ldv<VW>(r0 + o, q0); }
+        if constexpr (MODE == 3 || MODE == 4 || MODE == 5) { if (nt) ldv_nt<VW>(bhat + o, q0); else ldv<VW>(bhat + o, q0); }
 #pragma unroll
         for (int w = 0; w < VW; ++w) sum[w] = 0.0;
-        const int j0 = s_ptr[c - c0], j1 = s_ptr[c - c0 + 1];
+        const int j0 = s_ptr[c - c0] - jb, j1 = s_ptr[c - c0 + 1] - jb;
         constexpr int FB = CWR_FACE_BATCH;
         for (int j = j0; j < j1; j += FB) {
-          // up to FB faces at a time: all neighbour-row gathers are issued before the first is consumed
-          FaceRec fr[FB];
+          // up to FB faces at a time, branch-free: a slot past the row's end or a ghost face re-reads the row's own x
+          // with a zero coefficient; every neighbour-row gather is issued before the first is consumed
+          double coef[FB];
           double xn[FB][VW];
 #pragma unroll
           for (int u = 0; u < FB; ++u) {
-            if (j + u < j1) fr[u] = staged ? s_rec[j + u - jb] : rec[j + u];
-            else fr[u].nb = -1;
+            const FaceRec fr = s_rec[min(j + u, j1 - 1)];
+            const bool ok = (j + u < j1) & (fr.nb >= 0);
+            const double cf = (MODE == 5) ? fr.d : fmin((double)fr.a_c, 0.0) - fr.d;
+            coef[u] = ok ? cf : 0.0;
+            const unsigned row = ok ? (unsigned)fr.nb : (unsigned)c;
+            ldv<VW>(reinterpret_cast<const double*>(xbase + (row * rowB + colB)), xn[u]);
           }
 #pragma unroll
           for (int u = 0; u < FB; ++u) {
-            if (fr[u].nb >= 0) ldv<VW>(xin + (size_t)fr[u].nb * K + col, xn[u]);
-          }
 #pragma unroll
-          for (int u = 0; u < FB; ++u) {
-            if (fr[u].nb >= 0) {
-              const double off = fmin((double)fr[u].a_c, 0.0) - fr[u].d;
-#pragma unroll
-              for (int w = 0; w < VW; ++w) sum[w] += off * xn[u][w];
-            }
+            for (int w = 0; w < VW; ++w) sum[w] += coef[u] * xn[u][w];
           }
         }
         double y[VW];
@@ -383,15 +415,15 @@ __global__ void __launch_bounds__(BLOCK, CWR_APPLY_MIN_WAVES) k_apply(
 #pragma unroll
           for (int w = 0; w < VW; ++w) y[w] = dg * xc[w] + sum[w];
           stv<VW>(yout + o, y);
-        } else if constexpr (MODE == 4) {
+        } else if constexpr (MODE == 4 || MODE == 5) {
 #pragma unroll
           for (int w = 0; w < VW; ++w) {
-            y[w] = q0[w] - sum[w] / dg;
+            y[w] = (MODE == 5) ? q0[w] + sum[w] : q0[w] - sum[w] / dg;
             const double dx = y[w] - xc[w];
             part[0 * VW + w] += wdot * dx * dx;
             part[1 * VW + w] += wdot * q0[w] * q0[w];
           }
-          stv<VW>(yout + o, y);
+          stv_stream<VW>(yout + o, y);
         } else {
 #pragma unroll
           for (int w = 0; w < VW; ++w) y[w] = xc[w] + sum[w] / dg;
@@ -466,6 +498,42 @@ __global__ void __launch_bounds__(BLOCK) k_scatter_faces(int E, int n_owned, int
     if (P < n_owned) atomicAdd(&y[(size_t)P * K + g * VW + w], offP * xn[w]);
     if (N < n_owned) atomicAdd(&y[(size_t)N * K + g * VW + w], offN * xp[w]);
   }
+}
+
+// ------------------------------------------------------------------------------------------------ squared operator
+// w[j] = -offd_j / diag[row] >= 0: the Jacobi iteration matrix J = I - D^-1 A per adjacency entry (0 on ghost faces).
+__global__ void __launch_bounds__(BLOCK) k_entry_w(int n_rows, const int32_t* __restrict__ ptr, const FaceRec* __restrict__ rec,
+                                                 const double* __restrict__ diag, double* __restrict__ w) {
+  const int c = blockIdx.x * BLOCK + threadIdx.x;
+  if (c >= n_rows) return;
+  const double dg = diag[c];
+  const int j1 = ptr[c + 1];
+  for (int j = ptr[c]; j < j1; ++j) {
+    const FaceRec fr = rec[j];
+    w[j] = (fr.nb >= 0) ? (fr.d - fmin((double)fr.a_c, 0.0)) / dg : 0.0;
+  }
+}
+// Numeric J^2 on the static pattern (ptr2, col2, row2) built once on the host: one thread per OUTPUT entry (c, k);
+// products J[c,m] J[m,k] are summed in a fixed order (faces of c ascending, then faces of m ascending): deterministic.
+// Threads of one row are adjacent and re-read the same few adjacency rows: L1/L2 hits.
+__global__ void __launch_bounds__(BLOCK) k_build_sq(int nnz2, const int32_t* __restrict__ ptr, const int32_t* __restrict__ ent_nb,
+                                                  const double* __restrict__ w, const int32_t* __restrict__ row2,
+                                                  const int32_t* __restrict__ col2, FaceRec* __restrict__ rec2) {
+  const int s = blockIdx.x * BLOCK + threadIdx.x;
+  if (s >= nnz2) return;
+  const int c = row2[s], k = col2[s];
+  double acc = 0.0;
+  const int j1 = ptr[c + 1];
+  for (int j = ptr[c]; j < j1; ++j) {
+    const int m = ent_nb[j];
+    if (m < 0) continue;
+    const double wj = w[j];
+    const int i1 = ptr[m + 1];
+    for (int i = ptr[m]; i < i1; ++i)
+      if (ent_nb[i] == k) acc += wj * w[i];
+  }
+  FaceRec out; out.nb = k; out.a_c = 0.0f; out.d = acc;
+  rec2[s] = out;
 }
 
 // ------------------------------------------------------------------------------------------------ BiCGSTAB vector kernels

@@ -144,8 +144,9 @@ int32_t cwr_get_mass_flux(cwr_engine* e, double* advection, double* diffusion, d
 
 /* ---- measurement --------------------------------------------------------------------------------
  * cwr_time_apply: `reps` back-to-back launches of the operator of level t on device-resident vectors,
- * timed with HIP events on the engine's own stream; variant 0 = gather kernel (the solver's),
- * 1 = scatter kernel with global float64 atomics (A/B only).  avg_us = mean launch duration.
+ * timed with HIP events on the engine's own stream; variant 0 = the sweep kernel the last step used (the plain
+ * Jacobi sweep, or the J^2 double sweep), 1 = scatter form with global float64 atomics (A/B only),
+ * 2 = BiCGSTAB's first product.  avg_us = mean launch duration.
  * cwr_profile_read: event-timed totals of the operator launches made by steps run with
  * CWR_STEP_PROFILE since the last call: number of launches and their summed duration. */
 int32_t cwr_time_apply(cwr_engine* e, int32_t t, int32_t variant, int32_t reps, double* avg_us);
