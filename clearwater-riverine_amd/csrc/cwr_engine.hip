@@ -645,7 +645,7 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   eng->VW = (K % 2 == 0) ? 2 : 1;
   eng->G = K / eng->VW;
   eng->R = BLOCK / eng->G;
-  int tile_rows = 128, cu_cap = 8;                               // tunables (measured defaults; env overrides for sweeps)
+  int tile_rows = 128, cu_cap = 5;                               // measured: 4-8 blocks/CU within 3 %, 5 best (profiles/)                               // tunables (measured defaults; env overrides for sweeps)
   if (const char* v = getenv("CWR_TILE_ROWS")) tile_rows = std::max(1, atoi(v));
   if (const char* v = getenv("CWR_BLOCKS_PER_CU")) cu_cap = std::max(1, atoi(v));
   if (const char* v = getenv("CWR_JACOBI_LIMIT")) eng->jacobi_limit = std::max(2, atoi(v));
