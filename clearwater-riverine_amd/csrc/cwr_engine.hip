@@ -114,7 +114,7 @@ struct cwr_engine {
   // squared operator J^2 (two Jacobi sweeps per launch; single GPU, K >= sq_min_k)
   std::vector<int32_t> h_ptr, h_nb;      // host copies of the adjacency for the symbolic J^2
   bool use_sq = true, sq_pattern = false, sq_failed = false;
-  int sq_min_k = 8, nnz2 = 0, stage_cap2 = 0, apply_grid2 = 0;
+  int sq_min_k = 8, nnz2 = 0, n_sq = 0, stage_cap2 = 0, apply_grid2 = 0;
   size_t apply_lds2 = 0;
   int32_t *d_ptr2 = nullptr, *d_col2 = nullptr, *d_row2 = nullptr;
   FaceRec* d_rec2 = nullptr;
@@ -332,7 +332,14 @@ int alloc_flow(cwr_engine* e, int T) {
 // the device (k_entry_w, k_build_sq), then c2 = bhat + J bhat with one plain sweep of bhat.
 int ensure_sq_pattern(cwr_engine* e) {
   if (e->sq_pattern || e->sq_failed) return CWR_OK;
-  const int n = e->n_owned;
+  // rows with a J^2 row: the longest prefix of computed rows all of whose real neighbours have rows of their own
+  // (single GPU: every row; partitioned with halo depth s: the core and layers 1..s-2)
+  int n = e->n_owned;
+  for (int c = 0; c < e->n_owned && n == e->n_owned; ++c)
+    for (int j = e->h_ptr[c]; j < e->h_ptr[c + 1]; ++j)
+      if (e->h_nb[j] >= e->n_owned) { n = c; break; }
+  if (n < e->n_core) { e->sq_failed = true; return CWR_OK; }   // halo too shallow: plain sweeps only
+  e->n_sq = n;
   std::vector<int32_t> ptr2((size_t)n + 1, 0), col2;
   col2.reserve((size_t)e->nnz * 3 + 16);
   std::vector<int32_t> tmp;
@@ -342,11 +349,13 @@ int ensure_sq_pattern(cwr_engine* e) {
     for (int j = e->h_ptr[c]; j < e->h_ptr[c + 1]; ++j) {
       const int m = e->h_nb[j];
       if (m < 0) continue;
-      if (m >= n) { e->sq_failed = true; return CWR_OK; }     // a neighbour without a row of its own (halo): no J^2
-      for (int i = e->h_ptr[m]; i < e->h_ptr[m + 1]; ++i) if (e->h_nb[i] >= 0) tmp.push_back(e->h_nb[i]);
+      for (int i = e->h_ptr[m]; i < e->h_ptr[m + 1]; ++i) {
+        const int k = e->h_nb[i];
+        // columns in order of first discovery (faces ascending, then the neighbour's faces ascending): that order does
+        // not depend on the local numbering, so a partitioned run sums every row exactly like the single-GPU run
+        if (k >= 0 && std::find(tmp.begin(), tmp.end(), k) == tmp.end()) tmp.push_back(k);
+      }
     }
-    std::sort(tmp.begin(), tmp.end());
-    tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
     col2.insert(col2.end(), tmp.begin(), tmp.end());
     ptr2[c + 1] = (int32_t)col2.size();
   }
@@ -363,7 +372,7 @@ int ensure_sq_pattern(cwr_engine* e) {
   if (hipGetDeviceProperties(&prop, e->dev) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, BLOCK, e->apply_lds2) != hipSuccess || per_cu < 1) per_cu = 1;
   per_cu = std::min(per_cu, e->cu_cap);
-  e->apply_grid2 = std::max(N_XCD, std::min(cdiv(e->ntiles, N_XCD) * N_XCD, (n_cu * per_cu / N_XCD) * N_XCD));
+  e->apply_grid2 = std::max(N_XCD, std::min(cdiv(cdiv(n, TR), N_XCD) * N_XCD, (n_cu * per_cu / N_XCD) * N_XCD));
   if (e->apply_grid2 > std::max(e->apply_grid, 256 * 8)) e->apply_grid2 = std::max(e->apply_grid, 256 * 8);   // partials buffer size
   TRY(dev_alloc(e, &e->d_ptr2, (size_t)n + 1));
   TRY(dev_alloc(e, &e->d_col2, (size_t)e->nnz2));
@@ -385,7 +394,7 @@ int ensure_sq_pattern(cwr_engine* e) {
 // numeric J^2 and c2 (into d_t) for the step whose operator is prepared; active = false -> plain sweeps only
 int prepare_sq(cwr_engine* e, bool& active) {
   active = false;
-  if (e->comm || !e->use_sq || e->sq_failed || e->K < e->sq_min_k) return CWR_OK;
+  if (!e->use_sq || e->sq_failed || e->K < e->sq_min_k) return CWR_OK;
   TRY(ensure_sq_pattern(e));
   if (!e->sq_pattern) return CWR_OK;
   const int n = e->n_owned;
@@ -435,13 +444,13 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
       int doubles = (batch - 2) / 2;
       launches = doubles + 2;
       todo = 0;
-      if (!e->profiling && e->use_graphs) {
+      if (!e->comm && !e->profiling && e->use_graphs) {
         if (!e->sq_graph_tried) {
           e->sq_graph_tried = true;
           if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
             int rc = CWR_OK;
             for (int i = 0; i < cwr_engine::GRAPH_SWEEPS && rc == CWR_OK; ++i)
-              rc = launch_apply<5>(e, (i & 1) ? e->d_p : e->d_c, (i & 1) ? e->d_c : e->d_p, nullptr, e->d_t, nullptr, nullptr);
+              rc = launch_apply<5>(e, (i & 1) ? e->d_p : e->d_c, (i & 1) ? e->d_c : e->d_p, nullptr, e->d_t, nullptr, nullptr, e->n_sq);
             hipGraph_t g = nullptr;
             const hipError_t ec = hipStreamEndCapture(e->stream, &g);
             if (rc == CWR_OK && ec == hipSuccess && g && hipGraphInstantiate(&e->sq_exec, g, nullptr, nullptr, 0) == hipSuccess) e->sq_graph = g;
@@ -450,10 +459,19 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
         }
         while (e->sq_exec && doubles >= cwr_engine::GRAPH_SWEEPS) { HIP_TRY(e, hipGraphLaunch(e->sq_exec, e->stream)); doubles -= cwr_engine::GRAPH_SWEEPS; }
       }
-      for (int i = 0; i < doubles; ++i)
-        TRY(launch_apply<5>(e, (i & 1) ? e->d_p : e->d_c, (i & 1) ? e->d_c : e->d_p, nullptr, e->d_t, nullptr, nullptr));
+      // a J^2 pass uses up two halo layers of validity, a plain sweep one
+      for (int i = 0; i < doubles; ++i) {
+        double* src = (i & 1) ? e->d_p : e->d_c;
+        if (since_exchange + 2 > e->exch_every) { TRY(exchange_halo(e, src)); since_exchange = 0; }
+        TRY(launch_apply<5>(e, src, (i & 1) ? e->d_c : e->d_p, nullptr, e->d_t, nullptr, nullptr, e->n_sq));
+        since_exchange += 2;
+      }
+      if (since_exchange + 1 > e->exch_every) { TRY(exchange_halo(e, e->d_c)); since_exchange = 0; }
       TRY(launch_apply<4>(e, e->d_c, e->d_p, nullptr, e->d_b, nullptr, nullptr));
+      ++since_exchange;
+      if (since_exchange + 1 > e->exch_every) { TRY(exchange_halo(e, e->d_p)); since_exchange = 0; }
       TRY(launch_apply<4>(e, e->d_p, e->d_c, nullptr, e->d_b, nullptr, nullptr));
+      ++since_exchange;
     } else if (!e->comm && !e->profiling && e->use_graphs) {
       if (!e->graph_tried) {                               // capture GRAPH_SWEEPS sweeps once
         e->graph_tried = true;
@@ -1005,8 +1023,8 @@ int32_t cwr_time_apply(cwr_engine* e, int32_t t, int32_t variant, int32_t reps, 
   auto body = [&](int i) -> int {
     if (variant == 0) {                                        // the last step's dominant sweep kernel
       if (e->dominant_mode == 5)
-        return (i & 1) ? launch_apply<5>(e, e->d_s, e->d_v, nullptr, e->d_t, nullptr, nullptr)
-                       : launch_apply<5>(e, e->d_p, e->d_v, nullptr, e->d_t, nullptr, nullptr);
+        return (i & 1) ? launch_apply<5>(e, e->d_s, e->d_v, nullptr, e->d_t, nullptr, nullptr, e->n_sq)
+                       : launch_apply<5>(e, e->d_p, e->d_v, nullptr, e->d_t, nullptr, nullptr, e->n_sq);
       return (i & 1) ? launch_apply<4>(e, e->d_s, e->d_v, nullptr, e->d_b, nullptr, nullptr)
                      : launch_apply<4>(e, e->d_p, e->d_v, nullptr, e->d_b, nullptr, nullptr);
     }
@@ -1068,9 +1086,10 @@ int32_t cwr_apply_bytes(const cwr_engine* e, int64_t* bytes_read, int64_t* bytes
   const int64_t K = e->K;
   const bool sq = (e->dominant_mode == 5);
   const int64_t entries = sq ? e->nnz2 : e->nnz;
-  if (bytes_read) *bytes_read = 16LL * entries + 4LL * (e->n_owned + 1) + (sq ? 0LL : 8LL * e->n_owned) +
-                                8LL * K * e->n_real + 8LL * K * e->n_owned;
-  if (bytes_written) *bytes_written = 8LL * K * e->n_owned;
+  const int64_t rows = sq ? e->n_sq : e->n_owned;
+  if (bytes_read) *bytes_read = 16LL * entries + 4LL * (rows + 1) + (sq ? 0LL : 8LL * rows) +
+                                8LL * K * e->n_real + 8LL * K * rows;
+  if (bytes_written) *bytes_written = 8LL * K * rows;
   return CWR_OK;
 }
 

@@ -64,7 +64,8 @@ def _rank_main(rank, world, K, solver, depth, uid_pipe, out_queue):
 
 
 @pytest.mark.parametrize('world,K,solver,depth', [(2, 3, 'jacobi', 1), (2, 3, 'bicgstab', 1), (3, 16, 'auto', 1), (4, 1, 'auto', 1),
-                                                  (2, 3, 'jacobi', 4), (3, 2, 'bicgstab', 3), (4, 16, 'auto', 8), (3, 1, 'auto', 2)])
+                                                  (2, 3, 'jacobi', 4), (3, 2, 'bicgstab', 3), (4, 16, 'auto', 8), (3, 1, 'auto', 2),
+                                                  (2, 16, 'jacobi', 8), (3, 8, 'jacobi', 2), (2, 12, 'jacobi', 5)])
 def test_partitioned_step_matches_single_rank_and_oracle(gpu_lib, world, K, solver, depth):
     build_mock()
     ctx = mp.get_context('spawn')
