@@ -85,6 +85,7 @@ struct cwr_engine {
   // vectors: c is the full state [owned | halo | ghost] x K and doubles as the solver's x
   double *d_c = nullptr, *d_r = nullptr, *d_r0 = nullptr, *d_p = nullptr, *d_v = nullptr, *d_s = nullptr,
          *d_t = nullptr, *d_b = nullptr;
+  double* d_react = nullptr;     // K x K reaction matrix of cwr_react_linear
   double* d_scal = nullptr;      // acc[3][ACC_N][K] | rho[3][K] | bb[K]
   int32_t* d_counters = nullptr; // 8 ints
   double *d_fadv = nullptr, *d_fdif = nullptr, *d_ftot = nullptr;
@@ -770,7 +771,7 @@ void cwr_destroy(cwr_engine* e) {
   for (hipEvent_t ev : e->ev) hipEventDestroy(ev);
   void* ptrs[] = {e->d_f1, e->d_f2, e->d_ptr, e->d_ent_edge, e->d_ent_nb, e->d_adv, e->d_vel, e->d_vol, e->d_dif,
                   e->d_bc, e->d_rec, e->d_diag, e->d_c, e->d_r, e->d_r0, e->d_p, e->d_v, e->d_s, e->d_t, e->d_b,
-                  e->d_scal, e->d_counters, e->d_partial, e->d_fadv, e->d_fdif, e->d_ftot, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf, e->d_ptr2, e->d_col2, e->d_row2, e->d_rec2, e->d_w};
+                  e->d_scal, e->d_counters, e->d_partial, e->d_fadv, e->d_fdif, e->d_ftot, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf, e->d_ptr2, e->d_col2, e->d_row2, e->d_rec2, e->d_w, e->d_react};
   for (void* p : ptrs) if (p) hipFree(p);
   if (e->stream) hipStreamDestroy(e->stream);
   delete e;
@@ -857,6 +858,29 @@ int32_t cwr_set_state(cwr_engine* e, const double* conc_owned) {
   if (!e || !conc_owned) return e ? fail(e, CWR_ERR_BAD_ARG, "cwr_set_state: NULL") : CWR_ERR_BAD_ARG;
   HIP_TRY(e, hipSetDevice(e->dev));
   TRY(upload(e, e->d_c, conc_owned, (size_t)e->n_core * e->K));
+  return CWR_OK;
+}
+
+int32_t cwr_react_linear(cwr_engine* e, const double* M) {
+  if (!e || !M) return e ? fail(e, CWR_ERR_BAD_ARG, "cwr_react_linear: NULL") : CWR_ERR_BAD_ARG;
+  if (e->K > BLOCK) return fail(e, CWR_ERR_BAD_ARG, "cwr_react_linear: K too large");
+  HIP_TRY(e, hipSetDevice(e->dev));
+  const int K = e->K;
+  if (!e->d_react) TRY(dev_alloc(e, &e->d_react, (size_t)K * K));
+  TRY(upload(e, e->d_react, M, (size_t)K * K));
+  const int rows_pb = BLOCK / K;
+  const size_t lds = ((size_t)rows_pb * K + (size_t)K * K) * sizeof(double);
+  const int grid = std::max(1, std::min(cdiv(e->n_core, rows_pb), 256 * 8));
+  k_react_linear<<<grid, BLOCK, lds, e->stream>>>(e->n_core, K, e->d_react, e->d_c);
+  HIP_TRY(e, hipGetLastError());
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return CWR_OK;
+}
+
+int32_t cwr_state_device_ptr(cwr_engine* e, void** state, void** stream) {
+  if (!e || !state) return e ? fail(e, CWR_ERR_BAD_ARG, "cwr_state_device_ptr: NULL") : CWR_ERR_BAD_ARG;
+  *state = e->d_c;
+  if (stream) *stream = e->stream;
   return CWR_OK;
 }
 

@@ -687,6 +687,30 @@ __global__ void __launch_bounds__(BLOCK) k_mass_flux(
   }
 }
 
+// ------------------------------------------------------------------------------------------------ a-8 on device
+// Device-resident reaction step between two transport steps: c[cell, :] <- M c[cell, :] for every owned cell, M a
+// K x K matrix (first-order decay on the diagonal, pairwise exchange off it) -- the in-HBM stand-in for the host
+// callback of transport.py:233-236 (update_concentration), without the D2H / H2D round trip of the state.
+__global__ void __launch_bounds__(BLOCK) k_react_linear(int n_rows, int K, const double* __restrict__ M, double* __restrict__ c) {
+  extern __shared__ double s_tile[];               // [rows_per_block][K] state rows, then M
+  const int rows_pb = BLOCK / K;
+  double* s_M = s_tile + rows_pb * K;
+  for (int i = threadIdx.x; i < K * K; i += BLOCK) s_M[i] = M[i];
+  const int r = threadIdx.x / K, k = threadIdx.x - r * K;
+  for (int base = blockIdx.x * rows_pb; base < n_rows; base += gridDim.x * rows_pb) {
+    const int cell = base + r;
+    const bool live = (r < rows_pb) && (cell < n_rows);
+    __syncthreads();
+    if (live) s_tile[r * K + k] = c[(size_t)cell * K + k];
+    __syncthreads();
+    if (live) {
+      double acc = 0.0;
+      for (int j = 0; j < K; ++j) acc += s_M[k * K + j] * s_tile[r * K + j];
+      c[(size_t)cell * K + k] = acc;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ halo
 __global__ void __launch_bounds__(BLOCK) k_pack_rows(int64_t total, int K, const int32_t* __restrict__ cells,
                                                    const double* __restrict__ vec, double* __restrict__ buf) {

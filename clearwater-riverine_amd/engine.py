@@ -33,7 +33,7 @@ STEP_FORCE_JACOBI = 8
 ABI_SYMBOLS = (
     'cwr_abi_version', 'cwr_create', 'cwr_destroy', 'cwr_last_error', 'cwr_load_flow_field',
     'cwr_load_coefficients', 'cwr_get_coefficients', 'cwr_load_boundary', 'cwr_set_boundary_level',
-    'cwr_set_state', 'cwr_get_state', 'cwr_apply', 'cwr_rhs', 'cwr_step', 'cwr_get_mass_flux',
+    'cwr_set_state', 'cwr_get_state', 'cwr_react_linear', 'cwr_state_device_ptr', 'cwr_apply', 'cwr_rhs', 'cwr_step', 'cwr_get_mass_flux',
     'cwr_time_apply', 'cwr_profile_read', 'cwr_synchronize', 'cwr_apply_bytes',
     'cwr_comm_unique_id', 'cwr_attach_comm',
 )
@@ -91,6 +91,8 @@ def load_library(path: str | None = None) -> C.CDLL:
         'cwr_set_boundary_level': [vp, i32, vp],
         'cwr_set_state': [vp, vp],
         'cwr_get_state': [vp, vp],
+        'cwr_react_linear': [vp, vp],
+        'cwr_state_device_ptr': [vp, P(vp), P(vp)],
         'cwr_apply': [vp, i32, vp, vp],
         'cwr_rhs': [vp, i32, vp, vp],
         'cwr_step': [vp, i32, f64, i32, i32, P(StepInfo)],
@@ -227,6 +229,18 @@ class TransportEngine:
         out = np.empty((self.n_cells, self.K), np.float64)
         self._check(self._lib.cwr_get_state(self._h, _ptr(out)))
         return out
+
+    def react_linear(self, reaction_matrix):
+        """c[cell, :] <- M c[cell, :] on every owned cell, on the device (the in-HBM stand-in for the host
+        reaction callback of transport.py:233-236)."""
+        M = _arr(reaction_matrix, np.float64, (self.K, self.K), 'reaction_matrix')
+        self._check(self._lib.cwr_react_linear(self._h, _ptr(M)))
+
+    def state_device_ptr(self):
+        """(device pointer of the (n_cells, K) float64 state, hipStream_t) as integers."""
+        st, sm = C.c_void_p(), C.c_void_p()
+        self._check(self._lib.cwr_state_device_ptr(self._h, C.byref(st), C.byref(sm)))
+        return st.value, sm.value
 
     # ------------------------------------------------------------------ operator / rhs / step
     def apply(self, t: int, x) -> np.ndarray:

@@ -234,8 +234,12 @@ class ClearwaterRiverine:
         return self.engine.get_coefficients(t)
 
     # ------------------------------------------------------------------ the hot path
-    def update(self, update_concentration: Optional[dict] = None):
-        """Update a single timestep (transport.py:201-276)."""
+    def update(self, update_concentration: Optional[dict] = None, reaction_matrix=None):
+        """Update a single timestep (transport.py:201-276).
+
+        reaction_matrix (K, K), optional: apply c[cell, :] <- M c[cell, :] to the level-t state ON THE DEVICE before
+        the transport step -- the same effect as passing update_concentration = {name: (M c)[:, k]} but without
+        moving the state through the host."""
         t = self.time_step
         n = self._n
         if t + 1 >= self._T:
@@ -258,6 +262,12 @@ class ClearwaterRiverine:
                 inp = np.stack([self.constituent_dict[c].input_array[t, :n] for c in self.constituents], axis=1)
                 x = np.where(inp != 0, inp, x)
             self.engine.set_state(x)
+        if reaction_matrix is not None:
+            self.engine.react_linear(reaction_matrix)
+            if self.store_history:                               # keep mesh[name][t] consistent, as the override does
+                c_now = self.engine.get_state()
+                for k, cname in enumerate(self.constituents):
+                    self._row(cname, t)[0:n] = c_now[:n, k]
         self.last_step = self.engine.step(t, tol=self.tol, max_iter=self.max_iter, mass_flux=self.store_history,
                                           solver=self.solver)
         self._device_level = t + 1

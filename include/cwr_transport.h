@@ -120,6 +120,16 @@ int32_t cwr_set_boundary_level(cwr_engine* e, int32_t t, const double* ghost_con
 int32_t cwr_set_state(cwr_engine* e, const double* conc_owned);
 int32_t cwr_get_state(cwr_engine* e, double* conc_all_cells);
 
+/* ---- device-resident reaction hook (callers: examples/02_...tsm.ipynb cell[39] run_n_timesteps) -----
+ * The reference's coupling loop overrides c[t, 0:n] per constituent from a host reaction model before update()
+ * (transport.py:233-236).  These two entry points keep that step in HBM:
+ * cwr_react_linear: c[cell, :] <- M c[cell, :] on every owned cell, M (K, K) row-major host array (first-order
+ *   decay on the diagonal, pairwise exchange off it) -- the built-in stand-in for a TSM/NSM kinetics kernel;
+ * cwr_state_device_ptr: the device pointer of the (n_cells, K) float64 state and the engine's hipStream_t, for a
+ *   caller-supplied HIP reaction kernel launched between two cwr_step() calls (rows [0, n_owned) are the real cells). */
+int32_t cwr_react_linear(cwr_engine* e, const double* reaction_matrix);
+int32_t cwr_state_device_ptr(cwr_engine* e, void** state, void** stream);
+
 /* ---- the face-flux operator (exported for parity tests and roofline timing) ---------------------
  * y = A x with A the matrix LHS.update_values(mesh, t) + csr_matrix build (linalg.py:34-156,
  * transport.py:215-218), evaluated matrix-free per cell over the CSR face adjacency.
