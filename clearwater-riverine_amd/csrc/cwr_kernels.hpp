@@ -687,6 +687,115 @@ __global__ void __launch_bounds__(BLOCK) k_mass_flux(
   }
 }
 
+// ------------------------------------------------------------------------------------------------ small meshes
+// The reference's own meshes (Ohio River 2 943 cells, Sumwere Creek 367) fit one CU's LDS.  There a sweep launch
+// is pure latency (4-6 us for a few microseconds of work), so the WHOLE Jacobi solve of one constituent runs in one
+// 1024-thread workgroup: the column of x lives in LDS, every thread keeps its rows' bhat and 1/diag in registers,
+// face records stream from L2, two barriers per sweep; ||x'-x||^2 (the exact scaled residual of the sweep's input)
+// is block-reduced every `check_every` sweeps.  One workgroup per constituent (columns are independent systems).
+constexpr int SMALL_THREADS = 1024;
+constexpr int SMALL_RPT_MAX = 8;                 // rows per thread: meshes up to 8 192 real cells
+constexpr int SMALL_DEG = 8;                     // register-resident records: faces per row
+// RPT  rows per thread (compile time: static register indexing).
+// REGS the rows' face records (neighbour, coefficient / diag) live in registers too -- then a sweep touches LDS only.
+template <int RPT, bool REGS>
+__global__ void __launch_bounds__(SMALL_THREADS) k_small_jacobi(
+    int n, int K, const int32_t* __restrict__ ptr, const FaceRec* __restrict__ rec, const double* __restrict__ diag,
+    const double* __restrict__ bhat, double* __restrict__ x, double tol2, int max_sweeps, int check_every,
+    double* __restrict__ info /* [K][3]: sweeps, ||x'-x||^2, ||bhat||^2 */) {
+  extern __shared__ double s_x[];                // n doubles, then reduction scratch
+  double* s_red = s_x + n;
+  const int k = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  double bh[RPT], rdg[RPT];
+  int j0[RPT], j1[RPT];
+  int rnb[REGS ? RPT * SMALL_DEG : 1];
+  double rw[REGS ? RPT * SMALL_DEG : 1];
+  double bb = 0.0;
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int c = tid + i * SMALL_THREADS;
+    bh[i] = 0.0; rdg[i] = 0.0; j0[i] = 0; j1[i] = 0;
+    if (c < n) {
+      s_x[c] = x[(size_t)c * K + k];
+      bh[i] = bhat[(size_t)c * K + k];
+      rdg[i] = 1.0 / diag[c];
+      j0[i] = ptr[c]; j1[i] = ptr[c + 1];
+      bb += bh[i] * bh[i];
+    }
+    if constexpr (REGS) {
+#pragma unroll
+      for (int q = 0; q < SMALL_DEG; ++q) {
+        rnb[i * SMALL_DEG + q] = min(c, n - 1);  // padded slot: own row, zero weight
+        rw[i * SMALL_DEG + q] = 0.0;
+        if (c < n && j0[i] + q < j1[i]) {
+          const FaceRec fr = rec[j0[i] + q];
+          if (fr.nb >= 0) { rnb[i * SMALL_DEG + q] = fr.nb; rw[i * SMALL_DEG + q] = (fr.d - fmin((double)fr.a_c, 0.0)) * rdg[i]; }
+        }
+      }
+    }
+  }
+  auto block_sum = [&](double v) -> double {      // fixed-order reduction: shuffles inside a wave, then the 16 wave sums
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    __syncthreads();
+    if (lane == 0) s_red[wave] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < SMALL_THREADS / 64; ++w) t += s_red[w];
+    return t;
+  };
+  bb = block_sum(bb);
+  int sweep = 0;
+  double rr = 0.0;
+  for (;;) {
+    double xn[RPT];
+    double dx2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int c = tid + i * SMALL_THREADS;
+      xn[i] = 0.0;
+      if (c < n) {
+        double sum = 0.0;                          // sum = (J x)[c] * diag-free form: x' = bhat + sum
+        if constexpr (REGS) {
+#pragma unroll
+          for (int q = 0; q < SMALL_DEG; ++q) sum += rw[i * SMALL_DEG + q] * s_x[rnb[i * SMALL_DEG + q]];
+        } else {
+          for (int j = j0[i]; j < j1[i]; ++j) {
+            const FaceRec fr = rec[j];
+            const bool ok = fr.nb >= 0;
+            const double cf = ok ? (fr.d - fmin((double)fr.a_c, 0.0)) * rdg[i] : 0.0;
+            sum += cf * s_x[ok ? fr.nb : c];
+          }
+        }
+        xn[i] = bh[i] + sum;
+        const double dx = xn[i] - s_x[c];
+        dx2 += dx * dx;
+      }
+    }
+    __syncthreads();                             // every read of the old column is done
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int c = tid + i * SMALL_THREADS;
+      if (c < n) s_x[c] = xn[i];
+    }
+    ++sweep;
+    const bool check = (sweep % check_every == 0) || sweep >= max_sweeps;
+    if (check) {                                 // uniform
+      rr = block_sum(dx2);                       // (its barriers also publish the new column)
+      if (!(rr > tol2 * bb) || sweep >= max_sweeps) break;    // converged, NaN, or out of sweeps
+    } else {
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int c = tid + i * SMALL_THREADS;
+    if (c < n) x[(size_t)c * K + k] = s_x[c];
+  }
+  if (tid == 0) { info[k * 3 + 0] = (double)sweep; info[k * 3 + 1] = rr; info[k * 3 + 2] = bb; }
+}
+
 // ------------------------------------------------------------------------------------------------ a-8 on device
 // Device-resident reaction step between two transport steps: c[cell, :] <- M c[cell, :] for every owned cell, M a
 // K x K matrix (first-order decay on the diagonal, pairwise exchange off it) -- the in-HBM stand-in for the host

@@ -4,7 +4,7 @@ sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, 'oracle'))
 import numpy as np
 import clearwater_riverine_amd as cw
 import cwr_oracle as oracle
-for (nx, ny, nm, K) in [(109, 28, 109, 1), (109, 28, 109, 12), (200, 50, 0, 1), (200, 50, 0, 12)]:
+for (nx, ny, nm, K) in [(109, 28, 109, 1), (109, 28, 109, 12), (160, 50, 0, 1), (160, 50, 0, 12), (200, 50, 0, 12)]:
     steps = 40
     mesh = cw.synthetic.make_mesh(nx, ny, steps, seed=20100529, n_merge=nm, dx=75.0, dy=75.0, depth=3.0, dt=3600.0,
                                   velocity=0.3, breathing=0.0, diffusion_coefficient=0.1, period_steps=24)

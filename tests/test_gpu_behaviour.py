@@ -94,7 +94,7 @@ def test_stiff_step_switches_to_bicgstab(gpu_lib):
     """Large CFL (dt = 3600 s on 10 m cells, the Ohio River regime): the sweeps' measured contraction is too
     slow and the step finishes with BiCGSTAB; the result still matches the direct solve."""
     import clearwater_riverine_amd as cw
-    mesh = cw.synthetic.make_mesh(40, 12, 3, seed=3, dt=3600.0, breathing=0.0, n_merge=10)
+    mesh = cw.synthetic.make_mesh(160, 40, 3, seed=3, dt=3600.0, breathing=0.0, n_merge=10)   # > 4096 cells: multi-launch path
     oracle.derive_coefficients(mesh)
     inputs3 = cw.synthetic.boundary_input_array(mesh, 2, inlet_period_s=86400.0)
     n = mesh['nreal'] + 1
@@ -191,6 +191,7 @@ def test_single_rank_rccl_communicator(gpu_lib, monkeypatch):
     communicator-free engine bit for bit (an all-reduce over one rank is the identity)."""
     import clearwater_riverine_amd as cw
     monkeypatch.setenv('CWR_FORCE_COLLECTIVES', '1')
+    monkeypatch.setenv('CWR_NO_SMALL', '1')          # both engines on the multi-launch path (a communicator rules out the small one)
     mesh, inputs3 = synthetic_case(3, nx=30, ny=14, n_steps=3, seed=12, n_merge=15)
     n = mesh['nreal'] + 1
     outs = []

@@ -66,8 +66,9 @@ def _rank_main(rank, world, K, solver, depth, uid_pipe, out_queue):
 @pytest.mark.parametrize('world,K,solver,depth', [(2, 3, 'jacobi', 1), (2, 3, 'bicgstab', 1), (3, 16, 'auto', 1), (4, 1, 'auto', 1),
                                                   (2, 3, 'jacobi', 4), (3, 2, 'bicgstab', 3), (4, 16, 'auto', 8), (3, 1, 'auto', 2),
                                                   (2, 16, 'jacobi', 8), (3, 8, 'jacobi', 2), (2, 12, 'jacobi', 5)])
-def test_partitioned_step_matches_single_rank_and_oracle(gpu_lib, world, K, solver, depth):
+def test_partitioned_step_matches_single_rank_and_oracle(gpu_lib, world, K, solver, depth, monkeypatch):
     build_mock()
+    monkeypatch.setenv('CWR_NO_SMALL', '1')      # the single-rank reference run takes the same multi-launch path as the ranks
     ctx = mp.get_context('spawn')
     uid_pipe, out_queue = ctx.Queue(), ctx.Queue()
     procs = [ctx.Process(target=_rank_main, args=(r, world, K, solver, depth, uid_pipe, out_queue)) for r in range(world)]

@@ -98,13 +98,16 @@ def test_rhs_matches_reference_assembly(gpu_lib, K):
             assert np.max(np.abs(b[:, k] - r.vals)) <= TOL_OP * np.max(np.abs(r.vals))
 
 
-@pytest.mark.parametrize('solver', ['auto', 'bicgstab'])
+@pytest.mark.parametrize('solver', ['auto', 'bicgstab', 'multi-launch'])
 @pytest.mark.parametrize('plan,D,steps', [('plan01', 0.01, 30), ('plan02', 0.01, 24), ('plan03', 0.001, 30),
                                           ('plan01', 0.0, 10)])
-def test_facade_update_matches_oracle_on_reference_fixtures(gpu_lib, plan, D, steps, solver):
+def test_facade_update_matches_oracle_on_reference_fixtures(gpu_lib, plan, D, steps, solver, monkeypatch):
     """ClearwaterRiverine.update() loop == oracle (spsolve) on the reference's HDF fixtures:
     concentrations incl. ghost-cell NaN pattern, and the three mass-flux arrays."""
     import clearwater_riverine_amd as cw
+    if solver == 'multi-launch':
+        monkeypatch.setenv('CWR_NO_SMALL', '1')
+        solver = 'auto'
     mesh, inp, _ = load_plan(plan, D)
     ref = oracle_run(mesh, inp[:, :, None], steps)
     model = cw.ClearwaterRiverine(mesh=dict(mesh), diffusion_coefficient_input=D, input_arrays={'c0': inp.copy()},
@@ -120,11 +123,15 @@ def test_facade_update_matches_oracle_on_reference_fixtures(gpu_lib, plan, D, st
         assert rel_err(got[:steps], want[:steps]) <= 1e-8
 
 
+@pytest.mark.parametrize('path', ['one-launch small-mesh solver', 'multi-launch sweeps'])
 @pytest.mark.parametrize('solver', ['auto', 'jacobi', 'bicgstab'])
 @pytest.mark.parametrize('K', [1, 3, 12, 16])
-def test_facade_multi_constituent_and_override(gpu_lib, K, solver):
-    """K batched constituents + the update_concentration override of transport.py:233-236."""
+def test_facade_multi_constituent_and_override(gpu_lib, K, solver, path, monkeypatch):
+    """K batched constituents + the update_concentration override of transport.py:233-236, through both Jacobi
+    paths (the LDS-resident one-launch solver of small meshes, and the tiled sweeps / J^2 passes of large ones)."""
     import clearwater_riverine_amd as cw
+    if path == 'multi-launch sweeps':
+        monkeypatch.setenv('CWR_NO_SMALL', '1')
     mesh, inputs3 = synthetic_case(K, nx=30, ny=11, n_steps=12, seed=11, n_merge=25, n_dry=2)
     names = [f'c{k}' for k in range(K)]
     n = mesh['nreal'] + 1
