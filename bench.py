@@ -62,6 +62,8 @@ def main():
     ap.add_argument('--diffusion', type=float, default=0.5)
     ap.add_argument('--seed', type=int, default=4)
     ap.add_argument('--solver', default='auto', choices=['auto', 'jacobi', 'bicgstab'])
+    ap.add_argument('--renumber', default='hilbert', choices=['hilbert', 'none'],
+                    help='internal cell numbering (reference ids stay at the boundary)')
     ap.add_argument('--halo-depth', type=int, default=8, help='N > 1: halo layers = Jacobi sweeps between two exchanges')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-nx', type=int, default=640)
@@ -103,7 +105,8 @@ def main():
     uid = None
     if world > 1:
         uid = broadcast_bytes(TransportEngine.comm_unique_id() if rank == 0 else None, 128, src=0)
-    pt = PartitionedTransport(mesh, inputs3, rank, world, device=local_rank, unique_id=uid, halo_depth=args.halo_depth)
+    pt = PartitionedTransport(mesh, inputs3, rank, world, device=local_rank, unique_id=uid, halo_depth=args.halo_depth,
+                              renumber=None if args.renumber == 'none' else args.renumber)
     eng = pt.engine
 
     def barrier():
@@ -183,7 +186,7 @@ def main():
                                    f'{len(mesh["edges_face1"])} faces), {K} constituents, implicit upwind '
                                    f'advection-diffusion step, dt={args.dt} s, D={args.diffusion}',
                        'cells': n, 'faces': int(len(mesh['edges_face1'])), 'constituents': K,
-                       'partition': f'contiguous cell ranges x{world}' + (f', halo depth {pt.local.depth}' if world > 1 else ''),
+                       'numbering': args.renumber, 'partition': f'contiguous cell ranges x{world}' + (f', halo depth {pt.local.depth}' if world > 1 else ''),
                        'tol': args.tol},
             'solver': {'method': 'fused Jacobi sweeps, BiCGSTAB on stiff steps; K systems batched', 'iterations_per_step': iters,
                        'max_rel_residual': max_resid},

@@ -14,6 +14,7 @@ import numpy as np
 
 from .engine import TransportEngine
 from .model import face_to_face_distance, change_in_time
+from .ordering import hilbert_order, renumber_mesh
 from .partition import LocalMesh, partition_mesh, slice_fields
 
 
@@ -38,10 +39,19 @@ class PartitionedTransport:
     single-GPU engine (no halo, no communicator)."""
 
     def __init__(self, mesh: dict, inputs3: np.ndarray, rank: int, world: int, device: int = 0,
-                 unique_id: bytes | None = None, halo_depth: int = 1):
+                 unique_id: bytes | None = None, halo_depth: int = 1, renumber: str | None = None):
+        """renumber='hilbert': work in a space-filling-curve numbering of the real cells (ordering.py); every
+        array handed in or out of this class stays in the reference's numbering."""
+        n = int(np.asarray(mesh['edges_face1']).max()) + 1
+        self.order = None
+        if renumber == 'hilbert':
+            self.order = hilbert_order(mesh['face_x'], mesh['face_y'], n)
+            mesh = renumber_mesh(mesh, self.order)
+            inputs3 = np.concatenate([inputs3[:, self.order, :], inputs3[:, n:, :]], axis=1)
+        elif renumber is not None:
+            raise ValueError(f'unknown renumbering {renumber!r}')
         f1 = np.asarray(mesh['edges_face1'])
         f2 = np.asarray(mesh['edges_face2'])
-        n = int(f1.max()) + 1
         self.n_global = n
         self.K = int(inputs3.shape[2])
         self.local: LocalMesh = partition_mesh(f1, f2, n, world, rank, depth=halo_depth)
@@ -73,13 +83,22 @@ class PartitionedTransport:
     def owned_state(self) -> np.ndarray:
         return self.engine.get_state()[: self.local.n_core]
 
+    def owned_reference_ids(self) -> np.ndarray:
+        """Reference cell ids of the rows owned_state() returns."""
+        ids = np.arange(self.local.lo, self.local.hi)
+        return ids if self.order is None else self.order[ids]
+
     def gather_state(self) -> np.ndarray:
-        """(n_global, K) concentrations of all real cells on every rank (control-plane all_gather)."""
+        """(n_global, K) concentrations of all real cells, in the reference's numbering, on every rank
+        (control-plane all_gather)."""
         mine = self.owned_state()
-        if self.local.world == 1:
+        if self.local.world > 1:
+            import torch.distributed as dist
+            parts = [None] * self.local.world
+            dist.all_gather_object(parts, mine)
+            mine = np.concatenate(parts, axis=0)
+        if self.order is None:
             return mine
-        import torch
-        import torch.distributed as dist
-        parts = [None] * self.local.world
-        dist.all_gather_object(parts, mine)
-        return np.concatenate(parts, axis=0)
+        out = np.empty_like(mine)
+        out[self.order] = mine
+        return out

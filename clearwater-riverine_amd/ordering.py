@@ -1,0 +1,58 @@
+"""Internal cell renumbering (host side, numpy): a space-filling-curve order of the real cells.
+
+The reference's cell ids (HEC-RAS order) stay the ids of every boundary array; the engine may work in
+a permuted numbering in which a cell's face neighbours -- and the neighbours' neighbours the J^2 pass
+gathers -- are close in memory (SURVEY.md section 7 "gather locality").  Row sums do not depend on the
+numbering (the faces of a row are always visited in ascending face id), so concentrations are bitwise
+identical with and without renumbering; only the order in which norms are accumulated changes.
+Ghost cells are never renumbered.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def hilbert_index(gx: np.ndarray, gy: np.ndarray, bits: int = 16) -> np.ndarray:
+    """Hilbert-curve index of integer grid points (vectorised xy -> d)."""
+    x = gx.astype(np.int64).copy()
+    y = gy.astype(np.int64).copy()
+    d = np.zeros_like(x)
+    s = 1 << (bits - 1)
+    while s > 0:
+        rx = ((x & s) > 0).astype(np.int64)
+        ry = ((y & s) > 0).astype(np.int64)
+        d += s * s * ((3 * rx) ^ ry)
+        swap = ry == 0
+        flip = swap & (rx == 1)
+        x = np.where(flip, s - 1 - x, x)
+        y = np.where(flip, s - 1 - y, y)
+        x, y = np.where(swap, y, x), np.where(swap, x, y)
+        s >>= 1
+    return d
+
+
+def hilbert_order(face_x, face_y, n_real: int) -> np.ndarray:
+    """order[new id] = reference id, for the real cells 0..n_real-1, along a Hilbert curve through the cell centres."""
+    x = np.asarray(face_x, dtype=np.float64)[:n_real]
+    y = np.asarray(face_y, dtype=np.float64)[:n_real]
+    span = max(float(x.max() - x.min()), float(y.max() - y.min()), 1e-300)
+    gx = np.minimum(((x - x.min()) / span * 65535.0), 65535.0).astype(np.int64)
+    gy = np.minimum(((y - y.min()) / span * 65535.0), 65535.0).astype(np.int64)
+    return np.argsort(hilbert_index(gx, gy), kind='stable').astype(np.int64)
+
+
+def renumber_mesh(mesh: dict, order: np.ndarray) -> dict:
+    """A shallow copy of `mesh` in the numbering order[new] = old (real cells only; ghost ids unchanged)."""
+    n = len(order)
+    ncell = len(mesh['face_x'])
+    inv = np.arange(ncell, dtype=np.int64)
+    inv[order] = np.arange(n)
+    full = np.arange(ncell, dtype=np.int64)
+    full[:n] = order
+    m = dict(mesh)
+    m['edges_face1'] = inv[np.asarray(mesh['edges_face1'])].astype(np.int32)
+    m['edges_face2'] = inv[np.asarray(mesh['edges_face2'])].astype(np.int32)
+    m['face_x'] = np.asarray(mesh['face_x'])[full]
+    m['face_y'] = np.asarray(mesh['face_y'])[full]
+    m['volume'] = np.ascontiguousarray(np.asarray(mesh['volume'])[:, full])
+    return m

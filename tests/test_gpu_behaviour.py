@@ -240,3 +240,25 @@ def test_device_reaction_equals_host_callback_and_oracle(gpu_lib):
         assert rel_err(dev.mesh[nm], ref.constituent_dict[nm].state) <= 1e-9
     ptr, stream = dev.engine.state_device_ptr()
     assert ptr and stream
+
+
+def test_internal_hilbert_renumbering_is_transparent(gpu_lib, monkeypatch):
+    """ordering.py: results in the reference's numbering are bitwise identical with and without the internal
+    space-filling-curve renumbering (row sums visit faces in ascending face id either way)."""
+    from clearwater_riverine_amd.distributed import PartitionedTransport
+    monkeypatch.setenv('CWR_NO_SMALL', '1')
+    mesh, inputs3 = synthetic_case(8, nx=60, ny=33, n_steps=3, seed=17, n_merge=80)
+    outs = []
+    for ren in (None, 'hilbert'):
+        pt = PartitionedTransport(mesh, inputs3, 0, 1, renumber=ren)
+        for t in range(3):
+            pt.step(t, solver='jacobi')
+        outs.append(pt.gather_state())
+        assert np.array_equal(np.sort(pt.owned_reference_ids()), np.arange(mesh['nreal'] + 1))
+    assert np.array_equal(outs[0], outs[1])
+    ref = oracle.OracleModel(mesh, {f'c{k}': inputs3[:, :, k].copy() for k in range(8)})
+    for _ in range(3):
+        ref.update()
+    n = mesh['nreal'] + 1
+    want = np.stack([ref.constituent_dict[f'c{k}'].state[3, :n] for k in range(8)], axis=1)
+    assert rel_err(outs[1], want) <= 1e-9

@@ -87,3 +87,23 @@ def test_mesh_attribute_surface():
     m.attrs['nreal'] = 2
     m.attrs['diffusion_coefficient'] = 0.1
     assert m.nreal == 2 and m.diffusion_coefficient == 0.1 and m.volume.shape == (3,)
+
+
+def test_hilbert_order_is_a_permutation_with_local_neighbours():
+    import clearwater_riverine_amd as cw
+    from clearwater_riverine_amd.ordering import hilbert_order, renumber_mesh
+    m = cw.synthetic.make_mesh(64, 48, 2, seed=3, n_merge=50)
+    n = m['nreal'] + 1
+    order = hilbert_order(m['face_x'], m['face_y'], n)
+    assert np.array_equal(np.sort(order), np.arange(n))
+    r = renumber_mesh(m, order)
+    assert np.array_equal(r['face_x'][:n], m['face_x'][order]) and np.array_equal(r['volume'][:, :n], m['volume'][:, order])
+    assert np.array_equal(r['face_x'][n:], m['face_x'][n:])             # ghosts untouched
+    # same faces between the same cells, expressed in the new ids
+    f1, f2 = np.asarray(m['edges_face1']), np.asarray(m['edges_face2'])
+    full = np.arange(len(m['face_x'])); full[:n] = order
+    assert np.array_equal(full[r['edges_face1']], f1) and np.array_equal(full[r['edges_face2']], f2)
+    # locality: the median id distance of face neighbours shrinks well below the grid width
+    internal = f2 < n
+    d_new = np.abs(r['edges_face1'][internal].astype(np.int64) - r['edges_face2'][internal])
+    assert np.median(d_new) <= 8
