@@ -141,9 +141,10 @@ def main():
     launches, total_us = eng.profile_read()
     if rank == 0:
         b_r, b_w = eng.apply_bytes()
-        double_sweep = bool(iters) and world == 1 and r.operator_launches < r.sweeps
-        kernel_name = ('k_apply<VW,5>: J^2 double sweep (two Jacobi iterations per launch)' if double_sweep
-                       else 'k_apply<VW,4>: fused Jacobi sweep of the face-flux operator')
+        kernel_name = {4: 'k_apply<VW,4>: fused Jacobi sweep of the face-flux operator',
+                       5: 'k_apply<VW,5>: J^2 pass (two Jacobi iterations per launch)',
+                       6: 'k_sq_tiled<VW>: J^2 pass with the x tile staged in LDS, software-pipelined (two Jacobi iterations per launch)',
+                       7: 'k_small_jacobi: one-launch LDS-resident solve'}.get(r.sweep_kernel, 'k_apply<VW,1>: BiCGSTAB product')
         back_to_back_us = eng.time_apply(args.warmup, reps=50) if world == 1 else None
         traffic = None
         try:                                             # PMC-measured HBM bytes per launch of this exact config, if profiled

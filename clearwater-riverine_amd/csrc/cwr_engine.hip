@@ -119,6 +119,15 @@ struct cwr_engine {
   int sq_min_k = 8, nnz2 = 0, n_sq = 0, stage_cap2 = 0, apply_grid2 = 0;
   size_t apply_lds2 = 0;
   int32_t *d_ptr2 = nullptr, *d_col2 = nullptr, *d_row2 = nullptr;
+  // tiled J^2 pass: per tile the distinct x rows it touches, and per J^2 entry the row's index in that list
+  bool use_tcl = true, tcl_ready = false;
+  int tcl_TR = 0, tcl_ntiles = 0, tcl_max_cols = 0, tcl_stage_cap = 0, tcl_grid = 0;
+  size_t tcl_lds = 0, tcl_total_cols = 0;
+  int32_t *d_tcl_ptr = nullptr, *d_tcl_cols = nullptr, *d_loc2 = nullptr;
+  double* d_w2 = nullptr;
+  hipGraph_t tcl_graph = nullptr;
+  hipGraphExec_t tcl_exec = nullptr;
+  bool tcl_graph_tried = false;
   FaceRec* d_rec2 = nullptr;
   double* d_w = nullptr;
   hipGraph_t sq_graph = nullptr;
@@ -390,6 +399,54 @@ int ensure_sq_pattern(cwr_engine* e) {
     for (int c = 0; c < n; ++c) for (int q = ptr2[c]; q < ptr2[c + 1]; ++q) row2[q] = c;
     TRY(upload(e, e->d_row2, row2.data(), (size_t)e->nnz2));
   }
+  // ---- tiled variant: distinct x rows per tile (own rows first) and local indices; single GPU, fits-in-LDS only
+  if (e->use_tcl && !e->comm && n == e->n_owned) {
+    int tr_target = 64;
+    if (const char* v = getenv("CWR_TCL_ROWS")) tr_target = std::max(1, atoi(v));
+    int tr = tr_target;
+    while (tr > e->R && (tr % e->R) != 0) --tr;
+    tr = std::max(tr, e->R);
+    const int nt = cdiv(n, tr);
+    std::vector<int32_t> tptr((size_t)nt + 1, 0), tcols, loc2((size_t)e->nnz2);
+    tcols.reserve((size_t)n * 3);
+    std::vector<int32_t> stamp((size_t)e->n_real, -1), pos((size_t)e->n_real, 0), others;
+    int max_cols = 0, cap2 = 1;
+    for (int t = 0; t < nt; ++t) {
+      const int c0 = t * tr, c1 = std::min(c0 + tr, n);
+      const int base = (int)tcols.size();
+      for (int c = c0; c < c1; ++c) { stamp[c] = t; pos[c] = c - c0; tcols.push_back(c); }
+      others.clear();
+      for (int q = ptr2[c0]; q < ptr2[c1]; ++q) { const int k = col2[q]; if (stamp[k] != t) { stamp[k] = t; others.push_back(k); } }
+      std::sort(others.begin(), others.end());
+      for (size_t u = 0; u < others.size(); ++u) { pos[others[u]] = (c1 - c0) + (int)u; tcols.push_back(others[u]); }
+      for (int q = ptr2[c0]; q < ptr2[c1]; ++q) loc2[q] = pos[col2[q]];
+      tptr[t + 1] = (int32_t)tcols.size();
+      max_cols = std::max(max_cols, (int)tcols.size() - base);
+      cap2 = std::max(cap2, ptr2[c1] - ptr2[c0]);
+    }
+    const size_t lds = ((size_t)max_cols * e->K * sizeof(double) + (size_t)cap2 * (sizeof(double) + sizeof(int32_t)) +
+                        (size_t)(tr + 1) * sizeof(int32_t) + 15) & ~(size_t)15;
+    // the kernel's compile-time prefetch depths bound what a tile may hold; otherwise the plain J^2 pass stays
+    if (lds <= 64 * 1024 && max_cols <= TCL_XR * e->R && cap2 <= TCL_WR * BLOCK && tr <= TCL_U * e->R && tr + 1 <= BLOCK) {
+      const void* fn6 = (e->VW == 2) ? reinterpret_cast<const void*>(&k_sq_tiled<2>) : reinterpret_cast<const void*>(&k_sq_tiled<1>);
+      int pc = 1;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, fn6, BLOCK, lds) != hipSuccess || pc < 1) pc = 1;
+      pc = std::min(pc, 8);
+      e->tcl_TR = tr; e->tcl_ntiles = nt; e->tcl_max_cols = max_cols; e->tcl_stage_cap = cap2; e->tcl_lds = lds;
+      e->tcl_total_cols = tcols.size();
+      e->tcl_grid = std::max(N_XCD, std::min(cdiv(nt, N_XCD) * N_XCD, (n_cu * pc / N_XCD) * N_XCD));
+      TRY(dev_alloc(e, &e->d_tcl_ptr, (size_t)nt + 1));
+      TRY(dev_alloc(e, &e->d_tcl_cols, tcols.size()));
+      TRY(dev_alloc(e, &e->d_loc2, (size_t)e->nnz2));
+      TRY(dev_alloc(e, &e->d_w2, (size_t)e->nnz2));
+      TRY(upload(e, e->d_tcl_ptr, tptr.data(), (size_t)nt + 1));
+      TRY(upload(e, e->d_tcl_cols, tcols.data(), tcols.size()));
+      TRY(upload(e, e->d_loc2, loc2.data(), (size_t)e->nnz2));
+      e->tcl_ready = true;
+      if (getenv("CWR_VERBOSE")) fprintf(stderr, "[cwr] tiled J^2: tile=%d rows, %.2f distinct x rows per row, max %d per tile, lds=%zu, grid=%d\n",
+                                         tr, (double)tcols.size() / n, max_cols, lds, e->tcl_grid);
+    }
+  }
   e->sq_pattern = true;
   if (getenv("CWR_VERBOSE")) fprintf(stderr, "[cwr] J^2: nnz2=%d (%.1f per row) stage_cap2=%d lds2=%zu grid2=%d\n", e->nnz2, (double)e->nnz2 / n, e->stage_cap2, e->apply_lds2, e->apply_grid2);
   return CWR_OK;
@@ -403,7 +460,7 @@ int prepare_sq(cwr_engine* e, bool& active) {
   if (!e->sq_pattern) return CWR_OK;
   const int n = e->n_owned;
   k_entry_w<<<cdiv(n, BLOCK), BLOCK, 0, e->stream>>>(n, e->d_ptr, e->d_rec, e->d_diag, e->d_w);
-  k_build_sq<<<cdiv(e->nnz2, BLOCK), BLOCK, 0, e->stream>>>(e->nnz2, e->d_ptr, e->d_ent_nb, e->d_w, e->d_row2, e->d_col2, e->d_rec2);
+  k_build_sq<<<cdiv(e->nnz2, BLOCK), BLOCK, 0, e->stream>>>(e->nnz2, e->d_ptr, e->d_ent_nb, e->d_w, e->d_row2, e->d_col2, e->d_rec2, e->tcl_ready ? e->d_w2 : nullptr);
   HIP_TRY(e, hipGetLastError());
   const int keep = e->dominant_mode; e->dominant_mode = -1;                    // this set-up launch is not a profiled sweep
   const int rc = launch_apply<4>(e, e->d_b, e->d_t, nullptr, e->d_b, nullptr, nullptr);   // c2 = bhat + J bhat
@@ -413,8 +470,25 @@ int prepare_sq(cwr_engine* e, bool& active) {
   return CWR_OK;
 }
 
+int launch_sq_tiled(cwr_engine* e, const double* xin, double* yout) {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (e->profiling && e->dominant_mode == 6 && e->ev_used + 2 <= e->ev.size()) {
+    e0 = e->ev[e->ev_used++]; e1 = e->ev[e->ev_used++];
+    HIP_TRY(e, hipEventRecord(e0, e->stream));
+  }
+  if (e->VW == 2)
+    k_sq_tiled<2><<<e->tcl_grid, BLOCK, e->tcl_lds, e->stream>>>(e->n_sq, e->K, e->G, e->tcl_TR, e->tcl_ntiles, e->d_ptr2, e->d_loc2,
+        e->d_w2, e->d_tcl_ptr, e->d_tcl_cols, e->tcl_max_cols, e->tcl_stage_cap, xin, e->d_t, yout);
+  else
+    k_sq_tiled<1><<<e->tcl_grid, BLOCK, e->tcl_lds, e->stream>>>(e->n_sq, e->K, e->G, e->tcl_TR, e->tcl_ntiles, e->d_ptr2, e->d_loc2,
+        e->d_w2, e->d_tcl_ptr, e->d_tcl_cols, e->tcl_max_cols, e->tcl_stage_cap, xin, e->d_t, yout);
+  HIP_TRY(e, hipGetLastError());
+  if (e1) HIP_TRY(e, hipEventRecord(e1, e->stream));
+  return CWR_OK;
+}
+
 struct SolveStats {
-  int iterations = 0, sweeps = 0, restarts = 0, launches = 0, status = CWR_OK;
+  int iterations = 0, sweeps = 0, restarts = 0, launches = 0, status = CWR_OK, sweep_kernel = 0;
   double max_rel = 0.0;
 };
 
@@ -436,7 +510,9 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
   const int sweep_limit = forced ? max_iter : std::min(max_iter, e->jacobi_limit);
   bool sq = false;
   TRY(prepare_sq(e, sq));
-  e->dominant_mode = sq ? 5 : 4;
+  const bool tiled = sq && e->tcl_ready && !e->comm;
+  e->dominant_mode = tiled ? 6 : (sq ? 5 : 4);
+  st.sweep_kernel = e->dominant_mode;
   for (;;) {
     batch = std::max(2, std::min(batch, 128)) & ~1;                    // even: the result lands in the state vector
     int launches = batch;
@@ -449,25 +525,32 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
       launches = doubles + 2;
       todo = 0;
       if (!e->comm && !e->profiling && e->use_graphs) {
-        if (!e->sq_graph_tried) {
-          e->sq_graph_tried = true;
+        hipGraphExec_t& exec = tiled ? e->tcl_exec : e->sq_exec;
+        hipGraph_t& graph = tiled ? e->tcl_graph : e->sq_graph;
+        bool& tried = tiled ? e->tcl_graph_tried : e->sq_graph_tried;
+        if (!tried) {
+          tried = true;
           if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
             int rc = CWR_OK;
-            for (int i = 0; i < cwr_engine::GRAPH_SWEEPS && rc == CWR_OK; ++i)
-              rc = launch_apply<5>(e, (i & 1) ? e->d_p : e->d_c, (i & 1) ? e->d_c : e->d_p, nullptr, e->d_t, nullptr, nullptr, e->n_sq);
+            for (int i = 0; i < cwr_engine::GRAPH_SWEEPS && rc == CWR_OK; ++i) {
+              double* src = (i & 1) ? e->d_p : e->d_c;
+              double* dst = (i & 1) ? e->d_c : e->d_p;
+              rc = tiled ? launch_sq_tiled(e, src, dst) : launch_apply<5>(e, src, dst, nullptr, e->d_t, nullptr, nullptr, e->n_sq);
+            }
             hipGraph_t g = nullptr;
             const hipError_t ec = hipStreamEndCapture(e->stream, &g);
-            if (rc == CWR_OK && ec == hipSuccess && g && hipGraphInstantiate(&e->sq_exec, g, nullptr, nullptr, 0) == hipSuccess) e->sq_graph = g;
-            else { if (g) hipGraphDestroy(g); e->sq_exec = nullptr; (void)hipGetLastError(); }
+            if (rc == CWR_OK && ec == hipSuccess && g && hipGraphInstantiate(&exec, g, nullptr, nullptr, 0) == hipSuccess) graph = g;
+            else { if (g) hipGraphDestroy(g); exec = nullptr; (void)hipGetLastError(); }
           }
         }
-        while (e->sq_exec && doubles >= cwr_engine::GRAPH_SWEEPS) { HIP_TRY(e, hipGraphLaunch(e->sq_exec, e->stream)); doubles -= cwr_engine::GRAPH_SWEEPS; }
+        while (exec && doubles >= cwr_engine::GRAPH_SWEEPS) { HIP_TRY(e, hipGraphLaunch(exec, e->stream)); doubles -= cwr_engine::GRAPH_SWEEPS; }
       }
       // a J^2 pass uses up two halo layers of validity, a plain sweep one
       for (int i = 0; i < doubles; ++i) {
         double* src = (i & 1) ? e->d_p : e->d_c;
         if (since_exchange + 2 > e->exch_every) { TRY(exchange_halo(e, src)); since_exchange = 0; }
-        TRY(launch_apply<5>(e, src, (i & 1) ? e->d_c : e->d_p, nullptr, e->d_t, nullptr, nullptr, e->n_sq));
+        if (tiled) TRY(launch_sq_tiled(e, src, (i & 1) ? e->d_c : e->d_p));
+        else TRY(launch_apply<5>(e, src, (i & 1) ? e->d_c : e->d_p, nullptr, e->d_t, nullptr, nullptr, e->n_sq));
         since_exchange += 2;
       }
       if (since_exchange + 1 > e->exch_every) { TRY(exchange_halo(e, e->d_c)); since_exchange = 0; }
@@ -582,6 +665,7 @@ int solve_small(cwr_engine* e, double tol2, int max_iter, bool forced, SolveStat
   TRY(download(e, h.data(), e->d_info, (size_t)3 * K));
   handled = true;
   st.launches += 1;
+  st.sweep_kernel = 7;
   bool ok = true;
   int sweeps = 0;
   st.max_rel = 0.0;
@@ -721,6 +805,7 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   if (const char* v = getenv("CWR_NO_GRAPHS")) eng->use_graphs = atoi(v) == 0;
   if (const char* v = getenv("CWR_NO_SQ")) eng->use_sq = atoi(v) == 0;
   if (const char* v = getenv("CWR_NO_SMALL")) eng->use_small = atoi(v) == 0;
+  if (const char* v = getenv("CWR_NO_TCL")) eng->use_tcl = atoi(v) == 0;
   eng->nt_stream = (K >= 8) ? 1 : 0;
   if (const char* v = getenv("CWR_NT_STREAM")) eng->nt_stream = atoi(v) != 0;
   if (const char* v = getenv("CWR_SQ_MIN_K")) eng->sq_min_k = std::max(1, atoi(v));
@@ -818,11 +903,13 @@ void cwr_destroy(cwr_engine* e) {
   if (e->sweep_exec) hipGraphExecDestroy(e->sweep_exec);
   if (e->sweep_graph) hipGraphDestroy(e->sweep_graph);
   if (e->sq_exec) hipGraphExecDestroy(e->sq_exec);
+  if (e->tcl_exec) hipGraphExecDestroy(e->tcl_exec);
+  if (e->tcl_graph) hipGraphDestroy(e->tcl_graph);
   if (e->sq_graph) hipGraphDestroy(e->sq_graph);
   for (hipEvent_t ev : e->ev) hipEventDestroy(ev);
   void* ptrs[] = {e->d_f1, e->d_f2, e->d_ptr, e->d_ent_edge, e->d_ent_nb, e->d_adv, e->d_vel, e->d_vol, e->d_dif,
                   e->d_bc, e->d_rec, e->d_diag, e->d_c, e->d_r, e->d_r0, e->d_p, e->d_v, e->d_s, e->d_t, e->d_b,
-                  e->d_scal, e->d_counters, e->d_partial, e->d_fadv, e->d_fdif, e->d_ftot, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf, e->d_ptr2, e->d_col2, e->d_row2, e->d_rec2, e->d_w, e->d_react, e->d_info};
+                  e->d_scal, e->d_counters, e->d_partial, e->d_fadv, e->d_fdif, e->d_ftot, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf, e->d_ptr2, e->d_col2, e->d_row2, e->d_rec2, e->d_w, e->d_react, e->d_info, e->d_tcl_ptr, e->d_tcl_cols, e->d_loc2, e->d_w2};
   for (void* p : ptrs) if (p) hipFree(p);
   if (e->stream) hipStreamDestroy(e->stream);
   delete e;
@@ -1033,6 +1120,7 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
   local.iterations = st.iterations; local.sweeps = st.sweeps; local.restarts = st.restarts; local.operator_launches = st.launches;
   local.max_rel_residual = max_rel; local.status = st.status;
   local.solver = (st.iterations == 0 && !force_bicg) ? 0 : (st.sweeps == 0 ? 1 : 2);
+  local.sweep_kernel = st.sweep_kernel;
   if (st.status != CWR_OK) {
     if (info) *info = local;
     switch (st.status) {
@@ -1102,6 +1190,7 @@ int32_t cwr_time_apply(cwr_engine* e, int32_t t, int32_t variant, int32_t reps, 
   int rc = CWR_OK;
   auto body = [&](int i) -> int {
     if (variant == 0) {                                        // the last step's dominant sweep kernel
+      if (e->dominant_mode == 6) return launch_sq_tiled(e, (i & 1) ? e->d_s : e->d_p, e->d_v);
       if (e->dominant_mode == 5)
         return (i & 1) ? launch_apply<5>(e, e->d_s, e->d_v, nullptr, e->d_t, nullptr, nullptr, e->n_sq)
                        : launch_apply<5>(e, e->d_p, e->d_v, nullptr, e->d_t, nullptr, nullptr, e->n_sq);
@@ -1164,10 +1253,12 @@ int32_t cwr_apply_bytes(const cwr_engine* e, int64_t* bytes_read, int64_t* bytes
   // when the double sweep is active), CSR row pointers, diagonal (plain sweep only), the input vector (every real row
   // once), the bhat / c2 / r0 operand; one output row per computed row
   const int64_t K = e->K;
-  const bool sq = (e->dominant_mode == 5);
+  const bool sq = (e->dominant_mode == 5 || e->dominant_mode == 6);
   const int64_t entries = sq ? e->nnz2 : e->nnz;
   const int64_t rows = sq ? e->n_sq : e->n_owned;
-  if (bytes_read) *bytes_read = 16LL * entries + 4LL * (rows + 1) + (sq ? 0LL : 8LL * rows) +
+  // tiled J^2 pass: 8-B weight + 4-B local index per entry, + the per-tile lists of distinct x rows
+  const int64_t extra = (e->dominant_mode == 6) ? 4LL * (int64_t)e->tcl_total_cols - 4LL * e->nnz2 : 0LL;
+  if (bytes_read) *bytes_read = 16LL * entries + extra + 4LL * (rows + 1) + (sq ? 0LL : 8LL * rows) +
                                 8LL * K * e->n_real + 8LL * K * rows;
   if (bytes_written) *bytes_written = 8LL * K * rows;
   return CWR_OK;

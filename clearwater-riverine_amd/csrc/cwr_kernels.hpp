@@ -518,7 +518,8 @@ __global__ void __launch_bounds__(BLOCK) k_entry_w(int n_rows, const int32_t* __
 // Threads of one row are adjacent and re-read the same few adjacency rows: L1/L2 hits.
 __global__ void __launch_bounds__(BLOCK) k_build_sq(int nnz2, const int32_t* __restrict__ ptr, const int32_t* __restrict__ ent_nb,
                                                   const double* __restrict__ w, const int32_t* __restrict__ row2,
-                                                  const int32_t* __restrict__ col2, FaceRec* __restrict__ rec2) {
+                                                  const int32_t* __restrict__ col2, FaceRec* __restrict__ rec2,
+                                                  double* __restrict__ w2) {
   const int s = blockIdx.x * BLOCK + threadIdx.x;
   if (s >= nnz2) return;
   const int c = row2[s], k = col2[s];
@@ -534,6 +535,122 @@ __global__ void __launch_bounds__(BLOCK) k_build_sq(int nnz2, const int32_t* __r
   }
   FaceRec out; out.nb = k; out.a_c = 0.0f; out.d = acc;
   rec2[s] = out;
+  if (w2) w2[s] = acc;                              // compact copy for the tiled pass (which has its own index array)
+}
+
+// J^2 pass with the x tile in LDS, software-pipelined.  The plain J^2 pass (k_apply<.,5>) gathers 9-10 neighbour rows
+// per row from L2 and is bound by that L2->CU gather rate and its latency, not by HBM.  Here every tile of TR rows
+// comes with the list of the DISTINCT x rows its J^2 rows touch (built once on the host: own rows first, then the
+// others ascending; ~2.7 rows per row for 32-row tiles under a Hilbert numbering instead of 10).  A block keeps
+// three tiles in flight: it computes tile i from LDS while the x rows / weights / c2 rows of tile i+1 and the row
+// list of tile i+2 are arriving in registers -- the compute phase itself issues no global load (vmcnt retires in
+// order, so a load issued during compute would wait behind the prefetches).
+constexpr int TCL_XR = 6;     // x rows a lane group prefetches per tile   (max_cols <= TCL_XR * R)
+constexpr int TCL_WR = 4;     // J^2 entries a thread prefetches per tile  (entries per tile <= TCL_WR * BLOCK)
+constexpr int TCL_U = 4;      // rows of the tile per lane group           (TR <= TCL_U * R)
+template <int VW>
+__global__ void __launch_bounds__(BLOCK) k_sq_tiled(
+    int n_rows, int K, int G, int TR, int ntiles, const int32_t* __restrict__ ptr2, const int32_t* __restrict__ loc2,
+    const double* __restrict__ w2, const int32_t* __restrict__ tcl_ptr, const int32_t* __restrict__ tcl_cols,
+    int max_cols, int stage_cap, const double* __restrict__ xin, const double* __restrict__ c2, double* __restrict__ yout) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+  double* s_xt = reinterpret_cast<double*>(s_dyn);                                  // [max_cols][K]
+  double* s_w = s_xt + (size_t)max_cols * K;                                         // [stage_cap]
+  int32_t* s_loc = reinterpret_cast<int32_t*>(s_w + stage_cap);                      // [stage_cap]
+  int32_t* s_ptr = s_loc + stage_cap;                                                // [TR + 1]
+  const int R = BLOCK / G;
+  const int tid = threadIdx.x;
+  const int r = tid / G, g = tid - r * G;
+  const int col = g * VW;
+  const bool rowlane = r < R;
+  const int xcd = blockIdx.x % N_XCD, lidx = blockIdx.x / N_XCD, bpx = gridDim.x / N_XCD;
+  const int tpx = (ntiles + N_XCD - 1) / N_XCD;
+  auto tile_of = [&](int it) -> int {              // it-th tile of this block, or -1
+    const int i = lidx + it * bpx;
+    if (i >= tpx) return -1;
+    const int t = xcd * tpx + i;
+    return t < ntiles ? t : -1;
+  };
+  // prefetch registers
+  int cn[TCL_XR];                                  // row list of the tile after next (global x row ids)
+  double xr[TCL_XR][VW];                           // x rows of the next tile
+  double wr[TCL_WR]; int lr[TCL_WR];               // weights / local indices of the next tile
+  double q0[TCL_U][VW];                            // c2 rows of the next tile
+  int pr = 0;                                      // row pointer slice of the next tile
+  auto load_cols = [&](int t) {
+#pragma unroll
+    for (int u = 0; u < TCL_XR; ++u) cn[u] = -1;
+    if (t < 0 || !rowlane) return;
+    const int cb = tcl_ptr[t], ce = tcl_ptr[t + 1];
+#pragma unroll
+    for (int u = 0; u < TCL_XR; ++u) { const int q = r + u * R; if (q < ce - cb) cn[u] = tcl_cols[cb + q]; }
+  };
+  auto load_rows = [&](int t) {                    // uses cn (the row list loaded one tile earlier)
+    if (t < 0) return;
+#pragma unroll
+    for (int u = 0; u < TCL_XR; ++u) if (cn[u] >= 0) ldv<VW>(xin + (size_t)cn[u] * K + col, xr[u]);
+    const int c0 = t * TR, c1 = min(c0 + TR, n_rows);
+    const int jb = ptr2[c0], je = ptr2[c1];
+#pragma unroll
+    for (int u = 0; u < TCL_WR; ++u) { const int j = jb + tid + u * BLOCK; if (j < je) { wr[u] = w2[j]; lr[u] = loc2[j]; } }
+    if (tid <= c1 - c0) pr = ptr2[c0 + tid] - jb;
+    if (rowlane) {
+#pragma unroll
+      for (int u = 0; u < TCL_U; ++u) { const int c = c0 + r + u * R; if (c < c1) ldv_nt<VW>(c2 + (size_t)c * K + col, q0[u]); }
+    }
+  };
+  int t_cur = tile_of(0);
+  load_cols(t_cur);
+  load_rows(t_cur);                                // (the first tile's chain is not hidden)
+  int t_next = tile_of(1);
+  load_cols(t_next);
+  for (int it = 0; t_cur >= 0; ++it) {
+    const int c0 = t_cur * TR, c1 = min(c0 + TR, n_rows);
+    const int ncol = tcl_ptr[t_cur + 1] - tcl_ptr[t_cur];
+    const int nent = ptr2[c1] - ptr2[c0];
+    __syncthreads();                               // the previous tile's readers are done with LDS
+    if (rowlane) {
+#pragma unroll
+      for (int u = 0; u < TCL_XR; ++u) { const int q = r + u * R; if (q < ncol) stv<VW>(s_xt + (size_t)q * K + col, xr[u]); }
+    }
+#pragma unroll
+    for (int u = 0; u < TCL_WR; ++u) { const int j = tid + u * BLOCK; if (j < nent) { s_w[j] = wr[u]; s_loc[j] = lr[u]; } }
+    if (tid <= c1 - c0) s_ptr[tid] = pr;
+    double qc[TCL_U][VW];
+#pragma unroll
+    for (int u = 0; u < TCL_U; ++u)
+#pragma unroll
+      for (int w = 0; w < VW; ++w) qc[u][w] = q0[u][w];
+    __syncthreads();
+    // start the next tile's loads (x rows by the list already in registers) and the list of the tile after it
+    const int t_after = tile_of(it + 2);
+    load_rows(t_next);
+    load_cols(t_after);
+    if (rowlane) {
+#pragma unroll
+      for (int u = 0; u < TCL_U; ++u) {
+        const int c = c0 + r + u * R;
+        if (c < c1) {
+          double sum[VW];                          // same association as k_apply<.,5>: (sum of w x) first, + c2 last,
+#pragma unroll
+          for (int w = 0; w < VW; ++w) sum[w] = 0.0;  // so both J^2 kernels give bitwise equal rows
+          const int j0 = s_ptr[c - c0], j1 = s_ptr[c - c0 + 1];
+          for (int j = j0; j < j1; ++j) {
+            double xn[VW];
+            ldv<VW>(s_xt + (size_t)s_loc[j] * K + col, xn);
+            const double wj = s_w[j];
+#pragma unroll
+            for (int w = 0; w < VW; ++w) sum[w] += wj * xn[w];
+          }
+#pragma unroll
+          for (int w = 0; w < VW; ++w) sum[w] = qc[u][w] + sum[w];
+          stv_stream<VW>(yout + (size_t)c * K + col, sum);
+        }
+      }
+    }
+    t_cur = t_next;
+    t_next = t_after;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ BiCGSTAB vector kernels

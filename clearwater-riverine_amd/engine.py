@@ -46,7 +46,7 @@ class SolverNotConverged(RuntimeError):
 class StepInfo(C.Structure):
     _fields_ = [('iterations', C.c_int32), ('sweeps', C.c_int32), ('restarts', C.c_int32), ('status', C.c_int32),
                 ('operator_launches', C.c_int32), ('solver', C.c_int32), ('max_rel_residual', C.c_double),
-                ('solve_ms', C.c_double)]
+                ('solve_ms', C.c_double), ('sweep_kernel', C.c_int32), ('reserved', C.c_int32)]
 
 
 @dataclass
@@ -58,6 +58,7 @@ class StepResult:
     solver: int              # 0 Jacobi only, 1 BiCGSTAB only, 2 both
     max_rel_residual: float
     solve_ms: float
+    sweep_kernel: int = 0    # 4 plain sweep, 5 J^2 pass, 6 tiled J^2 pass, 7 one-launch small-mesh solver
 
 
 _lib = None
@@ -263,7 +264,7 @@ class TransportEngine:
         flags |= {'auto': 0, 'jacobi': STEP_FORCE_JACOBI, 'bicgstab': STEP_FORCE_BICGSTAB}[solver]
         self._check(self._lib.cwr_step(self._h, int(t), float(tol), int(max_iter), flags, C.byref(info)))
         return StepResult(info.iterations, info.sweeps, info.restarts, info.operator_launches, info.solver,
-                          info.max_rel_residual, info.solve_ms)
+                          info.max_rel_residual, info.solve_ms, info.sweep_kernel)
 
     def get_mass_flux(self):
         shape = (self.n_edges, self.K)

@@ -62,6 +62,9 @@ typedef struct cwr_step_info {
   int32_t solver;              /* 0 = Jacobi sweeps only, 1 = BiCGSTAB only, 2 = sweeps then BiCGSTAB */
   double max_rel_residual;     /* max over constituents of ||D^-1 (b - A x)||_2 / ||D^-1 b||_2 */
   double solve_ms;             /* host wall time of the step, for information only */
+  int32_t sweep_kernel;        /* which Jacobi kernel ran: 4 plain sweep, 5 J^2 pass, 6 tiled J^2 pass (x tile in LDS),
+                                  7 one-launch small-mesh solver, 0 none (BiCGSTAB only) */
+  int32_t reserved;
 } cwr_step_info;
 
 int32_t cwr_abi_version(void);
