@@ -121,7 +121,7 @@ struct cwr_engine {
   int32_t *d_ptr2 = nullptr, *d_col2 = nullptr, *d_row2 = nullptr;
   // tiled J^2 pass: per tile the distinct x rows it touches, and per J^2 entry the row's index in that list
   bool use_tcl = true, tcl_ready = false;
-  int tcl_TR = 0, tcl_ntiles = 0, tcl_max_cols = 0, tcl_stage_cap = 0, tcl_grid = 0;
+  int n_tcl = 0, tcl_TR = 0, tcl_ntiles = 0, tcl_max_cols = 0, tcl_stage_cap = 0, tcl_grid = 0;
   size_t tcl_lds = 0, tcl_total_cols = 0;
   int32_t *d_tcl_ptr = nullptr, *d_tcl_cols = nullptr, *d_loc2 = nullptr;
   double* d_w2 = nullptr;
@@ -205,9 +205,9 @@ int reduce_partials(cwr_engine* e, int nslots, int ND, double* o0, double* o1 = 
 
 template <int MODE>
 int launch_apply(cwr_engine* e, const double* xin, double* yout, const double* r0, const double* bhat,
-                 double* r0_out, double* p_out, int rows = -1) {
+                 double* r0_out, double* p_out, int rows = -1, int row0 = 0) {
   if (rows < 0) rows = e->n_owned;
-  const int ntiles = cdiv(rows, e->R * e->U);
+  const int ntiles = cdiv(rows - row0, e->R * e->U);
   const bool sq = (MODE == 5);
   const int max_grid = sq ? e->apply_grid2 : e->apply_grid;
   const int grid = std::max(N_XCD, std::min(max_grid, cdiv(ntiles, N_XCD) * N_XCD));
@@ -221,10 +221,10 @@ int launch_apply(cwr_engine* e, const double* xin, double* yout, const double* r
     HIP_TRY(e, hipEventRecord(e0, e->stream));
   }
   if (e->VW == 2)
-    k_apply<2, MODE><<<grid, BLOCK, lds, e->stream>>>(rows, e->n_core, e->K, e->G, e->U, ntiles, cap, e->nt_stream,
+    k_apply<2, MODE><<<grid, BLOCK, lds, e->stream>>>(row0, rows, e->n_core, e->K, e->G, e->U, ntiles, cap, e->nt_stream,
         ptr, rec, e->d_diag, xin, yout, r0, bhat, r0_out, p_out, e->d_partial);
   else
-    k_apply<1, MODE><<<grid, BLOCK, lds, e->stream>>>(rows, e->n_core, e->K, e->G, e->U, ntiles, cap, e->nt_stream,
+    k_apply<1, MODE><<<grid, BLOCK, lds, e->stream>>>(row0, rows, e->n_core, e->K, e->G, e->U, ntiles, cap, e->nt_stream,
         ptr, rec, e->d_diag, xin, yout, r0, bhat, r0_out, p_out, e->d_partial);
   e->last_apply_grid = grid;
   HIP_TRY(e, hipGetLastError());
@@ -399,20 +399,24 @@ int ensure_sq_pattern(cwr_engine* e) {
     for (int c = 0; c < n; ++c) for (int q = ptr2[c]; q < ptr2[c + 1]; ++q) row2[q] = c;
     TRY(upload(e, e->d_row2, row2.data(), (size_t)e->nnz2));
   }
-  // ---- tiled variant: distinct x rows per tile (own rows first) and local indices; single GPU, fits-in-LDS only
-  if (e->use_tcl && !e->comm && n == e->n_owned) {
+  // ---- tiled variant: distinct x rows per tile (own rows first) and local indices; only where a tile fits LDS
+  // (partitioned engines too: the lists simply reach into the halo rows of x)
+  if (e->use_tcl) {
+    // partitioned engines tile the core rows only: the replayed halo layers are numbered layer by layer, their 64-row
+    // tiles touch hundreds of distinct rows, and they go through the un-tiled pass instead
+    const int n_t = e->comm ? e->n_core : n;
     int tr_target = 64;
     if (const char* v = getenv("CWR_TCL_ROWS")) tr_target = std::max(1, atoi(v));
     int tr = tr_target;
     while (tr > e->R && (tr % e->R) != 0) --tr;
     tr = std::max(tr, e->R);
-    const int nt = cdiv(n, tr);
-    std::vector<int32_t> tptr((size_t)nt + 1, 0), tcols, loc2((size_t)e->nnz2);
-    tcols.reserve((size_t)n * 3);
+    const int nt = cdiv(n_t, tr);
+    std::vector<int32_t> tptr((size_t)nt + 1, 0), tcols, loc2((size_t)e->nnz2, 0);
+    tcols.reserve((size_t)n_t * 3);
     std::vector<int32_t> stamp((size_t)e->n_real, -1), pos((size_t)e->n_real, 0), others;
     int max_cols = 0, cap2 = 1;
     for (int t = 0; t < nt; ++t) {
-      const int c0 = t * tr, c1 = std::min(c0 + tr, n);
+      const int c0 = t * tr, c1 = std::min(c0 + tr, n_t);
       const int base = (int)tcols.size();
       for (int c = c0; c < c1; ++c) { stamp[c] = t; pos[c] = c - c0; tcols.push_back(c); }
       others.clear();
@@ -432,6 +436,7 @@ int ensure_sq_pattern(cwr_engine* e) {
       int pc = 1;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, fn6, BLOCK, lds) != hipSuccess || pc < 1) pc = 1;
       pc = std::min(pc, 8);
+      e->n_tcl = n_t;
       e->tcl_TR = tr; e->tcl_ntiles = nt; e->tcl_max_cols = max_cols; e->tcl_stage_cap = cap2; e->tcl_lds = lds;
       e->tcl_total_cols = tcols.size();
       e->tcl_grid = std::max(N_XCD, std::min(cdiv(nt, N_XCD) * N_XCD, (n_cu * pc / N_XCD) * N_XCD));
@@ -444,7 +449,10 @@ int ensure_sq_pattern(cwr_engine* e) {
       TRY(upload(e, e->d_loc2, loc2.data(), (size_t)e->nnz2));
       e->tcl_ready = true;
       if (getenv("CWR_VERBOSE")) fprintf(stderr, "[cwr] tiled J^2: tile=%d rows, %.2f distinct x rows per row, max %d per tile, lds=%zu, grid=%d\n",
-                                         tr, (double)tcols.size() / n, max_cols, lds, e->tcl_grid);
+                                         tr, (double)tcols.size() / n_t, max_cols, lds, e->tcl_grid);
+    } else if (getenv("CWR_VERBOSE")) {
+      fprintf(stderr, "[cwr] tiled J^2 not used: tile=%d rows, max %d distinct x rows per tile (limit %d), %d entries per tile (limit %d), lds=%zu\n",
+              tr, max_cols, TCL_XR * e->R, cap2, TCL_WR * BLOCK, lds);
     }
   }
   e->sq_pattern = true;
@@ -477,13 +485,15 @@ int launch_sq_tiled(cwr_engine* e, const double* xin, double* yout) {
     HIP_TRY(e, hipEventRecord(e0, e->stream));
   }
   if (e->VW == 2)
-    k_sq_tiled<2><<<e->tcl_grid, BLOCK, e->tcl_lds, e->stream>>>(e->n_sq, e->K, e->G, e->tcl_TR, e->tcl_ntiles, e->d_ptr2, e->d_loc2,
+    k_sq_tiled<2><<<e->tcl_grid, BLOCK, e->tcl_lds, e->stream>>>(e->n_tcl, e->K, e->G, e->tcl_TR, e->tcl_ntiles, e->d_ptr2, e->d_loc2,
         e->d_w2, e->d_tcl_ptr, e->d_tcl_cols, e->tcl_max_cols, e->tcl_stage_cap, xin, e->d_t, yout);
   else
-    k_sq_tiled<1><<<e->tcl_grid, BLOCK, e->tcl_lds, e->stream>>>(e->n_sq, e->K, e->G, e->tcl_TR, e->tcl_ntiles, e->d_ptr2, e->d_loc2,
+    k_sq_tiled<1><<<e->tcl_grid, BLOCK, e->tcl_lds, e->stream>>>(e->n_tcl, e->K, e->G, e->tcl_TR, e->tcl_ntiles, e->d_ptr2, e->d_loc2,
         e->d_w2, e->d_tcl_ptr, e->d_tcl_cols, e->tcl_max_cols, e->tcl_stage_cap, xin, e->d_t, yout);
   HIP_TRY(e, hipGetLastError());
   if (e1) HIP_TRY(e, hipEventRecord(e1, e->stream));
+  if (e->n_sq > e->n_tcl)                             // replayed halo layers (partitioned engines): un-tiled J^2 rows
+    TRY(launch_apply<5>(e, xin, yout, nullptr, e->d_t, nullptr, nullptr, e->n_sq, e->n_tcl));
   return CWR_OK;
 }
 
@@ -510,7 +520,7 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
   const int sweep_limit = forced ? max_iter : std::min(max_iter, e->jacobi_limit);
   bool sq = false;
   TRY(prepare_sq(e, sq));
-  const bool tiled = sq && e->tcl_ready && !e->comm;
+  const bool tiled = sq && e->tcl_ready;
   e->dominant_mode = tiled ? 6 : (sq ? 5 : 4);
   st.sweep_kernel = e->dominant_mode;
   for (;;) {
@@ -1255,7 +1265,7 @@ int32_t cwr_apply_bytes(const cwr_engine* e, int64_t* bytes_read, int64_t* bytes
   const int64_t K = e->K;
   const bool sq = (e->dominant_mode == 5 || e->dominant_mode == 6);
   const int64_t entries = sq ? e->nnz2 : e->nnz;
-  const int64_t rows = sq ? e->n_sq : e->n_owned;
+  const int64_t rows = (e->dominant_mode == 6) ? e->n_tcl : (sq ? e->n_sq : e->n_owned);
   // tiled J^2 pass: 8-B weight + 4-B local index per entry, + the per-tile lists of distinct x rows
   const int64_t extra = (e->dominant_mode == 6) ? 4LL * (int64_t)e->tcl_total_cols - 4LL * e->nnz2 : 0LL;
   if (bytes_read) *bytes_read = 16LL * entries + extra + 4LL * (rows + 1) + (sq ? 0LL : 8LL * rows) +

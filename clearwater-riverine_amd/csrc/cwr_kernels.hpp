@@ -334,7 +334,7 @@ __host__ __device__ inline int red_doubles(int G, int VW) {     // scratch of bl
 #endif
 template <int VW, int MODE>
 __global__ void __launch_bounds__(BLOCK, CWR_APPLY_MIN_WAVES) k_apply(
-    int n_owned, int n_dot, int K, int G, int U, int ntiles, int stage_cap, int nt, const int32_t* __restrict__ ptr,
+    int row0, int n_owned, int n_dot, int K, int G, int U, int ntiles, int stage_cap, int nt, const int32_t* __restrict__ ptr,
     const FaceRec* __restrict__ rec, const double* __restrict__ diag, const double* __restrict__ xin,
     double* __restrict__ yout, const double* __restrict__ r0, const double* __restrict__ bhat,
     double* __restrict__ r0_out, double* __restrict__ p_out, double* __restrict__ partial) {
@@ -358,7 +358,7 @@ __global__ void __launch_bounds__(BLOCK, CWR_APPLY_MIN_WAVES) k_apply(
   for (int i = lidx; i < tpx; i += bpx) {
     const int tile = xcd * tpx + i;
     if (tile >= ntiles) break;                      // uniform per block
-    const int c0 = tile * TR;
+    const int c0 = row0 + tile * TR;                // rows [row0, n_owned) are this launch's
     const int c1 = min(c0 + TR, n_owned);
     __syncthreads();                                // previous tile's readers are done with the LDS images
     for (int q = tid; q <= c1 - c0; q += BLOCK) s_ptr[q] = ptr[c0 + q];
