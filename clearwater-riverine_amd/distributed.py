@@ -39,7 +39,7 @@ class PartitionedTransport:
     single-GPU engine (no halo, no communicator)."""
 
     def __init__(self, mesh: dict, inputs3: np.ndarray, rank: int, world: int, device: int = 0,
-                 unique_id: bytes | None = None, halo_depth: int = 1, renumber: str | None = None):
+                 unique_id: bytes | None = None, halo_depth: int = 1, renumber: str | None = 'hilbert'):
         """renumber='hilbert': work in a space-filling-curve numbering of the real cells (ordering.py); every
         array handed in or out of this class stays in the reference's numbering."""
         n = int(np.asarray(mesh['edges_face1']).max()) + 1

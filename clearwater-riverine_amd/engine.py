@@ -136,7 +136,10 @@ class TransportEngine:
     """
 
     def __init__(self, face1, face2, n_cells: int, n_constituents: int, *, n_owned: int | None = None,
-                 n_halo: int = 0, device: int = 0):
+                 n_halo: int = 0, device: int = 0, cell_order=None):
+        """cell_order (optional, single-GPU engines): order[new id] = reference id of the real cells.  The engine
+        then works in that numbering (ordering.py: better gather locality); every array passed to or returned by
+        this class stays in the reference's numbering, and results are bitwise the same."""
         self._lib = load_library()
         self._h = C.c_void_p()
         f1 = _arr(face1, np.int32)
@@ -145,6 +148,20 @@ class TransportEngine:
             raise ValueError('edges_face1 must be one-dimensional')
         if n_owned is None:
             n_owned = int(f1.max()) + 1 if len(f1) else 0     # nreal + 1 (io/hdf.py:268)
+        self._order = None
+        if cell_order is not None:
+            if n_halo != 0:
+                raise ValueError('cell_order is for single-GPU engines (partitioned runs renumber before partitioning)')
+            order = np.ascontiguousarray(cell_order, dtype=np.int64)
+            if order.shape != (n_owned,) or not np.array_equal(np.sort(order), np.arange(n_owned)):
+                raise ValueError('cell_order must be a permutation of the real cell ids')
+            inv = np.arange(int(n_cells), dtype=np.int64)
+            inv[order] = np.arange(n_owned)
+            f1 = inv[f1].astype(np.int32)
+            f2 = inv[f2].astype(np.int32)
+            self._order = order
+            self._cols = np.arange(int(n_cells), dtype=np.int64)
+            self._cols[:n_owned] = order                      # device column -> reference column (ghosts unchanged)
         self.n_owned, self.n_halo, self.n_cells = int(n_owned), int(n_halo), int(n_cells)
         self.n_real = self.n_owned + self.n_halo
         self.n_ghost = self.n_cells - self.n_real
@@ -184,6 +201,8 @@ class TransportEngine:
         ff = _arr(ff, np.float32, (T, self.n_edges), 'face_flow')
         ev = _arr(edge_velocity, np.float32, (T, self.n_edges), 'edge_velocity')
         vol = _arr(volume, np.float32, (T, self.n_cells), 'volume')
+        if self._order is not None:
+            vol = np.ascontiguousarray(vol[:, self._cols])
         dtv = _arr(dt, np.float64, (T,), 'dt')
         dist = _arr(face_to_face_dist, np.float64, (self.n_edges,), 'face_to_face_dist')
         self._check(self._lib.cwr_load_flow_field(self._h, T, _ptr(ff), _ptr(ev), _ptr(vol), _ptr(dtv),
@@ -198,6 +217,8 @@ class TransportEngine:
         dif = _arr(coeff_to_diffusion, np.float64, (T, self.n_edges), 'coeff_to_diffusion')
         ev = _arr(edge_velocity, np.float32, (T, self.n_edges), 'edge_velocity')
         vol = _arr(volume, np.float32, (T, self.n_cells), 'volume')
+        if self._order is not None:
+            vol = np.ascontiguousarray(vol[:, self._cols])
         dtv = _arr(dt, np.float64, (T,), 'dt')
         self._check(self._lib.cwr_load_coefficients(self._h, T, _ptr(adv), _ptr(dif), _ptr(ev), _ptr(vol),
                                                     _ptr(dtv), float(diffusion_coefficient)))
@@ -224,11 +245,17 @@ class TransportEngine:
     def set_state(self, conc_owned):
         x = _arr(np.asarray(conc_owned, dtype=np.float64).reshape(self.n_core, -1), np.float64,
                  (self.n_core, self.K), 'conc_owned')
+        if self._order is not None:
+            x = np.ascontiguousarray(x[self._order])
         self._check(self._lib.cwr_set_state(self._h, _ptr(x)))
 
     def get_state(self) -> np.ndarray:
         out = np.empty((self.n_cells, self.K), np.float64)
         self._check(self._lib.cwr_get_state(self._h, _ptr(out)))
+        if self._order is not None:
+            ref = np.empty_like(out)
+            ref[self._cols] = out
+            return ref
         return out
 
     def react_linear(self, reaction_matrix):
@@ -246,14 +273,26 @@ class TransportEngine:
     # ------------------------------------------------------------------ operator / rhs / step
     def apply(self, t: int, x) -> np.ndarray:
         xv = _arr(np.asarray(x, dtype=np.float64).reshape(self.n_real, -1), np.float64, (self.n_real, self.K), 'x')
+        if self._order is not None:
+            xv = np.ascontiguousarray(xv[self._order])
         y = np.empty((self.n_owned, self.K), np.float64)
         self._check(self._lib.cwr_apply(self._h, int(t), _ptr(xv), _ptr(y)))
+        if self._order is not None:
+            ref = np.empty_like(y)
+            ref[self._order] = y
+            return ref
         return y
 
     def rhs(self, t: int, x_t) -> np.ndarray:
         xv = _arr(np.asarray(x_t, dtype=np.float64).reshape(self.n_owned, -1), np.float64, (self.n_owned, self.K), 'x_t')
+        if self._order is not None:
+            xv = np.ascontiguousarray(xv[self._order])
         b = np.empty((self.n_owned, self.K), np.float64)
         self._check(self._lib.cwr_rhs(self._h, int(t), _ptr(xv), _ptr(b)))
+        if self._order is not None:
+            ref = np.empty_like(b)
+            ref[self._order] = b
+            return ref
         return b
 
     def step(self, t: int, *, tol: float = 1e-12, max_iter: int = 2000, mass_flux: bool = True,

@@ -16,6 +16,7 @@ from typing import Any, Dict, Optional
 import numpy as np
 
 from .engine import TransportEngine, StepResult
+from .ordering import hilbert_order
 
 # variables.py names used on the path
 EDGES_FACE1 = 'edges_face1'
@@ -143,7 +144,7 @@ class ClearwaterRiverine:
                  datetime_range=None, mesh_file_path: Optional[str] = None, *,
                  mesh: Optional[dict] = None, input_arrays: Optional[Dict[str, np.ndarray]] = None,
                  device: int = 0, tol: float = 1e-12, max_iter: int = 5000, store_history: bool = True,
-                 solver: str = 'auto'):
+                 solver: str = 'auto', renumber: bool = True):
         self.gdf = None
         self.time_step = 0                                       # transport.py:102
         self.verbose = bool(verbose)
@@ -210,7 +211,9 @@ class ClearwaterRiverine:
         K = len(self.constituents)
 
         # engine: topology, flow field and boundary values resident in HBM
-        self.engine = TransportEngine(f1, f2, ncell, K, device=device)
+        # large meshes: internal space-filling-curve numbering (ordering.py); reference ids stay at this boundary
+        order = hilbert_order(m['face_x'], m['face_y'], n) if (renumber and n >= 16384) else None
+        self.engine = TransportEngine(f1, f2, ncell, K, device=device, cell_order=order)
         self.engine.load_flow_field(m[FLOW_ACROSS_FACE], m[EDGE_VELOCITY], m[VOLUME], m[CHANGE_IN_TIME],
                                     m[FACE_TO_FACE_DISTANCE], m.attrs['diffusion_coefficient'])
         ghost = np.stack([self.constituent_dict[c].input_array[:, n:] for c in self.constituents], axis=2)

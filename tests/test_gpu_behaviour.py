@@ -262,3 +262,34 @@ def test_internal_hilbert_renumbering_is_transparent(gpu_lib, monkeypatch):
     n = mesh['nreal'] + 1
     want = np.stack([ref.constituent_dict[f'c{k}'].state[3, :n] for k in range(8)], axis=1)
     assert rel_err(outs[1], want) <= 1e-9
+
+
+def test_engine_cell_order_is_transparent(gpu_lib, monkeypatch):
+    """TransportEngine(cell_order=...): apply / rhs / step / get_state in the reference's numbering are unchanged."""
+    import clearwater_riverine_amd as cw
+    from clearwater_riverine_amd.ordering import hilbert_order
+    monkeypatch.setenv('CWR_NO_SMALL', '1')
+    K = 8
+    mesh, inputs3 = synthetic_case(K, nx=50, ny=31, n_steps=3, seed=19, n_merge=40, n_dry=2)
+    n = mesh['nreal'] + 1
+    ncell = len(mesh['face_x'])
+    order = hilbert_order(mesh['face_x'], mesh['face_y'], n)
+    engs = []
+    for o in (None, order):
+        e = cw.TransportEngine(mesh['edges_face1'], mesh['edges_face2'], ncell, K, cell_order=o)
+        e.load_flow_field(mesh['face_flow'], mesh['edge_velocity'], mesh['volume'], mesh['dt'], mesh['face_to_face_dist'],
+                          mesh['diffusion_coefficient'])
+        e.load_boundary(inputs3[:, n:, :])
+        engs.append(e)
+    x = np.random.default_rng(3).standard_normal((n, K))
+    assert np.array_equal(engs[0].apply(1, x), engs[1].apply(1, x))
+    assert np.array_equal(engs[0].rhs(1, x), engs[1].rhs(1, x))
+    for e in engs:
+        e.set_state(inputs3[0, :n, :])
+        for t in range(3):
+            e.step(t, solver='jacobi')
+    assert np.array_equal(engs[0].get_state(), engs[1].get_state(), equal_nan=True)
+    a, b = engs[0].get_mass_flux(), engs[1].get_mass_flux()
+    assert all(np.array_equal(p, q, equal_nan=True) for p, q in zip(a, b))
+    with pytest.raises(ValueError):
+        cw.TransportEngine(mesh['edges_face1'], mesh['edges_face2'], ncell, K, cell_order=order[:-1])
