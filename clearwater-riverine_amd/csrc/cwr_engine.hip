@@ -116,11 +116,12 @@ struct cwr_engine {
   // squared operator J^2 (two Jacobi sweeps per launch; single GPU, K >= sq_min_k)
   std::vector<int32_t> h_ptr, h_nb;      // host copies of the adjacency for the symbolic J^2
   bool use_sq = true, sq_pattern = false, sq_failed = false;
-  int sq_min_k = 8, nnz2 = 0, n_sq = 0, stage_cap2 = 0, apply_grid2 = 0;
+  int sq_min_k = 1, nnz2 = 0, n_sq = 0, stage_cap2 = 0, apply_grid2 = 0;
   size_t apply_lds2 = 0;
   int32_t *d_ptr2 = nullptr, *d_col2 = nullptr, *d_row2 = nullptr;
   // tiled J^2 pass: per tile the distinct x rows it touches, and per J^2 entry the row's index in that list
   bool use_tcl = true, tcl_ready = false;
+  int tcl_wr = 4;
   int n_tcl = 0, tcl_TR = 0, tcl_ntiles = 0, tcl_max_cols = 0, tcl_stage_cap = 0, tcl_grid = 0;
   size_t tcl_lds = 0, tcl_total_cols = 0;
   int32_t *d_tcl_ptr = nullptr, *d_tcl_cols = nullptr, *d_loc2 = nullptr;
@@ -431,8 +432,10 @@ int ensure_sq_pattern(cwr_engine* e) {
     const size_t lds = ((size_t)max_cols * e->K * sizeof(double) + (size_t)cap2 * (sizeof(double) + sizeof(int32_t)) +
                         (size_t)(tr + 1) * sizeof(int32_t) + 15) & ~(size_t)15;
     // the kernel's compile-time prefetch depths bound what a tile may hold; otherwise the plain J^2 pass stays
-    if (lds <= 64 * 1024 && max_cols <= TCL_XR * e->R && cap2 <= TCL_WR * BLOCK && tr <= TCL_U * e->R && tr + 1 <= BLOCK) {
-      const void* fn6 = (e->VW == 2) ? reinterpret_cast<const void*>(&k_sq_tiled<2>) : reinterpret_cast<const void*>(&k_sq_tiled<1>);
+    e->tcl_wr = (cap2 <= TCL_WR * BLOCK) ? TCL_WR : TCL_WR_NARROW;
+    if (lds <= 64 * 1024 && max_cols <= TCL_XR * e->R && cap2 <= e->tcl_wr * BLOCK && tr <= TCL_U * e->R && tr <= BLOCK) {
+      const void* fn6 = (e->VW == 2) ? (e->tcl_wr == TCL_WR ? reinterpret_cast<const void*>(&k_sq_tiled<2, TCL_WR>) : reinterpret_cast<const void*>(&k_sq_tiled<2, TCL_WR_NARROW>))
+                                     : (e->tcl_wr == TCL_WR ? reinterpret_cast<const void*>(&k_sq_tiled<1, TCL_WR>) : reinterpret_cast<const void*>(&k_sq_tiled<1, TCL_WR_NARROW>));
       int pc = 1;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, fn6, BLOCK, lds) != hipSuccess || pc < 1) pc = 1;
       pc = std::min(pc, 8);
@@ -452,7 +455,7 @@ int ensure_sq_pattern(cwr_engine* e) {
                                          tr, (double)tcols.size() / n_t, max_cols, lds, e->tcl_grid);
     } else if (getenv("CWR_VERBOSE")) {
       fprintf(stderr, "[cwr] tiled J^2 not used: tile=%d rows, max %d distinct x rows per tile (limit %d), %d entries per tile (limit %d), lds=%zu\n",
-              tr, max_cols, TCL_XR * e->R, cap2, TCL_WR * BLOCK, lds);
+              tr, max_cols, TCL_XR * e->R, cap2, TCL_WR_NARROW * BLOCK, lds);
     }
   }
   e->sq_pattern = true;
@@ -484,12 +487,11 @@ int launch_sq_tiled(cwr_engine* e, const double* xin, double* yout) {
     e0 = e->ev[e->ev_used++]; e1 = e->ev[e->ev_used++];
     HIP_TRY(e, hipEventRecord(e0, e->stream));
   }
-  if (e->VW == 2)
-    k_sq_tiled<2><<<e->tcl_grid, BLOCK, e->tcl_lds, e->stream>>>(e->n_tcl, e->K, e->G, e->tcl_TR, e->tcl_ntiles, e->d_ptr2, e->d_loc2,
-        e->d_w2, e->d_tcl_ptr, e->d_tcl_cols, e->tcl_max_cols, e->tcl_stage_cap, xin, e->d_t, yout);
-  else
-    k_sq_tiled<1><<<e->tcl_grid, BLOCK, e->tcl_lds, e->stream>>>(e->n_tcl, e->K, e->G, e->tcl_TR, e->tcl_ntiles, e->d_ptr2, e->d_loc2,
-        e->d_w2, e->d_tcl_ptr, e->d_tcl_cols, e->tcl_max_cols, e->tcl_stage_cap, xin, e->d_t, yout);
+#define CWR_TILED(VWv, WRv) k_sq_tiled<VWv, WRv><<<e->tcl_grid, BLOCK, e->tcl_lds, e->stream>>>(e->n_tcl, e->K, e->G, e->tcl_TR,    \
+      e->tcl_ntiles, e->d_ptr2, e->d_loc2, e->d_w2, e->d_tcl_ptr, e->d_tcl_cols, e->tcl_max_cols, e->tcl_stage_cap, xin, e->d_t, yout)
+  if (e->VW == 2) { if (e->tcl_wr == TCL_WR) CWR_TILED(2, TCL_WR); else CWR_TILED(2, TCL_WR_NARROW); }
+  else            { if (e->tcl_wr == TCL_WR) CWR_TILED(1, TCL_WR); else CWR_TILED(1, TCL_WR_NARROW); }
+#undef CWR_TILED
   HIP_TRY(e, hipGetLastError());
   if (e1) HIP_TRY(e, hipEventRecord(e1, e->stream));
   if (e->n_sq > e->n_tcl)                             // replayed halo layers (partitioned engines): un-tiled J^2 rows

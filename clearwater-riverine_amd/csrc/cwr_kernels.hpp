@@ -546,9 +546,10 @@ __global__ void __launch_bounds__(BLOCK) k_build_sq(int nnz2, const int32_t* __r
 // list of tile i+2 are arriving in registers -- the compute phase itself issues no global load (vmcnt retires in
 // order, so a load issued during compute would wait behind the prefetches).
 constexpr int TCL_XR = 6;     // x rows a lane group prefetches per tile   (max_cols <= TCL_XR * R)
-constexpr int TCL_WR = 4;     // J^2 entries a thread prefetches per tile  (entries per tile <= TCL_WR * BLOCK)
+constexpr int TCL_WR = 4;     // J^2 entries a thread prefetches per tile  (entries per tile <= WRN * BLOCK): wide rows
+constexpr int TCL_WR_NARROW = 10;  // narrow rows (K < 8): a block's tile has 128-256 rows, i.e. up to ~2 300 entries
 constexpr int TCL_U = 4;      // rows of the tile per lane group           (TR <= TCL_U * R)
-template <int VW>
+template <int VW, int WRN>
 __global__ void __launch_bounds__(BLOCK) k_sq_tiled(
     int n_rows, int K, int G, int TR, int ntiles, const int32_t* __restrict__ ptr2, const int32_t* __restrict__ loc2,
     const double* __restrict__ w2, const int32_t* __restrict__ tcl_ptr, const int32_t* __restrict__ tcl_cols,
@@ -574,7 +575,7 @@ __global__ void __launch_bounds__(BLOCK) k_sq_tiled(
   // prefetch registers
   int cn[TCL_XR];                                  // row list of the tile after next (global x row ids)
   double xr[TCL_XR][VW];                           // x rows of the next tile
-  double wr[TCL_WR]; int lr[TCL_WR];               // weights / local indices of the next tile
+  double wr[WRN]; int lr[WRN];               // weights / local indices of the next tile
   double q0[TCL_U][VW];                            // c2 rows of the next tile
   int pr = 0;                                      // row pointer slice of the next tile
   auto load_cols = [&](int t) {
@@ -592,8 +593,8 @@ __global__ void __launch_bounds__(BLOCK) k_sq_tiled(
     const int c0 = t * TR, c1 = min(c0 + TR, n_rows);
     const int jb = ptr2[c0], je = ptr2[c1];
 #pragma unroll
-    for (int u = 0; u < TCL_WR; ++u) { const int j = jb + tid + u * BLOCK; if (j < je) { wr[u] = w2[j]; lr[u] = loc2[j]; } }
-    if (tid <= c1 - c0) pr = ptr2[c0 + tid] - jb;
+    for (int u = 0; u < WRN; ++u) { const int j = jb + tid + u * BLOCK; if (j < je) { wr[u] = w2[j]; lr[u] = loc2[j]; } }
+    if (tid < c1 - c0) pr = ptr2[c0 + tid] - jb;    // (the tile's last pointer is its entry count)
     if (rowlane) {
 #pragma unroll
       for (int u = 0; u < TCL_U; ++u) { const int c = c0 + r + u * R; if (c < c1) ldv_nt<VW>(c2 + (size_t)c * K + col, q0[u]); }
@@ -614,8 +615,9 @@ __global__ void __launch_bounds__(BLOCK) k_sq_tiled(
       for (int u = 0; u < TCL_XR; ++u) { const int q = r + u * R; if (q < ncol) stv<VW>(s_xt + (size_t)q * K + col, xr[u]); }
     }
 #pragma unroll
-    for (int u = 0; u < TCL_WR; ++u) { const int j = tid + u * BLOCK; if (j < nent) { s_w[j] = wr[u]; s_loc[j] = lr[u]; } }
-    if (tid <= c1 - c0) s_ptr[tid] = pr;
+    for (int u = 0; u < WRN; ++u) { const int j = tid + u * BLOCK; if (j < nent) { s_w[j] = wr[u]; s_loc[j] = lr[u]; } }
+    if (tid < c1 - c0) s_ptr[tid] = pr;
+    if (tid == 0) s_ptr[c1 - c0] = nent;
     double qc[TCL_U][VW];
 #pragma unroll
     for (int u = 0; u < TCL_U; ++u)

@@ -99,7 +99,8 @@ def test_partitioned_step_matches_single_rank_and_oracle(gpu_lib, world, K, solv
         single.step(t, tol=1e-12, mass_flux=True, solver=solver)
     single_state = single.gather_state()                     # reference numbering whatever the internal one
     assert rel_err(state, single_state) <= 1e-10
-    if solver == 'jacobi':                                   # sweeps replay the owner's arithmetic: independent of world and depth
+    if solver == 'jacobi' and depth >= 2:                    # same kernels on both sides (depth 1 cannot host J^2 passes):
+        # sweeps replay the owner's arithmetic, independent of world size, halo depth and numbering
         assert np.array_equal(state, single_state)
     # oracle
     oracle.derive_coefficients(mesh)
