@@ -118,7 +118,9 @@ struct cwr_engine {
   bool use_sq = true, sq_pattern = false, sq_failed = false;
   int sq_min_k = 1, nnz2 = 0, n_sq = 0, stage_cap2 = 0, apply_grid2 = 0;
   size_t apply_lds2 = 0;
-  int32_t *d_ptr2 = nullptr, *d_col2 = nullptr, *d_row2 = nullptr;
+  int32_t *d_ptr2 = nullptr, *d_col2 = nullptr, *d_row2 = nullptr, *d_pair_ptr = nullptr;
+  uint8_t* d_slots = nullptr;
+  bool sq_rowwise = false;
   // tiled J^2 pass: per tile the distinct x rows it touches, and per J^2 entry the row's index in that list
   bool use_tcl = true, tcl_ready = false;
   int tcl_wr = 4;
@@ -191,7 +193,7 @@ int prep_step(cwr_engine* e, int t) {
   if (e->prepared_t == t) return CWR_OK;
   k_prep_step<<<cdiv(e->n_owned, BLOCK), BLOCK, 0, e->stream>>>(
       e->n_owned, e->d_ptr, e->d_ent_edge, e->d_ent_nb, e->d_adv + (size_t)t * e->E,
-      e->d_dif + (size_t)t * e->E, e->d_vol + (size_t)(t + 1) * e->n_cells, e->dt[t], e->d_rec, e->d_diag);
+      e->d_dif + (size_t)t * e->E, e->d_vol + (size_t)(t + 1) * e->n_cells, e->dt[t], e->d_rec, e->d_diag, e->d_w);
   HIP_TRY(e, hipGetLastError());
   e->prepared_t = t;
   return CWR_OK;
@@ -354,8 +356,11 @@ int ensure_sq_pattern(cwr_engine* e) {
       if (e->h_nb[j] >= e->n_owned) { n = c; break; }
   if (n < e->n_core) { e->sq_failed = true; return CWR_OK; }   // halo too shallow: plain sweeps only
   e->n_sq = n;
-  std::vector<int32_t> ptr2((size_t)n + 1, 0), col2;
+  std::vector<int32_t> ptr2((size_t)n + 1, 0), col2, pair_ptr((size_t)n + 1, 0);
+  std::vector<uint8_t> slots;
   col2.reserve((size_t)e->nnz * 3 + 16);
+  slots.reserve((size_t)e->nnz * 4 + 16);
+  bool rowwise = true;
   std::vector<int32_t> tmp;
   const int TR = e->R * e->U;
   for (int c = 0; c < n; ++c) {
@@ -367,11 +372,16 @@ int ensure_sq_pattern(cwr_engine* e) {
         const int k = e->h_nb[i];
         // columns in order of first discovery (faces ascending, then the neighbour's faces ascending): that order does
         // not depend on the local numbering, so a partitioned run sums every row exactly like the single-GPU run
-        if (k >= 0 && std::find(tmp.begin(), tmp.end(), k) == tmp.end()) tmp.push_back(k);
+        if (k < 0) continue;
+        auto it = std::find(tmp.begin(), tmp.end(), k);
+        if (it == tmp.end()) { tmp.push_back(k); it = tmp.end() - 1; }
+        slots.push_back((uint8_t)std::min<size_t>(255, (size_t)(it - tmp.begin())));   // slot of every product, in order
       }
     }
+    if ((int)tmp.size() > SQN_MAXC) rowwise = false;             // such a row needs the per-entry kernel
     col2.insert(col2.end(), tmp.begin(), tmp.end());
     ptr2[c + 1] = (int32_t)col2.size();
+    pair_ptr[c + 1] = (int32_t)slots.size();
   }
   e->nnz2 = (int)col2.size();
   int cap = 1;
@@ -392,9 +402,15 @@ int ensure_sq_pattern(cwr_engine* e) {
   TRY(dev_alloc(e, &e->d_col2, (size_t)e->nnz2));
   TRY(dev_alloc(e, &e->d_row2, (size_t)e->nnz2));
   TRY(dev_alloc(e, &e->d_rec2, (size_t)e->nnz2));
-  TRY(dev_alloc(e, &e->d_w, (size_t)e->nnz));
   TRY(upload(e, e->d_ptr2, ptr2.data(), (size_t)n + 1));
   TRY(upload(e, e->d_col2, col2.data(), (size_t)e->nnz2));
+  if (rowwise && slots.size() < 2000000000u) {
+    TRY(dev_alloc(e, &e->d_pair_ptr, (size_t)n + 1));
+    TRY(dev_alloc(e, &e->d_slots, slots.size()));
+    TRY(upload(e, e->d_pair_ptr, pair_ptr.data(), (size_t)n + 1));
+    TRY(upload(e, e->d_slots, slots.data(), slots.size()));
+    e->sq_rowwise = true;
+  }
   {
     std::vector<int32_t> row2((size_t)e->nnz2);
     for (int c = 0; c < n; ++c) for (int q = ptr2[c]; q < ptr2[c + 1]; ++q) row2[q] = c;
@@ -470,8 +486,13 @@ int prepare_sq(cwr_engine* e, bool& active) {
   TRY(ensure_sq_pattern(e));
   if (!e->sq_pattern) return CWR_OK;
   const int n = e->n_owned;
-  k_entry_w<<<cdiv(n, BLOCK), BLOCK, 0, e->stream>>>(n, e->d_ptr, e->d_rec, e->d_diag, e->d_w);
-  k_build_sq<<<cdiv(e->nnz2, BLOCK), BLOCK, 0, e->stream>>>(e->nnz2, e->d_ptr, e->d_ent_nb, e->d_w, e->d_row2, e->d_col2, e->d_rec2, e->tcl_ready ? e->d_w2 : nullptr);
+  // (the entry weights w were written by k_prep_step)
+  const bool need_rec2 = !e->tcl_ready || e->n_sq > e->n_tcl;      // the un-tiled pass reads FaceRec-format rows
+  if (e->sq_rowwise)
+    k_sq_numeric<<<cdiv(e->n_sq, SQN_THREADS), SQN_THREADS, 0, e->stream>>>(e->n_sq, e->d_ptr, e->d_ent_nb, e->d_w, e->d_ptr2, e->d_col2,
+        e->d_pair_ptr, e->d_slots, need_rec2 ? e->d_rec2 : nullptr, e->tcl_ready ? e->d_w2 : nullptr);
+  else
+    k_build_sq<<<cdiv(e->nnz2, BLOCK), BLOCK, 0, e->stream>>>(e->nnz2, e->d_ptr, e->d_ent_nb, e->d_w, e->d_row2, e->d_col2, e->d_rec2, e->tcl_ready ? e->d_w2 : nullptr);
   HIP_TRY(e, hipGetLastError());
   const int keep = e->dominant_mode; e->dominant_mode = -1;                    // this set-up launch is not a profiled sweep
   const int rc = launch_apply<4>(e, e->d_b, e->d_t, nullptr, e->d_b, nullptr, nullptr);   // c2 = bhat + J bhat
@@ -878,6 +899,7 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   CREATE_TRY(dev_alloc(eng, &eng->d_ent_nb, (size_t)nnz));
   CREATE_TRY(dev_alloc(eng, &eng->d_rec, (size_t)nnz));
   CREATE_TRY(dev_alloc(eng, &eng->d_diag, (size_t)n_owned));
+  CREATE_TRY(dev_alloc(eng, &eng->d_w, (size_t)nnz));
   CREATE_TRY(dev_alloc(eng, &eng->d_c, (size_t)n_cells * K));
   CREATE_TRY(dev_alloc(eng, &eng->d_r, nK));
   CREATE_TRY(dev_alloc(eng, &eng->d_r0, nK));
@@ -921,7 +943,7 @@ void cwr_destroy(cwr_engine* e) {
   for (hipEvent_t ev : e->ev) hipEventDestroy(ev);
   void* ptrs[] = {e->d_f1, e->d_f2, e->d_ptr, e->d_ent_edge, e->d_ent_nb, e->d_adv, e->d_vel, e->d_vol, e->d_dif,
                   e->d_bc, e->d_rec, e->d_diag, e->d_c, e->d_r, e->d_r0, e->d_p, e->d_v, e->d_s, e->d_t, e->d_b,
-                  e->d_scal, e->d_counters, e->d_partial, e->d_fadv, e->d_fdif, e->d_ftot, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf, e->d_ptr2, e->d_col2, e->d_row2, e->d_rec2, e->d_w, e->d_react, e->d_info, e->d_tcl_ptr, e->d_tcl_cols, e->d_loc2, e->d_w2};
+                  e->d_scal, e->d_counters, e->d_partial, e->d_fadv, e->d_fdif, e->d_ftot, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf, e->d_ptr2, e->d_col2, e->d_row2, e->d_rec2, e->d_w, e->d_react, e->d_info, e->d_tcl_ptr, e->d_tcl_cols, e->d_loc2, e->d_w2, e->d_pair_ptr, e->d_slots};
   for (void* p : ptrs) if (p) hipFree(p);
   if (e->stream) hipStreamDestroy(e->stream);
   delete e;

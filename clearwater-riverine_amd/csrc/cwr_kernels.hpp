@@ -227,7 +227,8 @@ __global__ void __launch_bounds__(BLOCK) k_derive_coeff(
 __global__ void __launch_bounds__(BLOCK) k_prep_step(
     int n_owned, const int32_t* __restrict__ ptr, const int32_t* __restrict__ ent_edge,
     const int32_t* __restrict__ ent_nb, const float* __restrict__ adv_t, const double* __restrict__ dif_t,
-    const float* __restrict__ vol_next, double dt, FaceRec* __restrict__ rec, double* __restrict__ diag) {
+    const float* __restrict__ vol_next, double dt, FaceRec* __restrict__ rec, double* __restrict__ diag,
+    double* __restrict__ w) {
   const int c = blockIdx.x * BLOCK + threadIdx.x;
   if (c >= n_owned) return;
   const double vn = (double)vol_next[c];
@@ -244,6 +245,11 @@ __global__ void __launch_bounds__(BLOCK) k_prep_step(
     rec[j] = r;
   }
   diag[c] = dg;
+  // w[j] = -offd_j / diag >= 0: the Jacobi iteration matrix J = I - D^-1 A per adjacency entry (0 on ghost faces)
+  for (int j = ptr[c]; j < j1; ++j) {
+    const FaceRec fr = rec[j];
+    w[j] = (fr.nb >= 0) ? (fr.d - fmin((double)fr.a_c, 0.0)) / dg : 0.0;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ a-3
@@ -513,6 +519,42 @@ __global__ void __launch_bounds__(BLOCK) k_entry_w(int n_rows, const int32_t* __
     w[j] = (fr.nb >= 0) ? (fr.d - fmin((double)fr.a_c, 0.0)) / dg : 0.0;
   }
 }
+// Numeric J^2, row-wise: one thread per row c.  The host lists, for every product J[c,m] J[m,k] in the order (faces of
+// c ascending, then faces of m ascending; ghost faces skipped), the slot of column k in row c of J^2; the thread
+// accumulates into its own LDS row (strided: conflict-free) and writes the row out.  Same summation order as
+// k_build_sq (which stays for rows longer than SQN_MAXC): bitwise the same values.
+constexpr int SQN_THREADS = 128;
+constexpr int SQN_MAXC = 40;
+__global__ void __launch_bounds__(SQN_THREADS) k_sq_numeric(
+    int n, const int32_t* __restrict__ ptr, const int32_t* __restrict__ ent_nb, const double* __restrict__ w,
+    const int32_t* __restrict__ ptr2, const int32_t* __restrict__ col2, const int32_t* __restrict__ pair_ptr,
+    const uint8_t* __restrict__ slots, FaceRec* __restrict__ rec2, double* __restrict__ w2) {
+  __shared__ double s_acc[SQN_THREADS * SQN_MAXC];
+  const int c = blockIdx.x * SQN_THREADS + threadIdx.x;
+  if (c >= n) return;
+  double* acc = s_acc + threadIdx.x;
+  const int o = ptr2[c], len = ptr2[c + 1] - o;
+  for (int q = 0; q < len; ++q) acc[q * SQN_THREADS] = 0.0;
+  int pi = pair_ptr[c];
+  const int j1 = ptr[c + 1];
+  for (int j = ptr[c]; j < j1; ++j) {
+    const int m = ent_nb[j];
+    if (m < 0) continue;
+    const double wj = w[j];
+    const int i1 = ptr[m + 1];
+    for (int i = ptr[m]; i < i1; ++i) {
+      if (ent_nb[i] < 0) continue;
+      acc[(int)slots[pi] * SQN_THREADS] += wj * w[i];
+      ++pi;
+    }
+  }
+  for (int q = 0; q < len; ++q) {
+    const double v = acc[q * SQN_THREADS];
+    if (w2) w2[o + q] = v;
+    if (rec2) { FaceRec out; out.nb = col2[o + q]; out.a_c = 0.0f; out.d = v; rec2[o + q] = out; }
+  }
+}
+
 // Numeric J^2 on the static pattern (ptr2, col2, row2) built once on the host: one thread per OUTPUT entry (c, k);
 // products J[c,m] J[m,k] are summed in a fixed order (faces of c ascending, then faces of m ascending): deterministic.
 // Threads of one row are adjacent and re-read the same few adjacency rows: L1/L2 hits.
