@@ -123,7 +123,8 @@ struct cwr_engine {
   bool sq_rowwise = false;
   // tiled J^2 pass: per tile the distinct x rows it touches, and per J^2 entry the row's index in that list
   bool use_tcl = true, tcl_ready = false;
-  int tcl_wr = 4;
+  int tcl_cfg = -1;
+  int local_reps = 2;              // J^2 applications per tile and pass (1 = exact Jacobi; > 1 = block-asynchronous)
   int n_tcl = 0, tcl_TR = 0, tcl_ntiles = 0, tcl_max_cols = 0, tcl_stage_cap = 0, tcl_grid = 0;
   size_t tcl_lds = 0, tcl_total_cols = 0;
   int32_t *d_tcl_ptr = nullptr, *d_tcl_cols = nullptr, *d_loc2 = nullptr;
@@ -344,6 +345,12 @@ int alloc_flow(cwr_engine* e, int T) {
   return CWR_OK;
 }
 
+#define CWR_TCL_K(VWv, Q) k_sq_tiled<VWv, TCL_CFG[Q].wrn, TCL_CFG[Q].ut, TCL_CFG[Q].xr>
+const void* tcl_kernel(int vw, int cfg) {
+  if (vw == 2) return cfg == 0 ? reinterpret_cast<const void*>(&CWR_TCL_K(2, 0)) : cfg == 1 ? reinterpret_cast<const void*>(&CWR_TCL_K(2, 1)) : reinterpret_cast<const void*>(&CWR_TCL_K(2, 2));
+  return cfg == 0 ? reinterpret_cast<const void*>(&CWR_TCL_K(1, 0)) : cfg == 1 ? reinterpret_cast<const void*>(&CWR_TCL_K(1, 1)) : reinterpret_cast<const void*>(&CWR_TCL_K(1, 2));
+}
+
 // Symbolic J^2 (once): row c of J^2 has the columns reachable in two face steps.  Numeric values per step on
 // the device (k_entry_w, k_build_sq), then c2 = bhat + J bhat with one plain sweep of bhat.
 int ensure_sq_pattern(cwr_engine* e) {
@@ -448,10 +455,13 @@ int ensure_sq_pattern(cwr_engine* e) {
     const size_t lds = ((size_t)max_cols * e->K * sizeof(double) + (size_t)cap2 * (sizeof(double) + sizeof(int32_t)) +
                         (size_t)(tr + 1) * sizeof(int32_t) + 15) & ~(size_t)15;
     // the kernel's compile-time prefetch depths bound what a tile may hold; otherwise the plain J^2 pass stays
-    e->tcl_wr = (cap2 <= TCL_WR * BLOCK) ? TCL_WR : TCL_WR_NARROW;
-    if (lds <= 64 * 1024 && max_cols <= TCL_XR * e->R && cap2 <= e->tcl_wr * BLOCK && tr <= TCL_U * e->R && tr <= BLOCK) {
-      const void* fn6 = (e->VW == 2) ? (e->tcl_wr == TCL_WR ? reinterpret_cast<const void*>(&k_sq_tiled<2, TCL_WR>) : reinterpret_cast<const void*>(&k_sq_tiled<2, TCL_WR_NARROW>))
-                                     : (e->tcl_wr == TCL_WR ? reinterpret_cast<const void*>(&k_sq_tiled<1, TCL_WR>) : reinterpret_cast<const void*>(&k_sq_tiled<1, TCL_WR_NARROW>));
+    e->tcl_cfg = -1;
+    int q0 = 0;
+    if (const char* v = getenv("CWR_TCL_CFG")) q0 = std::max(0, std::min(2, atoi(v)));
+    for (int q = q0; q < 3 && e->tcl_cfg < 0; ++q)
+      if (max_cols <= TCL_CFG[q].xr * e->R && cap2 <= TCL_CFG[q].wrn * BLOCK && tr <= TCL_CFG[q].ut * e->R) e->tcl_cfg = q;
+    if (lds <= 64 * 1024 && e->tcl_cfg >= 0 && tr <= BLOCK) {
+      const void* fn6 = tcl_kernel(e->VW, e->tcl_cfg);
       int pc = 1;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, fn6, BLOCK, lds) != hipSuccess || pc < 1) pc = 1;
       pc = std::min(pc, 8);
@@ -471,7 +481,7 @@ int ensure_sq_pattern(cwr_engine* e) {
                                          tr, (double)tcols.size() / n_t, max_cols, lds, e->tcl_grid);
     } else if (getenv("CWR_VERBOSE")) {
       fprintf(stderr, "[cwr] tiled J^2 not used: tile=%d rows, max %d distinct x rows per tile (limit %d), %d entries per tile (limit %d), lds=%zu\n",
-              tr, max_cols, TCL_XR * e->R, cap2, TCL_WR_NARROW * BLOCK, lds);
+              tr, max_cols, TCL_CFG[2].xr * e->R, cap2, TCL_CFG[2].wrn * BLOCK, lds);
     }
   }
   e->sq_pattern = true;
@@ -485,7 +495,6 @@ int prepare_sq(cwr_engine* e, bool& active) {
   if (!e->use_sq || e->sq_failed || e->K < e->sq_min_k) return CWR_OK;
   TRY(ensure_sq_pattern(e));
   if (!e->sq_pattern) return CWR_OK;
-  const int n = e->n_owned;
   // (the entry weights w were written by k_prep_step)
   const bool need_rec2 = !e->tcl_ready || e->n_sq > e->n_tcl;      // the un-tiled pass reads FaceRec-format rows
   if (e->sq_rowwise)
@@ -508,10 +517,10 @@ int launch_sq_tiled(cwr_engine* e, const double* xin, double* yout) {
     e0 = e->ev[e->ev_used++]; e1 = e->ev[e->ev_used++];
     HIP_TRY(e, hipEventRecord(e0, e->stream));
   }
-#define CWR_TILED(VWv, WRv) k_sq_tiled<VWv, WRv><<<e->tcl_grid, BLOCK, e->tcl_lds, e->stream>>>(e->n_tcl, e->K, e->G, e->tcl_TR,    \
-      e->tcl_ntiles, e->d_ptr2, e->d_loc2, e->d_w2, e->d_tcl_ptr, e->d_tcl_cols, e->tcl_max_cols, e->tcl_stage_cap, xin, e->d_t, yout)
-  if (e->VW == 2) { if (e->tcl_wr == TCL_WR) CWR_TILED(2, TCL_WR); else CWR_TILED(2, TCL_WR_NARROW); }
-  else            { if (e->tcl_wr == TCL_WR) CWR_TILED(1, TCL_WR); else CWR_TILED(1, TCL_WR_NARROW); }
+#define CWR_TILED(VWv, Q) CWR_TCL_K(VWv, Q)<<<e->tcl_grid, BLOCK, e->tcl_lds, e->stream>>>(e->n_tcl, e->K, e->G, e->tcl_TR,    \
+      e->tcl_ntiles, e->d_ptr2, e->d_loc2, e->d_w2, e->d_tcl_ptr, e->d_tcl_cols, e->tcl_max_cols, e->tcl_stage_cap, e->local_reps, xin, e->d_t, yout)
+  if (e->VW == 2) { if (e->tcl_cfg == 0) CWR_TILED(2, 0); else if (e->tcl_cfg == 1) CWR_TILED(2, 1); else CWR_TILED(2, 2); }
+  else            { if (e->tcl_cfg == 0) CWR_TILED(1, 0); else if (e->tcl_cfg == 1) CWR_TILED(1, 1); else CWR_TILED(1, 2); }
 #undef CWR_TILED
   HIP_TRY(e, hipGetLastError());
   if (e1) HIP_TRY(e, hipEventRecord(e1, e->stream));
@@ -555,6 +564,7 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
       // exact scaled residual of its input, so the convergence criterion is unchanged
       batch += (6 - batch % 4) % 4;                                     // round up to 2 (mod 4)
       int doubles = (batch - 2) / 2;
+      const int passes = doubles;
       launches = doubles + 2;
       todo = 0;
       if (!e->comm && !e->profiling && e->use_graphs) {
@@ -586,6 +596,9 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
         else TRY(launch_apply<5>(e, src, (i & 1) ? e->d_c : e->d_p, nullptr, e->d_t, nullptr, nullptr, e->n_sq));
         since_exchange += 2;
       }
+      // block-asynchronous passes leave the replayed halo layers only approximately equal to their owners' rows: refresh
+      // them so that the two plain sweeps below are exact on the core and the check is the true residual
+      if (e->comm && tiled && e->local_reps > 1 && passes > 0) since_exchange = e->exch_every;
       if (since_exchange + 1 > e->exch_every) { TRY(exchange_halo(e, e->d_c)); since_exchange = 0; }
       TRY(launch_apply<4>(e, e->d_c, e->d_p, nullptr, e->d_b, nullptr, nullptr));
       ++since_exchange;
@@ -839,6 +852,10 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   if (const char* v = getenv("CWR_NO_SQ")) eng->use_sq = atoi(v) == 0;
   if (const char* v = getenv("CWR_NO_SMALL")) eng->use_small = atoi(v) == 0;
   if (const char* v = getenv("CWR_NO_TCL")) eng->use_tcl = atoi(v) == 0;
+  // tile-local J^2 applications per pass: each costs LDS time only (measured 15-25 us at K = 16, 4 us at K = 1 on 1 M cells)
+  // and cuts the passes from 46 to 28 (x2) / 24 (x3); narrow rows gain from the third application, wide rows do not
+  eng->local_reps = (K <= 4) ? 3 : 2;
+  if (const char* v = getenv("CWR_LOCAL_REPS")) eng->local_reps = std::max(1, std::min(16, atoi(v)));
   eng->nt_stream = (K >= 8) ? 1 : 0;
   if (const char* v = getenv("CWR_NT_STREAM")) eng->nt_stream = atoi(v) != 0;
   if (const char* v = getenv("CWR_SQ_MIN_K")) eng->sq_min_k = std::max(1, atoi(v));

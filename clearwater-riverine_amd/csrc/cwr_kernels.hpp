@@ -587,15 +587,18 @@ __global__ void __launch_bounds__(BLOCK) k_build_sq(int nnz2, const int32_t* __r
 // three tiles in flight: it computes tile i from LDS while the x rows / weights / c2 rows of tile i+1 and the row
 // list of tile i+2 are arriving in registers -- the compute phase itself issues no global load (vmcnt retires in
 // order, so a load issued during compute would wait behind the prefetches).
-constexpr int TCL_XR = 6;     // x rows a lane group prefetches per tile   (max_cols <= TCL_XR * R)
-constexpr int TCL_WR = 4;     // J^2 entries a thread prefetches per tile  (entries per tile <= WRN * BLOCK): wide rows
-constexpr int TCL_WR_NARROW = 10;  // narrow rows (K < 8): a block's tile has 128-256 rows, i.e. up to ~2 300 entries
-constexpr int TCL_U = 4;      // rows of the tile per lane group           (TR <= TCL_U * R)
-template <int VW, int WRN>
+// Compile-time prefetch depths of the tiled pass (registers holding the NEXT tile while the current one is computed):
+// XR x rows per lane group (distinct x rows per tile <= XR * R), WRN J^2 entries per thread (entries per tile <= WRN * BLOCK),
+// UT rows of the tile per lane group (tile rows <= UT * R).  The engine picks the cheapest configuration that fits.
+struct TclCfg { int wrn, ut, xr; };
+constexpr TclCfg TCL_CFG[3] = {{4, 2, 6},      // wide rows (K = 16: 64-row tiles)
+                               {10, 1, 3},     // narrow rows (K <= 8: one row per lane group, 64-256-row tiles)
+                               {10, 4, 8}};    // large tiles
+template <int VW, int WRN, int TCL_U, int TCL_XR>
 __global__ void __launch_bounds__(BLOCK) k_sq_tiled(
     int n_rows, int K, int G, int TR, int ntiles, const int32_t* __restrict__ ptr2, const int32_t* __restrict__ loc2,
     const double* __restrict__ w2, const int32_t* __restrict__ tcl_ptr, const int32_t* __restrict__ tcl_cols,
-    int max_cols, int stage_cap, const double* __restrict__ xin, const double* __restrict__ c2, double* __restrict__ yout) {
+    int max_cols, int stage_cap, int reps, const double* __restrict__ xin, const double* __restrict__ c2, double* __restrict__ yout) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
   double* s_xt = reinterpret_cast<double*>(s_dyn);                                  // [max_cols][K]
   double* s_w = s_xt + (size_t)max_cols * K;                                         // [stage_cap]
@@ -636,7 +639,8 @@ __global__ void __launch_bounds__(BLOCK) k_sq_tiled(
     const int jb = ptr2[c0], je = ptr2[c1];
 #pragma unroll
     for (int u = 0; u < WRN; ++u) { const int j = jb + tid + u * BLOCK; if (j < je) { wr[u] = w2[j]; lr[u] = loc2[j]; } }
-    if (tid < c1 - c0) pr = ptr2[c0 + tid] - jb;    // (the tile's last pointer is its entry count)
+    if (tid < c1 - c0) pr = ptr2[c0 + tid];         // raw: rebased when it is stored to LDS (a subtraction here would wait
+                                                    // for this load, and with it for every prefetch issued before it)
     if (rowlane) {
 #pragma unroll
       for (int u = 0; u < TCL_U; ++u) { const int c = c0 + r + u * R; if (c < c1) ldv_nt<VW>(c2 + (size_t)c * K + col, q0[u]); }
@@ -650,7 +654,8 @@ __global__ void __launch_bounds__(BLOCK) k_sq_tiled(
   for (int it = 0; t_cur >= 0; ++it) {
     const int c0 = t_cur * TR, c1 = min(c0 + TR, n_rows);
     const int ncol = tcl_ptr[t_cur + 1] - tcl_ptr[t_cur];
-    const int nent = ptr2[c1] - ptr2[c0];
+    const int jb0 = ptr2[c0];
+    const int nent = ptr2[c1] - jb0;
     __syncthreads();                               // the previous tile's readers are done with LDS
     if (rowlane) {
 #pragma unroll
@@ -658,7 +663,7 @@ __global__ void __launch_bounds__(BLOCK) k_sq_tiled(
     }
 #pragma unroll
     for (int u = 0; u < WRN; ++u) { const int j = tid + u * BLOCK; if (j < nent) { s_w[j] = wr[u]; s_loc[j] = lr[u]; } }
-    if (tid < c1 - c0) s_ptr[tid] = pr;
+    if (tid < c1 - c0) s_ptr[tid] = pr - jb0;
     if (tid == 0) s_ptr[c1 - c0] = nent;
     double qc[TCL_U][VW];
 #pragma unroll
@@ -670,27 +675,45 @@ __global__ void __launch_bounds__(BLOCK) k_sq_tiled(
     const int t_after = tile_of(it + 2);
     load_rows(t_next);
     load_cols(t_after);
-    if (rowlane) {
+    // reps > 1 (block-asynchronous Jacobi): the tile applies J^2 again to its own freshly computed rows, which sit first
+    // in the LDS x tile, while rows of other tiles keep the values of the pass's input.  A chaotic relaxation in the
+    // sense of Chazan-Miranker: it converges whenever rho(|J|) < 1 (always here: A is a strictly diagonally dominant
+    // M-matrix) and the inner applications cost LDS reads only.
+    double y[TCL_U][VW];
+    for (int rep = 0; rep < reps; ++rep) {
+      if (rep > 0) {
+        __syncthreads();                             // every reader of the previous round is done
+        if (rowlane) {
 #pragma unroll
-      for (int u = 0; u < TCL_U; ++u) {
-        const int c = c0 + r + u * R;
-        if (c < c1) {
-          double sum[VW];                          // same association as k_apply<.,5>: (sum of w x) first, + c2 last,
+          for (int u = 0; u < TCL_U; ++u) { const int c = c0 + r + u * R; if (c < c1) stv<VW>(s_xt + (size_t)(c - c0) * K + col, y[u]); }
+        }
+        __syncthreads();
+      }
+      if (rowlane) {
 #pragma unroll
-          for (int w = 0; w < VW; ++w) sum[w] = 0.0;  // so both J^2 kernels give bitwise equal rows
-          const int j0 = s_ptr[c - c0], j1 = s_ptr[c - c0 + 1];
-          for (int j = j0; j < j1; ++j) {
-            double xn[VW];
-            ldv<VW>(s_xt + (size_t)s_loc[j] * K + col, xn);
-            const double wj = s_w[j];
+        for (int u = 0; u < TCL_U; ++u) {
+          const int c = c0 + r + u * R;
+          if (c < c1) {
+            double sum[VW];                          // same association as k_apply<.,5>: (sum of w x) first, + c2 last,
 #pragma unroll
-            for (int w = 0; w < VW; ++w) sum[w] += wj * xn[w];
+            for (int w = 0; w < VW; ++w) sum[w] = 0.0;  // so both J^2 kernels give bitwise equal rows
+            const int j0 = s_ptr[c - c0], j1 = s_ptr[c - c0 + 1];
+            for (int j = j0; j < j1; ++j) {
+              double xn[VW];
+              ldv<VW>(s_xt + (size_t)s_loc[j] * K + col, xn);
+              const double wj = s_w[j];
+#pragma unroll
+              for (int w = 0; w < VW; ++w) sum[w] += wj * xn[w];
+            }
+#pragma unroll
+            for (int w = 0; w < VW; ++w) y[u][w] = qc[u][w] + sum[w];
           }
-#pragma unroll
-          for (int w = 0; w < VW; ++w) sum[w] = qc[u][w] + sum[w];
-          stv_stream<VW>(yout + (size_t)c * K + col, sum);
         }
       }
+    }
+    if (rowlane) {
+#pragma unroll
+      for (int u = 0; u < TCL_U; ++u) { const int c = c0 + r + u * R; if (c < c1) stv_stream<VW>(yout + (size_t)c * K + col, y[u]); }
     }
     t_cur = t_next;
     t_next = t_after;
