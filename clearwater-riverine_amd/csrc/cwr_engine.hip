@@ -5,6 +5,8 @@
 #include "cwr_kernels.hpp"
 
 #include <dlfcn.h>
+#include <atomic>
+#include <thread>
 
 #include <algorithm>
 #include <chrono>
@@ -87,6 +89,19 @@ struct cwr_engine {
   double *d_c = nullptr, *d_r = nullptr, *d_r0 = nullptr, *d_p = nullptr, *d_v = nullptr, *d_s = nullptr,
          *d_t = nullptr, *d_b = nullptr;
   double* d_react = nullptr;     // K x K reaction matrix of cwr_react_linear
+  // ---- output side (8f-4)
+  int n_lines = 0;
+  int32_t *d_line_ptr = nullptr, *d_line_faces = nullptr;
+  double *d_ledger = nullptr, *d_mass_out = nullptr;
+  struct OutSlot { double* h = nullptr; hipEvent_t done = nullptr; std::atomic<bool> busy{false}; };
+  std::vector<OutSlot> out_slots;
+  hipStream_t out_stream = nullptr;
+  hipEvent_t out_snap_ready = nullptr, out_copy_done = nullptr;
+  double* d_snap = nullptr;      // device snapshot the copy stream reads while the next steps compute
+  int32_t* d_out_order = nullptr;
+  int out_n = 0, out_next = 0;
+  bool out_flux = false, out_copy_pending = false;
+  size_t out_state_cnt = 0, out_slot_cnt = 0;
   double* d_scal = nullptr;      // acc[3][ACC_N][K] | rho[3][K] | bb[K]
   int32_t* d_counters = nullptr; // 8 ints
   double *d_fadv = nullptr, *d_fdif = nullptr, *d_ftot = nullptr;
@@ -801,7 +816,7 @@ int solve_bicgstab(cwr_engine* e, double tol2, int max_iter, SolveStats& st) {
 // ====================================================================================================
 extern "C" {
 
-int32_t cwr_abi_version(void) { return 1; }
+int32_t cwr_abi_version(void) { return 2; }
 
 const char* cwr_last_error(const cwr_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
 
@@ -950,6 +965,7 @@ void cwr_destroy(cwr_engine* e) {
   if (!e) return;
   hipSetDevice(e->dev);
   if (e->stream) hipStreamSynchronize(e->stream);
+  cwr_output_close(e);
   if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
   if (e->sweep_exec) hipGraphExecDestroy(e->sweep_exec);
   if (e->sweep_graph) hipGraphDestroy(e->sweep_graph);
@@ -960,7 +976,7 @@ void cwr_destroy(cwr_engine* e) {
   for (hipEvent_t ev : e->ev) hipEventDestroy(ev);
   void* ptrs[] = {e->d_f1, e->d_f2, e->d_ptr, e->d_ent_edge, e->d_ent_nb, e->d_adv, e->d_vel, e->d_vol, e->d_dif,
                   e->d_bc, e->d_rec, e->d_diag, e->d_c, e->d_r, e->d_r0, e->d_p, e->d_v, e->d_s, e->d_t, e->d_b,
-                  e->d_scal, e->d_counters, e->d_partial, e->d_fadv, e->d_fdif, e->d_ftot, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf, e->d_ptr2, e->d_col2, e->d_row2, e->d_rec2, e->d_w, e->d_react, e->d_info, e->d_tcl_ptr, e->d_tcl_cols, e->d_loc2, e->d_w2, e->d_pair_ptr, e->d_slots};
+                  e->d_scal, e->d_counters, e->d_partial, e->d_fadv, e->d_fdif, e->d_ftot, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf, e->d_ptr2, e->d_col2, e->d_row2, e->d_rec2, e->d_w, e->d_react, e->d_info, e->d_tcl_ptr, e->d_tcl_cols, e->d_loc2, e->d_w2, e->d_pair_ptr, e->d_slots, e->d_line_ptr, e->d_line_faces, e->d_ledger, e->d_mass_out};
   for (void* p : ptrs) if (p) hipFree(p);
   if (e->stream) hipStreamDestroy(e->stream);
   delete e;
@@ -1208,6 +1224,12 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
     HIP_TRY(e, hipGetLastError());
     e->flux_valid = true;
   }
+  if (flags & CWR_STEP_MASS_BALANCE) {
+    if (e->n_lines <= 0) return fail(e, CWR_ERR_STATE, "cwr_step: CWR_STEP_MASS_BALANCE without cwr_set_boundary_lines");
+    k_line_mass<<<e->n_lines, BLOCK, 0, e->stream>>>(K, e->n_core, e->d_line_ptr, e->d_line_faces, e->d_f1, e->d_f2,
+        e->d_adv + (size_t)t * e->E, e->d_dif + (size_t)t * e->E, e->dt[t], e->d_c, e->d_ledger);
+    HIP_TRY(e, hipGetLastError());
+  }
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   local.solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
   if (info) *info = local;
@@ -1288,6 +1310,165 @@ int32_t cwr_profile_read(cwr_engine* e, int64_t* launches, double* total_us) {
   if (launches) *launches = e->prof_launches;
   if (total_us) *total_us = e->prof_us;
   e->prof_launches = 0; e->prof_us = 0.0;
+  return CWR_OK;
+}
+
+// ------------------------------------------------------------------ output side (8f-4)
+int32_t cwr_set_boundary_lines(cwr_engine* e, int32_t n_lines, const int32_t* line_ptr, const int32_t* line_faces) {
+  if (!e) return CWR_ERR_BAD_ARG;
+  if (n_lines < 1 || !line_ptr) return fail(e, CWR_ERR_BAD_ARG, "cwr_set_boundary_lines: need >= 1 line and line_ptr");
+  if (e->K > BLOCK) return fail(e, CWR_ERR_BAD_ARG, "cwr_set_boundary_lines: K too large");
+  if (line_ptr[0] != 0) return fail(e, CWR_ERR_BAD_ARG, "cwr_set_boundary_lines: line_ptr[0] must be 0");
+  for (int l = 0; l < n_lines; ++l)
+    if (line_ptr[l + 1] < line_ptr[l]) return fail(e, CWR_ERR_BAD_ARG, "cwr_set_boundary_lines: line_ptr must not decrease");
+  const int nf = line_ptr[n_lines];
+  if (nf > 0 && !line_faces) return fail(e, CWR_ERR_BAD_ARG, "cwr_set_boundary_lines: line_faces is NULL");
+  for (int i = 0; i < nf; ++i)
+    if (line_faces[i] < 0 || line_faces[i] >= e->E) return fail(e, CWR_ERR_BAD_ARG, "cwr_set_boundary_lines: face id out of range");
+  HIP_TRY(e, hipSetDevice(e->dev));
+  hipFree(e->d_line_ptr); hipFree(e->d_line_faces); hipFree(e->d_ledger);
+  e->d_line_ptr = nullptr; e->d_line_faces = nullptr; e->d_ledger = nullptr; e->n_lines = 0;
+  TRY(dev_alloc(e, &e->d_line_ptr, (size_t)n_lines + 1));
+  TRY(dev_alloc(e, &e->d_line_faces, (size_t)std::max(nf, 1)));
+  TRY(dev_alloc(e, &e->d_ledger, (size_t)n_lines * 3 * e->K));
+  TRY(upload(e, e->d_line_ptr, line_ptr, (size_t)n_lines + 1));
+  if (nf > 0) TRY(upload(e, e->d_line_faces, line_faces, (size_t)nf));
+  e->n_lines = n_lines;
+  return cwr_reset_mass_balance(e);
+}
+
+int32_t cwr_reset_mass_balance(cwr_engine* e) {
+  if (!e) return CWR_ERR_BAD_ARG;
+  if (e->n_lines <= 0) return fail(e, CWR_ERR_STATE, "cwr_reset_mass_balance: no boundary lines set");
+  HIP_TRY(e, hipSetDevice(e->dev));
+  HIP_TRY(e, hipMemsetAsync(e->d_ledger, 0, (size_t)e->n_lines * 3 * e->K * sizeof(double), e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return CWR_OK;
+}
+
+int32_t cwr_get_mass_balance(cwr_engine* e, double* ledger) {
+  if (!e || !ledger) return e ? fail(e, CWR_ERR_BAD_ARG, "cwr_get_mass_balance: NULL") : CWR_ERR_BAD_ARG;
+  if (e->n_lines <= 0) return fail(e, CWR_ERR_STATE, "cwr_get_mass_balance: no boundary lines set");
+  HIP_TRY(e, hipSetDevice(e->dev));
+  TRY(download(e, ledger, e->d_ledger, (size_t)e->n_lines * 3 * e->K));
+  return CWR_OK;
+}
+
+int32_t cwr_domain_mass(cwr_engine* e, int32_t t_level, double* out) {
+  if (!e || !out) return e ? fail(e, CWR_ERR_BAD_ARG, "cwr_domain_mass: NULL") : CWR_ERR_BAD_ARG;
+  TRY(check_level(e, t_level, false));
+  if (e->K > BLOCK) return fail(e, CWR_ERR_BAD_ARG, "cwr_domain_mass: K too large");
+  HIP_TRY(e, hipSetDevice(e->dev));
+  const int K = e->K, per = BLOCK / K;
+  const int grid = std::max(1, std::min(cdiv(e->n_core, per), 512));
+  if (!e->d_mass_out) TRY(dev_alloc(e, &e->d_mass_out, (size_t)513 * (K + 1)));
+  k_domain_mass<<<grid, BLOCK, 0, e->stream>>>(e->n_core, K, e->d_vol + (size_t)t_level * e->n_cells, e->d_c, e->d_mass_out);
+  k_fold_partials<<<1, BLOCK, 0, e->stream>>>(grid, K + 1, e->d_mass_out, e->d_mass_out + (size_t)512 * (K + 1));
+  HIP_TRY(e, hipGetLastError());
+  TRY(download(e, out, e->d_mass_out + (size_t)512 * (K + 1), (size_t)K + 1));
+  return CWR_OK;
+}
+
+int32_t cwr_output_close(cwr_engine* e) {
+  if (!e) return CWR_ERR_BAD_ARG;
+  if (!e->out_stream) return CWR_OK;
+  hipSetDevice(e->dev);
+  hipStreamSynchronize(e->out_stream);
+  for (auto& sl : e->out_slots) { if (sl.h) hipHostFree(sl.h); if (sl.done) hipEventDestroy(sl.done); }
+  e->out_slots.clear();
+  if (e->out_snap_ready) hipEventDestroy(e->out_snap_ready);
+  if (e->out_copy_done) hipEventDestroy(e->out_copy_done);
+  e->out_snap_ready = e->out_copy_done = nullptr;
+  hipFree(e->d_snap); hipFree(e->d_out_order);
+  e->d_snap = nullptr; e->d_out_order = nullptr;
+  hipStreamDestroy(e->out_stream);
+  e->out_stream = nullptr;
+  e->out_copy_pending = false;
+  return CWR_OK;
+}
+
+int32_t cwr_output_open(cwr_engine* e, int32_t n_slots, int32_t with_flux, int32_t n_out, const int32_t* row_order) {
+  if (!e) return CWR_ERR_BAD_ARG;
+  if (e->out_stream) return fail(e, CWR_ERR_STATE, "cwr_output_open: already open");
+  if (n_slots < 1 || n_slots > 64 || n_out < 1 || n_out > e->n_cells) return fail(e, CWR_ERR_BAD_ARG, "cwr_output_open: bad n_slots / n_out");
+  if (row_order)
+    for (int i = 0; i < n_out; ++i)
+      if (row_order[i] < 0 || row_order[i] >= e->n_cells) return fail(e, CWR_ERR_BAD_ARG, "cwr_output_open: row_order entry out of range");
+  HIP_TRY(e, hipSetDevice(e->dev));
+  e->out_n = n_out; e->out_flux = with_flux != 0; e->out_next = 0;
+  e->out_state_cnt = (size_t)n_out * e->K;
+  e->out_slot_cnt = e->out_state_cnt + (e->out_flux ? (size_t)3 * e->E * e->K : 0);
+  HIP_TRY(e, hipStreamCreateWithFlags(&e->out_stream, hipStreamNonBlocking));
+  int rc = CWR_OK;
+  if (hipEventCreateWithFlags(&e->out_snap_ready, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&e->out_copy_done, hipEventDisableTiming) != hipSuccess) rc = fail(e, CWR_ERR_HIP, "cwr_output_open: event creation failed");
+  if (rc == CWR_OK) rc = dev_alloc(e, &e->d_snap, e->out_slot_cnt);
+  if (rc == CWR_OK && row_order) { rc = dev_alloc(e, &e->d_out_order, (size_t)n_out); if (rc == CWR_OK) rc = upload(e, e->d_out_order, row_order, (size_t)n_out); }
+  if (rc == CWR_OK) {
+    e->out_slots = std::vector<cwr_engine::OutSlot>((size_t)n_slots);
+    for (auto& sl : e->out_slots) {
+      if (hipHostMalloc(reinterpret_cast<void**>(&sl.h), e->out_slot_cnt * sizeof(double), hipHostMallocDefault) != hipSuccess ||
+          hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess) { rc = fail(e, CWR_ERR_HIP, "cwr_output_open: pinned host allocation failed"); break; }
+    }
+  }
+  if (rc != CWR_OK) { cwr_output_close(e); return rc; }
+  const size_t lds = (size_t)e->K * (SNAP_ROWS + 1) * sizeof(double);
+  if (lds > 48 * 1024) HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_snapshot_t), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  return CWR_OK;
+}
+
+int32_t cwr_output_push(cwr_engine* e, int32_t* slot) {
+  if (!e || !slot) return e ? fail(e, CWR_ERR_BAD_ARG, "cwr_output_push: NULL") : CWR_ERR_BAD_ARG;
+  if (!e->out_stream) return fail(e, CWR_ERR_STATE, "cwr_output_push: cwr_output_open first");
+  if (e->out_flux && !e->flux_valid) return fail(e, CWR_ERR_STATE, "cwr_output_push: the last step was not taken with CWR_STEP_MASS_FLUX");
+  HIP_TRY(e, hipSetDevice(e->dev));
+  const int s = e->out_next;
+  cwr_engine::OutSlot& sl = e->out_slots[(size_t)s];
+  for (int waited = 0; sl.busy.load(std::memory_order_acquire); ++waited) {           // the consumer still holds this slot
+    if (waited > 120000) return fail(e, CWR_ERR_STATE, "cwr_output_push: output ring full for 120 s (slot never released)");
+    std::this_thread::sleep_for(std::chrono::milliseconds(1));
+  }
+  // the device snapshot is rewritten only after the previous copy out of it has finished
+  if (e->out_copy_pending) HIP_TRY(e, hipStreamWaitEvent(e->stream, e->out_copy_done, 0));
+  const size_t lds = (size_t)e->K * (SNAP_ROWS + 1) * sizeof(double);
+  const int grid = std::max(1, std::min(cdiv(e->out_n, SNAP_ROWS), 256 * 8));
+  k_snapshot_t<<<grid, BLOCK, lds, e->stream>>>(e->out_n, e->K, e->d_out_order, e->d_c, e->d_snap);
+  if (e->out_flux) {
+    const int gridf = std::max(1, std::min(cdiv(e->E, SNAP_ROWS), 256 * 8));
+    const size_t EK = (size_t)e->E * e->K;
+    k_snapshot_t<<<gridf, BLOCK, lds, e->stream>>>(e->E, e->K, nullptr, e->d_fadv, e->d_snap + e->out_state_cnt);
+    k_snapshot_t<<<gridf, BLOCK, lds, e->stream>>>(e->E, e->K, nullptr, e->d_fdif, e->d_snap + e->out_state_cnt + EK);
+    k_snapshot_t<<<gridf, BLOCK, lds, e->stream>>>(e->E, e->K, nullptr, e->d_ftot, e->d_snap + e->out_state_cnt + 2 * EK);
+  }
+  HIP_TRY(e, hipGetLastError());
+  HIP_TRY(e, hipEventRecord(e->out_snap_ready, e->stream));
+  HIP_TRY(e, hipStreamWaitEvent(e->out_stream, e->out_snap_ready, 0));
+  HIP_TRY(e, hipMemcpyAsync(sl.h, e->d_snap, e->out_slot_cnt * sizeof(double), hipMemcpyDeviceToHost, e->out_stream));
+  HIP_TRY(e, hipEventRecord(sl.done, e->out_stream));
+  HIP_TRY(e, hipEventRecord(e->out_copy_done, e->out_stream));
+  e->out_copy_pending = true;
+  sl.busy.store(true, std::memory_order_release);
+  e->out_next = (s + 1) % (int)e->out_slots.size();
+  *slot = s;
+  return CWR_OK;
+}
+
+int32_t cwr_output_wait(cwr_engine* e, int32_t slot, const double** state, const double** flux) {
+  if (!e) return CWR_ERR_BAD_ARG;
+  if (!e->out_stream || slot < 0 || slot >= (int)e->out_slots.size()) return fail(e, CWR_ERR_BAD_ARG, "cwr_output_wait: bad slot");
+  cwr_engine::OutSlot& sl = e->out_slots[(size_t)slot];
+  if (!sl.busy.load(std::memory_order_acquire)) return fail(e, CWR_ERR_STATE, "cwr_output_wait: slot holds no snapshot");
+  // (no hipSetDevice: events carry their device; this may run on a consumer thread)
+  if (hipEventSynchronize(sl.done) != hipSuccess) return fail(e, CWR_ERR_HIP, "cwr_output_wait: event synchronize failed");
+  if (state) *state = sl.h;
+  if (flux) *flux = e->out_flux ? sl.h + e->out_state_cnt : nullptr;
+  return CWR_OK;
+}
+
+int32_t cwr_output_release(cwr_engine* e, int32_t slot) {
+  if (!e) return CWR_ERR_BAD_ARG;
+  if (!e->out_stream || slot < 0 || slot >= (int)e->out_slots.size()) return fail(e, CWR_ERR_BAD_ARG, "cwr_output_release: bad slot");
+  e->out_slots[(size_t)slot].busy.store(false, std::memory_order_release);
   return CWR_OK;
 }
 

@@ -871,6 +871,109 @@ __global__ void __launch_bounds__(BLOCK) k_mass_flux(
   }
 }
 
+// ------------------------------------------------------------------------------------------------ 8f-4 output side
+// Mass-balance ledger (postproc_util.py:84-139): one block per boundary-condition line.  For the line's faces owned by
+// this engine, total_mass_flux of this step (transport.py:414-429, concentrations of level t+1, ghost rows included)
+// is summed per constituent into ledger[line][0] (all), [1] (the part <= 0: into the domain) and [2] (the part >= 0);
+// `f * 0` instead of 0 keeps the reference's NaN propagation (np.where(x <= 0, x, x * 0)).  Fixed summation order.
+__global__ void __launch_bounds__(BLOCK) k_line_mass(
+    int K, int n_core, const int32_t* __restrict__ line_ptr, const int32_t* __restrict__ line_faces,
+    const int32_t* __restrict__ f1, const int32_t* __restrict__ f2, const float* __restrict__ adv_t,
+    const double* __restrict__ dif_t, double dt, const double* __restrict__ c, double* __restrict__ ledger) {
+  __shared__ double s_acc[3][BLOCK];
+  const int line = blockIdx.x, tid = threadIdx.x;
+  const int per = BLOCK / K;                       // faces in flight (K <= BLOCK checked by the host)
+  double tot = 0.0, tin = 0.0, tout = 0.0;
+  if (tid < per * K) {
+    const int k = tid % K;
+    for (int i = line_ptr[line] + tid / K; i < line_ptr[line + 1]; i += per) {
+      const int e = line_faces[i];
+      const int P = f1[e], N = f2[e];
+      if (P >= n_core) continue;                   // another rank owns this face
+      const float a = adv_t[e];
+      const double d = dif_t[e];
+      const double cp = c[(size_t)P * K + k], cn = c[(size_t)N * K + k];
+      const double f = ((a < 0.0f) ? (double)a * cn : (double)a * cp) * dt + d * (cn - cp) * dt;
+      tot += f;
+      tin += (f <= 0.0) ? f : f * 0.0;
+      tout += (f >= 0.0) ? f : f * 0.0;
+    }
+  }
+  s_acc[0][tid] = tot; s_acc[1][tid] = tin; s_acc[2][tid] = tout;
+  __syncthreads();
+  if (tid < K) {
+    for (int q = 0; q < 3; ++q) {
+      double sum = 0.0;
+      for (int j = 0; j < per; ++j) sum += s_acc[q][j * K + tid];
+      ledger[((size_t)line * 3 + q) * K + tid] += sum;
+    }
+  }
+}
+
+// out[k] = sum_c vol[c] * x[c, k] over the engine's own real cells, out[K] = sum_c vol[c]  (postproc_util.py:36-57).
+// Stage 1: per-block partials [grid][K + 1]; stage 2 (k_fold_partials): one block folds them in block order.
+__global__ void __launch_bounds__(BLOCK) k_domain_mass(int n, int K, const float* __restrict__ vol,
+                                                     const double* __restrict__ x, double* __restrict__ partial) {
+  __shared__ double s_acc[BLOCK];
+  __shared__ double s_vol[BLOCK];
+  const int tid = threadIdx.x, per = BLOCK / K;
+  double acc = 0.0, accv = 0.0;
+  if (tid < per * K) {
+    const int k = tid % K;
+    for (int c = blockIdx.x * per + tid / K; c < n; c += gridDim.x * per) {
+      const double v = (double)vol[c];
+      acc += v * x[(size_t)c * K + k];
+      if (k == 0) accv += v;
+    }
+  }
+  s_acc[tid] = acc; s_vol[tid] = accv;
+  __syncthreads();
+  if (tid < K) {
+    double sum = 0.0;
+    for (int j = 0; j < per; ++j) sum += s_acc[j * K + tid];
+    partial[(size_t)blockIdx.x * (K + 1) + tid] = sum;
+  }
+  if (tid == 0) {
+    double sum = 0.0;
+    for (int j = 0; j < per; ++j) sum += s_vol[j * K];
+    partial[(size_t)blockIdx.x * (K + 1) + K] = sum;
+  }
+}
+
+__global__ void __launch_bounds__(BLOCK) k_fold_partials(int nblocks, int width, const double* __restrict__ partial,
+                                                       double* __restrict__ out) {
+  const int k = threadIdx.x;
+  if (k >= width) return;
+  double sum = 0.0;
+  for (int b = 0; b < nblocks; ++b) sum += partial[(size_t)b * width + k];
+  out[k] = sum;
+}
+
+// Output snapshot, constituent-major: out[k * n_out + i] = x[row(i) * K + k], row(i) = order ? order[i] : i.
+// A block transposes SNAP_ROWS rows through LDS so that both the row reads (K consecutive doubles) and the column
+// writes (consecutive i) are coalesced.  Dynamic LDS: K * (SNAP_ROWS + 1) doubles.
+constexpr int SNAP_ROWS = 64;
+__global__ void __launch_bounds__(BLOCK) k_snapshot_t(int n_out, int K, const int32_t* __restrict__ order,
+                                                    const double* __restrict__ x, double* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+  double* s = reinterpret_cast<double*>(s_dyn);                    // [K][SNAP_ROWS + 1]
+  const int tid = threadIdx.x;
+  for (int i0 = blockIdx.x * SNAP_ROWS; i0 < n_out; i0 += gridDim.x * SNAP_ROWS) {
+    const int rows = min(SNAP_ROWS, n_out - i0);
+    for (int q = tid; q < rows * K; q += BLOCK) {
+      const int r = q / K, k = q - r * K;
+      const int src = order ? order[i0 + r] : i0 + r;
+      s[k * (SNAP_ROWS + 1) + r] = x[(size_t)src * K + k];
+    }
+    __syncthreads();
+    for (int q = tid; q < rows * K; q += BLOCK) {
+      const int k = q / rows, r = q - k * rows;
+      out[(size_t)k * n_out + i0 + r] = s[k * (SNAP_ROWS + 1) + r];
+    }
+    __syncthreads();
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ small meshes
 // The reference's own meshes (Ohio River 2 943 cells, Sumwere Creek 367) fit one CU's LDS.  There a sweep launch
 // is pure latency (4-6 us for a few microseconds of work), so the WHOLE Jacobi solve of one constituent runs in one

@@ -88,6 +88,39 @@ class PartitionedTransport:
         ids = np.arange(self.local.lo, self.local.hi)
         return ids if self.order is None else self.order[ids]
 
+    # ------------------------------------------------------------------ output side
+    def _sum_over_ranks(self, arr: np.ndarray) -> np.ndarray:
+        if self.local.world == 1:
+            return arr
+        import torch.distributed as dist
+        parts = [None] * self.local.world
+        dist.all_gather_object(parts, arr)
+        out = parts[0].copy()
+        for p in parts[1:]:                                       # fixed rank order: identical on every rank
+            out = out + p
+        return out
+
+    def set_boundary_lines(self, lines):
+        """lines: face-id arrays in the REFERENCE's face numbering, one per boundary-condition line.  Each rank
+        registers the faces it holds; the kernel adds only those whose face1 it owns."""
+        eg = self.local.edge_global
+        local = []
+        for faces in lines:
+            f = np.asarray(faces, dtype=np.int64).ravel()
+            pos = np.searchsorted(eg, f)
+            ok = (pos < len(eg)) & (eg[np.minimum(pos, len(eg) - 1)] == f)
+            local.append(pos[ok].astype(np.int32))
+        self.engine.set_boundary_lines(local)
+
+    def mass_balance(self) -> np.ndarray:
+        """(n_lines, 3, K) ledger summed over the ranks."""
+        return self._sum_over_ranks(self.engine.get_mass_balance())
+
+    def domain_mass(self, t_level: int):
+        mass, vol = self.engine.domain_mass(t_level)
+        tot = self._sum_over_ranks(np.append(mass, vol))
+        return tot[:-1], float(tot[-1])
+
     def gather_state(self) -> np.ndarray:
         """(n_global, K) concentrations of all real cells, in the reference's numbering, on every rank
         (control-plane all_gather)."""

@@ -28,6 +28,7 @@ STEP_MASS_FLUX = 1
 STEP_PROFILE = 2
 STEP_FORCE_BICGSTAB = 4
 STEP_FORCE_JACOBI = 8
+STEP_MASS_BALANCE = 16
 
 # every symbol include/cwr_transport.h declares (tests check that the library exports them all)
 ABI_SYMBOLS = (
@@ -36,6 +37,8 @@ ABI_SYMBOLS = (
     'cwr_set_state', 'cwr_get_state', 'cwr_react_linear', 'cwr_state_device_ptr', 'cwr_apply', 'cwr_rhs', 'cwr_step', 'cwr_get_mass_flux',
     'cwr_time_apply', 'cwr_profile_read', 'cwr_synchronize', 'cwr_apply_bytes',
     'cwr_comm_unique_id', 'cwr_attach_comm',
+    'cwr_set_boundary_lines', 'cwr_reset_mass_balance', 'cwr_get_mass_balance', 'cwr_domain_mass',
+    'cwr_output_open', 'cwr_output_push', 'cwr_output_wait', 'cwr_output_release', 'cwr_output_close',
 )
 
 
@@ -104,6 +107,15 @@ def load_library(path: str | None = None) -> C.CDLL:
         'cwr_apply_bytes': [vp, P(C.c_int64), P(C.c_int64)],
         'cwr_comm_unique_id': [vp],
         'cwr_attach_comm': [vp, i32, i32, vp, i32, i32, i32, vp, vp, vp, vp, vp],
+        'cwr_set_boundary_lines': [vp, i32, vp, vp],
+        'cwr_reset_mass_balance': [vp],
+        'cwr_get_mass_balance': [vp, vp],
+        'cwr_domain_mass': [vp, i32, vp],
+        'cwr_output_open': [vp, i32, i32, i32, vp],
+        'cwr_output_push': [vp, P(i32)],
+        'cwr_output_wait': [vp, i32, P(vp), P(vp)],
+        'cwr_output_release': [vp, i32],
+        'cwr_output_close': [vp],
     }
     for name, args in protos.items():
         fn = getattr(lib, name)
@@ -169,6 +181,7 @@ class TransportEngine:
         self.K = int(n_constituents)
         self.n_core = self.n_owned                 # rows owned by this rank (== n_owned unless deep halos are attached)
         self.n_times = 0
+        self.n_lines = 0
         rc = self._lib.cwr_create(self.n_owned, self.n_halo, self.n_cells, self.n_edges, self.K,
                                   _ptr(f1), _ptr(f2), int(device), C.byref(self._h))
         if rc != CWR_OK:
@@ -296,10 +309,12 @@ class TransportEngine:
         return b
 
     def step(self, t: int, *, tol: float = 1e-12, max_iter: int = 2000, mass_flux: bool = True,
-             profile: bool = False, solver: str = 'auto') -> StepResult:
-        """solver: 'auto' (Jacobi sweeps, switching to BiCGSTAB on stiff steps), 'jacobi', 'bicgstab'."""
+             profile: bool = False, solver: str = 'auto', mass_balance: bool = False) -> StepResult:
+        """solver: 'auto' (Jacobi sweeps, switching to BiCGSTAB on stiff steps), 'jacobi', 'bicgstab'.
+        mass_balance: add this step's boundary-line fluxes to the device ledger (set_boundary_lines first)."""
         info = StepInfo()
         flags = (STEP_MASS_FLUX if mass_flux else 0) | (STEP_PROFILE if profile else 0)
+        flags |= STEP_MASS_BALANCE if mass_balance else 0
         flags |= {'auto': 0, 'jacobi': STEP_FORCE_JACOBI, 'bicgstab': STEP_FORCE_BICGSTAB}[solver]
         self._check(self._lib.cwr_step(self._h, int(t), float(tol), int(max_iter), flags, C.byref(info)))
         return StepResult(info.iterations, info.sweeps, info.restarts, info.operator_launches, info.solver,
@@ -310,6 +325,68 @@ class TransportEngine:
         adv, dif, tot = (np.empty(shape, np.float64) for _ in range(3))
         self._check(self._lib.cwr_get_mass_flux(self._h, _ptr(adv), _ptr(dif), _ptr(tot)))
         return adv, dif, tot
+
+    # ------------------------------------------------------------------ output side
+    def set_boundary_lines(self, lines):
+        """lines: sequence of face-id arrays, one per boundary-condition line (the 'Face Index' rows of the
+        reference's boundary_data grouped by 'BC Line ID', postproc_util.py:84-90).  Clears the ledger."""
+        lines = [np.ascontiguousarray(f, dtype=np.int32).ravel() for f in lines]
+        ptr = np.zeros(len(lines) + 1, np.int32)
+        ptr[1:] = np.cumsum([len(f) for f in lines])
+        faces = np.concatenate(lines).astype(np.int32) if len(lines) and ptr[-1] else np.zeros(0, np.int32)
+        self._check(self._lib.cwr_set_boundary_lines(self._h, len(lines), _ptr(ptr), _ptr(faces) if len(faces) else None))
+        self.n_lines = len(lines)
+
+    def reset_mass_balance(self):
+        self._check(self._lib.cwr_reset_mass_balance(self._h))
+
+    def get_mass_balance(self) -> np.ndarray:
+        """(n_lines, 3, K): per line the summed total_mass_flux of the steps taken with mass_balance=True,
+        its part <= 0 (into the domain) and its part >= 0 (postproc_util.py:99-139)."""
+        out = np.empty((self.n_lines, 3, self.K), np.float64)
+        self._check(self._lib.cwr_get_mass_balance(self._h, _ptr(out)))
+        return out
+
+    def domain_mass(self, t_level: int):
+        """(mass[K], volume): sums over this engine's own real cells of volume[t_level] * state and of
+        volume[t_level] (postproc_util.py:36-57)."""
+        out = np.empty(self.K + 1, np.float64)
+        self._check(self._lib.cwr_domain_mass(self._h, int(t_level), _ptr(out)))
+        return out[:self.K].copy(), float(out[self.K])
+
+    def output_open(self, n_slots: int = 3, with_flux: bool = False, real_cells_only: bool = False):
+        """Open the streamed-output ring.  Rows come back in the REFERENCE's cell numbering (all cells, or the
+        real cells only), constituent-major."""
+        n_out = self.n_core if real_cells_only else self.n_cells
+        order = None
+        if self._order is not None:                      # reference id i lives in device row inv[i]
+            inv = np.arange(self.n_cells, dtype=np.int64)
+            inv[self._order] = np.arange(self.n_owned)
+            order = np.ascontiguousarray(inv[:n_out], dtype=np.int32)
+        self._check(self._lib.cwr_output_open(self._h, int(n_slots), int(bool(with_flux)), int(n_out), _ptr(order)))
+        self._out_n, self._out_flux = n_out, bool(with_flux)
+
+    def output_push(self) -> int:
+        slot = C.c_int32(-1)
+        self._check(self._lib.cwr_output_push(self._h, C.byref(slot)))
+        return slot.value
+
+    def output_wait(self, slot: int):
+        """(state (K, n_out), flux (3, K, n_edges) or None): numpy VIEWS of the pinned slot, valid until
+        output_release(slot).  May be called from a consumer thread."""
+        st, fx = C.c_void_p(), C.c_void_p()
+        self._check(self._lib.cwr_output_wait(self._h, int(slot), C.byref(st), C.byref(fx)))
+        state = np.ctypeslib.as_array(C.cast(st, C.POINTER(C.c_double)), shape=(self.K, self._out_n))
+        flux = None
+        if fx.value:
+            flux = np.ctypeslib.as_array(C.cast(fx, C.POINTER(C.c_double)), shape=(3, self.K, self.n_edges))
+        return state, flux
+
+    def output_release(self, slot: int):
+        self._check(self._lib.cwr_output_release(self._h, int(slot)))
+
+    def output_close(self):
+        self._check(self._lib.cwr_output_close(self._h))
 
     # ------------------------------------------------------------------ measurement
     def time_apply(self, t: int, reps: int = 50, variant: int = 0) -> float:

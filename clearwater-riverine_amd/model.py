@@ -15,6 +15,8 @@ from typing import Any, Dict, Optional
 
 import numpy as np
 
+from .mass_balance import assemble, boundary_lines, volume_columns
+from .outputs import StreamedOutput, ZarrStreamWriter
 from .engine import TransportEngine, StepResult
 from .ordering import hilbert_order
 
@@ -144,7 +146,8 @@ class ClearwaterRiverine:
                  datetime_range=None, mesh_file_path: Optional[str] = None, *,
                  mesh: Optional[dict] = None, input_arrays: Optional[Dict[str, np.ndarray]] = None,
                  device: int = 0, tol: float = 1e-12, max_iter: int = 5000, store_history: bool = True,
-                 solver: str = 'auto', renumber: bool = True):
+                 solver: str = 'auto', renumber: bool = True, output_store: Optional[str] = None,
+                 output_flux: bool = False, host_state: bool = True):
         self.gdf = None
         self.time_step = 0                                       # transport.py:102
         self.verbose = bool(verbose)
@@ -227,6 +230,19 @@ class ClearwaterRiverine:
         self._device_level = -1
         self.last_step: Optional[StepResult] = None
 
+        # output side: device mass-balance ledger over the boundary-condition lines, streamed zarr output
+        self.host_state = bool(host_state)
+        self._lines = []
+        bd = self.boundary_data if self.boundary_data is not None else m.attrs.get('boundary_faces')
+        if bd is not None and len(bd):
+            self._lines = boundary_lines(bd)
+            self.engine.set_boundary_lines([f for _, f in self._lines])
+        self._mass_start = None
+        self._stream = None
+        if output_store is not None:
+            self._stream = StreamedOutput(self.engine, output_store, self.constituents, T, with_flux=output_flux,
+                                          attrs={'diffusion_coefficient': m.attrs['diffusion_coefficient']})
+
     # ------------------------------------------------------------------ helpers
     def _row(self, name: str, t: int) -> np.ndarray:
         st = self.mesh[name]
@@ -271,9 +287,20 @@ class ClearwaterRiverine:
                 c_now = self.engine.get_state()
                 for k, cname in enumerate(self.constituents):
                     self._row(cname, t)[0:n] = c_now[:n, k]
-        self.last_step = self.engine.step(t, tol=self.tol, max_iter=self.max_iter, mass_flux=self.store_history,
-                                          solver=self.solver)
+        if self._mass_start is None:                             # postproc_util.py:36-45: mass in the domain at level 0
+            self._mass_start = self.engine.domain_mass(t)
+            if self._stream is not None:                         # level 0 is host data (input_array row 0)
+                for cname in self.constituents:
+                    self._stream.writer.write_level(cname, t, np.ascontiguousarray(self._row(cname, t), dtype=np.float64))
+        want_flux = self.store_history or (self._stream is not None and self._stream.with_flux)
+        self.last_step = self.engine.step(t, tol=self.tol, max_iter=self.max_iter, mass_flux=want_flux,
+                                          solver=self.solver, mass_balance=bool(self._lines))
         self._device_level = t + 1
+        if self._stream is not None:
+            self._stream.push(t + 1)                             # asynchronous: pinned ring + writer thread
+        if not self.host_state:                                  # results live in the store / on the device only
+            self.time_step += 1
+            return
         c_all = self.engine.get_state()                          # (ncell, K): transport.py:252-264
         for k, cname in enumerate(self.constituents):
             self._row(cname, t + 1)[:] = c_all[:, k]
@@ -302,9 +329,42 @@ class ClearwaterRiverine:
             self.constituent_dict[nme].max_value = int(np.nanmax(real))
             self.constituent_dict[nme].min_value = int(np.nanmin(real))
 
+    def mass_bal_global(self, constituent_name: str) -> dict:
+        """postproc_util._mass_bal_global (:21-166) for the levels simulated so far, from the device ledger: a dict
+        keyed by the reference's DataFrame columns."""
+        if not self._lines:
+            raise ValueError('boundary_data_path input required')           # postproc_util.py:367-368
+        if self._mass_start is None:
+            raise IndexError('no step taken yet')
+        k = self.constituents.index(constituent_name)
+        m = self.mesh
+        vols = volume_columns(m[FLOW_ACROSS_FACE], m[CHANGE_IN_TIME], self._lines)
+        mass0, vol0 = self._mass_start
+        mass1, vol1 = self.engine.domain_mass(self.time_step)
+        return assemble(self._lines, vols, self.engine.get_mass_balance()[:, :, k], vol0, float(mass0[k]), vol1, float(mass1[k]))
+
+    def close_output(self):
+        """Drain the streamed-output ring and finish the store."""
+        if self._stream is not None:
+            self._stream.close()
+            self._stream = None
+
     def finalize(self, save: bool = False, output_filepath: Optional[str] = None):
-        """transport.py:385-395 without the zarr/netCDF writer (out of scope): sets value ranges."""
-        self.set_value_range()
-        if save:
+        """transport.py:385-395: value ranges, then (save=True) the mesh as a zarr store (io/outputs.py:11-17;
+        '.zarr' paths) or an .npz archive; netCDF needs a package this image does not have."""
+        self.close_output()
+        if self.host_state and self.store_history:
+            self.set_value_range()
+        if save and str(output_filepath).endswith('.zarr'):
+            if not self.store_history:
+                raise ValueError('no history in RAM: construct with output_store=... to stream the run to zarr')
+            arrays = {c: (self._ncell, 'nface') for c in self.constituents}
+            w = ZarrStreamWriter(output_filepath, arrays, self._T, {'diffusion_coefficient': self.mesh.attrs['diffusion_coefficient']})
+            for c in self.constituents:
+                for t in range(self._T):
+                    w.write_level(c, t, np.ascontiguousarray(self.mesh[c][t], dtype=np.float64))
+        elif save and str(output_filepath).endswith('.nc'):
+            raise ValueError('Cannot save as .nc: netCDF output needs the netCDF4 package')
+        elif save:
             np.savez_compressed(output_filepath, **{k: np.asarray(v) for k, v in self.mesh.items()
                                                     if isinstance(v, np.ndarray)})

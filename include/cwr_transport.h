@@ -50,7 +50,8 @@ enum {
   CWR_STEP_MASS_FLUX = 1,      /* also evaluate the three per-face mass-flux arrays (transport.py:406-429) */
   CWR_STEP_PROFILE = 2,        /* bracket every operator launch with HIP events (see cwr_profile_read)     */
   CWR_STEP_FORCE_BICGSTAB = 4, /* skip the Jacobi fast path                                                */
-  CWR_STEP_FORCE_JACOBI = 8    /* never switch to BiCGSTAB (fails with CWR_ERR_NOT_CONVERGED instead)      */
+  CWR_STEP_FORCE_JACOBI = 8,   /* never switch to BiCGSTAB (fails with CWR_ERR_NOT_CONVERGED instead)      */
+  CWR_STEP_MASS_BALANCE = 16   /* add this step's boundary-line mass fluxes to the device ledger (cwr_set_boundary_lines) */
 };
 
 typedef struct cwr_step_info {
@@ -185,6 +186,39 @@ int32_t cwr_comm_unique_id(uint8_t id_out[128]);
 int32_t cwr_attach_comm(cwr_engine* e, int32_t rank, int32_t world, const uint8_t unique_id[128], int32_t n_core,
                         int32_t exchange_every, int32_t n_peers, const int32_t* peers, const int32_t* send_ptr,
                         const int32_t* send_cells, const int32_t* recv_ptr, const int32_t* recv_cells);
+
+/* ------------------------------------------------------------------ output side
+ * Mass balance on the device (replaces the host post-processing of postproc_util.py:21-166, which needs the whole
+ * (T, ncell) state and (T, nedge) flux history in RAM).
+ * cwr_set_boundary_lines: the faces of every boundary-condition line (postproc_util.py:84-90: the 'Face Index' rows
+ *   of boundary_data grouped by 'BC Line ID'), CSR over line_ptr[n_lines + 1]; clears the ledger.
+ * A cwr_step taken with CWR_STEP_MASS_BALANCE adds, for every line and constituent, that step's
+ *   sum over the line's faces of total_mass_flux (transport.py:414-429), its part <= 0 (inflow) and its part >= 0
+ *   (outflow) to the ledger -- postproc_util.py:99-139; NaN propagates as in the reference.  The per-face flux arrays
+ *   are not materialised for this.  Partitioned engines add the faces whose face1 they own; the host adds the ranks.
+ * cwr_get_mass_balance: ledger[(line * 3 + q) * K + k], q = 0 total, 1 inflow part, 2 outflow part.
+ * cwr_domain_mass: out[k] = sum over this engine's own real cells of volume[t_level, c] * state[c, k], out[K] = sum of
+ *   volume[t_level, c]  (postproc_util.py:36-57, with the CURRENT state standing for level t_level). */
+int32_t cwr_set_boundary_lines(cwr_engine* e, int32_t n_lines, const int32_t* line_ptr, const int32_t* line_faces);
+int32_t cwr_reset_mass_balance(cwr_engine* e);
+int32_t cwr_get_mass_balance(cwr_engine* e, double* ledger);
+int32_t cwr_domain_mass(cwr_engine* e, int32_t t_level, double* out);
+
+/* Streamed output (replaces the RAM-resident (T, ncell) / (T, nedge) float64 arrays of constituents.py:28-48 and the
+ * write-everything-at-the-end of io/outputs.py): a ring of pinned host slots filled by asynchronous copies on a second
+ * HIP stream while the next steps compute.
+ * cwr_output_open: n_slots >= 1 slots of n_out * K doubles (+ 3 * n_edges * K with with_flux != 0).  row_order
+ *   (n_out engine cell ids, or NULL for 0..n_out-1) selects and orders the state rows that are written.
+ * cwr_output_push: snapshot the current state (and the flux arrays of the last step taken with CWR_STEP_MASS_FLUX)
+ *   CONSTITUENT-MAJOR -- slot[k * n_out + i] = state[row_order[i], k], the (1, nface) chunk of constituent k's
+ *   (time, nface) array -- and start its copy to the host; returns the slot.  Blocks only while that slot is still held.
+ * cwr_output_wait: block until the slot's copy has landed; returns host pointers valid until cwr_output_release.
+ *   flux (if any) = three consecutive (K, n_edges) blocks: advection, diffusion, total. */
+int32_t cwr_output_open(cwr_engine* e, int32_t n_slots, int32_t with_flux, int32_t n_out, const int32_t* row_order);
+int32_t cwr_output_push(cwr_engine* e, int32_t* slot);
+int32_t cwr_output_wait(cwr_engine* e, int32_t slot, const double** state, const double** flux);
+int32_t cwr_output_release(cwr_engine* e, int32_t slot);
+int32_t cwr_output_close(cwr_engine* e);
 
 #ifdef __cplusplus
 }

@@ -433,6 +433,53 @@ class OracleModel:
         self.time_step += 1                                                  # :276
 
 
+# --------------------------------------------------------------------------- 8f-4: global mass balance
+def mass_bal_global(model: 'OracleModel', constituent_name: str, lines) -> dict:
+    """postproc_util.py:21-166 restated over arrays.  lines: [(name, face ids)] in 'BC Line ID' order (:72-74).
+    dtype semantics kept: volumes are float32 and xarray sums them in float32 with NaN skipped (:37,41,94-95);
+    total_mass_flux is a numpy array, so its sums propagate NaN (:99-100) and np.where(x <= 0, x, x * 0) (:118,136)
+    keeps NaN in both parts."""
+    mesh = model.mesh
+    con = model.constituent_dict[constituent_name]
+    n = mesh[NUMBER_OF_REAL_CELLS] + 1                                        # :35
+    vol = np.asarray(mesh[VOLUME], dtype=np.float32)
+    t_max = len(mesh['time_seconds']) - 1                                     # :49
+    d = {'Vol_start': np.nansum(vol[0][0:n], dtype=np.float32),               # :36-41
+         'Mass_start': (vol[0][0:n] * con.state[0][0:n]).sum(),               # :38-42 (float32 * float64)
+         'Vol_end': np.nansum(vol[t_max][0:n], dtype=np.float32),             # :50-55
+         'Mass_end': (vol[t_max][0:n] * con.state[t_max][0:n]).sum()}
+    flow = np.asarray(mesh[FLOW_ACROSS_FACE], dtype=np.float32)
+    dt = np.asarray(mesh[CHANGE_IN_TIME], dtype=np.float64)
+    tot = dict.fromkeys(('v', 'vi', 'vo', 'm', 'mi', 'mo'), 0.0)
+    for name, faces in lines:                                                 # :84
+        faces = np.asarray(faces, dtype=np.int64)
+        edge_vol = flow[:, faces] * dt[:, None]                               # :92-93 (promotes to float64)
+        v = np.nansum(edge_vol)                                               # :94 (xarray: skipna)
+        mass = con.total_mass_flux[:, faces]                                  # :99
+        m = mass.sum()                                                        # :100 (numpy: NaN propagates)
+        vi = np.nansum(np.where(edge_vol <= 0, edge_vol, 0.0))                # :108-109 (.where(cond, other=0))
+        mi = np.where(mass <= 0, mass, mass * 0).sum()                        # :118-119
+        vo = np.nansum(np.where(edge_vol >= 0, edge_vol, 0.0))                # :126-127
+        mo = np.where(mass >= 0, mass, mass * 0).sum()                        # :136-137
+        d[f'{name}_vol'], d[f'{name}_mass'] = v, m
+        d[f'{name}_in_vol'], d[f'{name}_in_mass'] = vi, mi
+        d[f'{name}_out_vol'], d[f'{name}_out_mass'] = vo, mo
+        for key, val in zip(('v', 'vi', 'vo', 'm', 'mi', 'mo'), (v, vi, vo, m, mi, mo)):
+            tot[key] = tot[key] + val
+    d.update(bcTotalVolInOutAll=tot['v'], bcTotalVolInAll=tot['vi'], bcTotalVolOutAll=tot['vo'],     # :145-151
+             bcTotalMassInOutAll=tot['m'], bcTotalMassInAll=tot['mi'], bcTotalMassOutAll=tot['mo'])
+    with np.errstate(divide='ignore', invalid='ignore'):
+        vol_end_calc = d['Vol_start'] + -1 * tot['vi'] + -1 * tot['vo']       # :153
+        mass_end_calc = d['Mass_start'] + -1 * tot['mi'] + -1 * tot['mo']     # :154
+        d['vol_end_calc'] = vol_end_calc                                      # :156
+        d['error_vol'] = vol_end_calc - d['Vol_end']                          # :157
+        d['prct_error_vol'] = np.float64(d['error_vol']) / np.float64(tot['vi']) * 100      # :158
+        d['mass_end_calc'] = mass_end_calc                                    # :160
+        d['error_mass'] = mass_end_calc - d['Mass_end']                       # :161
+        d['prct_error_mass'] = np.float64(d['error_mass']) / np.float64(tot['mi']) * 100    # :162
+    return d
+
+
 # --------------------------------------------------------------------------- helpers for tests / bench
 def parse_ras_stamps(stamps) -> np.ndarray:
     """'%d%b%Y %H:%M:%S' stamps (io/hdf.py:155-156) -> seconds since the first one."""

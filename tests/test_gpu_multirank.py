@@ -37,6 +37,12 @@ def make_case(K):
     return mesh, inputs3
 
 
+def case_lines(mesh):
+    """Three boundary-condition lines: the ghost faces of the mesh dealt round-robin (reference face ids)."""
+    gf = np.nonzero(np.asarray(mesh['edges_face2']) > mesh['nreal'])[0]
+    return [gf[0::3], gf[1::3], gf[2::3]]
+
+
 def _rank_main(rank, world, K, solver, depth, uid_pipe, out_queue):
     try:
         os.environ['CWR_RCCL_LIB'] = MOCK_LIB
@@ -52,16 +58,18 @@ def _rank_main(rank, world, K, solver, depth, uid_pipe, out_queue):
         pt = PartitionedTransport(mesh, inputs3, rank, world, device=0, unique_id=uid, halo_depth=depth,
                                   renumber='hilbert' if depth >= 4 else None)
         infos = []
+        pt.set_boundary_lines(case_lines(mesh))
+        mass0 = pt.engine.domain_mass(0)
         for t in range(3):
-            r = pt.step(t, tol=1e-12, mass_flux=True, solver=solver)
+            r = pt.step(t, tol=1e-12, mass_flux=True, solver=solver, mass_balance=True)
             infos.append((r.sweeps, r.iterations))
         adv, dif, tot = pt.engine.get_mass_flux()
         owned_faces = pt.local.face1 < pt.local.n_core
         out_queue.put((rank, pt.owned_reference_ids(), pt.local.hi, pt.owned_state(), pt.local.edge_global[owned_faces],
-                       tot[owned_faces], infos, None))
+                       tot[owned_faces], infos, None, pt.engine.get_mass_balance(), mass0, pt.engine.domain_mass(3)))
         pt.engine.close()
     except Exception as exc:                                  # surface the failure in the parent
-        out_queue.put((rank, 0, 0, None, None, None, None, repr(exc)))
+        out_queue.put((rank, 0, 0, None, None, None, None, repr(exc), None, None, None))
 
 
 @pytest.mark.parametrize('world,K,solver,depth', [(2, 3, 'jacobi', 1), (2, 3, 'bicgstab', 1), (3, 16, 'auto', 1), (4, 1, 'auto', 1),
@@ -100,8 +108,16 @@ def test_partitioned_step_matches_single_rank_and_oracle(gpu_lib, world, K, solv
     import clearwater_riverine_amd as cw
     from clearwater_riverine_amd.distributed import PartitionedTransport
     single = PartitionedTransport(mesh, inputs3, 0, 1)
+    single.set_boundary_lines(case_lines(mesh))
+    single_mass0 = single.domain_mass(0)
     for t in range(3):
-        single.step(t, tol=1e-12, mass_flux=True, solver=solver)
+        single.step(t, tol=1e-12, mass_flux=True, solver=solver, mass_balance=True)
+    # output side (8f-4): every rank adds the boundary faces / cells it owns; the host adds the ranks
+    ledger = sum(r[8] for r in results)
+    assert np.allclose(ledger, single.mass_balance(), rtol=1e-9, atol=1e-12, equal_nan=True)
+    for idx, ref_val in ((9, single_mass0), (10, single.domain_mass(3))):
+        assert np.allclose(sum(r[idx][0] for r in results), ref_val[0], rtol=1e-9)
+        assert sum(r[idx][1] for r in results) == pytest.approx(ref_val[1], rel=1e-12)
     single_state = single.gather_state()                     # reference numbering whatever the internal one
     assert rel_err(state, single_state) <= 1e-10
     if solver == 'jacobi' and depth >= 2 and local_reps == '1':   # same kernels on both sides (depth 1 cannot host J^2 passes):

@@ -1,0 +1,186 @@
+"""GPU tests of the output side, through the C ABI: the device mass-balance ledger
+(cwr_set_boundary_lines / CWR_STEP_MASS_BALANCE / cwr_domain_mass) against the oracle's restatement of
+postproc_util._mass_bal_global, and the streamed zarr output (cwr_output_*) against the RAM-resident history."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import cwr_oracle as oracle
+from util import load_plan, multi_inputs, oracle_run, rel_err
+from test_gpu_parity import synthetic_case
+
+pytestmark = pytest.mark.gpu
+
+
+def ghost_face_lines(mesh, n_lines=3):
+    """Boundary-condition lines of a synthetic mesh: its ghost faces, dealt into n_lines groups."""
+    n = mesh['nreal'] + 1
+    gf = np.nonzero(np.asarray(mesh['edges_face2']) >= n)[0]
+    return {f'line{li}': gf[li::n_lines] for li in range(n_lines)}
+
+
+def close_enough(got, want, key):
+    if 'error' in key or 'prct' in key:
+        return True                                # differences of nearly equal sums: checked through their parts
+    is_vol = 'vol' in key.lower() and 'mass' not in key.lower()
+    return np.allclose(got, want, rtol=1e-6 if is_vol else 1e-9, atol=0.0 if not is_vol else 1e-3, equal_nan=True)
+
+
+@pytest.mark.parametrize('case', ['plan02', 'plan01', 'synthetic', 'synthetic-hilbert'])
+def test_device_mass_balance_matches_restated_reference(gpu_lib, case, monkeypatch):
+    import clearwater_riverine_amd as cw
+    K = 3
+    if case.startswith('plan'):
+        mesh, inp, z = load_plan(case, 0.01)
+        steps = 24 if case == 'plan02' else 20
+        inputs3 = multi_inputs(inp, K)
+        faces = np.asarray(z['bc_face_index'])
+        lines = {'US_Flow': faces[: max(1, len(faces) // 2)], 'DS_Stage': faces[max(1, len(faces) // 2):]}
+    else:
+        monkeypatch.setenv('CWR_NO_SMALL', '1')
+        mesh, inputs3 = synthetic_case(K, nx=40, ny=21, n_steps=10, seed=31, n_merge=30, n_dry=2)
+        steps = 10
+        lines = ghost_face_lines(mesh)
+    for key in ('face_flow', 'edge_velocity', 'volume', 'time_seconds', 'advection_coeff', 'coeff_to_diffusion',
+                'edge_vertical_area', 'dt'):
+        if key in mesh:
+            mesh[key] = np.asarray(mesh[key])[:steps + 1].copy()
+    mesh['dt'][-1] = np.nan
+    inputs3 = inputs3[:steps + 1]
+    names = [f'c{k}' for k in range(K)]
+    ref = oracle_run(mesh, inputs3, steps)
+    m = dict(mesh)
+    model = cw.ClearwaterRiverine(mesh=m, diffusion_coefficient_input=mesh['diffusion_coefficient'],
+                                  input_arrays={nm: inputs3[:, :, k].copy() for k, nm in enumerate(names)},
+                                  store_history=False)
+    if case == 'synthetic-hilbert':                                   # force the internal renumbering on a small mesh
+        from clearwater_riverine_amd.ordering import hilbert_order
+        n = mesh['nreal'] + 1
+        model.engine.close()
+        model.engine = cw.TransportEngine(mesh['edges_face1'], mesh['edges_face2'], len(mesh['face_x']), K,
+                                          cell_order=hilbert_order(mesh['face_x'], mesh['face_y'], n))
+        model.engine.load_flow_field(mesh['face_flow'], mesh['edge_velocity'], mesh['volume'], mesh['dt'],
+                                     mesh['face_to_face_dist'], mesh['diffusion_coefficient'])
+        model.engine.load_boundary(inputs3[:, n:, :])
+    from clearwater_riverine_amd.mass_balance import boundary_lines
+    model._lines = boundary_lines(lines)
+    model.engine.set_boundary_lines([f for _, f in model._lines])
+    for _ in range(steps):
+        model.update()
+    for nm in names:
+        want = oracle.mass_bal_global(ref, nm, model._lines)
+        got = model.mass_bal_global(nm)
+        assert list(got) == list(want)
+        for key in want:
+            assert close_enough(got[key], want[key], key), (key, got[key], want[key])
+    # lines with a face whose ghost cell has no boundary value: NaN in the reference, NaN here
+    if case == 'synthetic':
+        assert any(np.isnan(model.mass_bal_global('c0')[f'{name}_mass']) == np.isnan(oracle.mass_bal_global(ref, 'c0', model._lines)[f'{name}_mass'])
+                   for name, _ in model._lines)
+
+
+def test_mass_balance_errors(gpu_lib):
+    import clearwater_riverine_amd as cw
+    mesh, inputs3 = synthetic_case(2, nx=12, ny=8, n_steps=3, seed=5)
+    n = mesh['nreal'] + 1
+    eng = cw.TransportEngine(mesh['edges_face1'], mesh['edges_face2'], len(mesh['face_x']), 2)
+    eng.load_flow_field(mesh['face_flow'], mesh['edge_velocity'], mesh['volume'], mesh['dt'], mesh['face_to_face_dist'], 0.1)
+    eng.load_boundary(inputs3[:, n:, :])
+    eng.set_state(inputs3[0, :n, :])
+    with pytest.raises(IndexError):
+        eng.step(0, mass_balance=True)                     # no lines registered
+    with pytest.raises(ValueError):
+        eng.set_boundary_lines([[len(mesh['edges_face1'])]])   # face id out of range
+    eng.set_boundary_lines([[0, 1], []])
+    eng.step(0, mass_balance=True)
+    first = eng.get_mass_balance()
+    assert first.shape == (2, 3, 2) and np.all(first[1] == 0.0)
+    assert np.allclose(first[0, 0], first[0, 1] + first[0, 2], rtol=1e-12, atol=1e-300)
+    eng.reset_mass_balance()
+    assert np.all(eng.get_mass_balance() == 0.0)
+    mass, vol = eng.domain_mass(1)
+    assert vol == pytest.approx(float(np.asarray(mesh['volume'], np.float64)[1, :n].sum()), rel=1e-12)
+
+
+@pytest.mark.parametrize('with_flux', [False, True])
+@pytest.mark.parametrize('renumbered', [False, True])
+def test_streamed_zarr_output_equals_ram_history(gpu_lib, tmp_path, with_flux, renumbered, monkeypatch):
+    """output_store=...: every level written by the pinned-ring writer thread equals the reference-style RAM history
+    of an identical run (bitwise), with a ring shorter than the run and no per-step state download."""
+    import clearwater_riverine_amd as cw
+    from clearwater_riverine_amd.outputs import read_zarr_level
+    monkeypatch.setenv('CWR_NO_SMALL', '1')
+    K, steps = 4, 9
+    mesh, inputs3 = synthetic_case(K, nx=36, ny=17, n_steps=steps, seed=41, n_merge=20, n_dry=1)
+    names = [f'c{k}' for k in range(K)]
+    arrays = {nm: inputs3[:, :, k].copy() for k, nm in enumerate(names)}
+    ram = cw.ClearwaterRiverine(mesh=dict(mesh), input_arrays={k: v.copy() for k, v in arrays.items()})
+    store = str(tmp_path / 'run.zarr')
+    streamed = cw.ClearwaterRiverine(mesh=dict(mesh), input_arrays={k: v.copy() for k, v in arrays.items()},
+                                     store_history=False, host_state=False, output_store=store, output_flux=with_flux)
+    if renumbered:
+        pytest.importorskip('numpy')
+        from clearwater_riverine_amd.ordering import hilbert_order
+        n = mesh['nreal'] + 1
+        for mdl in (ram, streamed):
+            if mdl._stream is not None:
+                mdl._stream.close()
+            mdl.engine.close()
+            mdl.engine = cw.TransportEngine(mesh['edges_face1'], mesh['edges_face2'], len(mesh['face_x']), K,
+                                            cell_order=hilbert_order(mesh['face_x'], mesh['face_y'], n))
+            mdl.engine.load_flow_field(mesh['face_flow'], mesh['edge_velocity'], mesh['volume'], mesh['dt'],
+                                       mesh['face_to_face_dist'], mesh['diffusion_coefficient'])
+            mdl.engine.load_boundary(inputs3[:, n:, :])
+        from clearwater_riverine_amd.outputs import StreamedOutput
+        streamed._stream = StreamedOutput(streamed.engine, store, names, steps + 1, with_flux=with_flux, n_slots=2)
+    for _ in range(steps):
+        ram.update()
+        streamed.update()
+    streamed.finalize()
+    assert streamed._stream is None
+    cons = json.load(open(os.path.join(store, '.zmetadata')))
+    assert cons['metadata'][f'{names[0]}/.zarray']['shape'] == [steps + 1, len(mesh['face_x'])]
+    for nm in names:
+        for t in range(steps + 1):
+            assert np.array_equal(read_zarr_level(store, nm, t), ram.mesh[nm][t], equal_nan=True), (nm, t)
+        if with_flux:
+            con = ram.constituent_dict[nm]
+            for t in range(steps):
+                assert np.array_equal(read_zarr_level(store, f'{nm}_total_mass_flux', t), con.total_mass_flux[t], equal_nan=True)
+                assert np.array_equal(read_zarr_level(store, f'{nm}_advection_mass_flux', t), con.advection_mass_flux[t], equal_nan=True)
+                assert np.array_equal(read_zarr_level(store, f'{nm}_diffusion_mass_flux', t), con.diffusion_mass_flux[t], equal_nan=True)
+    # finalize(save=True, '*.zarr') of the RAM model writes the same store from its history (io/outputs.py:11-17)
+    store2 = str(tmp_path / 'final.zarr')
+    ram.finalize(save=True, output_filepath=store2)
+    assert np.array_equal(read_zarr_level(store2, names[1], steps), read_zarr_level(store, names[1], steps), equal_nan=True)
+
+
+def test_output_ring_api_errors(gpu_lib):
+    import clearwater_riverine_amd as cw
+    mesh, inputs3 = synthetic_case(2, nx=12, ny=8, n_steps=3, seed=5)
+    n = mesh['nreal'] + 1
+    eng = cw.TransportEngine(mesh['edges_face1'], mesh['edges_face2'], len(mesh['face_x']), 2)
+    eng.load_flow_field(mesh['face_flow'], mesh['edge_velocity'], mesh['volume'], mesh['dt'], mesh['face_to_face_dist'], 0.1)
+    eng.load_boundary(inputs3[:, n:, :])
+    eng.set_state(inputs3[0, :n, :])
+    with pytest.raises(IndexError):
+        eng.output_push()                                  # not open
+    eng.output_open(n_slots=2, with_flux=True)
+    with pytest.raises(IndexError):
+        eng.output_open()                                  # already open
+    eng.step(0, mass_flux=False)
+    with pytest.raises(IndexError):
+        eng.output_push()                                  # fluxes requested but the step did not compute them
+    eng.step(1, mass_flux=True)
+    s = eng.output_push()
+    state, flux = eng.output_wait(s)
+    want = eng.get_state()
+    assert np.array_equal(state.T, want, equal_nan=True)
+    assert np.array_equal(flux[2].T, eng.get_mass_flux()[2], equal_nan=True)
+    eng.output_release(s)
+    with pytest.raises(IndexError):
+        eng.output_wait(s)                                 # released: holds no snapshot
+    eng.output_close()
+    eng.close()
