@@ -213,7 +213,8 @@ int32_t cwr_domain_mass(cwr_engine* e, int32_t t_level, double* out);
  *   CONSTITUENT-MAJOR -- slot[k * n_out + i] = state[row_order[i], k], the (1, nface) chunk of constituent k's
  *   (time, nface) array -- and start its copy to the host; returns the slot.  Blocks only while that slot is still held.
  * cwr_output_wait: block until the slot's copy has landed; returns host pointers valid until cwr_output_release.
- *   flux (if any) = three consecutive (K, n_edges) blocks: advection, diffusion, total. */
+ *   flux (if any) = three consecutive (K, n_edges) blocks: advection, diffusion, total.
+ * cwr_output_wait and cwr_output_release may be called from a second (writer) thread. */
 int32_t cwr_output_open(cwr_engine* e, int32_t n_slots, int32_t with_flux, int32_t n_out, const int32_t* row_order);
 int32_t cwr_output_push(cwr_engine* e, int32_t* slot);
 int32_t cwr_output_wait(cwr_engine* e, int32_t slot, const double** state, const double** flux);
