@@ -88,6 +88,7 @@ struct cwr_engine {
   // vectors: c is the full state [owned | halo | ghost] x K and doubles as the solver's x
   double *d_c = nullptr, *d_r = nullptr, *d_r0 = nullptr, *d_p = nullptr, *d_v = nullptr, *d_s = nullptr,
          *d_t = nullptr, *d_b = nullptr;
+  double* d_chk = nullptr;       // [2][K] convergence-check scalars of the Jacobi path
   double* d_react = nullptr;     // K x K reaction matrix of cwr_react_linear
   // ---- output side (8f-4)
   int n_lines = 0;
@@ -256,7 +257,9 @@ int vec_grid(const cwr_engine* e) {
   return std::max(1, std::min(cdiv(e->n_core, e->R), 256 * 4));
 }
 
-int exchange_halo(cwr_engine* e, double* vec) {
+// vec2 (optional): a second vector whose halo rows receive the same values -- the ping-pong partner of a J^2 pass, whose
+// outermost (never computed) layers would otherwise keep the values of an exchange several passes back
+int exchange_halo(cwr_engine* e, double* vec, double* vec2 = nullptr) {
   if (!e->comm || e->peers.empty()) return CWR_OK;
   const int64_t total = (int64_t)e->n_send * e->K;
   if (total > 0) {
@@ -274,6 +277,7 @@ int exchange_halo(cwr_engine* e, double* vec) {
   const int64_t rtotal = (int64_t)e->n_recv * e->K;
   if (rtotal > 0) {
     k_unpack_rows<<<cdiv(rtotal, BLOCK), BLOCK, 0, e->stream>>>(rtotal, e->K, e->d_recv_cells, e->d_recvbuf, vec);
+    if (vec2) k_unpack_rows<<<cdiv(rtotal, BLOCK), BLOCK, 0, e->stream>>>(rtotal, e->K, e->d_recv_cells, e->d_recvbuf, vec2);
     HIP_TRY(e, hipGetLastError());
   }
   return CWR_OK;
@@ -441,9 +445,12 @@ int ensure_sq_pattern(cwr_engine* e) {
   // ---- tiled variant: distinct x rows per tile (own rows first) and local indices; only where a tile fits LDS
   // (partitioned engines too: the lists simply reach into the halo rows of x)
   if (e->use_tcl) {
-    // partitioned engines tile the core rows only: the replayed halo layers are numbered layer by layer, their 64-row
-    // tiles touch hundreds of distinct rows, and they go through the un-tiled pass instead
-    const int n_t = e->comm ? e->n_core : n;
+    // partitioned engines: first try to tile every J^2 row (partition.py numbers the replayed layers 1..s-2 along the
+    // cell curve, so their tiles are as compact as core tiles); if a halo tile does not fit, tile the core rows only and
+    // run the replayed layers through the un-tiled pass
+    for (int attempt = 0; attempt < 2 && !e->tcl_ready; ++attempt) {
+    const int n_t = (e->comm && attempt == 1) ? e->n_core : n;
+    if (attempt == 1 && (!e->comm || e->n_core == n)) break;
     int tr_target = 64;
     if (const char* v = getenv("CWR_TCL_ROWS")) tr_target = std::max(1, atoi(v));
     int tr = tr_target;
@@ -495,8 +502,9 @@ int ensure_sq_pattern(cwr_engine* e) {
       if (getenv("CWR_VERBOSE")) fprintf(stderr, "[cwr] tiled J^2: tile=%d rows, %.2f distinct x rows per row, max %d per tile, lds=%zu, grid=%d\n",
                                          tr, (double)tcols.size() / n_t, max_cols, lds, e->tcl_grid);
     } else if (getenv("CWR_VERBOSE")) {
-      fprintf(stderr, "[cwr] tiled J^2 not used: tile=%d rows, max %d distinct x rows per tile (limit %d), %d entries per tile (limit %d), lds=%zu\n",
-              tr, max_cols, TCL_CFG[2].xr * e->R, cap2, TCL_CFG[2].wrn * BLOCK, lds);
+      fprintf(stderr, "[cwr] tiled J^2 not used over %d rows: tile=%d rows, max %d distinct x rows per tile (limit %d), %d entries per tile (limit %d), lds=%zu\n",
+              n_t, tr, max_cols, TCL_CFG[2].xr * e->R, cap2, TCL_CFG[2].wrn * BLOCK, lds);
+    }
     }
   }
   e->sq_pattern = true;
@@ -558,8 +566,9 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
   const int K = e->K;
   need_bicg = false;
   std::vector<double> h(2 * (size_t)K);
-  double* d_rr = e->acc(0) + ACC_RR * K;      // device rows for the two reduced inner products
-  double* d_bb = e->bb();
+  // the two reduced inner products (||x'-x||^2, ||bhat||^2) land side by side: one all-reduce and one download per check
+  double* d_rr = e->d_chk;
+  double* d_bb = e->d_chk + K;
   double prev_worst = -1.0;
   int prev_sweeps = 0;
   int since_exchange = 0;                     // the caller exchanged the state's halo just before the right-hand side
@@ -568,6 +577,11 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
   bool sq = false;
   TRY(prepare_sq(e, sq));
   const bool tiled = sq && e->tcl_ready;
+  if (e->comm && sq && e->n_real > e->n_core)
+    // the ping-pong partner starts with this step's halo values too (its never-computed outer layers would otherwise
+    // still hold the previous step's): block-asynchronous passes spread what those layers hold four rows per pass
+    HIP_TRY(e, hipMemcpyAsync(e->d_p + (size_t)e->n_core * K, e->d_c + (size_t)e->n_core * K,
+                              (size_t)(e->n_real - e->n_core) * K * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
   e->dominant_mode = tiled ? 6 : (sq ? 5 : 4);
   st.sweep_kernel = e->dominant_mode;
   for (;;) {
@@ -606,7 +620,7 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
       // a J^2 pass uses up two halo layers of validity, a plain sweep one
       for (int i = 0; i < doubles; ++i) {
         double* src = (i & 1) ? e->d_p : e->d_c;
-        if (since_exchange + 2 > e->exch_every) { TRY(exchange_halo(e, src)); since_exchange = 0; }
+        if (since_exchange + 2 > e->exch_every) { TRY(exchange_halo(e, src, (i & 1) ? e->d_c : e->d_p)); since_exchange = 0; }
         if (tiled) TRY(launch_sq_tiled(e, src, (i & 1) ? e->d_c : e->d_p));
         else TRY(launch_apply<5>(e, src, (i & 1) ? e->d_c : e->d_p, nullptr, e->d_t, nullptr, nullptr, e->n_sq));
         since_exchange += 2;
@@ -652,10 +666,8 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
     }
     st.sweeps += batch; st.launches += launches;
     TRY(reduce_partials(e, e->last_apply_grid, 2, d_rr, d_bb));
-    TRY(allreduce(e, d_rr, K));
-    TRY(allreduce(e, d_bb, K));
-    TRY(download(e, h.data(), d_rr, (size_t)K));
-    TRY(download(e, h.data() + K, d_bb, (size_t)K));
+    TRY(allreduce(e, d_rr, 2 * (size_t)K));
+    TRY(download(e, h.data(), d_rr, 2 * (size_t)K));
     bool ok = true;
     double worst = 0.0;                                                   // max over columns of rr / (tol^2 bb)
     st.max_rel = 0.0;
@@ -932,6 +944,7 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   CREATE_TRY(dev_alloc(eng, &eng->d_rec, (size_t)nnz));
   CREATE_TRY(dev_alloc(eng, &eng->d_diag, (size_t)n_owned));
   CREATE_TRY(dev_alloc(eng, &eng->d_w, (size_t)nnz));
+  CREATE_TRY(dev_alloc(eng, &eng->d_chk, 2 * (size_t)K));
   CREATE_TRY(dev_alloc(eng, &eng->d_c, (size_t)n_cells * K));
   CREATE_TRY(dev_alloc(eng, &eng->d_r, nK));
   CREATE_TRY(dev_alloc(eng, &eng->d_r0, nK));
@@ -976,7 +989,7 @@ void cwr_destroy(cwr_engine* e) {
   for (hipEvent_t ev : e->ev) hipEventDestroy(ev);
   void* ptrs[] = {e->d_f1, e->d_f2, e->d_ptr, e->d_ent_edge, e->d_ent_nb, e->d_adv, e->d_vel, e->d_vol, e->d_dif,
                   e->d_bc, e->d_rec, e->d_diag, e->d_c, e->d_r, e->d_r0, e->d_p, e->d_v, e->d_s, e->d_t, e->d_b,
-                  e->d_scal, e->d_counters, e->d_partial, e->d_fadv, e->d_fdif, e->d_ftot, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf, e->d_ptr2, e->d_col2, e->d_row2, e->d_rec2, e->d_w, e->d_react, e->d_info, e->d_tcl_ptr, e->d_tcl_cols, e->d_loc2, e->d_w2, e->d_pair_ptr, e->d_slots, e->d_line_ptr, e->d_line_faces, e->d_ledger, e->d_mass_out};
+                  e->d_scal, e->d_counters, e->d_partial, e->d_fadv, e->d_fdif, e->d_ftot, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf, e->d_ptr2, e->d_col2, e->d_row2, e->d_rec2, e->d_w, e->d_react, e->d_info, e->d_tcl_ptr, e->d_tcl_cols, e->d_loc2, e->d_w2, e->d_pair_ptr, e->d_slots, e->d_line_ptr, e->d_line_faces, e->d_ledger, e->d_mass_out, e->d_chk};
   for (void* p : ptrs) if (p) hipFree(p);
   if (e->stream) hipStreamDestroy(e->stream);
   delete e;

@@ -17,7 +17,7 @@ computes the adjacent row.
 Everything here is pure index logic on the host (numpy), identical on every rank, so that send and
 receive lists agree without any negotiation.  Local numbering handed to the engine:
     [0, n_core)                 core rows (global id - lo)
-    [n_core, n_rows)            halo layers 1..s-1, layer by layer, ascending global id inside a layer
+    [n_core, n_rows)            halo layers 1..s-2 merged in ascending global id, then layer s-1
     [n_rows, n_rows + n_halo)   halo layer s (read only)
     [n_rows + n_halo, n_cells)  ghost cells, ascending global id
 Local faces keep ascending global face id (the reference's last-write-wins order, linalg.py:349-351).
@@ -103,7 +103,14 @@ def partition_mesh(face1, face2, n_real_cells: int, world: int, rank: int, depth
     if world == 1:
         depth = 1
     layers = halo_layers(f1, f2, n_real_cells, lo, hi, depth)
-    computed_halo = np.concatenate(layers[:-1]) if depth > 1 else np.zeros(0, dtype=np.int64)
+    # computed halo rows: layers 1..s-2 merged in ascending global id (with a space-filling-curve numbering that keeps
+    # the strip around the core spatially coherent, so the engine can tile it like the core), then layer s-1
+    if depth > 2:
+        computed_halo = np.concatenate([np.sort(np.concatenate(layers[:-2])), layers[-2]])
+    elif depth == 2:
+        computed_halo = layers[0]
+    else:
+        computed_halo = np.zeros(0, dtype=np.int64)
     last = layers[-1]
     n_rows = n_core + len(computed_halo)
     n_halo = len(last)

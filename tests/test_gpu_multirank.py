@@ -32,7 +32,10 @@ def build_mock():
 
 def make_case(K):
     import clearwater_riverine_amd as cw
-    mesh = cw.synthetic.make_mesh(48, 20, 4, seed=21, n_merge=60, shuffle_window=16, n_dry=2)
+    if os.environ.get('CWR_TEST_BIG'):           # several 64-row tiles per rank, stiff enough for ~50 sweeps
+        mesh = cw.synthetic.make_mesh(160, 96, 4, seed=22, n_merge=200, shuffle_window=16, dt=40.0, diffusion_coefficient=0.5)
+    else:
+        mesh = cw.synthetic.make_mesh(48, 20, 4, seed=21, n_merge=60, shuffle_window=16, n_dry=2)
     inputs3 = cw.synthetic.boundary_input_array(mesh, K)
     return mesh, inputs3
 
@@ -137,3 +140,38 @@ def test_partitioned_step_matches_single_rank_and_oracle(gpu_lib, world, K, solv
         tot[r[4]] = r[5]
     want_flux = np.stack([ref.constituent_dict[f'c{k}'].total_mass_flux[2] for k in range(K)], axis=1)
     assert rel_err(tot, want_flux) <= 1e-8
+
+
+@pytest.mark.parametrize('world,K,depth', [(2, 4, 8), (4, 16, 8), (3, 1, 6)])
+def test_partitioned_block_asynchronous_passes_keep_the_single_rank_sweep_count(gpu_lib, world, K, depth, monkeypatch):
+    """Deep halos + tile-local re-application: the replayed layers (tiled like the core) and the never-computed outer
+    layers of BOTH ping-pong vectors must hold this exchange's values, otherwise old iterates leak into the core and
+    the solve needs many more passes (seen: 78 instead of 58 sweeps at 2 ranks, no convergence at 4)."""
+    build_mock()
+    monkeypatch.setenv('CWR_NO_SMALL', '1')
+    monkeypatch.setenv('CWR_TEST_BIG', '1')
+    ctx = mp.get_context('spawn')
+    uid_pipe, out_queue = ctx.Queue(), ctx.Queue()
+    procs = [ctx.Process(target=_rank_main, args=(r, world, K, 'jacobi', depth, uid_pipe, out_queue)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [out_queue.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        if p.is_alive():
+            p.terminate()
+    errs = [r[7] for r in results if r[7]]
+    assert not errs, errs
+    from clearwater_riverine_amd.distributed import PartitionedTransport
+    mesh, inputs3 = make_case(K)
+    single = PartitionedTransport(mesh, inputs3, 0, 1)
+    single_sweeps = [single.step(t, tol=1e-12, mass_flux=True, solver='jacobi').sweeps for t in range(3)]
+    n = mesh['nreal'] + 1
+    state = np.full((n, K), np.nan)
+    for r in results:
+        state[r[1]] = r[3]
+    assert rel_err(state, single.gather_state()) <= 1e-10
+    for r in results:
+        got = [s for s, _ in r[6]]
+        assert all(g <= s + 4 for g, s in zip(got[1:], single_sweeps[1:])), (got, single_sweeps)
+    assert min(single_sweeps) >= 20                           # the case really iterates
