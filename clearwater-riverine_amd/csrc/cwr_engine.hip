@@ -89,6 +89,8 @@ struct cwr_engine {
   double *d_c = nullptr, *d_r = nullptr, *d_r0 = nullptr, *d_p = nullptr, *d_v = nullptr, *d_s = nullptr,
          *d_t = nullptr, *d_b = nullptr;
   double* d_chk = nullptr;       // [2][K] convergence-check scalars of the Jacobi path
+  bool halo_fresh = false;       // the halo rows of the state hold their owners' current values (set by the end-of-step
+                                 // exchange of a CWR_STEP_MASS_FLUX step, cleared by anything that may change the state)
   double* d_react = nullptr;     // K x K reaction matrix of cwr_react_linear
   // ---- output side (8f-4)
   int n_lines = 0;
@@ -1075,6 +1077,7 @@ int32_t cwr_set_boundary_level(cwr_engine* e, int32_t t, const double* level) {
 int32_t cwr_set_state(cwr_engine* e, const double* conc_owned) {
   if (!e || !conc_owned) return e ? fail(e, CWR_ERR_BAD_ARG, "cwr_set_state: NULL") : CWR_ERR_BAD_ARG;
   HIP_TRY(e, hipSetDevice(e->dev));
+  e->halo_fresh = false;
   TRY(upload(e, e->d_c, conc_owned, (size_t)e->n_core * e->K));
   return CWR_OK;
 }
@@ -1084,6 +1087,7 @@ int32_t cwr_react_linear(cwr_engine* e, const double* M) {
   if (e->K > BLOCK) return fail(e, CWR_ERR_BAD_ARG, "cwr_react_linear: K too large");
   HIP_TRY(e, hipSetDevice(e->dev));
   const int K = e->K;
+  e->halo_fresh = false;
   if (!e->d_react) TRY(dev_alloc(e, &e->d_react, (size_t)K * K));
   TRY(upload(e, e->d_react, M, (size_t)K * K));
   const int rows_pb = BLOCK / K;
@@ -1098,6 +1102,7 @@ int32_t cwr_react_linear(cwr_engine* e, const double* M) {
 int32_t cwr_state_device_ptr(cwr_engine* e, void** state, void** stream) {
   if (!e || !state) return e ? fail(e, CWR_ERR_BAD_ARG, "cwr_state_device_ptr: NULL") : CWR_ERR_BAD_ARG;
   *state = e->d_c;
+  e->halo_fresh = false;                              // the caller may rewrite the state
   if (stream) *stream = e->stream;
   return CWR_OK;
 }
@@ -1158,7 +1163,11 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
   TRY(prep_step(e, t));
   HIP_TRY(e, hipMemsetAsync(e->d_counters, 0, 8 * sizeof(int32_t), e->stream));
   HIP_TRY(e, hipMemsetAsync(e->d_scal, 0, e->scal_count() * sizeof(double), e->stream));
-  TRY(exchange_halo(e, e->d_c));                      // the inner halo layers need x_t for their right-hand sides
+  // the inner halo layers need x_t for their right-hand sides; the exchange that closed the previous step (for its face
+  // fluxes) already delivered it unless the state was touched in between.  Every rank makes the same calls, so every
+  // rank takes the same branch.
+  if (!e->halo_fresh) TRY(exchange_halo(e, e->d_c));
+  e->halo_fresh = false;
   TRY(launch_rhs(e, t, e->d_c, e->d_b, true));
   if (!e->comm) {
     // one GPU: stop before the solve touches the state.  Partitioned runs keep going instead -- the violating
@@ -1236,6 +1245,7 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
     else            k_mass_flux<1><<<grid, BLOCK, 0, e->stream>>>(e->E, e->n_core, K, e->G, e->d_f1, e->d_f2, adv_t, dif_t, e->dt[t], e->d_c, e->d_fadv, e->d_fdif, e->d_ftot);
     HIP_TRY(e, hipGetLastError());
     e->flux_valid = true;
+    e->halo_fresh = true;
   }
   if (flags & CWR_STEP_MASS_BALANCE) {
     if (e->n_lines <= 0) return fail(e, CWR_ERR_STATE, "cwr_step: CWR_STEP_MASS_BALANCE without cwr_set_boundary_lines");
