@@ -141,7 +141,7 @@ struct cwr_engine {
   bool sq_rowwise = false;
   // tiled J^2 pass: per tile the distinct x rows it touches, and per J^2 entry the row's index in that list
   bool use_tcl = true, tcl_ready = false;
-  int tcl_cfg = -1;
+  int tcl_cfg = -1, tcl_vw = 0;   // tcl_vw: constituents per lane in the tiled pass (4 = wide rows, else VW)
   int local_reps = 2;              // J^2 applications per tile and pass (1 = exact Jacobi; > 1 = block-asynchronous)
   int n_tcl = 0, tcl_TR = 0, tcl_ntiles = 0, tcl_max_cols = 0, tcl_stage_cap = 0, tcl_grid = 0;
   size_t tcl_lds = 0, tcl_total_cols = 0;
@@ -368,6 +368,7 @@ int alloc_flow(cwr_engine* e, int T) {
 
 #define CWR_TCL_K(VWv, Q) k_sq_tiled<VWv, TCL_CFG[Q].wrn, TCL_CFG[Q].ut, TCL_CFG[Q].xr>
 const void* tcl_kernel(int vw, int cfg) {
+  if (vw == 4) return reinterpret_cast<const void*>(&CWR_TCL_K(4, 3));
   if (vw == 2) return cfg == 0 ? reinterpret_cast<const void*>(&CWR_TCL_K(2, 0)) : cfg == 1 ? reinterpret_cast<const void*>(&CWR_TCL_K(2, 1)) : reinterpret_cast<const void*>(&CWR_TCL_K(2, 2));
   return cfg == 0 ? reinterpret_cast<const void*>(&CWR_TCL_K(1, 0)) : cfg == 1 ? reinterpret_cast<const void*>(&CWR_TCL_K(1, 1)) : reinterpret_cast<const void*>(&CWR_TCL_K(1, 2));
 }
@@ -482,10 +483,17 @@ int ensure_sq_pattern(cwr_engine* e) {
     e->tcl_cfg = -1;
     int q0 = 0;
     if (const char* v = getenv("CWR_TCL_CFG")) q0 = std::max(0, std::min(2, atoi(v)));
+    // wide rows: four constituents per lane halve the lanes that re-read every (weight, index) pair from LDS
+    bool want4 = (e->K % 16 == 0);
+    if (const char* v = getenv("CWR_TCL_VW")) want4 = atoi(v) == 4 && (e->K % 16 == 0);
+    const int R4 = want4 ? BLOCK / (e->K / 4) : 0;
+    e->tcl_vw = e->VW;
+    // (fetch mapping: K/2 lanes per row; compute mapping: K/4 lanes per row)
+    if (want4 && max_cols <= TCL_CFG[3].xr * (BLOCK / (e->K / 2)) && cap2 <= TCL_CFG[3].wrn * BLOCK && tr <= TCL_CFG[3].ut * R4) { e->tcl_cfg = 3; e->tcl_vw = 4; }
     for (int q = q0; q < 3 && e->tcl_cfg < 0; ++q)
       if (max_cols <= TCL_CFG[q].xr * e->R && cap2 <= TCL_CFG[q].wrn * BLOCK && tr <= TCL_CFG[q].ut * e->R) e->tcl_cfg = q;
     if (lds <= 64 * 1024 && e->tcl_cfg >= 0 && tr <= BLOCK) {
-      const void* fn6 = tcl_kernel(e->VW, e->tcl_cfg);
+      const void* fn6 = tcl_kernel(e->tcl_vw, e->tcl_cfg);
       int pc = 1;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, fn6, BLOCK, lds) != hipSuccess || pc < 1) pc = 1;
       pc = std::min(pc, 8);
@@ -542,9 +550,10 @@ int launch_sq_tiled(cwr_engine* e, const double* xin, double* yout) {
     e0 = e->ev[e->ev_used++]; e1 = e->ev[e->ev_used++];
     HIP_TRY(e, hipEventRecord(e0, e->stream));
   }
-#define CWR_TILED(VWv, Q) CWR_TCL_K(VWv, Q)<<<e->tcl_grid, BLOCK, e->tcl_lds, e->stream>>>(e->n_tcl, e->K, e->G, e->tcl_TR,    \
+#define CWR_TILED(VWv, Q) CWR_TCL_K(VWv, Q)<<<e->tcl_grid, BLOCK, e->tcl_lds, e->stream>>>(e->n_tcl, e->K, e->K / VWv, e->tcl_TR,    \
       e->tcl_ntiles, e->d_ptr2, e->d_loc2, e->d_w2, e->d_tcl_ptr, e->d_tcl_cols, e->tcl_max_cols, e->tcl_stage_cap, e->local_reps, xin, e->d_t, yout)
-  if (e->VW == 2) { if (e->tcl_cfg == 0) CWR_TILED(2, 0); else if (e->tcl_cfg == 1) CWR_TILED(2, 1); else CWR_TILED(2, 2); }
+  if (e->tcl_vw == 4) CWR_TILED(4, 3);
+  else if (e->VW == 2) { if (e->tcl_cfg == 0) CWR_TILED(2, 0); else if (e->tcl_cfg == 1) CWR_TILED(2, 1); else CWR_TILED(2, 2); }
   else            { if (e->tcl_cfg == 0) CWR_TILED(1, 0); else if (e->tcl_cfg == 1) CWR_TILED(1, 1); else CWR_TILED(1, 2); }
 #undef CWR_TILED
   HIP_TRY(e, hipGetLastError());

@@ -57,6 +57,10 @@ template <> struct VecT<1> { using type = double; };
 template <> struct VecT<2> { using type = double2; };
 
 template <int VW> __device__ __forceinline__ void ldv(const double* p, double (&v)[VW]) {
+  if constexpr (VW == 4) {
+    const double2 t = *reinterpret_cast<const double2*>(p), u = *reinterpret_cast<const double2*>(p + 2);
+    v[0] = t.x; v[1] = t.y; v[2] = u.x; v[3] = u.y;
+  } else
   if constexpr (VW == 2) { const double2 t = *reinterpret_cast<const double2*>(p); v[0] = t.x; v[1] = t.y; }
   else { v[0] = *p; }
 }
@@ -67,7 +71,11 @@ template <int VW> __device__ __forceinline__ void ldv(const double* p, double (&
 #endif
 template <int VW> __device__ __forceinline__ void ldv_nt(const double* p, double (&v)[VW]) {
 #if CWR_NT
-  if constexpr (VW == 2) {
+  if constexpr (VW == 4) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const d2 t = __builtin_nontemporal_load(reinterpret_cast<const d2*>(p)), u = __builtin_nontemporal_load(reinterpret_cast<const d2*>(p + 2));
+    v[0] = t.x; v[1] = t.y; v[2] = u.x; v[3] = u.y;
+  } else if constexpr (VW == 2) {
     typedef double d2 __attribute__((ext_vector_type(2)));
     const d2 t = __builtin_nontemporal_load(reinterpret_cast<const d2*>(p)); v[0] = t.x; v[1] = t.y;
   } else { v[0] = __builtin_nontemporal_load(p); }
@@ -95,7 +103,8 @@ template <int VW> __device__ __forceinline__ void stv_stream(double* p, const do
     __builtin_nontemporal_store(t, reinterpret_cast<d2*>(p));
   } else { __builtin_nontemporal_store(v[0], p); }
 #else
-  if constexpr (VW == 2) { *reinterpret_cast<double2*>(p) = make_double2(v[0], v[1]); } else { *p = v[0]; }
+  if constexpr (VW == 4) { *reinterpret_cast<double2*>(p) = make_double2(v[0], v[1]); *reinterpret_cast<double2*>(p + 2) = make_double2(v[2], v[3]); }
+  else if constexpr (VW == 2) { *reinterpret_cast<double2*>(p) = make_double2(v[0], v[1]); } else { *p = v[0]; }
 #endif
 }
 template <int VW> __device__ __forceinline__ void stv_nt(double* p, const double (&v)[VW]) {
@@ -110,7 +119,8 @@ template <int VW> __device__ __forceinline__ void stv_nt(double* p, const double
 #endif
 }
 template <int VW> __device__ __forceinline__ void stv(double* p, const double (&v)[VW]) {
-  if constexpr (VW == 2) { *reinterpret_cast<double2*>(p) = make_double2(v[0], v[1]); }
+  if constexpr (VW == 4) { *reinterpret_cast<double2*>(p) = make_double2(v[0], v[1]); *reinterpret_cast<double2*>(p + 2) = make_double2(v[2], v[3]); }
+  else if constexpr (VW == 2) { *reinterpret_cast<double2*>(p) = make_double2(v[0], v[1]); }
   else { *p = v[0]; }
 }
 
@@ -591,9 +601,12 @@ __global__ void __launch_bounds__(BLOCK) k_build_sq(int nnz2, const int32_t* __r
 // XR x rows per lane group (distinct x rows per tile <= XR * R), WRN J^2 entries per thread (entries per tile <= WRN * BLOCK),
 // UT rows of the tile per lane group (tile rows <= UT * R).  The engine picks the cheapest configuration that fits.
 struct TclCfg { int wrn, ut, xr; };
-constexpr TclCfg TCL_CFG[3] = {{4, 2, 6},      // wide rows (K = 16: 64-row tiles)
+constexpr int TCL_NCFG = 4;
+constexpr TclCfg TCL_CFG[TCL_NCFG] = {{4, 2, 6},      // wide rows (K = 16: 64-row tiles)
                                {10, 1, 3},     // narrow rows (K <= 8: one row per lane group, 64-256-row tiles)
-                               {10, 4, 8}};    // large tiles
+                               {10, 4, 8},     // large tiles
+                               {4, 1, 6}};     // wide rows, four constituents per lane in the compute phase (K = 16: 4 lanes per
+                                               // row, 64 rows per pass); x rows fetched 8 lanes per row, 6 per lane group
 template <int VW, int WRN, int TCL_U, int TCL_XR>
 __global__ void __launch_bounds__(BLOCK) k_sq_tiled(
     int n_rows, int K, int G, int TR, int ntiles, const int32_t* __restrict__ ptr2, const int32_t* __restrict__ loc2,
@@ -608,7 +621,38 @@ __global__ void __launch_bounds__(BLOCK) k_sq_tiled(
   const int tid = threadIdx.x;
   const int r = tid / G, g = tid - r * G;
   const int col = g * VW;
+  // VW == 4 (wide rows): a lane owns two 16-byte pieces of its row, {2g, 2g+1} and {K/2 + 2g, K/2 + 2g + 1}, and the odd
+  // row slots of a wave hold them in swapped register order.  The 8 lanes that an LDS b128 read serves together then
+  // cover all 32 banks (low half of one row, high half of the next) instead of hitting the same 16 banks twice.
+  const int offA = (VW == 4) ? ((r & 1) ? K / 2 + 2 * g : 2 * g) : col;
+  const int offB = (VW == 4) ? ((r & 1) ? 2 * g : K / 2 + 2 * g) : col;
+  auto ld_row = [&](const double* rowp, double (&v)[VW]) {
+    if constexpr (VW == 4) {
+      const double2 a = *reinterpret_cast<const double2*>(rowp + offA), b = *reinterpret_cast<const double2*>(rowp + offB);
+      v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+    } else ldv<VW>(rowp + col, v);
+  };
+  auto ld_row_nt = [&](const double* rowp, double (&v)[VW]) {
+    if constexpr (VW == 4) {
+      typedef double d2 __attribute__((ext_vector_type(2)));
+      const d2 a = __builtin_nontemporal_load(reinterpret_cast<const d2*>(rowp + offA));
+      const d2 b = __builtin_nontemporal_load(reinterpret_cast<const d2*>(rowp + offB));
+      v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+    } else ldv_nt<VW>(rowp + col, v);
+  };
+  auto st_row = [&](double* rowp, const double (&v)[VW]) {
+    if constexpr (VW == 4) {
+      *reinterpret_cast<double2*>(rowp + offA) = make_double2(v[0], v[1]);
+      *reinterpret_cast<double2*>(rowp + offB) = make_double2(v[2], v[3]);
+    } else stv<VW>(rowp + col, v);
+  };
   const bool rowlane = r < R;
+  // x rows are FETCHED (global -> registers -> LDS) one whole 128-byte row per 8 lanes whatever VW is: with VW == 4 the
+  // compute mapping above would fetch half rows (measured +6 us per pass)
+  constexpr int XW = (VW == 4) ? 2 : VW;
+  const int GL = (VW == 4) ? K / 2 : G, RL = BLOCK / GL;
+  const int rl = tid / GL, gl = tid - rl * GL;
+  const bool loadlane = rl < RL;
   const int xcd = blockIdx.x % N_XCD, lidx = blockIdx.x / N_XCD, bpx = gridDim.x / N_XCD;
   const int tpx = (ntiles + N_XCD - 1) / N_XCD;
   auto tile_of = [&](int it) -> int {              // it-th tile of this block, or -1
@@ -619,22 +663,22 @@ __global__ void __launch_bounds__(BLOCK) k_sq_tiled(
   };
   // prefetch registers
   int cn[TCL_XR];                                  // row list of the tile after next (global x row ids)
-  double xr[TCL_XR][VW];                           // x rows of the next tile
+  double xr[TCL_XR][XW];                           // x rows of the next tile (fetch mapping)
   double wr[WRN]; int lr[WRN];               // weights / local indices of the next tile
   double q0[TCL_U][VW];                            // c2 rows of the next tile
   int pr = 0;                                      // row pointer slice of the next tile
   auto load_cols = [&](int t) {
 #pragma unroll
     for (int u = 0; u < TCL_XR; ++u) cn[u] = -1;
-    if (t < 0 || !rowlane) return;
+    if (t < 0 || !loadlane) return;
     const int cb = tcl_ptr[t], ce = tcl_ptr[t + 1];
 #pragma unroll
-    for (int u = 0; u < TCL_XR; ++u) { const int q = r + u * R; if (q < ce - cb) cn[u] = tcl_cols[cb + q]; }
+    for (int u = 0; u < TCL_XR; ++u) { const int q = rl + u * RL; if (q < ce - cb) cn[u] = tcl_cols[cb + q]; }
   };
   auto load_rows = [&](int t) {                    // uses cn (the row list loaded one tile earlier)
     if (t < 0) return;
 #pragma unroll
-    for (int u = 0; u < TCL_XR; ++u) if (cn[u] >= 0) ldv<VW>(xin + (size_t)cn[u] * K + col, xr[u]);
+    for (int u = 0; u < TCL_XR; ++u) if (cn[u] >= 0) ldv<XW>(xin + (size_t)cn[u] * K + gl * XW, xr[u]);
     const int c0 = t * TR, c1 = min(c0 + TR, n_rows);
     const int jb = ptr2[c0], je = ptr2[c1];
 #pragma unroll
@@ -643,7 +687,7 @@ __global__ void __launch_bounds__(BLOCK) k_sq_tiled(
                                                     // for this load, and with it for every prefetch issued before it)
     if (rowlane) {
 #pragma unroll
-      for (int u = 0; u < TCL_U; ++u) { const int c = c0 + r + u * R; if (c < c1) ldv_nt<VW>(c2 + (size_t)c * K + col, q0[u]); }
+      for (int u = 0; u < TCL_U; ++u) { const int c = c0 + r + u * R; if (c < c1) ld_row_nt(c2 + (size_t)c * K, q0[u]); }
     }
   };
   int t_cur = tile_of(0);
@@ -657,9 +701,9 @@ __global__ void __launch_bounds__(BLOCK) k_sq_tiled(
     const int jb0 = ptr2[c0];
     const int nent = ptr2[c1] - jb0;
     __syncthreads();                               // the previous tile's readers are done with LDS
-    if (rowlane) {
+    if (loadlane) {
 #pragma unroll
-      for (int u = 0; u < TCL_XR; ++u) { const int q = r + u * R; if (q < ncol) stv<VW>(s_xt + (size_t)q * K + col, xr[u]); }
+      for (int u = 0; u < TCL_XR; ++u) { const int q = rl + u * RL; if (q < ncol) stv<XW>(s_xt + (size_t)q * K + gl * XW, xr[u]); }
     }
 #pragma unroll
     for (int u = 0; u < WRN; ++u) { const int j = tid + u * BLOCK; if (j < nent) { s_w[j] = wr[u]; s_loc[j] = lr[u]; } }
@@ -685,7 +729,7 @@ __global__ void __launch_bounds__(BLOCK) k_sq_tiled(
         __syncthreads();                             // every reader of the previous round is done
         if (rowlane) {
 #pragma unroll
-          for (int u = 0; u < TCL_U; ++u) { const int c = c0 + r + u * R; if (c < c1) stv<VW>(s_xt + (size_t)(c - c0) * K + col, y[u]); }
+          for (int u = 0; u < TCL_U; ++u) { const int c = c0 + r + u * R; if (c < c1) st_row(s_xt + (size_t)(c - c0) * K, y[u]); }
         }
         __syncthreads();
       }
@@ -700,7 +744,7 @@ __global__ void __launch_bounds__(BLOCK) k_sq_tiled(
             const int j0 = s_ptr[c - c0], j1 = s_ptr[c - c0 + 1];
             for (int j = j0; j < j1; ++j) {
               double xn[VW];
-              ldv<VW>(s_xt + (size_t)s_loc[j] * K + col, xn);
+              ld_row(s_xt + (size_t)s_loc[j] * K, xn);
               const double wj = s_w[j];
 #pragma unroll
               for (int w = 0; w < VW; ++w) sum[w] += wj * xn[w];
@@ -713,7 +757,7 @@ __global__ void __launch_bounds__(BLOCK) k_sq_tiled(
     }
     if (rowlane) {
 #pragma unroll
-      for (int u = 0; u < TCL_U; ++u) { const int c = c0 + r + u * R; if (c < c1) stv_stream<VW>(yout + (size_t)c * K + col, y[u]); }
+      for (int u = 0; u < TCL_U; ++u) { const int c = c0 + r + u * R; if (c < c1) st_row(yout + (size_t)c * K, y[u]); }
     }
     t_cur = t_next;
     t_next = t_after;
