@@ -145,3 +145,25 @@ def test_facade_multi_constituent_and_override(gpu_lib, K, solver, path, monkeyp
     for nm in names:
         assert rel_err(model.mesh[nm], ref.constituent_dict[nm].state) <= TOL_CONC
         assert rel_err(model.constituent_dict[nm].total_mass_flux[:12], ref.constituent_dict[nm].total_mass_flux[:12]) <= 1e-8
+
+
+@pytest.mark.parametrize('K', [2, 5, 7, 8, 24, 32, 64])
+def test_step_parity_across_constituent_counts_on_tiled_meshes(gpu_lib, K, monkeypatch):
+    """Every lane mapping of the sweep kernels (VW = 1 for odd K, 2, and the four-wide split-row mapping of
+    K % 16 == 0; wide rows that do not fit the tiled pass fall back to the un-tiled J^2 pass) against the oracle's
+    spsolve, on a mesh of many 64-row tiles with merged (5-6 face) cells and a dry cell."""
+    import clearwater_riverine_amd as cw
+    monkeypatch.setenv('CWR_NO_SMALL', '1')
+    mesh, inputs3 = synthetic_case(K, nx=96, ny=48, n_steps=3, seed=13, n_merge=150, n_dry=1, dt=30.0,
+                                   diffusion_coefficient=0.4)
+    n = mesh['nreal'] + 1
+    names = [f'c{k}' for k in range(K)]
+    model = cw.ClearwaterRiverine(mesh=dict(mesh), input_arrays={nm: inputs3[:, :, k].copy() for k, nm in enumerate(names)},
+                                  store_history=True)
+    ref = oracle_run(mesh, inputs3[:, :, [0, K - 1]], 3)        # the oracle solves per constituent: first and last suffice
+    for _ in range(3):
+        model.update()
+        assert model.last_step.sweep_kernel in (5, 6) and model.last_step.max_rel_residual <= 1e-12
+    for kk, nm in ((0, names[0]), (1, names[-1])):
+        assert rel_err(model.mesh[nm], ref.constituent_dict[f'c{kk}'].state) <= TOL_CONC
+        assert rel_err(model.constituent_dict[nm].total_mass_flux[:3], ref.constituent_dict[f'c{kk}'].total_mass_flux[:3]) <= 1e-8
