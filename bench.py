@@ -154,13 +154,28 @@ def main():
             pass
         if launches > 0:
             avg_us = total_us / launches
-            achieved = b_r / (avg_us * 1e-6) / 1e9
+            # ALGORITHMIC bytes of a launch = SURVEY.md section 8(d)'s per-apply figure x the operator applies one launch performs:
+            #   B_r(apply) = 24 E + 8 K n + 12 n + 4 + 4 (2 E_int + E_ghost)      (faces, x once, diagonal, CSR adjacency)
+            # a J^2 pass advances two Jacobi iterations = two applies (its tile-local re-applications are not counted).
+            lm = pt.local
+            f2 = np.asarray(lm.face2)
+            E_loc = len(f2)
+            E_ghost = int(np.count_nonzero(f2 >= lm.n_rows + lm.n_halo))
+            n_loc = lm.n_rows
+            survey_apply = 24 * E_loc + 8 * K * n_loc + 12 * n_loc + 4 + 4 * (2 * (E_loc - E_ghost) + E_ghost)
+            applies = 2 if r.sweep_kernel in (5, 6) else 1
+            alg = applies * survey_apply
+            achieved = alg / (avg_us * 1e-6) / 1e9
+            kernel_rate = b_r / (avg_us * 1e-6) / 1e9
             roofline = {
                 'bound': 'hbm', 'kernel': kernel_name,
                 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
-                'bytes_read': b_r, 'bytes_written': b_w, 'avg_launch_us': round(avg_us, 2),
-                'launches_timed': launches,
+                'algorithmic_bytes': alg, 'applies_per_launch': applies, 'survey_bytes_per_apply': survey_apply,
+                'avg_launch_us': round(avg_us, 2), 'launches_timed': launches,
+                # the bytes THIS kernel has to read / write per launch (pre-multiplied J^2 entries: fewer than two applies' worth)
+                'kernel_bytes_read': b_r, 'kernel_bytes_written': b_w,
+                'achieved_kernel_bytes_read': round(kernel_rate, 1), 'frac_kernel_bytes_read': round(kernel_rate / HBM_PEAK_GBS, 4),
                 'achieved_read_plus_write': round((b_r + b_w) / (avg_us * 1e-6) / 1e9, 1),
                 'frac_rw_of_measured_stream_peak': round((b_r + b_w) / (avg_us * 1e-6) / 1e9 / HBM_MEASURED_GBS, 4),
                 'back_to_back_launch_us': None if back_to_back_us is None else round(back_to_back_us, 2),

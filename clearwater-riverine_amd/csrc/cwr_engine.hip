@@ -145,7 +145,8 @@ struct cwr_engine {
   int local_reps = 2;              // J^2 applications per tile and pass (1 = exact Jacobi; > 1 = block-asynchronous)
   int n_tcl = 0, tcl_TR = 0, tcl_ntiles = 0, tcl_max_cols = 0, tcl_stage_cap = 0, tcl_grid = 0;
   size_t tcl_lds = 0, tcl_total_cols = 0;
-  int32_t *d_tcl_ptr = nullptr, *d_tcl_cols = nullptr, *d_loc2 = nullptr;
+  int32_t *d_tcl_ptr = nullptr, *d_tcl_cols = nullptr;
+  uint16_t* d_loc2 = nullptr;    // local (in-tile) column of every J^2 entry: 16 bits (a tile holds < 65 536 x rows)
   double* d_w2 = nullptr;
   hipGraph_t tcl_graph = nullptr;
   hipGraphExec_t tcl_exec = nullptr;
@@ -460,7 +461,8 @@ int ensure_sq_pattern(cwr_engine* e) {
     while (tr > e->R && (tr % e->R) != 0) --tr;
     tr = std::max(tr, e->R);
     const int nt = cdiv(n_t, tr);
-    std::vector<int32_t> tptr((size_t)nt + 1, 0), tcols, loc2((size_t)e->nnz2, 0);
+    std::vector<int32_t> tptr((size_t)nt + 1, 0), tcols;
+    std::vector<uint16_t> loc2((size_t)e->nnz2, 0);
     tcols.reserve((size_t)n_t * 3);
     std::vector<int32_t> stamp((size_t)e->n_real, -1), pos((size_t)e->n_real, 0), others;
     int max_cols = 0, cap2 = 1;
@@ -472,12 +474,13 @@ int ensure_sq_pattern(cwr_engine* e) {
       for (int q = ptr2[c0]; q < ptr2[c1]; ++q) { const int k = col2[q]; if (stamp[k] != t) { stamp[k] = t; others.push_back(k); } }
       std::sort(others.begin(), others.end());
       for (size_t u = 0; u < others.size(); ++u) { pos[others[u]] = (c1 - c0) + (int)u; tcols.push_back(others[u]); }
-      for (int q = ptr2[c0]; q < ptr2[c1]; ++q) loc2[q] = pos[col2[q]];
+      for (int q = ptr2[c0]; q < ptr2[c1]; ++q) loc2[q] = (uint16_t)pos[col2[q]];
       tptr[t + 1] = (int32_t)tcols.size();
       max_cols = std::max(max_cols, (int)tcols.size() - base);
       cap2 = std::max(cap2, ptr2[c1] - ptr2[c0]);
     }
-    const size_t lds = ((size_t)max_cols * e->K * sizeof(double) + (size_t)cap2 * (sizeof(double) + sizeof(int32_t)) +
+    cap2 += cap2 & 1;                                            // even: the 16-bit index array keeps what follows 4-byte aligned
+    const size_t lds = ((size_t)max_cols * e->K * sizeof(double) + (size_t)cap2 * (sizeof(double) + sizeof(uint16_t)) +
                         (size_t)(tr + 1) * sizeof(int32_t) + 15) & ~(size_t)15;
     // the kernel's compile-time prefetch depths bound what a tile may hold; otherwise the plain J^2 pass stays
     e->tcl_cfg = -1;
@@ -1520,8 +1523,8 @@ int32_t cwr_apply_bytes(const cwr_engine* e, int64_t* bytes_read, int64_t* bytes
   const bool sq = (e->dominant_mode == 5 || e->dominant_mode == 6);
   const int64_t entries = sq ? e->nnz2 : e->nnz;
   const int64_t rows = (e->dominant_mode == 6) ? e->n_tcl : (sq ? e->n_sq : e->n_owned);
-  // tiled J^2 pass: 8-B weight + 4-B local index per entry, + the per-tile lists of distinct x rows
-  const int64_t extra = (e->dominant_mode == 6) ? 4LL * (int64_t)e->tcl_total_cols - 4LL * e->nnz2 : 0LL;
+  // tiled J^2 pass: 8-B weight + 2-B local index per entry, + the per-tile lists of distinct x rows
+  const int64_t extra = (e->dominant_mode == 6) ? 4LL * (int64_t)e->tcl_total_cols - 6LL * e->nnz2 : 0LL;
   if (bytes_read) *bytes_read = 16LL * entries + extra + 4LL * (rows + 1) + (sq ? 0LL : 8LL * rows) +
                                 8LL * K * e->n_real + 8LL * K * rows;
   if (bytes_written) *bytes_written = 8LL * K * rows;

@@ -609,14 +609,14 @@ constexpr TclCfg TCL_CFG[TCL_NCFG] = {{4, 2, 6},      // wide rows (K = 16: 64-r
                                                // row, 64 rows per pass); x rows fetched 8 lanes per row, 6 per lane group
 template <int VW, int WRN, int TCL_U, int TCL_XR>
 __global__ void __launch_bounds__(BLOCK) k_sq_tiled(
-    int n_rows, int K, int G, int TR, int ntiles, const int32_t* __restrict__ ptr2, const int32_t* __restrict__ loc2,
+    int n_rows, int K, int G, int TR, int ntiles, const int32_t* __restrict__ ptr2, const uint16_t* __restrict__ loc2,
     const double* __restrict__ w2, const int32_t* __restrict__ tcl_ptr, const int32_t* __restrict__ tcl_cols,
     int max_cols, int stage_cap, int reps, const double* __restrict__ xin, const double* __restrict__ c2, double* __restrict__ yout) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
   double* s_xt = reinterpret_cast<double*>(s_dyn);                                  // [max_cols][K]
   double* s_w = s_xt + (size_t)max_cols * K;                                         // [stage_cap]
-  int32_t* s_loc = reinterpret_cast<int32_t*>(s_w + stage_cap);                      // [stage_cap]
-  int32_t* s_ptr = s_loc + stage_cap;                                                // [TR + 1]
+  uint16_t* s_loc = reinterpret_cast<uint16_t*>(s_w + stage_cap);                    // [stage_cap] (stage_cap is even)
+  int32_t* s_ptr = reinterpret_cast<int32_t*>(s_loc + stage_cap);                    // [TR + 1]
   const int R = BLOCK / G;
   const int tid = threadIdx.x;
   const int r = tid / G, g = tid - r * G;
@@ -706,7 +706,7 @@ __global__ void __launch_bounds__(BLOCK) k_sq_tiled(
       for (int u = 0; u < TCL_XR; ++u) { const int q = rl + u * RL; if (q < ncol) stv<XW>(s_xt + (size_t)q * K + gl * XW, xr[u]); }
     }
 #pragma unroll
-    for (int u = 0; u < WRN; ++u) { const int j = tid + u * BLOCK; if (j < nent) { s_w[j] = wr[u]; s_loc[j] = lr[u]; } }
+    for (int u = 0; u < WRN; ++u) { const int j = tid + u * BLOCK; if (j < nent) { s_w[j] = wr[u]; s_loc[j] = (uint16_t)lr[u]; } }
     if (tid < c1 - c0) s_ptr[tid] = pr - jb0;
     if (tid == 0) s_ptr[c1 - c0] = nent;
     double qc[TCL_U][VW];
@@ -744,7 +744,7 @@ __global__ void __launch_bounds__(BLOCK) k_sq_tiled(
             const int j0 = s_ptr[c - c0], j1 = s_ptr[c - c0 + 1];
             for (int j = j0; j < j1; ++j) {
               double xn[VW];
-              ld_row(s_xt + (size_t)s_loc[j] * K, xn);
+              ld_row(s_xt + (size_t)(int)s_loc[j] * K, xn);
               const double wj = s_w[j];
 #pragma unroll
               for (int w = 0; w < VW; ++w) sum[w] += wj * xn[w];
