@@ -146,11 +146,14 @@ def main():
                        6: 'k_sq_tiled<VW>: J^2 pass with the x tile staged in LDS, software-pipelined (two Jacobi iterations per launch)',
                        7: 'k_small_jacobi: one-launch LDS-resident solve'}.get(r.sweep_kernel, 'k_apply<VW,1>: BiCGSTAB product')
         back_to_back_us = eng.time_apply(args.warmup, reps=50) if world == 1 else None
-        traffic = None
+        traffic = traffic_rw = None
         try:                                             # PMC-measured HBM bytes per launch of this exact config, if profiled
             with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as fh:
-                traffic = json.load(fh).get(f'{args.nx}x{args.ny}', {}).get(str(K)) if world == 1 and args.solver == 'auto' else None
-        except OSError:
+                ent = json.load(fh).get(f'{args.nx}x{args.ny}', {}).get(str(K)) if world == 1 and args.solver == 'auto' else None
+            if ent:
+                traffic_rw = (int(ent['read']), int(ent['written']))
+                traffic = sum(traffic_rw)
+        except (OSError, KeyError, TypeError, ValueError):
             pass
         if launches > 0:
             avg_us = total_us / launches
@@ -171,6 +174,8 @@ def main():
                 'bound': 'hbm', 'kernel': kernel_name,
                 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                'traffic_read': None if traffic_rw is None else traffic_rw[0],
+                'traffic_written': None if traffic_rw is None else traffic_rw[1],
                 'algorithmic_bytes': alg, 'applies_per_launch': applies, 'survey_bytes_per_apply': survey_apply,
                 'avg_launch_us': round(avg_us, 2), 'launches_timed': launches,
                 # the bytes THIS kernel has to read / write per launch (pre-multiplied J^2 entries: fewer than two applies' worth)
