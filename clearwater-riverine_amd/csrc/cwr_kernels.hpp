@@ -695,6 +695,11 @@ __global__ void __launch_bounds__(BLOCK) k_sq_tiled(
   load_rows(t_cur);                                // (the first tile's chain is not hidden)
   int t_next = tile_of(1);
   load_cols(t_next);
+  // Results are stored one tile LATE, right before the next tile's prefetch is issued: on gfx9 stores count in vmcnt like
+  // loads, so a store issued at the end of a tile would be the youngest entry the next tile's `wait for the prefetch` has
+  // to drain (a full write latency per tile); deferred, it has the whole compute phase to retire.
+  double y[TCL_U][VW];
+  int pc0 = 0, pc1 = 0;                            // rows of the tile whose results y still holds
   for (int it = 0; t_cur >= 0; ++it) {
     const int c0 = t_cur * TR, c1 = min(c0 + TR, n_rows);
     const int ncol = tcl_ptr[t_cur + 1] - tcl_ptr[t_cur];
@@ -715,6 +720,10 @@ __global__ void __launch_bounds__(BLOCK) k_sq_tiled(
 #pragma unroll
       for (int w = 0; w < VW; ++w) qc[u][w] = q0[u][w];
     __syncthreads();
+    if (rowlane) {                                 // the previous tile's results
+#pragma unroll
+      for (int u = 0; u < TCL_U; ++u) { const int c = pc0 + r + u * R; if (c < pc1) st_row(yout + (size_t)c * K, y[u]); }
+    }
     // start the next tile's loads (x rows by the list already in registers) and the list of the tile after it
     const int t_after = tile_of(it + 2);
     load_rows(t_next);
@@ -723,7 +732,6 @@ __global__ void __launch_bounds__(BLOCK) k_sq_tiled(
     // in the LDS x tile, while rows of other tiles keep the values of the pass's input.  A chaotic relaxation in the
     // sense of Chazan-Miranker: it converges whenever rho(|J|) < 1 (always here: A is a strictly diagonally dominant
     // M-matrix) and the inner applications cost LDS reads only.
-    double y[TCL_U][VW];
     for (int rep = 0; rep < reps; ++rep) {
       if (rep > 0) {
         __syncthreads();                             // every reader of the previous round is done
@@ -755,12 +763,13 @@ __global__ void __launch_bounds__(BLOCK) k_sq_tiled(
         }
       }
     }
-    if (rowlane) {
-#pragma unroll
-      for (int u = 0; u < TCL_U; ++u) { const int c = c0 + r + u * R; if (c < c1) st_row(yout + (size_t)c * K, y[u]); }
-    }
+    pc0 = c0; pc1 = c1;
     t_cur = t_next;
     t_next = t_after;
+  }
+  if (rowlane) {                                   // the last tile's results
+#pragma unroll
+    for (int u = 0; u < TCL_U; ++u) { const int c = pc0 + r + u * R; if (c < pc1) st_row(yout + (size_t)c * K, y[u]); }
   }
 }
 
