@@ -74,6 +74,8 @@ struct cwr_engine {
   size_t apply_lds = 0;
   // static topology
   int32_t *d_f1 = nullptr, *d_f2 = nullptr, *d_ptr = nullptr, *d_ent_edge = nullptr, *d_ent_nb = nullptr;
+  int32_t* d_face_orig = nullptr;          // internal face index -> reference face id (k_faces_in / k_faces_out)
+  std::vector<int32_t> h_face_pos;         // reference face id -> internal face index
   // flow field, all levels resident in HBM
   int T = 0, T_bc = 0;
   float *d_adv = nullptr, *d_vel = nullptr, *d_vol = nullptr;
@@ -139,6 +141,7 @@ struct cwr_engine {
   int32_t *d_ptr2 = nullptr, *d_col2 = nullptr, *d_row2 = nullptr, *d_pair_ptr = nullptr;
   uint8_t* d_slots = nullptr;
   bool sq_rowwise = false;
+  int sq_max_row = 0;              // longest J^2 row
   // tiled J^2 pass: per tile the distinct x rows it touches, and per J^2 entry the row's index in that list
   bool use_tcl = true, tcl_ready = false;
   int tcl_cfg = -1, tcl_vw = 0;   // tcl_vw: constituents per lane in the tiled pass (4 = wide rows, else VW)
@@ -409,6 +412,7 @@ int ensure_sq_pattern(cwr_engine* e) {
       }
     }
     if ((int)tmp.size() > SQN_MAXC) rowwise = false;             // such a row needs the per-entry kernel
+    e->sq_max_row = std::max(e->sq_max_row, (int)tmp.size());
     col2.insert(col2.end(), tmp.begin(), tmp.end());
     ptr2[c + 1] = (int32_t)col2.size();
     pair_ptr[c + 1] = (int32_t)slots.size();
@@ -533,8 +537,11 @@ int prepare_sq(cwr_engine* e, bool& active) {
   if (!e->sq_pattern) return CWR_OK;
   // (the entry weights w were written by k_prep_step)
   const bool need_rec2 = !e->tcl_ready || e->n_sq > e->n_tcl;      // the un-tiled pass reads FaceRec-format rows
-  if (e->sq_rowwise)
-    k_sq_numeric<<<cdiv(e->n_sq, SQN_THREADS), SQN_THREADS, 0, e->stream>>>(e->n_sq, e->d_ptr, e->d_ent_nb, e->d_w, e->d_ptr2, e->d_col2,
+  if (e->sq_rowwise && e->sq_max_row <= 16)
+    k_sq_numeric<16><<<cdiv(e->n_sq, SQN_THREADS), SQN_THREADS, 0, e->stream>>>(e->n_sq, e->d_ptr, e->d_ent_nb, e->d_w, e->d_ptr2, e->d_col2,
+        e->d_pair_ptr, e->d_slots, need_rec2 ? e->d_rec2 : nullptr, e->tcl_ready ? e->d_w2 : nullptr);
+  else if (e->sq_rowwise)
+    k_sq_numeric<SQN_MAXC><<<cdiv(e->n_sq, SQN_THREADS), SQN_THREADS, 0, e->stream>>>(e->n_sq, e->d_ptr, e->d_ent_nb, e->d_w, e->d_ptr2, e->d_col2,
         e->d_pair_ptr, e->d_slots, need_rec2 ? e->d_rec2 : nullptr, e->tcl_ready ? e->d_w2 : nullptr);
   else
     k_build_sq<<<cdiv(e->nnz2, BLOCK), BLOCK, 0, e->stream>>>(e->nnz2, e->d_ptr, e->d_ent_nb, e->d_w, e->d_row2, e->d_col2, e->d_rec2, e->tcl_ready ? e->d_w2 : nullptr);
@@ -867,11 +874,24 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   }
   for (int c = 0; c < n_owned; ++c) cnt[c + 1] += cnt[c];
   const int nnz = cnt[n_owned];
+  // internal face order: ascending smaller cell id (stable), so per-face data of neighbouring cells is contiguous
+  std::vector<int32_t> face_orig((size_t)n_edges), face_pos((size_t)n_edges);
+  for (int e = 0; e < n_edges; ++e) face_orig[(size_t)e] = e;
+  if (!getenv("CWR_NO_FACE_ORDER"))
+    std::stable_sort(face_orig.begin(), face_orig.end(), [&](int32_t a, int32_t b) {
+      const int ka = (face2[a] < n_real) ? std::min(face1[a], face2[a]) : face1[a];
+      const int kb = (face2[b] < n_real) ? std::min(face1[b], face2[b]) : face1[b];
+      return ka < kb;
+    });
+  for (int p = 0; p < n_edges; ++p) face_pos[(size_t)face_orig[(size_t)p]] = p;
+  std::vector<int32_t> f1p((size_t)std::max(n_edges, 1)), f2p((size_t)std::max(n_edges, 1));
+  for (int p = 0; p < n_edges; ++p) { f1p[(size_t)p] = face1[face_orig[(size_t)p]]; f2p[(size_t)p] = face2[face_orig[(size_t)p]]; }
   std::vector<int32_t> ent_edge((size_t)std::max(nnz, 1)), ent_nb((size_t)std::max(nnz, 1)), fill(cnt.begin(), cnt.end() - 1);
-  for (int e = 0; e < n_edges; ++e) {           // ascending face id inside every cell (last-write-wins order)
+  for (int e = 0; e < n_edges; ++e) {           // ascending REFERENCE face id inside every cell (last-write-wins order)
     const int P = face1[e], N = face2[e];
-    if (P < n_owned) { const int j = fill[P]++; ent_edge[j] = (e << 1); ent_nb[j] = (N < n_real) ? N : -1 - (N - n_real); }
-    if (N < n_owned) { const int j = fill[N]++; ent_edge[j] = (e << 1) | 1; ent_nb[j] = P; }
+    const int pe = face_pos[(size_t)e];
+    if (P < n_owned) { const int j = fill[P]++; ent_edge[j] = (pe << 1); ent_nb[j] = (N < n_real) ? N : -1 - (N - n_real); }
+    if (N < n_owned) { const int j = fill[N]++; ent_edge[j] = (pe << 1) | 1; ent_nb[j] = P; }
   }
 
   cwr_engine* eng = new cwr_engine();
@@ -971,8 +991,11 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   CREATE_TRY(dev_alloc(eng, &eng->d_counters, (size_t)8));
   CREATE_TRY(dev_alloc(eng, &eng->d_partial, (size_t)std::max(eng->apply_grid, 256 * 8) * 4 * K));
   if (getenv("CWR_VERBOSE")) fprintf(stderr, "[cwr] K=%d VW=%d G=%d U=%d tiles=%d stage_cap=%d lds=%zu grid=%d\n", K, eng->VW, eng->G, eng->U, eng->ntiles, eng->stage_cap, eng->apply_lds, eng->apply_grid);
-  CREATE_TRY(upload(eng, eng->d_f1, face1, (size_t)n_edges));
-  CREATE_TRY(upload(eng, eng->d_f2, face2, (size_t)n_edges));
+  CREATE_TRY(upload(eng, eng->d_f1, f1p.data(), (size_t)n_edges));
+  CREATE_TRY(upload(eng, eng->d_f2, f2p.data(), (size_t)n_edges));
+  CREATE_TRY(dev_alloc(eng, &eng->d_face_orig, (size_t)std::max(n_edges, 1)));
+  CREATE_TRY(upload(eng, eng->d_face_orig, face_orig.data(), (size_t)n_edges));
+  eng->h_face_pos = face_pos;
   CREATE_TRY(upload(eng, eng->d_ptr, cnt.data(), (size_t)n_owned + 1));
   CREATE_TRY(upload(eng, eng->d_ent_edge, ent_edge.data(), (size_t)nnz));
   CREATE_TRY(upload(eng, eng->d_ent_nb, ent_nb.data(), (size_t)nnz));
@@ -1003,7 +1026,7 @@ void cwr_destroy(cwr_engine* e) {
   for (hipEvent_t ev : e->ev) hipEventDestroy(ev);
   void* ptrs[] = {e->d_f1, e->d_f2, e->d_ptr, e->d_ent_edge, e->d_ent_nb, e->d_adv, e->d_vel, e->d_vol, e->d_dif,
                   e->d_bc, e->d_rec, e->d_diag, e->d_c, e->d_r, e->d_r0, e->d_p, e->d_v, e->d_s, e->d_t, e->d_b,
-                  e->d_scal, e->d_counters, e->d_partial, e->d_fadv, e->d_fdif, e->d_ftot, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf, e->d_ptr2, e->d_col2, e->d_row2, e->d_rec2, e->d_w, e->d_react, e->d_info, e->d_tcl_ptr, e->d_tcl_cols, e->d_loc2, e->d_w2, e->d_pair_ptr, e->d_slots, e->d_line_ptr, e->d_line_faces, e->d_ledger, e->d_mass_out, e->d_chk};
+                  e->d_scal, e->d_counters, e->d_partial, e->d_fadv, e->d_fdif, e->d_ftot, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf, e->d_ptr2, e->d_col2, e->d_row2, e->d_rec2, e->d_w, e->d_react, e->d_info, e->d_tcl_ptr, e->d_tcl_cols, e->d_loc2, e->d_w2, e->d_pair_ptr, e->d_slots, e->d_line_ptr, e->d_line_faces, e->d_ledger, e->d_mass_out, e->d_chk, e->d_face_orig};
   for (void* p : ptrs) if (p) hipFree(p);
   if (e->stream) hipStreamDestroy(e->stream);
   delete e;
@@ -1017,20 +1040,26 @@ int32_t cwr_load_flow_field(cwr_engine* e, int32_t T, const float* face_flow, co
   HIP_TRY(e, hipSetDevice(e->dev));
   TRY(alloc_flow(e, T));
   const size_t TE = (size_t)T * e->E;
-  // raw flow goes through d_adv's storage; a temporary holds the distances
-  float* d_flow = nullptr; double* d_dist = nullptr;
+  // the host arrays arrive in the reference's face order: upload to temporaries, gather into the internal face order
+  float *d_flow = nullptr, *d_tmpf = nullptr; double *d_dist = nullptr, *d_tmpd = nullptr;
   TRY(dev_alloc(e, &d_flow, TE));
+  TRY(dev_alloc(e, &d_tmpf, TE));
   TRY(dev_alloc(e, &d_dist, (size_t)e->E));
-  int rc = upload(e, d_flow, face_flow, TE);
-  if (rc == CWR_OK) rc = upload(e, e->d_vel, edge_velocity, TE);
+  TRY(dev_alloc(e, &d_tmpd, (size_t)e->E));
+  const int gridTE = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv((int64_t)TE, BLOCK), 256 * 16));
+  int rc = upload(e, d_tmpf, face_flow, TE);
+  if (rc == CWR_OK && TE > 0) k_faces_in<float><<<gridTE, BLOCK, 0, e->stream>>>((int64_t)TE, e->E, e->d_face_orig, d_tmpf, d_flow);
+  if (rc == CWR_OK) rc = upload(e, d_tmpf, edge_velocity, TE);         // (upload synchronises: the gather above is done)
+  if (rc == CWR_OK && TE > 0) k_faces_in<float><<<gridTE, BLOCK, 0, e->stream>>>((int64_t)TE, e->E, e->d_face_orig, d_tmpf, e->d_vel);
   if (rc == CWR_OK) rc = upload(e, e->d_vol, volume, (size_t)T * e->n_cells);
-  if (rc == CWR_OK) rc = upload(e, d_dist, dist, (size_t)e->E);
+  if (rc == CWR_OK) rc = upload(e, d_tmpd, dist, (size_t)e->E);
+  if (rc == CWR_OK && e->E > 0) k_faces_in<double><<<cdiv(e->E, BLOCK), BLOCK, 0, e->stream>>>((int64_t)e->E, e->E, e->d_face_orig, d_tmpd, d_dist);
   if (rc == CWR_OK && TE > 0) {
-    const int grid = std::min(cdiv((int64_t)TE, BLOCK), 256 * 16);
-    k_derive_coeff<<<grid, BLOCK, 0, e->stream>>>((int64_t)TE, e->E, d_flow, e->d_vel, d_dist, (float)D, e->d_adv, e->d_dif);
+    k_derive_coeff<<<gridTE, BLOCK, 0, e->stream>>>((int64_t)TE, e->E, d_flow, e->d_vel, d_dist, (float)D, e->d_adv, e->d_dif);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess)
       rc = fail(e, CWR_ERR_HIP, "k_derive_coeff failed");
   }
+  hipFree(d_tmpf); hipFree(d_tmpd);
   hipFree(d_flow); hipFree(d_dist);
   if (rc != CWR_OK) { e->T = 0; return rc; }
   e->dt.assign(dt, dt + T);
@@ -1046,9 +1075,19 @@ int32_t cwr_load_coefficients(cwr_engine* e, int32_t T, const float* adv, const 
   HIP_TRY(e, hipSetDevice(e->dev));
   TRY(alloc_flow(e, T));
   const size_t TE = (size_t)T * e->E;
-  TRY(upload(e, e->d_adv, adv, TE));
-  TRY(upload(e, e->d_dif, dif, TE));
-  TRY(upload(e, e->d_vel, vel, TE));
+  float* d_tmpf = nullptr; double* d_tmpd = nullptr;               // reference face order -> internal face order
+  TRY(dev_alloc(e, &d_tmpf, TE));
+  TRY(dev_alloc(e, &d_tmpd, TE));
+  const int gridTE = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv((int64_t)TE, BLOCK), 256 * 16));
+  int rc = upload(e, d_tmpf, adv, TE);
+  if (rc == CWR_OK) k_faces_in<float><<<gridTE, BLOCK, 0, e->stream>>>((int64_t)TE, e->E, e->d_face_orig, d_tmpf, e->d_adv);
+  if (rc == CWR_OK) rc = upload(e, d_tmpf, vel, TE);
+  if (rc == CWR_OK) k_faces_in<float><<<gridTE, BLOCK, 0, e->stream>>>((int64_t)TE, e->E, e->d_face_orig, d_tmpf, e->d_vel);
+  if (rc == CWR_OK) rc = upload(e, d_tmpd, dif, TE);
+  if (rc == CWR_OK) k_faces_in<double><<<gridTE, BLOCK, 0, e->stream>>>((int64_t)TE, e->E, e->d_face_orig, d_tmpd, e->d_dif);
+  if (rc == CWR_OK && (hipGetLastError() != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess)) rc = fail(e, CWR_ERR_HIP, "k_faces_in failed");
+  hipFree(d_tmpf); hipFree(d_tmpd);
+  if (rc != CWR_OK) { e->T = 0; return rc; }
   TRY(upload(e, e->d_vol, volume, (size_t)T * e->n_cells));
   e->dt.assign(dt, dt + T);
   e->D = D;
@@ -1059,9 +1098,20 @@ int32_t cwr_get_coefficients(cwr_engine* e, int32_t t, float* adv, double* dif) 
   if (!e) return CWR_ERR_BAD_ARG;
   TRY(check_level(e, t, false));
   HIP_TRY(e, hipSetDevice(e->dev));
-  if (adv) TRY(download(e, adv, e->d_adv + (size_t)t * e->E, (size_t)e->E));
-  if (dif) TRY(download(e, dif, e->d_dif + (size_t)t * e->E, (size_t)e->E));
-  return CWR_OK;
+  float* d_tmpf = nullptr; double* d_tmpd = nullptr;               // internal face order -> reference face order
+  int rc = CWR_OK;
+  if (adv) {
+    rc = dev_alloc(e, &d_tmpf, (size_t)std::max(e->E, 1));
+    if (rc == CWR_OK) { k_faces_out<float><<<cdiv(std::max(e->E, 1), BLOCK), BLOCK, 0, e->stream>>>(e->E, e->d_face_orig, e->d_adv + (size_t)t * e->E, d_tmpf);
+                        rc = download(e, adv, d_tmpf, (size_t)e->E); }
+  }
+  if (rc == CWR_OK && dif) {
+    rc = dev_alloc(e, &d_tmpd, (size_t)std::max(e->E, 1));
+    if (rc == CWR_OK) { k_faces_out<double><<<cdiv(std::max(e->E, 1), BLOCK), BLOCK, 0, e->stream>>>(e->E, e->d_face_orig, e->d_dif + (size_t)t * e->E, d_tmpd);
+                        rc = download(e, dif, d_tmpd, (size_t)e->E); }
+  }
+  hipFree(d_tmpf); hipFree(d_tmpd);
+  return rc;
 }
 
 int32_t cwr_load_boundary(cwr_engine* e, int32_t T, const double* ghost_conc) {
@@ -1253,8 +1303,8 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
     const int grid = std::max(1, std::min(cdiv(e->E, e->R), 256 * 8));
     const float* adv_t = e->d_adv + (size_t)t * e->E;
     const double* dif_t = e->d_dif + (size_t)t * e->E;
-    if (e->VW == 2) k_mass_flux<2><<<grid, BLOCK, 0, e->stream>>>(e->E, e->n_core, K, e->G, e->d_f1, e->d_f2, adv_t, dif_t, e->dt[t], e->d_c, e->d_fadv, e->d_fdif, e->d_ftot);
-    else            k_mass_flux<1><<<grid, BLOCK, 0, e->stream>>>(e->E, e->n_core, K, e->G, e->d_f1, e->d_f2, adv_t, dif_t, e->dt[t], e->d_c, e->d_fadv, e->d_fdif, e->d_ftot);
+    if (e->VW == 2) k_mass_flux<2><<<grid, BLOCK, 0, e->stream>>>(e->E, e->n_core, K, e->G, e->d_f1, e->d_f2, adv_t, dif_t, e->dt[t], e->d_c, e->d_face_orig, e->d_fadv, e->d_fdif, e->d_ftot);
+    else            k_mass_flux<1><<<grid, BLOCK, 0, e->stream>>>(e->E, e->n_core, K, e->G, e->d_f1, e->d_f2, adv_t, dif_t, e->dt[t], e->d_c, e->d_face_orig, e->d_fadv, e->d_fdif, e->d_ftot);
     HIP_TRY(e, hipGetLastError());
     e->flux_valid = true;
     e->halo_fresh = true;
@@ -1367,7 +1417,11 @@ int32_t cwr_set_boundary_lines(cwr_engine* e, int32_t n_lines, const int32_t* li
   TRY(dev_alloc(e, &e->d_line_faces, (size_t)std::max(nf, 1)));
   TRY(dev_alloc(e, &e->d_ledger, (size_t)n_lines * 3 * e->K));
   TRY(upload(e, e->d_line_ptr, line_ptr, (size_t)n_lines + 1));
-  if (nf > 0) TRY(upload(e, e->d_line_faces, line_faces, (size_t)nf));
+  if (nf > 0) {
+    std::vector<int32_t> internal((size_t)nf);
+    for (int i = 0; i < nf; ++i) internal[(size_t)i] = e->h_face_pos[(size_t)line_faces[i]];
+    TRY(upload(e, e->d_line_faces, internal.data(), (size_t)nf));
+  }
   e->n_lines = n_lines;
   return cwr_reset_mass_balance(e);
 }

@@ -210,6 +210,24 @@ __global__ void __launch_bounds__(RBLOCK) k_reduce_partials(int nslots, int ND, 
   }
 }
 
+// Internal face order: the engine stores every per-face array sorted by the smaller cell id of the face, so that the
+// faces of neighbouring cells are neighbours in memory (per-entry gathers of k_prep_step, both cell rows of k_mass_flux).
+// dst[t, p] = src[t, orig[p]] on the way in, dst[orig[p]] = src[p] on the way out; ids at the C ABI stay the reference's.
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) k_faces_in(int64_t total, int E, const int32_t* __restrict__ orig,
+                                                  const T* __restrict__ src, T* __restrict__ dst) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * BLOCK) {
+    const int64_t t = i / E; const int p = (int)(i - t * E);
+    dst[i] = src[t * E + orig[p]];
+  }
+}
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) k_faces_out(int E, const int32_t* __restrict__ orig, const T* __restrict__ src,
+                                                   T* __restrict__ dst) {
+  const int p = blockIdx.x * BLOCK + threadIdx.x;
+  if (p < E) dst[orig[p]] = src[p];
+}
+
 // ------------------------------------------------------------------------------------------------ a-1
 // utilities.py:514-535, one thread per (time level, face).
 __global__ void __launch_bounds__(BLOCK) k_derive_coeff(
@@ -234,31 +252,45 @@ __global__ void __launch_bounds__(BLOCK) k_derive_coeff(
 //   diag[c] = V[t+1,c]/dt + [V[t+1,c]==0] + sum_faces ( d + max(a_c, 0) )
 // (linalg.py:76-103 dry dummy, V/dt, diffusion diagonals; :113-115 outflow incl. ghost faces;
 //  :139-141 inflow seen from the neighbour).  One thread per owned cell.
+constexpr int PREP_CAP = 1536;      // adjacency entries of a 256-row block staged in LDS (4-6 per row on HEC-RAS meshes)
 __global__ void __launch_bounds__(BLOCK) k_prep_step(
     int n_owned, const int32_t* __restrict__ ptr, const int32_t* __restrict__ ent_edge,
     const int32_t* __restrict__ ent_nb, const float* __restrict__ adv_t, const double* __restrict__ dif_t,
     const float* __restrict__ vol_next, double dt, FaceRec* __restrict__ rec, double* __restrict__ diag,
     double* __restrict__ w) {
-  const int c = blockIdx.x * BLOCK + threadIdx.x;
-  if (c >= n_owned) return;
-  const double vn = (double)vol_next[c];
-  double dg = vn / dt + (vn == 0.0 ? 1.0 : 0.0);
-  const int j1 = ptr[c + 1];
-  for (int j = ptr[c]; j < j1; ++j) {
-    const int code = ent_edge[j];
-    const int e = code >> 1;
-    const float a = adv_t[e];
-    const double d = dif_t[e];
-    const float a_c = (code & 1) ? -a : a;
-    dg += d + fmax((double)a_c, 0.0);
-    FaceRec r; r.nb = ent_nb[j]; r.a_c = a_c; r.d = d;
-    rec[j] = r;
+  // rows are worked one per thread, but their records and weights leave through LDS as one contiguous, coalesced stream
+  // (a thread's own 16-byte stores at a 64-byte stride cost 2.6 x the bytes at the HBM side: PMC, profiles/r01_k_*)
+  __shared__ FaceRec s_rec[PREP_CAP];
+  __shared__ double s_w[PREP_CAP];
+  const int c0 = blockIdx.x * BLOCK, c1 = min(c0 + BLOCK, n_owned);
+  const int jb = ptr[c0], nent = ptr[c1] - jb;
+  const bool staged = nent <= PREP_CAP;              // uniform per block
+  const int c = c0 + threadIdx.x;
+  if (c < n_owned) {
+    const double vn = (double)vol_next[c];
+    double dg = vn / dt + (vn == 0.0 ? 1.0 : 0.0);
+    const int j0 = ptr[c], j1 = ptr[c + 1];
+    for (int j = j0; j < j1; ++j) {
+      const int code = ent_edge[j];
+      const int e = code >> 1;
+      const float a = adv_t[e];
+      const double d = dif_t[e];
+      const float a_c = (code & 1) ? -a : a;
+      dg += d + fmax((double)a_c, 0.0);
+      FaceRec r; r.nb = ent_nb[j]; r.a_c = a_c; r.d = d;
+      if (staged) s_rec[j - jb] = r; else rec[j] = r;
+    }
+    diag[c] = dg;
+    // w[j] = -offd_j / diag >= 0: the Jacobi iteration matrix J = I - D^-1 A per adjacency entry (0 on ghost faces)
+    for (int j = j0; j < j1; ++j) {
+      const FaceRec fr = staged ? s_rec[j - jb] : rec[j];
+      const double wj = (fr.nb >= 0) ? (fr.d - fmin((double)fr.a_c, 0.0)) / dg : 0.0;
+      if (staged) s_w[j - jb] = wj; else w[j] = wj;
+    }
   }
-  diag[c] = dg;
-  // w[j] = -offd_j / diag >= 0: the Jacobi iteration matrix J = I - D^-1 A per adjacency entry (0 on ghost faces)
-  for (int j = ptr[c]; j < j1; ++j) {
-    const FaceRec fr = rec[j];
-    w[j] = (fr.nb >= 0) ? (fr.d - fmin((double)fr.a_c, 0.0)) / dg : 0.0;
+  if (staged) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < nent; i += BLOCK) { rec[jb + i] = s_rec[i]; w[jb + i] = s_w[i]; }
   }
 }
 
@@ -534,12 +566,13 @@ __global__ void __launch_bounds__(BLOCK) k_entry_w(int n_rows, const int32_t* __
 // accumulates into its own LDS row (strided: conflict-free) and writes the row out.  Same summation order as
 // k_build_sq (which stays for rows longer than SQN_MAXC): bitwise the same values.
 constexpr int SQN_THREADS = 128;
-constexpr int SQN_MAXC = 40;
+constexpr int SQN_MAXC = 40;            // longest J^2 row the row-wise kernel takes (MAXC = 16: the common case, 2.5 x the waves per CU)
+template <int MAXC>
 __global__ void __launch_bounds__(SQN_THREADS) k_sq_numeric(
     int n, const int32_t* __restrict__ ptr, const int32_t* __restrict__ ent_nb, const double* __restrict__ w,
     const int32_t* __restrict__ ptr2, const int32_t* __restrict__ col2, const int32_t* __restrict__ pair_ptr,
     const uint8_t* __restrict__ slots, FaceRec* __restrict__ rec2, double* __restrict__ w2) {
-  __shared__ double s_acc[SQN_THREADS * SQN_MAXC];
+  __shared__ double s_acc[SQN_THREADS * MAXC];
   const int c = blockIdx.x * SQN_THREADS + threadIdx.x;
   if (c >= n) return;
   double* acc = s_acc + threadIdx.x;
@@ -895,14 +928,14 @@ template <int VW>
 __global__ void __launch_bounds__(BLOCK) k_mass_flux(
     int E, int n_owned, int K, int G, const int32_t* __restrict__ f1, const int32_t* __restrict__ f2,
     const float* __restrict__ adv_t, const double* __restrict__ dif_t, double dt,
-    const double* __restrict__ c, double* __restrict__ fadv, double* __restrict__ fdif,
-    double* __restrict__ ftot) {
+    const double* __restrict__ c, const int32_t* __restrict__ face_orig, double* __restrict__ fadv,
+    double* __restrict__ fdif, double* __restrict__ ftot) {
   const int R = BLOCK / G;
   const int r = threadIdx.x / G, g = threadIdx.x - r * G;
   if (r >= R) return;
-  for (int e = blockIdx.x * R + r; e < E; e += gridDim.x * R) {
+  for (int e = blockIdx.x * R + r; e < E; e += gridDim.x * R) {   // e: internal face index (faces sorted along the cell order)
     const int P = f1[e], N = f2[e];
-    const size_t o = (size_t)e * K + g * VW;
+    const size_t o = (size_t)face_orig[e] * K + g * VW;           // the outputs keep the reference's face order
     double oa[VW], od[VW], ot[VW];
     if (P >= n_owned) {                 // face owned by another rank
 #pragma unroll
