@@ -75,6 +75,7 @@ struct cwr_engine {
   // static topology
   int32_t *d_f1 = nullptr, *d_f2 = nullptr, *d_ptr = nullptr, *d_ent_edge = nullptr, *d_ent_nb = nullptr;
   int32_t* d_face_orig = nullptr;          // internal face index -> reference face id (k_faces_in / k_faces_out)
+  uint8_t* d_row_ghost = nullptr;          // 1 where a computed row has a boundary (ghost) face
   std::vector<int32_t> h_face_pos;         // reference face id -> internal face index
   // flow field, all levels resident in HBM
   int T = 0, T_bc = 0;
@@ -298,7 +299,7 @@ int allreduce(cwr_engine* e, double* p, size_t count) {
 #define TRY(call) do { int _rc = (call); if (_rc != CWR_OK) return _rc; } while (0)
 
 int launch_rhs(cwr_engine* e, int t, const double* x, double* b, bool scale) {
-  const int grid = cdiv(e->n_owned, e->R);
+  const int grid = std::max(1, std::min(cdiv(e->n_owned, e->R), 256 * 16));
   const size_t E = e->E;
   const float* vol_t = e->d_vol + (size_t)t * e->n_cells;
   const float* vel_n = e->d_vel + (size_t)(t + 1) * E;
@@ -307,7 +308,7 @@ int launch_rhs(cwr_engine* e, int t, const double* x, double* b, bool scale) {
   const double* bc_n = e->d_bc + (size_t)(t + 1) * e->n_ghost * e->K;
   const int used = (e->D != 0.0) ? 1 : 0;
 #define CWR_RHS(VWv, SC) k_rhs<VWv, SC><<<grid, BLOCK, 0, e->stream>>>(e->n_owned, e->K, e->G, e->d_ptr, e->d_ent_edge, \
-    e->d_ent_nb, vol_t, e->dt[t], vel_n, adv_n, dif_n, used, bc_n, x, e->d_diag, b, e->d_counters)
+    e->d_ent_nb, vol_t, e->dt[t], vel_n, adv_n, dif_n, used, bc_n, x, e->d_diag, e->d_row_ghost, b, e->d_counters)
   if (e->VW == 2) { if (scale) CWR_RHS(2, true); else CWR_RHS(2, false); }
   else            { if (scale) CWR_RHS(1, true); else CWR_RHS(1, false); }
 #undef CWR_RHS
@@ -996,6 +997,13 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   CREATE_TRY(dev_alloc(eng, &eng->d_face_orig, (size_t)std::max(n_edges, 1)));
   CREATE_TRY(upload(eng, eng->d_face_orig, face_orig.data(), (size_t)n_edges));
   eng->h_face_pos = face_pos;
+  {
+    std::vector<uint8_t> row_ghost((size_t)n_owned, 0);
+    for (int c = 0; c < n_owned; ++c)
+      for (int j = cnt[c]; j < cnt[c + 1]; ++j) if (ent_nb[(size_t)j] < 0) row_ghost[(size_t)c] = 1;
+    CREATE_TRY(dev_alloc(eng, &eng->d_row_ghost, (size_t)n_owned));
+    CREATE_TRY(upload(eng, eng->d_row_ghost, row_ghost.data(), (size_t)n_owned));
+  }
   CREATE_TRY(upload(eng, eng->d_ptr, cnt.data(), (size_t)n_owned + 1));
   CREATE_TRY(upload(eng, eng->d_ent_edge, ent_edge.data(), (size_t)nnz));
   CREATE_TRY(upload(eng, eng->d_ent_nb, ent_nb.data(), (size_t)nnz));
@@ -1026,7 +1034,7 @@ void cwr_destroy(cwr_engine* e) {
   for (hipEvent_t ev : e->ev) hipEventDestroy(ev);
   void* ptrs[] = {e->d_f1, e->d_f2, e->d_ptr, e->d_ent_edge, e->d_ent_nb, e->d_adv, e->d_vel, e->d_vol, e->d_dif,
                   e->d_bc, e->d_rec, e->d_diag, e->d_c, e->d_r, e->d_r0, e->d_p, e->d_v, e->d_s, e->d_t, e->d_b,
-                  e->d_scal, e->d_counters, e->d_partial, e->d_fadv, e->d_fdif, e->d_ftot, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf, e->d_ptr2, e->d_col2, e->d_row2, e->d_rec2, e->d_w, e->d_react, e->d_info, e->d_tcl_ptr, e->d_tcl_cols, e->d_loc2, e->d_w2, e->d_pair_ptr, e->d_slots, e->d_line_ptr, e->d_line_faces, e->d_ledger, e->d_mass_out, e->d_chk, e->d_face_orig};
+                  e->d_scal, e->d_counters, e->d_partial, e->d_fadv, e->d_fdif, e->d_ftot, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf, e->d_ptr2, e->d_col2, e->d_row2, e->d_rec2, e->d_w, e->d_react, e->d_info, e->d_tcl_ptr, e->d_tcl_cols, e->d_loc2, e->d_w2, e->d_pair_ptr, e->d_slots, e->d_line_ptr, e->d_line_faces, e->d_ledger, e->d_mass_out, e->d_chk, e->d_face_orig, e->d_row_ghost};
   for (void* p : ptrs) if (p) hipFree(p);
   if (e->stream) hipStreamDestroy(e->stream);
   delete e;

@@ -304,20 +304,22 @@ __global__ void __launch_bounds__(BLOCK) k_rhs(
     const int32_t* __restrict__ ent_nb, const float* __restrict__ vol_t, double dt,
     const float* __restrict__ vel_n, const float* __restrict__ adv_n, const double* __restrict__ dif_n,
     int use_diffusion, const double* __restrict__ bc_n, const double* __restrict__ x,
-    const double* __restrict__ diag, double* __restrict__ b, int32_t* __restrict__ counters) {
+    const double* __restrict__ diag, const uint8_t* __restrict__ row_ghost, double* __restrict__ b,
+    int32_t* __restrict__ counters) {
   const int R = BLOCK / G;
   const int r = threadIdx.x / G, g = threadIdx.x - r * G;
   if (r >= R) return;
-  const int c = blockIdx.x * R + r;
-  if (c >= n_owned) return;
   const int col = g * VW;
+  for (int c = blockIdx.x * R + r; c < n_owned; c += gridDim.x * R) {      // grid-stride: a block works many row groups
   double xv[VW], gin[VW], gout[VW];
   bool bad = false;
   ldv<VW>(x + (size_t)c * K + col, xv);
 #pragma unroll
   for (int w = 0; w < VW; ++w) { gin[w] = 0.0; gout[w] = 0.0; }
-  const int j1 = ptr[c + 1];
-  for (int j = ptr[c]; j < j1; ++j) {
+  // only rows with a boundary (ghost) face walk their entries: for the others the two dependent loads (row pointer ->
+  // neighbour id) would be pure latency
+  const int j1 = row_ghost[c] ? ptr[c + 1] : 0;
+  for (int j = row_ghost[c] ? ptr[c] : 0; j < j1; ++j) {
     const int nb = ent_nb[j];
     if (nb >= 0) continue;
     const int e = ent_edge[j] >> 1;
@@ -348,6 +350,7 @@ __global__ void __launch_bounds__(BLOCK) k_rhs(
     if (bad) out[w] = __builtin_nan("");
   }
   stv<VW>(b + (size_t)c * K + col, out);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ the operator
