@@ -76,6 +76,7 @@ struct cwr_engine {
   int32_t *d_f1 = nullptr, *d_f2 = nullptr, *d_ptr = nullptr, *d_ent_edge = nullptr, *d_ent_nb = nullptr;
   int32_t* d_face_orig = nullptr;          // internal face index -> reference face id (k_faces_in / k_faces_out)
   uint8_t* d_row_ghost = nullptr;          // 1 where a computed row has a boundary (ghost) face
+  std::vector<int32_t> bad_level;          // per time level: the zero-coefficient precondition is violated (k_check_ghost_levels)
   std::vector<int32_t> h_face_pos;         // reference face id -> internal face index
   // flow field, all levels resident in HBM
   int T = 0, T_bc = 0;
@@ -369,6 +370,27 @@ int alloc_flow(cwr_engine* e, int T) {
   e->T = T;
   e->prepared_t = -1;
   return CWR_OK;
+}
+
+// flags of the reference's zero-coefficient ValueError for every loaded level (see k_check_ghost_levels)
+int check_ghost_levels(cwr_engine* e) {
+  const int T = e->T;
+  e->bad_level.assign((size_t)T, 0);
+  if (T <= 0 || e->E <= 0) return CWR_OK;
+  int32_t* d_flags = nullptr;
+  TRY(dev_alloc(e, &d_flags, (size_t)T));
+  int rc = CWR_OK;
+  if (hipMemsetAsync(d_flags, 0, (size_t)T * sizeof(int32_t), e->stream) != hipSuccess) rc = fail(e, CWR_ERR_HIP, "hipMemsetAsync failed");
+  if (rc == CWR_OK) {
+    const int64_t total = (int64_t)T * e->E;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(total, BLOCK), 256 * 16));
+    k_check_ghost_levels<<<grid, BLOCK, 0, e->stream>>>(total, e->E, e->n_owned, e->n_real, e->d_f1, e->d_f2, e->d_vel, e->d_adv,
+                                                       e->d_dif, e->D != 0.0 ? 1 : 0, d_flags);
+    if (hipGetLastError() != hipSuccess) rc = fail(e, CWR_ERR_HIP, "k_check_ghost_levels failed");
+  }
+  if (rc == CWR_OK) rc = download(e, e->bad_level.data(), d_flags, (size_t)T);
+  hipFree(d_flags);
+  return rc;
 }
 
 #define CWR_TCL_K(VWv, Q) k_sq_tiled<VWv, TCL_CFG[Q].wrn, TCL_CFG[Q].ut, TCL_CFG[Q].xr>
@@ -1072,7 +1094,7 @@ int32_t cwr_load_flow_field(cwr_engine* e, int32_t T, const float* face_flow, co
   if (rc != CWR_OK) { e->T = 0; return rc; }
   e->dt.assign(dt, dt + T);
   e->D = D;
-  return CWR_OK;
+  return check_ghost_levels(e);
 }
 
 int32_t cwr_load_coefficients(cwr_engine* e, int32_t T, const float* adv, const double* dif, const float* vel,
@@ -1099,7 +1121,7 @@ int32_t cwr_load_coefficients(cwr_engine* e, int32_t T, const float* adv, const 
   TRY(upload(e, e->d_vol, volume, (size_t)T * e->n_cells));
   e->dt.assign(dt, dt + T);
   e->D = D;
-  return CWR_OK;
+  return check_ghost_levels(e);
 }
 
 int32_t cwr_get_coefficients(cwr_engine* e, int32_t t, float* adv, double* dif) {
@@ -1230,6 +1252,12 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
   e->ev_used = 0;
   e->flux_valid = false;
 
+  // one GPU: the zero-coefficient precondition of level t+1 is known from the flow field (check_ghost_levels): stop before
+  // anything touches the state, without a device round trip.  Partitioned runs keep going instead -- the violating
+  // rank's right-hand side is NaN-poisoned by k_rhs, so every rank leaves the solve together (no rank is left in a collective)
+  if (!e->comm && (size_t)(t + 1) < e->bad_level.size() && e->bad_level[(size_t)t + 1])
+    return fail(e, CWR_ERR_GHOST_COEFF, "active ghost face with a zero advection/diffusion coefficient at level t+1 "
+                "(the reference raises a shape-mismatch ValueError, linalg.py:349-351)");
   TRY(prep_step(e, t));
   HIP_TRY(e, hipMemsetAsync(e->d_counters, 0, 8 * sizeof(int32_t), e->stream));
   HIP_TRY(e, hipMemsetAsync(e->d_scal, 0, e->scal_count() * sizeof(double), e->stream));
@@ -1239,15 +1267,6 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
   if (!e->halo_fresh) TRY(exchange_halo(e, e->d_c));
   e->halo_fresh = false;
   TRY(launch_rhs(e, t, e->d_c, e->d_b, true));
-  if (!e->comm) {
-    // one GPU: stop before the solve touches the state.  Partitioned runs keep going instead -- the violating
-    // rank's right-hand side is NaN-poisoned, so every rank leaves the solve together (no rank is left in a collective)
-    int32_t h_cnt[8];
-    TRY(download(e, h_cnt, e->d_counters, (size_t)8));
-    if (h_cnt[2]) return fail(e, CWR_ERR_GHOST_COEFF, "active ghost face with a zero advection/diffusion coefficient at level t+1 "
-                              "(the reference raises a shape-mismatch ValueError, linalg.py:349-351)");
-  }
-
   SolveStats st;
   int rc_solve = CWR_OK;
   const bool force_bicg = (flags & CWR_STEP_FORCE_BICGSTAB) != 0;
@@ -1269,7 +1288,7 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
   const int status = st.status;
   const int total_it = st.iterations + st.sweeps;
   const double max_rel = st.max_rel;
-  {
+  if (e->comm) {                                                           // (one GPU: checked before the step began)
     int32_t h_cnt[8];
     TRY(download(e, h_cnt, e->d_counters, (size_t)8));
     if (h_cnt[2]) st.status = CWR_ERR_GHOST_COEFF;                         // takes precedence over the NaN it caused

@@ -294,6 +294,24 @@ __global__ void __launch_bounds__(BLOCK) k_prep_step(
   }
 }
 
+// The reference's zero-coefficient ValueError (linalg.py:349-351) depends on the flow field only: flags[t] = 1 when
+// level t has an active ghost face (edge_velocity != 0) of a computed row whose advection coefficient (inflow) or
+// diffusion coefficient (either direction, D != 0) is exactly 0 -- the condition k_rhs tests at level t+1 of a step.
+// Evaluated once per loaded flow field, so a single-GPU step needs no device round trip to raise the error.
+__global__ void __launch_bounds__(BLOCK) k_check_ghost_levels(
+    int64_t total, int E, int n_owned, int n_real, const int32_t* __restrict__ f1, const int32_t* __restrict__ f2,
+    const float* __restrict__ vel, const float* __restrict__ adv, const double* __restrict__ dif, int use_diffusion,
+    int32_t* __restrict__ flags) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * BLOCK) {
+    const int64_t t = i / E; const int e = (int)(i - t * E);
+    if (f2[e] < n_real || f1[e] >= n_owned) continue;
+    const float v = vel[i];
+    if (!(v < 0.0f) && !(v > 0.0f)) continue;
+    const bool d0 = use_diffusion && fabs(dif[i]) == 0.0;
+    if (v < 0.0f ? (fabs((double)adv[i]) == 0.0 || d0) : d0) flags[t] = 1;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ a-3
 // b[c,k] = V[t,c]*x[c,k]/dt + G_in[c,k] + G_out[c,k]; boundary terms from level t+1, selected by the
 // sign of edge_velocity[t+1]; the highest active ghost-face id of a cell wins in each set
