@@ -93,6 +93,8 @@ struct cwr_engine {
   double *d_c = nullptr, *d_r = nullptr, *d_r0 = nullptr, *d_p = nullptr, *d_v = nullptr, *d_s = nullptr,
          *d_t = nullptr, *d_b = nullptr;
   double* d_chk = nullptr;       // [2][K] convergence-check scalars of the Jacobi path
+  bool tail_done = false;        // the step's tail (step_tail) was enqueued speculatively and the check then passed
+  int spec_t = -1, spec_flags = 0; // >= 0: solve_jacobi may enqueue step_tail(spec_t, spec_flags) before its check download
   bool halo_fresh = false;       // the halo rows of the state hold their owners' current values (set by the end-of-step
                                  // exchange of a CWR_STEP_MASS_FLUX step, cleared by anything that may change the state)
   double* d_react = nullptr;     // K x K reaction matrix of cwr_react_linear
@@ -596,6 +598,36 @@ int launch_sq_tiled(cwr_engine* e, const double* xin, double* yout) {
   return CWR_OK;
 }
 
+// What follows the solve of step t: ghost write-back (transport.py:258-264) and, on request, the per-face mass fluxes
+// (transport.py:406-429).  On one GPU the Jacobi path enqueues it SPECULATIVELY right behind the batch whose convergence
+// check is about to be downloaded: when the check passes (the steady state: one check per step) the GPU went straight on
+// instead of idling through the host round trip; when it fails, more sweeps follow and the tail simply runs again
+// (it only writes ghost rows, which no sweep reads, and the flux arrays).
+int step_tail(cwr_engine* e, int t, int flags) {
+  const int K = e->K;
+  const int64_t gk = (int64_t)e->n_ghost * K;
+  if (gk > 0) {
+    k_ghost_writeback<<<cdiv(gk, BLOCK), BLOCK, 0, e->stream>>>(gk, e->d_bc + (size_t)(t + 1) * gk, e->d_c + (size_t)e->n_real * K);
+    HIP_TRY(e, hipGetLastError());
+  }
+  if (flags & CWR_STEP_MASS_FLUX) {
+    TRY(exchange_halo(e, e->d_c));
+    if (!e->d_fadv) {
+      const size_t cnt = (size_t)e->E * K;
+      TRY(dev_alloc(e, &e->d_fadv, cnt)); TRY(dev_alloc(e, &e->d_fdif, cnt)); TRY(dev_alloc(e, &e->d_ftot, cnt));
+    }
+    const int grid = std::max(1, std::min(cdiv(e->E, e->R), 256 * 8));
+    const float* adv_t = e->d_adv + (size_t)t * e->E;
+    const double* dif_t = e->d_dif + (size_t)t * e->E;
+    if (e->VW == 2) k_mass_flux<2><<<grid, BLOCK, 0, e->stream>>>(e->E, e->n_core, K, e->G, e->d_f1, e->d_f2, adv_t, dif_t, e->dt[t], e->d_c, e->d_face_orig, e->d_fadv, e->d_fdif, e->d_ftot);
+    else            k_mass_flux<1><<<grid, BLOCK, 0, e->stream>>>(e->E, e->n_core, K, e->G, e->d_f1, e->d_f2, adv_t, dif_t, e->dt[t], e->d_c, e->d_face_orig, e->d_fadv, e->d_fdif, e->d_ftot);
+    HIP_TRY(e, hipGetLastError());
+    e->flux_valid = true;
+    e->halo_fresh = true;
+  }
+  return CWR_OK;
+}
+
 struct SolveStats {
   int iterations = 0, sweeps = 0, restarts = 0, launches = 0, status = CWR_OK, sweep_kernel = 0;
   double max_rel = 0.0;
@@ -710,6 +742,8 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
     }
     st.sweeps += batch; st.launches += launches;
     TRY(reduce_partials(e, e->last_apply_grid, 2, d_rr, d_bb));
+    bool speculated = false;
+    if (e->spec_t >= 0 && !e->comm) { TRY(step_tail(e, e->spec_t, e->spec_flags)); speculated = true; }
     TRY(allreduce(e, d_rr, 2 * (size_t)K));
     TRY(download(e, h.data(), d_rr, 2 * (size_t)K));
     bool ok = true;
@@ -729,6 +763,7 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
       if (worst > 0.0 && worst < 1.0 && e->last_rate > 0.0 && e->last_rate < 1.0)
         extra = (int)std::floor(0.5 * std::log(1.0 / worst) / -std::log(e->last_rate));
       e->last_sweeps = std::max(2, st.sweeps - extra);
+      e->tail_done = speculated;
       return CWR_OK;
     }
     if (st.sweeps >= sweep_limit) {
@@ -1251,6 +1286,7 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
   }
   e->ev_used = 0;
   e->flux_valid = false;
+  e->tail_done = false;
 
   // one GPU: the zero-coefficient precondition of level t+1 is known from the flow field (check_ghost_levels): stop before
   // anything touches the state, without a device round trip.  Partitioned runs keep going instead -- the violating
@@ -1277,7 +1313,9 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
     rc_solve = solve_small(e, tol2, max_iter, force_jac, st, handled, need_bicg);
     if (rc_solve != CWR_OK && st.status == CWR_OK) return rc_solve;
     if (!handled) {
+      e->spec_t = (!e->comm && !e->profiling) ? t : -1; e->spec_flags = flags;
       rc_solve = solve_jacobi(e, tol2, max_iter, force_jac, st, need_bicg);
+      e->spec_t = -1;
       if (rc_solve != CWR_OK && st.status == CWR_OK) return rc_solve;     // HIP / RCCL failure
     }
   }
@@ -1300,6 +1338,7 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
   local.solver = (st.iterations == 0 && !force_bicg) ? 0 : (st.sweeps == 0 ? 1 : 2);
   local.sweep_kernel = st.sweep_kernel;
   if (st.status != CWR_OK) {
+    e->flux_valid = false; e->halo_fresh = false; e->tail_done = false;   // (a speculative tail may have run)
     if (info) *info = local;
     switch (st.status) {
       case CWR_ERR_GHOST_COEFF: return fail(e, st.status, "active ghost face with a zero advection/diffusion coefficient at level t+1 "
@@ -1315,27 +1354,8 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
   }
   (void)status; (void)total_it;
 
-  // write-back: real cells are already in place (x lives in the state vector); ghost rows from input_array[t+1]
-  const int64_t gk = (int64_t)e->n_ghost * K;
-  if (gk > 0) {
-    k_ghost_writeback<<<cdiv(gk, BLOCK), BLOCK, 0, e->stream>>>(gk, e->d_bc + (size_t)(t + 1) * gk, e->d_c + (size_t)e->n_real * K);
-    HIP_TRY(e, hipGetLastError());
-  }
-  if (flags & CWR_STEP_MASS_FLUX) {
-    TRY(exchange_halo(e, e->d_c));
-    if (!e->d_fadv) {
-      const size_t cnt = (size_t)e->E * K;
-      TRY(dev_alloc(e, &e->d_fadv, cnt)); TRY(dev_alloc(e, &e->d_fdif, cnt)); TRY(dev_alloc(e, &e->d_ftot, cnt));
-    }
-    const int grid = std::max(1, std::min(cdiv(e->E, e->R), 256 * 8));
-    const float* adv_t = e->d_adv + (size_t)t * e->E;
-    const double* dif_t = e->d_dif + (size_t)t * e->E;
-    if (e->VW == 2) k_mass_flux<2><<<grid, BLOCK, 0, e->stream>>>(e->E, e->n_core, K, e->G, e->d_f1, e->d_f2, adv_t, dif_t, e->dt[t], e->d_c, e->d_face_orig, e->d_fadv, e->d_fdif, e->d_ftot);
-    else            k_mass_flux<1><<<grid, BLOCK, 0, e->stream>>>(e->E, e->n_core, K, e->G, e->d_f1, e->d_f2, adv_t, dif_t, e->dt[t], e->d_c, e->d_face_orig, e->d_fadv, e->d_fdif, e->d_ftot);
-    HIP_TRY(e, hipGetLastError());
-    e->flux_valid = true;
-    e->halo_fresh = true;
-  }
+  if (!e->tail_done) TRY(step_tail(e, t, flags));
+  e->tail_done = false;
   if (flags & CWR_STEP_MASS_BALANCE) {
     if (e->n_lines <= 0) return fail(e, CWR_ERR_STATE, "cwr_step: CWR_STEP_MASS_BALANCE without cwr_set_boundary_lines");
     k_line_mass<<<e->n_lines, BLOCK, 0, e->stream>>>(K, e->n_core, e->d_line_ptr, e->d_line_faces, e->d_f1, e->d_f2,
