@@ -1362,7 +1362,8 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
         e->d_adv + (size_t)t * e->E, e->d_dif + (size_t)t * e->E, e->dt[t], e->d_c, e->d_ledger);
     HIP_TRY(e, hipGetLastError());
   }
-  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  // no synchronisation here: convergence is known, and the tail kernels are ordered on the engine's stream before
+  // everything a later call does (read-outs synchronise themselves), so the host can already enqueue the next step
   local.solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
   if (info) *info = local;
   return CWR_OK;

@@ -149,7 +149,10 @@ int32_t cwr_rhs(cwr_engine* e, int32_t t, const double* x_t, double* b);
  * Jacobi-scaled BiCGSTAB; the K systems share A), write-back of the real cells and of the ghost cells,
  * optional mass flux.  State advances from level t to t+1.
  * tol: target for ||D^-1 (b - A x)||_2 / ||D^-1 b||_2 per constituent (e.g. 1e-12); max_iter bounds
- * sweeps and BiCGSTAB iterations each.  info may be NULL. */
+ * sweeps and BiCGSTAB iterations each.  info may be NULL.
+ * The call returns as soon as convergence is known: the ghost write-back and flux kernels that close the step may still
+ * be running on the engine's stream.  Every read-out (cwr_get_state, cwr_get_mass_flux, ...), every later step and
+ * cwr_synchronize are ordered behind them; cwr_step_info.solve_ms is the time until convergence was known. */
 int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t flags,
                  cwr_step_info* info);
 /* The three (n_edges, K) arrays of the last step taken with CWR_STEP_MASS_FLUX
