@@ -403,7 +403,7 @@ const void* tcl_kernel(int vw, int cfg) {
 }
 
 // Symbolic J^2 (once): row c of J^2 has the columns reachable in two face steps.  Numeric values per step on
-// the device (k_entry_w, k_build_sq), then c2 = bhat + J bhat with one plain sweep of bhat.
+// the device (k_sq_numeric; k_build_sq for very long rows), then c2 = bhat + J bhat with one plain sweep of bhat.
 int ensure_sq_pattern(cwr_engine* e) {
   if (e->sq_pattern || e->sq_failed) return CWR_OK;
   // rows with a J^2 row: the longest prefix of computed rows all of whose real neighbours have rows of their own

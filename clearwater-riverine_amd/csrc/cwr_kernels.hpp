@@ -570,18 +570,7 @@ __global__ void __launch_bounds__(BLOCK) k_scatter_faces(int E, int n_owned, int
 }
 
 // ------------------------------------------------------------------------------------------------ squared operator
-// w[j] = -offd_j / diag[row] >= 0: the Jacobi iteration matrix J = I - D^-1 A per adjacency entry (0 on ghost faces).
-__global__ void __launch_bounds__(BLOCK) k_entry_w(int n_rows, const int32_t* __restrict__ ptr, const FaceRec* __restrict__ rec,
-                                                 const double* __restrict__ diag, double* __restrict__ w) {
-  const int c = blockIdx.x * BLOCK + threadIdx.x;
-  if (c >= n_rows) return;
-  const double dg = diag[c];
-  const int j1 = ptr[c + 1];
-  for (int j = ptr[c]; j < j1; ++j) {
-    const FaceRec fr = rec[j];
-    w[j] = (fr.nb >= 0) ? (fr.d - fmin((double)fr.a_c, 0.0)) / dg : 0.0;
-  }
-}
+// (the Jacobi weights w[j] = -offd_j / diag[row] >= 0 of J = I - D^-1 A are written by k_prep_step)
 // Numeric J^2, row-wise: one thread per row c.  The host lists, for every product J[c,m] J[m,k] in the order (faces of
 // c ascending, then faces of m ascending; ghost faces skipped), the slot of column k in row c of J^2; the thread
 // accumulates into its own LDS row (strided: conflict-free) and writes the row out.  Same summation order as
