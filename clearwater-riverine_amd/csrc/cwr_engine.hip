@@ -200,6 +200,14 @@ template <typename T> int dev_alloc(cwr_engine* e, T** p, size_t count) {
   HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(count, 1) * sizeof(T)));
   return CWR_OK;
 }
+// device temporary of a call: freed on every way out
+template <typename T> struct DevTmp {
+  T* p = nullptr;
+  ~DevTmp() { if (p) hipFree(p); }
+  DevTmp() = default;
+  DevTmp(const DevTmp&) = delete;
+  DevTmp& operator=(const DevTmp&) = delete;
+};
 template <typename T> int upload(cwr_engine* e, T* dst, const T* src, size_t count) {
   if (count == 0) return CWR_OK;
   HIP_TRY(e, hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyHostToDevice, e->stream));
@@ -379,8 +387,9 @@ int check_ghost_levels(cwr_engine* e) {
   const int T = e->T;
   e->bad_level.assign((size_t)T, 0);
   if (T <= 0 || e->E <= 0) return CWR_OK;
-  int32_t* d_flags = nullptr;
-  TRY(dev_alloc(e, &d_flags, (size_t)T));
+  DevTmp<int32_t> t_flags;
+  TRY(dev_alloc(e, &t_flags.p, (size_t)T));
+  int32_t* d_flags = t_flags.p;
   int rc = CWR_OK;
   if (hipMemsetAsync(d_flags, 0, (size_t)T * sizeof(int32_t), e->stream) != hipSuccess) rc = fail(e, CWR_ERR_HIP, "hipMemsetAsync failed");
   if (rc == CWR_OK) {
@@ -391,7 +400,6 @@ int check_ghost_levels(cwr_engine* e) {
     if (hipGetLastError() != hipSuccess) rc = fail(e, CWR_ERR_HIP, "k_check_ghost_levels failed");
   }
   if (rc == CWR_OK) rc = download(e, e->bad_level.data(), d_flags, (size_t)T);
-  hipFree(d_flags);
   return rc;
 }
 
@@ -1108,11 +1116,12 @@ int32_t cwr_load_flow_field(cwr_engine* e, int32_t T, const float* face_flow, co
   TRY(alloc_flow(e, T));
   const size_t TE = (size_t)T * e->E;
   // the host arrays arrive in the reference's face order: upload to temporaries, gather into the internal face order
-  float *d_flow = nullptr, *d_tmpf = nullptr; double *d_dist = nullptr, *d_tmpd = nullptr;
-  TRY(dev_alloc(e, &d_flow, TE));
-  TRY(dev_alloc(e, &d_tmpf, TE));
-  TRY(dev_alloc(e, &d_dist, (size_t)e->E));
-  TRY(dev_alloc(e, &d_tmpd, (size_t)e->E));
+  DevTmp<float> t_flow, t_tmpf; DevTmp<double> t_dist, t_tmpd;
+  TRY(dev_alloc(e, &t_flow.p, TE));
+  TRY(dev_alloc(e, &t_tmpf.p, TE));
+  TRY(dev_alloc(e, &t_dist.p, (size_t)e->E));
+  TRY(dev_alloc(e, &t_tmpd.p, (size_t)e->E));
+  float *d_flow = t_flow.p, *d_tmpf = t_tmpf.p; double *d_dist = t_dist.p, *d_tmpd = t_tmpd.p;
   const int gridTE = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv((int64_t)TE, BLOCK), 256 * 16));
   int rc = upload(e, d_tmpf, face_flow, TE);
   if (rc == CWR_OK && TE > 0) k_faces_in<float><<<gridTE, BLOCK, 0, e->stream>>>((int64_t)TE, e->E, e->d_face_orig, d_tmpf, d_flow);
@@ -1126,8 +1135,6 @@ int32_t cwr_load_flow_field(cwr_engine* e, int32_t T, const float* face_flow, co
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess)
       rc = fail(e, CWR_ERR_HIP, "k_derive_coeff failed");
   }
-  hipFree(d_tmpf); hipFree(d_tmpd);
-  hipFree(d_flow); hipFree(d_dist);
   if (rc != CWR_OK) { e->T = 0; return rc; }
   e->dt.assign(dt, dt + T);
   e->D = D;
@@ -1142,9 +1149,10 @@ int32_t cwr_load_coefficients(cwr_engine* e, int32_t T, const float* adv, const 
   HIP_TRY(e, hipSetDevice(e->dev));
   TRY(alloc_flow(e, T));
   const size_t TE = (size_t)T * e->E;
-  float* d_tmpf = nullptr; double* d_tmpd = nullptr;               // reference face order -> internal face order
-  TRY(dev_alloc(e, &d_tmpf, TE));
-  TRY(dev_alloc(e, &d_tmpd, TE));
+  DevTmp<float> t_tmpf; DevTmp<double> t_tmpd;                     // reference face order -> internal face order
+  TRY(dev_alloc(e, &t_tmpf.p, TE));
+  TRY(dev_alloc(e, &t_tmpd.p, TE));
+  float* d_tmpf = t_tmpf.p; double* d_tmpd = t_tmpd.p;
   const int gridTE = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv((int64_t)TE, BLOCK), 256 * 16));
   int rc = upload(e, d_tmpf, adv, TE);
   if (rc == CWR_OK) k_faces_in<float><<<gridTE, BLOCK, 0, e->stream>>>((int64_t)TE, e->E, e->d_face_orig, d_tmpf, e->d_adv);
@@ -1153,7 +1161,6 @@ int32_t cwr_load_coefficients(cwr_engine* e, int32_t T, const float* adv, const 
   if (rc == CWR_OK) rc = upload(e, d_tmpd, dif, TE);
   if (rc == CWR_OK) k_faces_in<double><<<gridTE, BLOCK, 0, e->stream>>>((int64_t)TE, e->E, e->d_face_orig, d_tmpd, e->d_dif);
   if (rc == CWR_OK && (hipGetLastError() != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess)) rc = fail(e, CWR_ERR_HIP, "k_faces_in failed");
-  hipFree(d_tmpf); hipFree(d_tmpd);
   if (rc != CWR_OK) { e->T = 0; return rc; }
   TRY(upload(e, e->d_vol, volume, (size_t)T * e->n_cells));
   e->dt.assign(dt, dt + T);
@@ -1165,7 +1172,8 @@ int32_t cwr_get_coefficients(cwr_engine* e, int32_t t, float* adv, double* dif) 
   if (!e) return CWR_ERR_BAD_ARG;
   TRY(check_level(e, t, false));
   HIP_TRY(e, hipSetDevice(e->dev));
-  float* d_tmpf = nullptr; double* d_tmpd = nullptr;               // internal face order -> reference face order
+  DevTmp<float> t_tmpf; DevTmp<double> t_tmpd;                     // internal face order -> reference face order
+  float*& d_tmpf = t_tmpf.p; double*& d_tmpd = t_tmpd.p;
   int rc = CWR_OK;
   if (adv) {
     rc = dev_alloc(e, &d_tmpf, (size_t)std::max(e->E, 1));
@@ -1177,7 +1185,6 @@ int32_t cwr_get_coefficients(cwr_engine* e, int32_t t, float* adv, double* dif) 
     if (rc == CWR_OK) { k_faces_out<double><<<cdiv(std::max(e->E, 1), BLOCK), BLOCK, 0, e->stream>>>(e->E, e->d_face_orig, e->d_dif + (size_t)t * e->E, d_tmpd);
                         rc = download(e, dif, d_tmpd, (size_t)e->E); }
   }
-  hipFree(d_tmpf); hipFree(d_tmpd);
   return rc;
 }
 
