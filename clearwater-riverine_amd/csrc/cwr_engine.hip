@@ -294,8 +294,7 @@ int exchange_halo(cwr_engine* e, double* vec, double* vec2 = nullptr) {
   NCCL_TRY(e, g_rccl.GroupEnd());
   const int64_t rtotal = (int64_t)e->n_recv * e->K;
   if (rtotal > 0) {
-    k_unpack_rows<<<cdiv(rtotal, BLOCK), BLOCK, 0, e->stream>>>(rtotal, e->K, e->d_recv_cells, e->d_recvbuf, vec);
-    if (vec2) k_unpack_rows<<<cdiv(rtotal, BLOCK), BLOCK, 0, e->stream>>>(rtotal, e->K, e->d_recv_cells, e->d_recvbuf, vec2);
+    k_unpack_rows<<<cdiv(rtotal, BLOCK), BLOCK, 0, e->stream>>>(rtotal, e->K, e->d_recv_cells, e->d_recvbuf, vec, vec2);
     HIP_TRY(e, hipGetLastError());
   }
   return CWR_OK;

@@ -1213,13 +1213,18 @@ __global__ void __launch_bounds__(BLOCK) k_pack_rows(int64_t total, int K, const
   buf[i] = vec[(size_t)cells[row] * K + k];
 }
 
+// vec2 (optional): the ping-pong partner of vec receives the same rows
 __global__ void __launch_bounds__(BLOCK) k_unpack_rows(int64_t total, int K, const int32_t* __restrict__ cells,
-                                                     const double* __restrict__ buf, double* __restrict__ vec) {
+                                                     const double* __restrict__ buf, double* __restrict__ vec,
+                                                     double* __restrict__ vec2) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= total) return;
   const int64_t row = i / K;
   const int k = (int)(i - row * K);
-  vec[(size_t)cells[row] * K + k] = buf[i];
+  const size_t o = (size_t)cells[row] * K + k;
+  const double v = buf[i];
+  vec[o] = v;
+  if (vec2) vec2[o] = v;
 }
 
 }  // namespace cwr
