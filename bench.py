@@ -64,7 +64,8 @@ def main():
     ap.add_argument('--solver', default='auto', choices=['auto', 'jacobi', 'bicgstab'])
     ap.add_argument('--renumber', default='hilbert', choices=['hilbert', 'none'],
                     help='internal cell numbering (reference ids stay at the boundary)')
-    ap.add_argument('--halo-depth', type=int, default=8, help='N > 1: halo layers = Jacobi sweeps between two exchanges')
+    ap.add_argument('--halo-depth', type=int, default=0,
+                    help='N > 1: halo layers = Jacobi sweeps between two exchanges (0: from the per-rank size, distributed.auto_halo_depth)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-nx', type=int, default=640)
     ap.add_argument('--cpu-sample-steps', type=int, default=3)

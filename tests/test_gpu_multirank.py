@@ -142,7 +142,7 @@ def test_partitioned_step_matches_single_rank_and_oracle(gpu_lib, world, K, solv
     assert rel_err(tot, want_flux) <= 1e-8
 
 
-@pytest.mark.parametrize('world,K,depth', [(2, 4, 8), (4, 16, 8), (3, 1, 6)])
+@pytest.mark.parametrize('world,K,depth', [(2, 4, 8), (4, 16, 8), (3, 1, 6), (2, 16, 14), (4, 4, 16)])
 def test_partitioned_block_asynchronous_passes_keep_the_single_rank_sweep_count(gpu_lib, world, K, depth, monkeypatch):
     """Deep halos + tile-local re-application: the replayed layers (tiled like the core) and the never-computed outer
     layers of BOTH ping-pong vectors must hold this exchange's values, otherwise old iterates leak into the core and

@@ -29,7 +29,7 @@ def local_oracle_mesh(mesh, lm):
     }
 
 
-@pytest.mark.parametrize('depth', [1, 2, 4])
+@pytest.mark.parametrize('depth', [1, 2, 4, 12])
 @pytest.mark.parametrize('world', [1, 2, 3, 4, 8])
 def test_partition_invariants_and_local_operator(world, depth):
     from clearwater_riverine_amd.partition import partition_mesh, range_bounds
@@ -205,3 +205,11 @@ def test_halo_exchange_world_size_2_gloo():
         if p.is_alive():
             p.terminate()
     assert list(ok) == [1] * world
+
+
+def test_auto_halo_depth_tracks_the_per_rank_size():
+    from clearwater_riverine_amd.distributed import auto_halo_depth
+    assert auto_halo_depth(1_000_000, 1) == 1
+    assert [auto_halo_depth(1_000_000, w) for w in (2, 4, 8)] == [16, 16, 14]
+    assert auto_halo_depth(10_000, 4) == 8 and auto_halo_depth(64_000_000, 8) == 16
+    assert all(auto_halo_depth(n, w) % 2 == 0 for n in (5_000, 123_456, 9_999_999) for w in (2, 3, 8))
