@@ -129,7 +129,11 @@ struct cwr_engine {
   bool profiling = false;
   int64_t prof_launches = 0;
   double prof_us = 0.0;
-  int last_iters = 0, last_sweeps = 0, jacobi_limit = 400;
+  // jacobi_limit: predicted sweeps beyond which a step is handed to BiCGSTAB.  Effectively off by default: measured on
+  // 160x40 ... 1000x1000-cell meshes from CFL 2.5 to the steady-state limit (dt = 20 000 s), the block-asynchronous passes
+  // need 60-900 sweep equivalents and beat BiCGSTAB (120-2000 iterations of ~4.7 sweeps' traffic each) by 10-20 x
+  // (scratch/stiff_probe.py); BiCGSTAB stays as the fallback for a stalled or exhausted (max_iter) sweep phase.
+  int last_iters = 0, last_sweeps = 0, jacobi_limit = 1 << 30;
   double last_rate = 0.0;       // contraction per sweep measured in the previous step (first-check prediction)
   // a batch of fused sweeps captured once as a hipGraph (kernel arguments never change between steps: only the
   // contents of the buffers do), replayed to keep small meshes from being host-launch-bound
@@ -668,7 +672,7 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
   e->dominant_mode = tiled ? 6 : (sq ? 5 : 4);
   st.sweep_kernel = e->dominant_mode;
   for (;;) {
-    batch = std::max(2, std::min(batch, 128)) & ~1;                    // even: the result lands in the state vector
+    batch = std::max(2, std::min(batch, 4096)) & ~1;                   // even: the result lands in the state vector
     int launches = batch;
     int todo = batch;
     if (sq) {
@@ -773,8 +777,8 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
       e->tail_done = speculated;
       return CWR_OK;
     }
-    if (st.sweeps >= sweep_limit) {
-      if (forced || sweep_limit >= max_iter) { st.status = CWR_ERR_NOT_CONVERGED; return CWR_ERR_NOT_CONVERGED; }
+    if (st.sweeps >= sweep_limit) {                                       // max_iter bounds the sweeps and the BiCGSTAB iterations each
+      if (forced) { st.status = CWR_ERR_NOT_CONVERGED; return CWR_ERR_NOT_CONVERGED; }
       need_bicg = true; e->last_sweeps = 0; return CWR_OK;
     }
     // contraction per sweep from the last two checks (worst is a squared, normalised residual)
