@@ -210,7 +210,7 @@ def main():
                        'cells': n, 'faces': int(len(mesh['edges_face1'])), 'constituents': K,
                        'numbering': args.renumber, 'partition': f'contiguous cell ranges x{world}' + (f', halo depth {pt.local.depth}' if world > 1 else ''),
                        'tol': args.tol},
-            'solver': {'method': 'fused Jacobi sweeps, BiCGSTAB on stiff steps; K systems batched', 'iterations_per_step': iters,
+            'solver': {'method': 'block-asynchronous J^2 passes of fused Jacobi sweeps (BiCGSTAB fallback); K systems batched', 'iterations_per_step': iters,
                        'max_rel_residual': max_resid},
             'roofline': roofline, 'cpu_baseline': cpu,
         }
