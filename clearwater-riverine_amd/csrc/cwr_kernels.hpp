@@ -725,7 +725,12 @@ __global__ void __launch_bounds__(BLOCK) k_sq_tiled(
     const int c0 = t * TR, c1 = min(c0 + TR, n_rows);
     const int jb = ptr2[c0], je = ptr2[c1];
 #pragma unroll
-    for (int u = 0; u < WRN; ++u) { const int j = jb + tid + u * BLOCK; if (j < je) { wr[u] = w2[j]; lr[u] = loc2[j]; } }
+    for (int u = 0; u < WRN; ++u) { const int j = jb + tid + u * BLOCK; if (j < je) {
+      // wide rows (the four-wide mapping): the entry stream bypasses cache retention so that the gathered x rows keep the L2
+      // (97 vs 103 us per pass at K = 16); narrow rows lose from it (32 vs 26 us at K = 1: the entries ARE their traffic)
+      if constexpr (VW == 4) { wr[u] = __builtin_nontemporal_load(w2 + j); lr[u] = __builtin_nontemporal_load(loc2 + j); }
+      else { wr[u] = w2[j]; lr[u] = loc2[j]; }
+    } }
     if (tid < c1 - c0) pr = ptr2[c0 + tid];         // raw: rebased when it is stored to LDS (a subtraction here would wait
                                                     // for this load, and with it for every prefetch issued before it)
     if (rowlane) {
