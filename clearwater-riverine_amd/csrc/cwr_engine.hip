@@ -497,9 +497,15 @@ int ensure_sq_pattern(cwr_engine* e) {
     if (attempt == 1 && (!e->comm || e->n_core == n)) break;
     int tr_target = 64;
     if (const char* v = getenv("CWR_TCL_ROWS")) tr_target = std::max(1, atoi(v));
+    // wide rows: four constituents per lane halve the lanes that re-read every (weight, index) pair from LDS
+    bool want4 = (e->K % 4 == 0) && e->K >= 12;
+    if (const char* v = getenv("CWR_TCL_VW")) want4 = atoi(v) == 4 && (e->K % 4 == 0);
+    const int R4 = want4 ? BLOCK / (e->K / 4) : 0;
+    const int Rt = want4 ? R4 : e->R;                            // rows one pass of the compute mapping covers
     int tr = tr_target;
-    while (tr > e->R && (tr % e->R) != 0) --tr;
-    tr = std::max(tr, e->R);
+    while (tr > Rt && (tr % Rt) != 0) --tr;
+    tr = std::max(tr, Rt);
+    if (want4) tr = Rt;                                          // (the four-wide configuration holds one row per lane group)
     const int nt = cdiv(n_t, tr);
     std::vector<int32_t> tptr((size_t)nt + 1, 0), tcols;
     std::vector<uint16_t> loc2((size_t)e->nnz2, 0);
@@ -526,10 +532,6 @@ int ensure_sq_pattern(cwr_engine* e) {
     e->tcl_cfg = -1;
     int q0 = 0;
     if (const char* v = getenv("CWR_TCL_CFG")) q0 = std::max(0, std::min(2, atoi(v)));
-    // wide rows: four constituents per lane halve the lanes that re-read every (weight, index) pair from LDS
-    bool want4 = (e->K % 16 == 0);
-    if (const char* v = getenv("CWR_TCL_VW")) want4 = atoi(v) == 4 && (e->K % 16 == 0);
-    const int R4 = want4 ? BLOCK / (e->K / 4) : 0;
     e->tcl_vw = e->VW;
     // (fetch mapping: K/2 lanes per row; compute mapping: K/4 lanes per row)
     if (want4 && max_cols <= TCL_CFG[3].xr * (BLOCK / (e->K / 2)) && cap2 <= TCL_CFG[3].wrn * BLOCK && tr <= TCL_CFG[3].ut * R4) { e->tcl_cfg = 3; e->tcl_vw = 4; }

@@ -147,7 +147,7 @@ def test_facade_multi_constituent_and_override(gpu_lib, K, solver, path, monkeyp
         assert rel_err(model.constituent_dict[nm].total_mass_flux[:12], ref.constituent_dict[nm].total_mass_flux[:12]) <= 1e-8
 
 
-@pytest.mark.parametrize('K', [2, 5, 7, 8, 24, 32, 64])
+@pytest.mark.parametrize('K', [2, 5, 7, 8, 12, 20, 24, 32, 64])
 def test_step_parity_across_constituent_counts_on_tiled_meshes(gpu_lib, K, monkeypatch):
     """Every lane mapping of the sweep kernels (VW = 1 for odd K, 2, and the four-wide split-row mapping of
     K % 16 == 0; wide rows that do not fit the tiled pass fall back to the un-tiled J^2 pass) against the oracle's
