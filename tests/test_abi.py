@@ -66,3 +66,23 @@ def test_product_code_never_imports_the_oracle():
             if fn.endswith(('.py', '.hip', '.hpp', '.h', '.cpp')):
                 text = open(os.path.join(dirpath, fn)).read()
                 assert 'cwr_oracle' not in text and 'import oracle' not in text, f'{fn} references the oracle'
+
+
+def test_step_info_layout_matches_the_header(tmp_path):
+    """The ctypes StepInfo of engine.py is cwr_step_info of the header, field for field (compiled with gcc as plain C)."""
+    import subprocess
+    from clearwater_riverine_amd.engine import StepInfo
+    src = tmp_path / 'layout.c'
+    fields = [name for name, _ in StepInfo._fields_]
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "cwr_transport.h"\nint main(void) {\n'
+                   '  printf("%zu", sizeof(cwr_step_info));\n'
+                   + ''.join(f'  printf(" %zu", offsetof(cwr_step_info, {f}));\n' for f in fields) + '  return 0;\n}\n')
+    exe = tmp_path / 'layout'
+    subprocess.run(['gcc', '-std=c99', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)], check=True)
+    out = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert out[0] == ctypes.sizeof(StepInfo)
+    assert out[1:] == [getattr(StepInfo, f).offset for f in fields]
+    # the raw stub shown in INTEGRATION.md declares the same fields
+    text = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    for f in fields:
+        assert f'"{f}"' in text, f'INTEGRATION.md stub lacks {f}'
