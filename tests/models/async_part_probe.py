@@ -2,7 +2,7 @@
 How many passes does the solve need, as a function of (reps on core tiles, reps on replayed halo tiles, passes between
 two exchanges)?  Oracle operator of the synthetic mesh (test infrastructure); contiguous ranges of the Hilbert numbering."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, scipy.sparse as sp
 import clearwater_riverine_amd as cw
 from clearwater_riverine_amd.ordering import hilbert_order, renumber_mesh

@@ -1,7 +1,7 @@
 """CPU experiment: tile-local repeated application of J (not J^2) on a PARTITIONED mesh with deep halos:
 passes needed vs (local applications L, passes between exchanges)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, scipy.sparse as sp
 import clearwater_riverine_amd as cw
 from clearwater_riverine_amd.ordering import hilbert_order, renumber_mesh

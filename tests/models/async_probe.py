@@ -1,7 +1,7 @@
 """CPU experiment: how many passes does a tile-local repeated J^2 application (block-asynchronous Jacobi)
 need against plain J^2 passes?  Uses the oracle operator of the synthetic mesh (test infrastructure)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, scipy.sparse as sp
 import clearwater_riverine_amd as cw
 from clearwater_riverine_amd.ordering import hilbert_order, renumber_mesh

@@ -1,6 +1,6 @@
 """CPU experiment: tile-local repeated application of J itself (no pre-multiplied J^2) against J^2 tiles."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, scipy.sparse as sp
 import clearwater_riverine_amd as cw
 from clearwater_riverine_amd.ordering import hilbert_order, renumber_mesh

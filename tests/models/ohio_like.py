@@ -1,5 +1,5 @@
 import sys, os, time
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, 'oracle'))
 import numpy as np
 import clearwater_riverine_amd as cw
