@@ -408,7 +408,7 @@ int check_ghost_levels(cwr_engine* e) {
 
 #define CWR_TCL_K(VWv, Q) k_sq_tiled<VWv, TCL_CFG[Q].wrn, TCL_CFG[Q].ut, TCL_CFG[Q].xr>
 const void* tcl_kernel(int vw, int cfg) {
-  if (vw == 4) return cfg == 3 ? reinterpret_cast<const void*>(&CWR_TCL_K(4, 3)) : reinterpret_cast<const void*>(&CWR_TCL_K(4, 4));
+  if (vw == 4) return cfg == 3 ? reinterpret_cast<const void*>(&CWR_TCL_K(4, 3)) : cfg == 4 ? reinterpret_cast<const void*>(&CWR_TCL_K(4, 4)) : reinterpret_cast<const void*>(&CWR_TCL_K(4, 5));
   if (vw == 2) return cfg == 0 ? reinterpret_cast<const void*>(&CWR_TCL_K(2, 0)) : cfg == 1 ? reinterpret_cast<const void*>(&CWR_TCL_K(2, 1)) : reinterpret_cast<const void*>(&CWR_TCL_K(2, 2));
   return cfg == 0 ? reinterpret_cast<const void*>(&CWR_TCL_K(1, 0)) : cfg == 1 ? reinterpret_cast<const void*>(&CWR_TCL_K(1, 1)) : reinterpret_cast<const void*>(&CWR_TCL_K(1, 2));
 }
@@ -534,7 +534,9 @@ int ensure_sq_pattern(cwr_engine* e) {
     if (const char* v = getenv("CWR_TCL_CFG")) q0 = std::max(0, std::min(2, atoi(v)));
     e->tcl_vw = e->VW;
     // (fetch mapping: K/2 lanes per row; compute mapping: K/4 lanes per row)
-    for (int q = 3; q < 5 && want4 && e->tcl_cfg < 0; ++q)
+    int q4 = 3;
+    if (const char* v = getenv("CWR_TCL_CFG")) q4 = std::max(3, std::min(TCL_NCFG - 1, atoi(v)));
+    for (int q = q4; q < TCL_NCFG && want4 && e->tcl_cfg < 0; ++q)
       if (max_cols <= TCL_CFG[q].xr * (BLOCK / (e->K / 2)) && cap2 <= TCL_CFG[q].wrn * BLOCK && tr <= TCL_CFG[q].ut * R4) { e->tcl_cfg = q; e->tcl_vw = 4; }
     for (int q = q0; q < 3 && e->tcl_cfg < 0; ++q)
       if (max_cols <= TCL_CFG[q].xr * e->R && cap2 <= TCL_CFG[q].wrn * BLOCK && tr <= TCL_CFG[q].ut * e->R) e->tcl_cfg = q;
@@ -601,7 +603,7 @@ int launch_sq_tiled(cwr_engine* e, const double* xin, double* yout) {
   }
 #define CWR_TILED(VWv, Q) CWR_TCL_K(VWv, Q)<<<e->tcl_grid, BLOCK, e->tcl_lds, e->stream>>>(e->n_tcl, e->K, e->K / VWv, e->tcl_TR,    \
       e->tcl_ntiles, e->d_ptr2, e->d_loc2, e->d_w2, e->d_tcl_ptr, e->d_tcl_cols, e->tcl_max_cols, e->tcl_stage_cap, e->local_reps, xin, e->d_t, yout)
-  if (e->tcl_vw == 4) { if (e->tcl_cfg == 3) CWR_TILED(4, 3); else CWR_TILED(4, 4); }
+  if (e->tcl_vw == 4) { if (e->tcl_cfg == 3) CWR_TILED(4, 3); else if (e->tcl_cfg == 4) CWR_TILED(4, 4); else CWR_TILED(4, 5); }
   else if (e->VW == 2) { if (e->tcl_cfg == 0) CWR_TILED(2, 0); else if (e->tcl_cfg == 1) CWR_TILED(2, 1); else CWR_TILED(2, 2); }
   else            { if (e->tcl_cfg == 0) CWR_TILED(1, 0); else if (e->tcl_cfg == 1) CWR_TILED(1, 1); else CWR_TILED(1, 2); }
 #undef CWR_TILED
