@@ -408,7 +408,8 @@ int check_ghost_levels(cwr_engine* e) {
 
 #define CWR_TCL_K(VWv, Q) k_sq_tiled<VWv, TCL_CFG[Q].wrn, TCL_CFG[Q].ut, TCL_CFG[Q].xr>
 const void* tcl_kernel(int vw, int cfg) {
-  if (vw == 4) return cfg == 3 ? reinterpret_cast<const void*>(&CWR_TCL_K(4, 3)) : cfg == 4 ? reinterpret_cast<const void*>(&CWR_TCL_K(4, 4)) : reinterpret_cast<const void*>(&CWR_TCL_K(4, 5));
+  if (vw == 4) return cfg == 3 ? reinterpret_cast<const void*>(&CWR_TCL_K(4, 3)) : cfg == 4 ? reinterpret_cast<const void*>(&CWR_TCL_K(4, 4))
+                    : cfg == 5 ? reinterpret_cast<const void*>(&CWR_TCL_K(4, 5)) : reinterpret_cast<const void*>(&CWR_TCL_K(4, 6));
   if (vw == 2) return cfg == 0 ? reinterpret_cast<const void*>(&CWR_TCL_K(2, 0)) : cfg == 1 ? reinterpret_cast<const void*>(&CWR_TCL_K(2, 1)) : reinterpret_cast<const void*>(&CWR_TCL_K(2, 2));
   return cfg == 0 ? reinterpret_cast<const void*>(&CWR_TCL_K(1, 0)) : cfg == 1 ? reinterpret_cast<const void*>(&CWR_TCL_K(1, 1)) : reinterpret_cast<const void*>(&CWR_TCL_K(1, 2));
 }
@@ -603,7 +604,7 @@ int launch_sq_tiled(cwr_engine* e, const double* xin, double* yout) {
   }
 #define CWR_TILED(VWv, Q) CWR_TCL_K(VWv, Q)<<<e->tcl_grid, BLOCK, e->tcl_lds, e->stream>>>(e->n_tcl, e->K, e->K / VWv, e->tcl_TR,    \
       e->tcl_ntiles, e->d_ptr2, e->d_loc2, e->d_w2, e->d_tcl_ptr, e->d_tcl_cols, e->tcl_max_cols, e->tcl_stage_cap, e->local_reps, xin, e->d_t, yout)
-  if (e->tcl_vw == 4) { if (e->tcl_cfg == 3) CWR_TILED(4, 3); else if (e->tcl_cfg == 4) CWR_TILED(4, 4); else CWR_TILED(4, 5); }
+  if (e->tcl_vw == 4) { if (e->tcl_cfg == 3) CWR_TILED(4, 3); else if (e->tcl_cfg == 4) CWR_TILED(4, 4); else if (e->tcl_cfg == 5) CWR_TILED(4, 5); else CWR_TILED(4, 6); }
   else if (e->VW == 2) { if (e->tcl_cfg == 0) CWR_TILED(2, 0); else if (e->tcl_cfg == 1) CWR_TILED(2, 1); else CWR_TILED(2, 2); }
   else            { if (e->tcl_cfg == 0) CWR_TILED(1, 0); else if (e->tcl_cfg == 1) CWR_TILED(1, 1); else CWR_TILED(1, 2); }
 #undef CWR_TILED

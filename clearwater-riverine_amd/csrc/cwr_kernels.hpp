@@ -644,15 +644,16 @@ __global__ void __launch_bounds__(BLOCK) k_build_sq(int nnz2, const int32_t* __r
 // XR x rows per lane group (distinct x rows per tile <= XR * R), WRN J^2 entries per thread (entries per tile <= WRN * BLOCK),
 // UT rows of the tile per lane group (tile rows <= UT * R).  The engine picks the cheapest configuration that fits.
 struct TclCfg { int wrn, ut, xr; };
-constexpr int TCL_NCFG = 6;
+constexpr int TCL_NCFG = 7;
 constexpr TclCfg TCL_CFG[TCL_NCFG] = {{4, 2, 6},      // wide rows (K = 16: 64-row tiles)
                                {10, 1, 3},     // narrow rows (K <= 8: one row per lane group, 64-256-row tiles)
                                {10, 4, 8},     // large tiles
                                {4, 1, 6},     // wide rows, four constituents per lane in the compute phase (K = 16: 4 lanes per
                                                // row, 64 rows per pass); x rows fetched 8 lanes per row, 6 per lane group
-                               {5, 1, 6},      // the same with room for 1280 entries per tile (K = 8: 128-row tiles)
-                               {5, 1, 8}};     // ... and for 8 x rows per lane group (halo tiles of partitioned engines may touch
-                                               // more than 192 distinct rows)
+                               {4, 1, 7},      // the same with 7 x rows per lane group: halo tiles of partitioned engines may touch
+                                               // a few more than 192 distinct rows (200 on one of 8 ranks of the 1 M-cell mesh)
+                               {5, 1, 6},      // room for 1280 entries per tile (K = 8: 128-row tiles)
+                               {5, 1, 8}};     // both, 8 x rows per lane group: last resort before the un-tiled pass
 template <int VW, int WRN, int TCL_U, int TCL_XR>
 __global__ void __launch_bounds__(BLOCK) k_sq_tiled(
     int n_rows, int K, int G, int TR, int ntiles, const int32_t* __restrict__ ptr2, const uint16_t* __restrict__ loc2,
