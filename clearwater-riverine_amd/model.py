@@ -214,8 +214,9 @@ class ClearwaterRiverine:
         K = len(self.constituents)
 
         # engine: topology, flow field and boundary values resident in HBM
-        # large meshes: internal space-filling-curve numbering (ordering.py); reference ids stay at this boundary
-        order = hilbert_order(m['face_x'], m['face_y'], n) if (renumber and n >= 16384) else None
+        # meshes beyond the one-launch solver (> 4 096 cells): internal space-filling-curve numbering (ordering.py), which
+        # is what keeps the 64-row tiles of the sweep kernels compact; reference ids stay at this boundary
+        order = hilbert_order(m["face_x"], m["face_y"], n) if (renumber and n > 4096) else None
         self.engine = TransportEngine(f1, f2, ncell, K, device=device, cell_order=order)
         self.engine.load_flow_field(m[FLOW_ACROSS_FACE], m[EDGE_VELOCITY], m[VOLUME], m[CHANGE_IN_TIME],
                                     m[FACE_TO_FACE_DISTANCE], m.attrs['diffusion_coefficient'])

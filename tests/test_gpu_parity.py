@@ -167,3 +167,30 @@ def test_step_parity_across_constituent_counts_on_tiled_meshes(gpu_lib, K, monke
     for kk, nm in ((0, names[0]), (1, names[-1])):
         assert rel_err(model.mesh[nm], ref.constituent_dict[f'c{kk}'].state) <= TOL_CONC
         assert rel_err(model.constituent_dict[nm].total_mass_flux[:3], ref.constituent_dict[f'c{kk}'].total_mass_flux[:3]) <= 1e-8
+
+
+@pytest.mark.parametrize('K', [1, 12])
+@pytest.mark.parametrize('n_target', [2943, 10000])
+def test_baseline_configs_2_and_3_river_band_mesh(gpu_lib, K, n_target):
+    """BASELINE configs 2 / 3: a river-band mesh of the Ohio River's size (2 943 cells; 10 000 nominal) with
+    jittered, partly merged 5-6-sided cells and a locally shuffled numbering, dt = 3600 s (CFL ~ 18), one tracer and the
+    12-constituent NSM-I state vector, through the facade against the oracle's spsolve.  2 943 cells take the one-launch
+    LDS-resident solver, 10 000 the tiled block-asynchronous passes."""
+    import clearwater_riverine_amd as cw
+    nx, ny, nm = (109, 28, 109) if n_target == 2943 else (200, 51, 200)
+    mesh = cw.synthetic.make_mesh(nx, ny, 6, seed=20100529 % 100000, n_merge=nm, dx=75.0, dy=75.0, dt=3600.0, velocity=0.4,
+                                  diffusion_coefficient=0.1, period_steps=24)
+    oracle.derive_coefficients(mesh)
+    n = mesh['nreal'] + 1
+    assert abs(n - n_target) <= 0.01 * n_target
+    inputs3 = cw.synthetic.boundary_input_array(mesh, K, inlet_period_s=24 * 3600.0)
+    names = [f'c{k}' for k in range(K)]
+    model = cw.ClearwaterRiverine(mesh=dict(mesh), input_arrays={nm_: inputs3[:, :, k].copy() for k, nm_ in enumerate(names)})
+    cols = [0, K - 1] if K > 1 else [0]
+    ref = oracle_run(mesh, inputs3[:, :, cols], 6)
+    for _ in range(6):
+        model.update()
+    assert model.last_step.sweep_kernel == (7 if n_target == 2943 else 6) and model.last_step.iterations == 0
+    for kk, col in enumerate(cols):
+        assert rel_err(model.mesh[names[col]], ref.constituent_dict[f'c{kk}'].state) <= TOL_CONC
+        assert rel_err(model.constituent_dict[names[col]].total_mass_flux[:6], ref.constituent_dict[f'c{kk}'].total_mass_flux[:6]) <= 1e-8
