@@ -507,6 +507,10 @@ int ensure_sq_pattern(cwr_engine* e) {
     while (tr > Rt && (tr % Rt) != 0) --tr;
     tr = std::max(tr, Rt);
     if (want4) tr = Rt;                                          // (the four-wide configuration holds one row per lane group)
+    // a tile that holds too many entries or distinct rows for every compiled configuration (dense adjacency: many 5-8-face
+    // cells; narrow rows use 256-row tiles) is retried at half the rows -- part of the lanes then idle in the compute phase,
+    // which still beats the un-tiled exact pass by far
+    for (int shrink = 0; shrink < 3 && !e->tcl_ready; ++shrink, tr = std::max(16, tr / 2)) {
     const int nt = cdiv(n_t, tr);
     std::vector<int32_t> tptr((size_t)nt + 1, 0), tcols;
     std::vector<uint16_t> loc2((size_t)e->nnz2, 0);
@@ -563,6 +567,7 @@ int ensure_sq_pattern(cwr_engine* e) {
     } else if (getenv("CWR_VERBOSE")) {
       fprintf(stderr, "[cwr] tiled J^2 not used over %d rows: tile=%d rows, max %d distinct x rows per tile (limit %d), %d entries per tile (limit %d), lds=%zu\n",
               n_t, tr, max_cols, TCL_CFG[2].xr * e->R, cap2, TCL_CFG[2].wrn * BLOCK, lds);
+    }
     }
     }
   }

@@ -194,3 +194,23 @@ def test_baseline_configs_2_and_3_river_band_mesh(gpu_lib, K, n_target):
     for kk, col in enumerate(cols):
         assert rel_err(model.mesh[names[col]], ref.constituent_dict[f'c{kk}'].state) <= TOL_CONC
         assert rel_err(model.constituent_dict[names[col]].total_mass_flux[:6], ref.constituent_dict[f'c{kk}'].total_mass_flux[:6]) <= 1e-8
+
+
+@pytest.mark.parametrize('K', [1, 16])
+def test_dense_adjacency_mesh_is_tiled_and_matches_the_oracle(gpu_lib, K, monkeypatch):
+    """A third of the cells merged into 5-6-face cells (4.7 faces and 12 J^2 entries per row on average): a 256-row tile
+    of a one-constituent engine then holds more entries than any compiled configuration, and the engine must retry with
+    half-size tiles instead of falling back to the un-tiled exact pass."""
+    import clearwater_riverine_amd as cw
+    monkeypatch.setenv('CWR_NO_SMALL', '1')
+    mesh, inputs3 = synthetic_case(K, nx=120, ny=60, n_steps=3, seed=7, n_merge=1800, dt=60.0, diffusion_coefficient=0.3)
+    n = mesh['nreal'] + 1
+    names = [f'c{k}' for k in range(K)]
+    model = cw.ClearwaterRiverine(mesh=dict(mesh), input_arrays={nm: inputs3[:, :, k].copy() for k, nm in enumerate(names)})
+    cols = [0, K - 1] if K > 1 else [0]
+    ref = oracle_run(mesh, inputs3[:, :, cols], 3)
+    for _ in range(3):
+        model.update()
+        assert model.last_step.sweep_kernel == 6 and model.last_step.max_rel_residual <= 1e-12
+    for kk, col in enumerate(cols):
+        assert rel_err(model.mesh[names[col]], ref.constituent_dict[f'c{kk}'].state) <= TOL_CONC
