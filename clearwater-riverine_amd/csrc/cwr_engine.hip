@@ -6,6 +6,7 @@
 
 #include <dlfcn.h>
 #include <atomic>
+#include <map>
 #include <thread>
 
 #include <algorithm>
@@ -159,6 +160,8 @@ struct cwr_engine {
   int32_t *d_tcl_ptr = nullptr, *d_tcl_cols = nullptr;
   uint16_t* d_loc2 = nullptr;    // local (in-tile) column of every J^2 entry: 16 bits (a tile holds < 65 536 x rows)
   double* d_w2 = nullptr;
+  std::map<int, hipGraphExec_t> batch_exec;   // whole-batch graphs by number of passes (see solve_jacobi)
+  int batch_last = -1;
   hipGraph_t tcl_graph = nullptr;
   hipGraphExec_t tcl_exec = nullptr;
   bool tcl_graph_tried = false;
@@ -686,6 +689,7 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
     batch = std::max(2, std::min(batch, 4096)) & ~1;                   // even: the result lands in the state vector
     int launches = batch;
     int todo = batch;
+    bool batch_graph = false;
     if (sq) {
       // batch = 2*doubles + 2 with an even number of J^2 passes, then two plain sweeps: the last one's ||x'-x|| is the
       // exact scaled residual of its input, so the convergence criterion is unchanged
@@ -694,6 +698,36 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
       const int passes = doubles;
       launches = doubles + 2;
       todo = 0;
+      // steady state (the same batch shape as the previous check): the WHOLE batch -- passes, closing sweeps, reduction --
+      // is one hipGraph, captured the second time a shape is seen (the kernel arguments of a batch never change)
+      if (!e->comm && !e->profiling && e->use_graphs) {
+        auto it = e->batch_exec.find(doubles);
+        if (it == e->batch_exec.end() && e->batch_last == doubles && e->batch_exec.size() < 6) {
+          hipGraphExec_t ex = nullptr;
+          if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            int rc = CWR_OK;
+            for (int i = 0; i < doubles && rc == CWR_OK; ++i) {
+              double* src = (i & 1) ? e->d_p : e->d_c;
+              double* dst = (i & 1) ? e->d_c : e->d_p;
+              rc = tiled ? launch_sq_tiled(e, src, dst) : launch_apply<5>(e, src, dst, nullptr, e->d_t, nullptr, nullptr, e->n_sq);
+            }
+            if (rc == CWR_OK) rc = launch_apply<4>(e, e->d_c, e->d_p, nullptr, e->d_b, nullptr, nullptr);
+            if (rc == CWR_OK) rc = launch_apply<4>(e, e->d_p, e->d_c, nullptr, e->d_b, nullptr, nullptr);
+            if (rc == CWR_OK) rc = reduce_partials(e, e->last_apply_grid, 2, d_rr, d_bb);
+            hipGraph_t g = nullptr;
+            const hipError_t ec = hipStreamEndCapture(e->stream, &g);
+            if (!(rc == CWR_OK && ec == hipSuccess && g && hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess)) { ex = nullptr; (void)hipGetLastError(); }
+            if (g) hipGraphDestroy(g);
+          }
+          it = e->batch_exec.emplace(doubles, ex).first;      // (nullptr: capture failed, do not try this shape again)
+        }
+        e->batch_last = doubles;
+        if (it != e->batch_exec.end() && it->second) {
+          HIP_TRY(e, hipGraphLaunch(it->second, e->stream));
+          batch_graph = true;
+        }
+      }
+      if (!batch_graph) {
       if (!e->comm && !e->profiling && e->use_graphs) {
         hipGraphExec_t& exec = tiled ? e->tcl_exec : e->sq_exec;
         hipGraph_t& graph = tiled ? e->tcl_graph : e->sq_graph;
@@ -732,6 +766,7 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
       if (since_exchange + 1 > e->exch_every) { TRY(exchange_halo(e, e->d_p)); since_exchange = 0; }
       TRY(launch_apply<4>(e, e->d_p, e->d_c, nullptr, e->d_b, nullptr, nullptr));
       ++since_exchange;
+      }
     } else if (!e->comm && !e->profiling && e->use_graphs) {
       if (!e->graph_tried) {                               // capture GRAPH_SWEEPS sweeps once
         e->graph_tried = true;
@@ -763,7 +798,7 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
       ++since_exchange;
     }
     st.sweeps += batch; st.launches += launches;
-    TRY(reduce_partials(e, e->last_apply_grid, 2, d_rr, d_bb));
+    if (!batch_graph) TRY(reduce_partials(e, e->last_apply_grid, 2, d_rr, d_bb));
     bool speculated = false;
     if (e->spec_t >= 0 && !e->comm) { TRY(step_tail(e, e->spec_t, e->spec_flags)); speculated = true; }
     TRY(allreduce(e, d_rr, 2 * (size_t)K));
@@ -1109,6 +1144,7 @@ void cwr_destroy(cwr_engine* e) {
   if (e->sweep_exec) hipGraphExecDestroy(e->sweep_exec);
   if (e->sweep_graph) hipGraphDestroy(e->sweep_graph);
   if (e->sq_exec) hipGraphExecDestroy(e->sq_exec);
+  for (auto& kv : e->batch_exec) if (kv.second) hipGraphExecDestroy(kv.second);
   if (e->tcl_exec) hipGraphExecDestroy(e->tcl_exec);
   if (e->tcl_graph) hipGraphDestroy(e->tcl_graph);
   if (e->sq_graph) hipGraphDestroy(e->sq_graph);
