@@ -59,6 +59,7 @@ struct Rccl {
 Rccl g_rccl;
 constexpr int NCCL_FLOAT64 = 8;   // ncclDataType_t::ncclFloat64
 constexpr int NCCL_SUM = 0;       // ncclRedOp_t::ncclSum
+constexpr int NCCL_MAX = 2;       // ncclRedOp_t::ncclMax
 
 }  // namespace
 
@@ -93,7 +94,21 @@ struct cwr_engine {
   // vectors: c is the full state [owned | halo | ghost] x K and doubles as the solver's x
   double *d_c = nullptr, *d_r = nullptr, *d_r0 = nullptr, *d_p = nullptr, *d_v = nullptr, *d_s = nullptr,
          *d_t = nullptr, *d_b = nullptr;
-  double* d_chk = nullptr;       // [2][K] convergence-check scalars of the Jacobi path
+  double* d_chk = nullptr;       // [4][K] convergence-check scalars of the Jacobi path: ||x'-x||^2, ||bhat||^2 (sums) and the
+                                 // element-wise measures max(|x'-x| - ew_rel |x'|), max |x'| (k_apply MODE 4)
+  double* d_keep = nullptr;      // x_t (computed rows, written by k_rhs) and the ghost rows as the step found them: a failed
+                                 // step restores the state from here
+  // element-wise stopping rule on top of the norm criterion: |x'_i - x_i| <= ew_rel |x'_i| + ew_abs max|x'| for every cell
+  // and constituent, with (ew_rel, ew_abs) = s (1e6 tol, tol) and s = 0.3 (1-rho)/rho from the measured contraction
+  // (Jacobi's a-posteriori bound |e| <= rho/(1-rho) |x'-x|), i.e. forward error <= 1e-6 |x| + 1e-12 max|x| at tol = 1e-12
+  bool ew_enabled = true;
+  double ew_rel = 0.0, ew_abs = 0.0;
+  int info_flags = 0;            // CWR_INFO_* bits of the step in progress
+  bool ptr_exported = false;     // cwr_state_device_ptr handed the state out: the caller may rewrite it at any time
+  // real-cell entries of input_array (levels >= 1): applied to the solved level before the mass fluxes
+  std::map<int, std::pair<int, int>> in_levels;   // level -> (first entry, count)
+  int32_t* d_in_rows = nullptr;
+  double* d_in_vals = nullptr;
   bool tail_done = false;        // the step's tail (step_tail) was enqueued speculatively and the check then passed
   int spec_t = -1, spec_flags = 0; // >= 0: solve_jacobi may enqueue step_tail(spec_t, spec_flags) before its check download
   bool halo_fresh = false;       // the halo rows of the state hold their owners' current values (set by the end-of-step
@@ -241,9 +256,10 @@ int prep_step(cwr_engine* e, int t) {
   return CWR_OK;
 }
 
-int reduce_partials(cwr_engine* e, int nslots, int ND, double* o0, double* o1 = nullptr, double* o2 = nullptr, double* o3 = nullptr) {
+int reduce_partials(cwr_engine* e, int nslots, int ND, double* o0, double* o1 = nullptr, double* o2 = nullptr, double* o3 = nullptr,
+                    int max_from = 1 << 20) {
   ReduceOuts outs; outs.p[0] = o0; outs.p[1] = o1; outs.p[2] = o2; outs.p[3] = o3;
-  k_reduce_partials<<<ND, RBLOCK, 0, e->stream>>>(nslots, ND, e->K, e->d_partial, outs);
+  k_reduce_partials<<<ND, RBLOCK, 0, e->stream>>>(nslots, ND, e->K, e->d_partial, outs, max_from);
   HIP_TRY(e, hipGetLastError());
   return CWR_OK;
 }
@@ -267,10 +283,10 @@ int launch_apply(cwr_engine* e, const double* xin, double* yout, const double* r
   }
   if (e->VW == 2)
     k_apply<2, MODE><<<grid, BLOCK, lds, e->stream>>>(row0, rows, e->n_core, e->K, e->G, e->U, ntiles, cap, e->nt_stream,
-        ptr, rec, e->d_diag, xin, yout, r0, bhat, r0_out, p_out, e->d_partial);
+        ptr, rec, e->d_diag, xin, yout, r0, bhat, r0_out, p_out, e->d_partial, e->ew_rel);
   else
     k_apply<1, MODE><<<grid, BLOCK, lds, e->stream>>>(row0, rows, e->n_core, e->K, e->G, e->U, ntiles, cap, e->nt_stream,
-        ptr, rec, e->d_diag, xin, yout, r0, bhat, r0_out, p_out, e->d_partial);
+        ptr, rec, e->d_diag, xin, yout, r0, bhat, r0_out, p_out, e->d_partial, e->ew_rel);
   e->last_apply_grid = grid;
   HIP_TRY(e, hipGetLastError());
   if (e1) HIP_TRY(e, hipEventRecord(e1, e->stream));
@@ -313,9 +329,34 @@ int allreduce(cwr_engine* e, double* p, size_t count) {
   return CWR_OK;
 }
 
+int allreduce_max(cwr_engine* e, double* p, size_t count) {
+  if (!e->comm || (e->world == 1 && !e->force_coll)) return CWR_OK;
+  NCCL_TRY(e, g_rccl.AllReduce(p, p, count, NCCL_FLOAT64, NCCL_MAX, e->comm, e->stream));
+  return CWR_OK;
+}
+
 #define TRY(call) do { int _rc = (call); if (_rc != CWR_OK) return _rc; } while (0)
 
-int launch_rhs(cwr_engine* e, int t, const double* x, double* b, bool scale) {
+// the closing check of a batch of sweeps: fold the per-block partials of the last MODE 4 launch into d_chk
+int reduce_check(cwr_engine* e) {
+  const int K = e->K;
+  return reduce_partials(e, e->last_apply_grid, 4, e->d_chk, e->d_chk + K, e->d_chk + 2 * K, e->d_chk + 3 * K, 2);
+}
+
+// element-wise verdict from the downloaded check scalars h = [rr | bb | m1 | m2]; ratio: by how much |x'-x| still has to fall
+bool elementwise_ok(const cwr_engine* e, const double* h, double* ratio) {
+  const int K = e->K;
+  double worst = 0.0;
+  if (e->ew_enabled)
+    for (int k = 0; k < K; ++k) {
+      const double m1 = h[2 * K + k], m2 = h[3 * K + k];
+      if (m1 > 0.0) worst = std::max(worst, m2 > 0.0 ? m1 / (e->ew_abs * m2) : (double)INFINITY);
+    }
+  if (ratio) *ratio = worst;
+  return !(worst > 1.0);
+}
+
+int launch_rhs(cwr_engine* e, int t, const double* x, double* b, bool scale, double* keep = nullptr) {
   const int grid = std::max(1, std::min(cdiv(e->n_owned, e->R), 256 * 16));
   const size_t E = e->E;
   const float* vol_t = e->d_vol + (size_t)t * e->n_cells;
@@ -325,7 +366,7 @@ int launch_rhs(cwr_engine* e, int t, const double* x, double* b, bool scale) {
   const double* bc_n = e->d_bc + (size_t)(t + 1) * e->n_ghost * e->K;
   const int used = (e->D != 0.0) ? 1 : 0;
 #define CWR_RHS(VWv, SC) k_rhs<VWv, SC><<<grid, BLOCK, 0, e->stream>>>(e->n_owned, e->K, e->G, e->d_ptr, e->d_ent_edge, \
-    e->d_ent_nb, vol_t, e->dt[t], vel_n, adv_n, dif_n, used, bc_n, x, e->d_diag, e->d_row_ghost, b, e->d_counters)
+    e->d_ent_nb, vol_t, e->dt[t], vel_n, adv_n, dif_n, used, bc_n, x, e->d_diag, e->d_row_ghost, b, e->d_counters, keep)
   if (e->VW == 2) { if (scale) CWR_RHS(2, true); else CWR_RHS(2, false); }
   else            { if (scale) CWR_RHS(1, true); else CWR_RHS(1, false); }
 #undef CWR_RHS
@@ -631,6 +672,15 @@ int launch_sq_tiled(cwr_engine* e, const double* xin, double* yout) {
 int step_tail(cwr_engine* e, int t, int flags) {
   const int K = e->K;
   const int64_t gk = (int64_t)e->n_ghost * K;
+  {
+    auto it = e->in_levels.find(t + 1);             // transport.py:258-264 on real cells (never speculative: see cwr_step)
+    if (it != e->in_levels.end() && it->second.second > 0) {
+      const int64_t total = (int64_t)it->second.second * K;
+      k_apply_inputs<<<cdiv(total, BLOCK), BLOCK, 0, e->stream>>>(total, K, e->d_in_rows + it->second.first,
+                                                                  e->d_in_vals + (size_t)it->second.first * K, e->d_c);
+      HIP_TRY(e, hipGetLastError());
+    }
+  }
   if (gk > 0) {
     k_ghost_writeback<<<cdiv(gk, BLOCK), BLOCK, 0, e->stream>>>(gk, e->d_bc + (size_t)(t + 1) * gk, e->d_c + (size_t)e->n_real * K);
     HIP_TRY(e, hipGetLastError());
@@ -666,10 +716,9 @@ struct SolveStats {
 int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveStats& st, bool& need_bicg) {
   const int K = e->K;
   need_bicg = false;
-  std::vector<double> h(2 * (size_t)K);
-  // the two reduced inner products (||x'-x||^2, ||bhat||^2) land side by side: one all-reduce and one download per check
+  std::vector<double> h(4 * (size_t)K);
+  // the reduced check scalars (||x'-x||^2, ||bhat||^2 | element-wise maxima) land side by side: one download per check
   double* d_rr = e->d_chk;
-  double* d_bb = e->d_chk + K;
   double prev_worst = -1.0;
   int prev_sweeps = 0;
   int since_exchange = 0;                     // the caller exchanged the state's halo just before the right-hand side
@@ -686,6 +735,7 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
   e->dominant_mode = tiled ? 6 : (sq ? 5 : 4);
   st.sweep_kernel = e->dominant_mode;
   for (;;) {
+    batch = std::min(batch, std::max(2, (sweep_limit - st.sweeps + 1) & ~1));   // max_iter bounds the first batch too
     batch = std::max(2, std::min(batch, 4096)) & ~1;                   // even: the result lands in the state vector
     int launches = batch;
     int todo = batch;
@@ -713,7 +763,7 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
             }
             if (rc == CWR_OK) rc = launch_apply<4>(e, e->d_c, e->d_p, nullptr, e->d_b, nullptr, nullptr);
             if (rc == CWR_OK) rc = launch_apply<4>(e, e->d_p, e->d_c, nullptr, e->d_b, nullptr, nullptr);
-            if (rc == CWR_OK) rc = reduce_partials(e, e->last_apply_grid, 2, d_rr, d_bb);
+            if (rc == CWR_OK) rc = reduce_check(e);
             hipGraph_t g = nullptr;
             const hipError_t ec = hipStreamEndCapture(e->stream, &g);
             if (!(rc == CWR_OK && ec == hipSuccess && g && hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess)) { ex = nullptr; (void)hipGetLastError(); }
@@ -798,11 +848,12 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
       ++since_exchange;
     }
     st.sweeps += batch; st.launches += launches;
-    if (!batch_graph) TRY(reduce_partials(e, e->last_apply_grid, 2, d_rr, d_bb));
+    if (!batch_graph) TRY(reduce_check(e));
     bool speculated = false;
     if (e->spec_t >= 0 && !e->comm) { TRY(step_tail(e, e->spec_t, e->spec_flags)); speculated = true; }
     TRY(allreduce(e, d_rr, 2 * (size_t)K));
-    TRY(download(e, h.data(), d_rr, 2 * (size_t)K));
+    TRY(allreduce_max(e, e->d_chk + 2 * (size_t)K, 2 * (size_t)K));
+    TRY(download(e, h.data(), d_rr, 4 * (size_t)K));
     bool ok = true;
     double worst = 0.0;                                                   // max over columns of rr / (tol^2 bb)
     st.max_rel = 0.0;
@@ -813,6 +864,11 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
       if (rr > tol2 * bb) ok = false;
       worst = std::max(worst, bb > 0.0 ? rr / (tol2 * bb) : (rr > 0.0 ? (double)INFINITY : 0.0));
     }
+    // element-wise rule: every |x'_i - x_i| within ew_rel |x'_i| + ew_abs max|x'| (plume fronts far below the peak are
+    // invisible to the 2-norm).  Folded into `worst` (a squared ratio) so that the sweep prediction serves both rules.
+    double ew_ratio = 0.0;
+    if (!elementwise_ok(e, h.data(), &ew_ratio)) ok = false;
+    worst = std::max(worst, ew_ratio * ew_ratio);
     if (ok) {
       // remember the sweeps this step really needed (the margin below the tolerance, converted with the measured
       // contraction), so that the next step's first batch neither overshoots nor needs a second check
@@ -855,7 +911,7 @@ int solve_small(cwr_engine* e, double tol2, int max_iter, bool forced, SolveStat
   // multi-launch path (4.3 vs 1.5 ms at 8-10 k cells), so larger meshes do not come here.
   if (e->comm || !e->use_small || e->n_halo != 0 || e->n_owned > SMALL_THREADS * 4 || e->max_degree > SMALL_DEG) return CWR_OK;
   const int K = e->K, n = e->n_owned;
-  if (!e->d_info) TRY(dev_alloc(e, &e->d_info, (size_t)3 * K));
+  if (!e->d_info) TRY(dev_alloc(e, &e->d_info, (size_t)5 * K));
   const size_t lds = ((size_t)n + 32) * sizeof(double);
   const int limit = forced ? max_iter : std::min(max_iter, e->jacobi_limit);
   const int rpt = cdiv(n, SMALL_THREADS);
@@ -864,14 +920,14 @@ int solve_small(cwr_engine* e, double tol2, int max_iter, bool forced, SolveStat
     if (!attr_done) { HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_small_jacobi<RPTv, REGSv>),     \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_done = true; }        \
     k_small_jacobi<RPTv, REGSv><<<K, SMALL_THREADS, lds, e->stream>>>(n, K, e->d_ptr, e->d_rec, e->d_diag, e->d_b,    \
-        e->d_c, tol2, limit, 4, e->d_info); } while (0)
+        e->d_c, tol2, e->ew_enabled ? e->ew_rel : 1.0, e->ew_enabled ? e->ew_abs : 1.0, limit, 4, e->d_info); } while (0)
   if (rpt <= 1) CWR_SMALL(1, true);
   else if (rpt <= 2) CWR_SMALL(2, true);
   else CWR_SMALL(4, true);
 #undef CWR_SMALL
   HIP_TRY(e, hipGetLastError());
-  std::vector<double> h((size_t)3 * K);
-  TRY(download(e, h.data(), e->d_info, (size_t)3 * K));
+  std::vector<double> h((size_t)5 * K);
+  TRY(download(e, h.data(), e->d_info, (size_t)5 * K));
   handled = true;
   st.launches += 1;
   st.sweep_kernel = 7;
@@ -879,15 +935,18 @@ int solve_small(cwr_engine* e, double tol2, int max_iter, bool forced, SolveStat
   int sweeps = 0;
   st.max_rel = 0.0;
   for (int k = 0; k < K; ++k) {
-    const double rr = h[3 * k + 1], bb = h[3 * k + 2];
-    sweeps = std::max(sweeps, (int)h[3 * k]);
+    const double rr = h[5 * k + 1], bb = h[5 * k + 2];
+    sweeps = std::max(sweeps, (int)h[5 * k]);
     if (!std::isfinite(rr) || !std::isfinite(bb)) { st.status = CWR_ERR_NONFINITE; st.sweeps += sweeps; return CWR_ERR_NONFINITE; }
     st.max_rel = std::max(st.max_rel, bb > 0.0 ? std::sqrt(rr / bb) : (rr > 0.0 ? (double)INFINITY : 0.0));
     if (rr > tol2 * bb) ok = false;
+    if (e->ew_enabled && h[5 * k + 3] > e->ew_abs * h[5 * k + 4]) ok = false;      // element-wise rule (see k_apply MODE 4)
   }
   st.sweeps += sweeps;
   if (!ok) {
-    if (forced || limit >= max_iter) { st.status = CWR_ERR_NOT_CONVERGED; return CWR_ERR_NOT_CONVERGED; }
+    // sweeps exhausted: the reference's direct solve has no such outcome, so unless the caller forced the sweeps
+    // BiCGSTAB continues from the current iterate (as solve_jacobi does)
+    if (forced) { st.status = CWR_ERR_NOT_CONVERGED; return CWR_ERR_NOT_CONVERGED; }
     need_bicg = true;
   }
   return CWR_OK;
@@ -902,7 +961,12 @@ int solve_bicgstab(cwr_engine* e, double tol2, int max_iter, SolveStats& st) {
   bool converged = false;
   e->dominant_mode = 1;                       // profile the first-product launches of BiCGSTAB steps
   HIP_TRY(e, hipMemsetAsync(e->d_scal, 0, e->scal_count() * sizeof(double), e->stream));
-  for (int round = 0; !converged; ++round) {
+  int round = 0;
+  // ew_try: after the norm criterion is met the element-wise rule is verified with two plain Jacobi sweeps (whose
+  // ||x'-x|| measures are the ones solve_jacobi uses); if it fails, BiCGSTAB restarts from there with tol / 10
+  for (int ew_try = 0;; ++ew_try) {
+  converged = false;
+  for (int round0 = round; !converged; ++round) {
     // (re)start: true residual of the current x; r0 = p = r
     if (round > 0) HIP_TRY(e, hipMemsetAsync(e->d_scal, 0, (size_t)3 * ACC_N * K * sizeof(double) + (size_t)3 * K * sizeof(double), e->stream));
     TRY(exchange_halo(e, e->d_c));
@@ -926,7 +990,12 @@ int solve_bicgstab(cwr_engine* e, double tol2, int max_iter, SolveStats& st) {
       }
       if (status != CWR_OK) break;
       if (ok) { converged = true; break; }
-      if (total_it >= max_iter || round > 6) { if (loose && round > 6) { converged = true; break; } status = CWR_ERR_NOT_CONVERGED; break; }
+      if (total_it >= max_iter || round - round0 > 6) {
+        // stagnation within 100 x tol after 6 verified restarts: the attainable accuracy of this system in float64.
+        // Accepted, but never silently: CWR_INFO_LOOSE_RESIDUAL is set in cwr_step_info.flags (the facade warns)
+        if (loose && round - round0 > 6) { converged = true; e->info_flags |= CWR_INFO_LOOSE_RESIDUAL; break; }
+        status = CWR_ERR_NOT_CONVERGED; break;
+      }
       ++restarts;
     }
     // iterate until the recurrence residual says converged, a breakdown is flagged, or max_iter
@@ -954,6 +1023,29 @@ int solve_bicgstab(cwr_engine* e, double tol2, int max_iter, SolveStats& st) {
     }
     if (status != CWR_OK) break;
   }
+  if (status != CWR_OK || !e->ew_enabled) break;
+  {
+    std::vector<double> h(4 * (size_t)K);
+    const int keep = e->dominant_mode; e->dominant_mode = -1;
+    int rc = exchange_halo(e, e->d_c);
+    if (rc == CWR_OK) rc = launch_apply<4>(e, e->d_c, e->d_p, nullptr, e->d_b, nullptr, nullptr, e->n_core);
+    if (rc == CWR_OK) rc = exchange_halo(e, e->d_p);
+    if (rc == CWR_OK) rc = launch_apply<4>(e, e->d_p, e->d_c, nullptr, e->d_b, nullptr, nullptr, e->n_core);
+    e->dominant_mode = keep;
+    if (rc != CWR_OK) return rc;
+    launches += 2; st.sweeps += 2;
+    TRY(reduce_check(e));
+    TRY(allreduce(e, e->d_chk, 2 * (size_t)K));
+    TRY(allreduce_max(e, e->d_chk + 2 * (size_t)K, 2 * (size_t)K));
+    TRY(download(e, h.data(), e->d_chk, 4 * (size_t)K));
+    bool finite = true;
+    for (int k = 0; k < K; ++k) if (!std::isfinite(h[k])) finite = false;
+    if (!finite) { status = CWR_ERR_NONFINITE; break; }
+    if (elementwise_ok(e, h.data(), nullptr)) break;
+    if (ew_try >= 3 || total_it >= max_iter) { e->info_flags |= CWR_INFO_ELEMENTWISE_MISSED; break; }
+    tol2 *= 1.0e-2;
+  }
+  }
   st.iterations += total_it; st.restarts += restarts; st.launches += launches; st.max_rel = max_rel; st.status = status;
   if (status == CWR_OK) e->last_iters = std::max(1, total_it - 1);
   return status;
@@ -964,7 +1056,7 @@ int solve_bicgstab(cwr_engine* e, double tol2, int max_iter, SolveStats& st) {
 // ====================================================================================================
 extern "C" {
 
-int32_t cwr_abi_version(void) { return 2; }
+int32_t cwr_abi_version(void) { return 3; }
 
 const char* cwr_last_error(const cwr_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
 
@@ -1095,7 +1187,9 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   CREATE_TRY(dev_alloc(eng, &eng->d_rec, (size_t)nnz));
   CREATE_TRY(dev_alloc(eng, &eng->d_diag, (size_t)n_owned));
   CREATE_TRY(dev_alloc(eng, &eng->d_w, (size_t)nnz));
-  CREATE_TRY(dev_alloc(eng, &eng->d_chk, 2 * (size_t)K));
+  CREATE_TRY(dev_alloc(eng, &eng->d_chk, 4 * (size_t)K));
+  CREATE_TRY(dev_alloc(eng, &eng->d_keep, (size_t)n_cells * K));
+  if (const char* v = getenv("CWR_NO_ELEMENTWISE")) eng->ew_enabled = atoi(v) == 0;
   CREATE_TRY(dev_alloc(eng, &eng->d_c, (size_t)n_cells * K));
   CREATE_TRY(dev_alloc(eng, &eng->d_r, nK));
   CREATE_TRY(dev_alloc(eng, &eng->d_r0, nK));
@@ -1151,7 +1245,7 @@ void cwr_destroy(cwr_engine* e) {
   for (hipEvent_t ev : e->ev) hipEventDestroy(ev);
   void* ptrs[] = {e->d_f1, e->d_f2, e->d_ptr, e->d_ent_edge, e->d_ent_nb, e->d_adv, e->d_vel, e->d_vol, e->d_dif,
                   e->d_bc, e->d_rec, e->d_diag, e->d_c, e->d_r, e->d_r0, e->d_p, e->d_v, e->d_s, e->d_t, e->d_b,
-                  e->d_scal, e->d_counters, e->d_partial, e->d_fadv, e->d_fdif, e->d_ftot, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf, e->d_ptr2, e->d_col2, e->d_row2, e->d_rec2, e->d_w, e->d_react, e->d_info, e->d_tcl_ptr, e->d_tcl_cols, e->d_loc2, e->d_w2, e->d_pair_ptr, e->d_slots, e->d_line_ptr, e->d_line_faces, e->d_ledger, e->d_mass_out, e->d_chk, e->d_face_orig, e->d_row_ghost};
+                  e->d_scal, e->d_counters, e->d_partial, e->d_fadv, e->d_fdif, e->d_ftot, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf, e->d_ptr2, e->d_col2, e->d_row2, e->d_rec2, e->d_w, e->d_react, e->d_info, e->d_tcl_ptr, e->d_tcl_cols, e->d_loc2, e->d_w2, e->d_pair_ptr, e->d_slots, e->d_line_ptr, e->d_line_faces, e->d_ledger, e->d_mass_out, e->d_chk, e->d_face_orig, e->d_row_ghost, e->d_keep, e->d_in_rows, e->d_in_vals};
   for (void* p : ptrs) if (p) hipFree(p);
   if (e->stream) hipStreamDestroy(e->stream);
   delete e;
@@ -1260,6 +1354,30 @@ int32_t cwr_set_boundary_level(cwr_engine* e, int32_t t, const double* level) {
   return CWR_OK;
 }
 
+int32_t cwr_load_real_inputs(cwr_engine* e, int32_t n_entries, const int32_t* level, const int32_t* row, const double* values) {
+  if (!e) return CWR_ERR_BAD_ARG;
+  if (n_entries < 0 || (n_entries > 0 && (!level || !row || !values))) return fail(e, CWR_ERR_BAD_ARG, "cwr_load_real_inputs: bad arguments");
+  for (int i = 0; i < n_entries; ++i) {
+    if (row[i] < 0 || row[i] >= e->n_core) return fail(e, CWR_ERR_BAD_ARG, "cwr_load_real_inputs: row outside this engine's own real cells");
+    if (level[i] < 1) return fail(e, CWR_ERR_BAD_ARG, "cwr_load_real_inputs: level must be >= 1 (level 0 is the initial state: cwr_set_state)");
+    if (i > 0 && level[i] < level[i - 1]) return fail(e, CWR_ERR_BAD_ARG, "cwr_load_real_inputs: entries must be sorted by level");
+  }
+  HIP_TRY(e, hipSetDevice(e->dev));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  hipFree(e->d_in_rows); hipFree(e->d_in_vals);
+  e->d_in_rows = nullptr; e->d_in_vals = nullptr; e->in_levels.clear();
+  if (n_entries == 0) return CWR_OK;
+  TRY(dev_alloc(e, &e->d_in_rows, (size_t)n_entries));
+  TRY(dev_alloc(e, &e->d_in_vals, (size_t)n_entries * e->K));
+  TRY(upload(e, e->d_in_rows, row, (size_t)n_entries));
+  TRY(upload(e, e->d_in_vals, values, (size_t)n_entries * e->K));
+  for (int i = 0; i < n_entries; ++i) {
+    auto it = e->in_levels.find(level[i]);
+    if (it == e->in_levels.end()) e->in_levels[level[i]] = std::make_pair(i, 1); else it->second.second += 1;
+  }
+  return CWR_OK;
+}
+
 int32_t cwr_set_state(cwr_engine* e, const double* conc_owned) {
   if (!e || !conc_owned) return e ? fail(e, CWR_ERR_BAD_ARG, "cwr_set_state: NULL") : CWR_ERR_BAD_ARG;
   HIP_TRY(e, hipSetDevice(e->dev));
@@ -1288,7 +1406,8 @@ int32_t cwr_react_linear(cwr_engine* e, const double* M) {
 int32_t cwr_state_device_ptr(cwr_engine* e, void** state, void** stream) {
   if (!e || !state) return e ? fail(e, CWR_ERR_BAD_ARG, "cwr_state_device_ptr: NULL") : CWR_ERR_BAD_ARG;
   *state = e->d_c;
-  e->halo_fresh = false;                              // the caller may rewrite the state
+  e->halo_fresh = false;                              // the caller may rewrite the state,
+  e->ptr_exported = true;                             // now and between any two later steps (the pointer never changes)
   if (stream) *stream = e->stream;
   return CWR_OK;
 }
@@ -1346,6 +1465,15 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
   e->ev_used = 0;
   e->flux_valid = false;
   e->tail_done = false;
+  e->info_flags = 0;
+  {
+    // element-wise rule: targets (1e6 tol, tol) = (1e-6, 1e-12) at the default tolerance, scaled by s = 0.3 (1-rho)/rho
+    // (clamped to [1e-3, 0.1]) so that Jacobi's a-posteriori bound |e| <= rho/(1-rho) |x'-x| keeps the forward error inside them
+    const double rho = (e->last_rate > 0.0 && e->last_rate < 1.0) ? e->last_rate : 0.9;
+    const double sc = std::min(0.1, std::max(1.0e-3, 0.3 * (1.0 - rho) / rho));
+    e->ew_rel = sc * std::min(1.0e-2, 1.0e6 * tol);
+    e->ew_abs = sc * tol;
+  }
 
   // one GPU: the zero-coefficient precondition of level t+1 is known from the flow field (check_ghost_levels): stop before
   // anything touches the state, without a device round trip.  Partitioned runs keep going instead -- the violating
@@ -1359,9 +1487,15 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
   // the inner halo layers need x_t for their right-hand sides; the exchange that closed the previous step (for its face
   // fluxes) already delivered it unless the state was touched in between.  Every rank makes the same calls, so every
   // rank takes the same branch.
-  if (!e->halo_fresh) TRY(exchange_halo(e, e->d_c));
+  // (a caller holding the state pointer may have rewritten the state since: then the exchange is never skipped)
+  if (!e->halo_fresh || e->ptr_exported) TRY(exchange_halo(e, e->d_c));
   e->halo_fresh = false;
-  TRY(launch_rhs(e, t, e->d_c, e->d_b, true));
+  // keep x_t (k_rhs writes the computed rows aside) and the ghost rows: a failed solve restores them
+  if (e->n_ghost > 0)
+    HIP_TRY(e, hipMemcpyAsync(e->d_keep + (size_t)e->n_real * K, e->d_c + (size_t)e->n_real * K, (size_t)e->n_ghost * K * sizeof(double),
+                              hipMemcpyDeviceToDevice, e->stream));
+  TRY(launch_rhs(e, t, e->d_c, e->d_b, true, e->d_keep));
+  const bool has_inputs = e->in_levels.count(t + 1) != 0;   // the tail writes real rows then: it must not run speculatively
   SolveStats st;
   int rc_solve = CWR_OK;
   const bool force_bicg = (flags & CWR_STEP_FORCE_BICGSTAB) != 0;
@@ -1372,7 +1506,7 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
     rc_solve = solve_small(e, tol2, max_iter, force_jac, st, handled, need_bicg);
     if (rc_solve != CWR_OK && st.status == CWR_OK) return rc_solve;
     if (!handled) {
-      e->spec_t = (!e->comm && !e->profiling) ? t : -1; e->spec_flags = flags;
+      e->spec_t = (!e->comm && !e->profiling && !has_inputs) ? t : -1; e->spec_flags = flags;
       rc_solve = solve_jacobi(e, tol2, max_iter, force_jac, st, need_bicg);
       e->spec_t = -1;
       if (rc_solve != CWR_OK && st.status == CWR_OK) return rc_solve;     // HIP / RCCL failure
@@ -1396,8 +1530,16 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
   local.max_rel_residual = max_rel; local.status = st.status;
   local.solver = (st.iterations == 0 && !force_bicg) ? 0 : (st.sweeps == 0 ? 1 : 2);
   local.sweep_kernel = st.sweep_kernel;
+  local.flags = e->info_flags;
   if (st.status != CWR_OK) {
     e->flux_valid = false; e->halo_fresh = false; e->tail_done = false;   // (a speculative tail may have run)
+    // the solver iterated in place: put x_t and the ghost rows back, so that the state is what the step found and the
+    // caller may retry (other tolerance, other solver) or read it
+    hipMemcpyAsync(e->d_c, e->d_keep, (size_t)e->n_owned * K * sizeof(double), hipMemcpyDeviceToDevice, e->stream);
+    if (e->n_ghost > 0)
+      hipMemcpyAsync(e->d_c + (size_t)e->n_real * K, e->d_keep + (size_t)e->n_real * K, (size_t)e->n_ghost * K * sizeof(double),
+                     hipMemcpyDeviceToDevice, e->stream);
+    e->last_sweeps = 0;
     if (info) *info = local;
     switch (st.status) {
       case CWR_ERR_GHOST_COEFF: return fail(e, st.status, "active ghost face with a zero advection/diffusion coefficient at level t+1 "

@@ -129,14 +129,18 @@ template <int VW> __device__ __forceinline__ void stv(double* p, const double (&
 // are bitwise reproducible; k_reduce_partials folds the slots in a fixed order afterwards.  Threads
 // are laid out tid = r*G + g (row-in-tile, lane group); when G divides 64 the rows of a wave are
 // folded with xor-shuffles (DPP / ds_bpermute class cross-lane ops), otherwise through LDS.
-template <int NV, int VW>
+// Dots with index >= MAXFROM are folded with max instead of + (the element-wise convergence measures of MODE 4).
+template <int NV, int VW, int MAXFROM = 1 << 20>
 __device__ __forceinline__ void block_reduce_cols(double (&val)[NV], int G, int K, double* out, double* lds) {
   const int tid = threadIdx.x;
   constexpr int ND = NV / VW;
   if ((64 % G) == 0) {
     for (int off = 32; off >= G; off >>= 1) {
 #pragma unroll
-      for (int i = 0; i < NV; ++i) val[i] += __shfl_xor(val[i], off, 64);
+      for (int i = 0; i < NV; ++i) {
+        const double o = __shfl_xor(val[i], off, 64);
+        val[i] = (i / VW >= MAXFROM) ? fmax(val[i], o) : val[i] + o;
+      }
     }
     const int lane = tid & 63, wave = tid >> 6;
     if (lane < G) {
@@ -150,8 +154,8 @@ __device__ __forceinline__ void block_reduce_cols(double (&val)[NV], int G, int 
 #pragma unroll
         for (int w = 0; w < VW; ++w) {
           const int i = d * VW + w;
-          double s = 0.0;
-          for (int wv = 0; wv < BLOCK / 64; ++wv) s += lds[(wv * G + tid) * NV + i];
+          double s = lds[tid * NV + i];
+          for (int wv = 1; wv < BLOCK / 64; ++wv) { const double o = lds[(wv * G + tid) * NV + i]; s = (d >= MAXFROM) ? fmax(s, o) : s + o; }
           out[d * K + tid * VW + w] = s;
         }
     }
@@ -166,8 +170,8 @@ __device__ __forceinline__ void block_reduce_cols(double (&val)[NV], int G, int 
 #pragma unroll
         for (int w = 0; w < VW; ++w) {
           const int i = d * VW + w;
-          double s = 0.0;
-          for (int r = 0; r < R; ++r) s += lds[(r * G + tid) * NV + i];
+          double s = lds[tid * NV + i];
+          for (int r = 1; r < R; ++r) { const double o = lds[(r * G + tid) * NV + i]; s = (d >= MAXFROM) ? fmax(s, o) : s + o; }
           out[d * K + tid * VW + w] = s;
         }
     }
@@ -180,7 +184,7 @@ __device__ __forceinline__ void block_reduce_cols(double (&val)[NV], int G, int 
 struct ReduceOuts { double* p[4]; };
 constexpr int RBLOCK = 1024;
 __global__ void __launch_bounds__(RBLOCK) k_reduce_partials(int nslots, int ND, int K, const double* __restrict__ partial,
-                                                          ReduceOuts outs) {
+                                                          ReduceOuts outs, int max_from) {
   __shared__ double sm[RBLOCK];
   const int d = blockIdx.x;
   double* out = outs.p[d];
@@ -190,6 +194,18 @@ __global__ void __launch_bounds__(RBLOCK) k_reduce_partials(int nslots, int ND, 
   const int k = tid % K, l = tid / K;
   const size_t stride = (size_t)ND * K;
   const double* base = partial + (size_t)d * K + k;
+  if (d >= max_from) {                          // dots folded with max (uniform per block); -inf is the identity
+    double m = -INFINITY;
+    if (l < S) for (int slot = l; slot < nslots; slot += S) m = fmax(m, base[(size_t)slot * stride]);
+    sm[tid] = m;
+    __syncthreads();
+    if (tid < K) {
+      double tot = -INFINITY;
+      for (int i = 0; i < S; ++i) tot = fmax(tot, sm[i * K + tid]);
+      out[tid] = tot;
+    }
+    return;
+  }
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;   // four independent chains keep four loads in flight
   if (l < S) {
     int slot = l;
@@ -323,7 +339,7 @@ __global__ void __launch_bounds__(BLOCK) k_rhs(
     const float* __restrict__ vel_n, const float* __restrict__ adv_n, const double* __restrict__ dif_n,
     int use_diffusion, const double* __restrict__ bc_n, const double* __restrict__ x,
     const double* __restrict__ diag, const uint8_t* __restrict__ row_ghost, double* __restrict__ b,
-    int32_t* __restrict__ counters) {
+    int32_t* __restrict__ counters, double* __restrict__ x_keep) {
   const int R = BLOCK / G;
   const int r = threadIdx.x / G, g = threadIdx.x - r * G;
   if (r >= R) return;
@@ -332,6 +348,9 @@ __global__ void __launch_bounds__(BLOCK) k_rhs(
   double xv[VW], gin[VW], gout[VW];
   bool bad = false;
   ldv<VW>(x + (size_t)c * K + col, xv);
+  // x_t is kept aside: the solver iterates in place in the state vector, and a step that fails (no convergence, NaN)
+  // must leave the state as it found it so that the caller can retry (cwr_step restores it from this copy)
+  if (x_keep) stv<VW>(x_keep + (size_t)c * K + col, xv);
 #pragma unroll
   for (int w = 0; w < VW; ++w) { gin[w] = 0.0; gout[w] = 0.0; }
   // only rows with a boundary (ghost) face walk their entries: for the others the two dependent loads (row pointer ->
@@ -406,7 +425,7 @@ __global__ void __launch_bounds__(BLOCK, CWR_APPLY_MIN_WAVES) k_apply(
     int row0, int n_owned, int n_dot, int K, int G, int U, int ntiles, int stage_cap, int nt, const int32_t* __restrict__ ptr,
     const FaceRec* __restrict__ rec, const double* __restrict__ diag, const double* __restrict__ xin,
     double* __restrict__ yout, const double* __restrict__ r0, const double* __restrict__ bhat,
-    double* __restrict__ r0_out, double* __restrict__ p_out, double* __restrict__ partial) {
+    double* __restrict__ r0_out, double* __restrict__ p_out, double* __restrict__ partial, double ew_rel) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
   FaceRec* s_rec = reinterpret_cast<FaceRec*>(s_dyn);
   double* s_red = reinterpret_cast<double*>(s_dyn + (size_t)stage_cap * sizeof(FaceRec));
@@ -416,11 +435,15 @@ __global__ void __launch_bounds__(BLOCK, CWR_APPLY_MIN_WAVES) k_apply(
   const int tid = threadIdx.x;
   const int r = tid / G, g = tid - r * G;
   const int col = g * VW;
-  constexpr int ND = (MODE == 1) ? 1 : (MODE == 2 ? 4 : ((MODE == 3 || MODE == 4 || MODE == 5) ? 2 : 0));
+  // MODE 4 carries two more partials, folded with max: the element-wise convergence measures of the sweep
+  //   [2] max_i ( |x'_i - x_i| - ew_rel |x'_i| )      [3] max_i |x'_i|
+  // (host: converged element-wise when [2] <= ew_abs * [3]; see solve_jacobi)
+  constexpr int ND = (MODE == 1) ? 1 : ((MODE == 2 || MODE == 4) ? 4 : ((MODE == 3 || MODE == 5) ? 2 : 0));
   constexpr int NP = (ND > 0 ? ND : 1) * VW;
+  constexpr int MAXFROM = (MODE == 4) ? 2 : (1 << 20);
   double part[NP];
 #pragma unroll
-  for (int i = 0; i < NP; ++i) part[i] = 0.0;
+  for (int i = 0; i < NP; ++i) part[i] = (MODE == 4 && i >= 2 * VW && i < 3 * VW) ? -INFINITY : 0.0;
 
   const int xcd = blockIdx.x % N_XCD, lidx = blockIdx.x / N_XCD, bpx = gridDim.x / N_XCD;
   const int tpx = (ntiles + N_XCD - 1) / N_XCD;
@@ -491,6 +514,12 @@ __global__ void __launch_bounds__(BLOCK, CWR_APPLY_MIN_WAVES) k_apply(
             const double dx = y[w] - xc[w];
             part[0 * VW + w] += wdot * dx * dx;
             part[1 * VW + w] += wdot * q0[w] * q0[w];
+            if constexpr (MODE == 4) {
+              if (c < n_dot) {
+                part[2 * VW + w] = fmax(part[2 * VW + w], fabs(dx) - ew_rel * fabs(y[w]));
+                part[3 * VW + w] = fmax(part[3 * VW + w], fabs(y[w]));
+              }
+            }
           }
           stv_stream<VW>(yout + o, y);
         } else {
@@ -525,7 +554,7 @@ __global__ void __launch_bounds__(BLOCK, CWR_APPLY_MIN_WAVES) k_apply(
   }
   if constexpr (ND > 0) {
     __syncthreads();
-    block_reduce_cols<NP, VW>(part, G, K, partial + (size_t)blockIdx.x * ND * K, s_red);
+    block_reduce_cols<NP, VW, MAXFROM>(part, G, K, partial + (size_t)blockIdx.x * ND * K, s_red);
   }
 }
 
@@ -941,6 +970,19 @@ __global__ void __launch_bounds__(BLOCK) k_ghost_writeback(int64_t total, const 
   ghost_rows[i] = (v != 0.0) ? v : __builtin_nan("");
 }
 
+// Real-cell entries of input_array[t+1] (point sources / fixed concentrations inside the domain): the reference
+// overwrites the solved level with every non-zero entry before the mass fluxes are taken (transport.py:258-264).
+// Sparse: (row, K values) per entry of the level; zero = "no input" as everywhere in the reference.
+__global__ void __launch_bounds__(BLOCK) k_apply_inputs(int64_t total, int K, const int32_t* __restrict__ rows,
+                                                      const double* __restrict__ vals, double* __restrict__ c) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= total) return;
+  const int64_t ent = i / K;
+  const int k = (int)(i - ent * K);
+  const double v = vals[i];
+  if (v != 0.0) c[(size_t)rows[ent] * K + k] = v;
+}
+
 // ------------------------------------------------------------------------------------------------ a-6
 // transport.py:414-429 with c = concentrations of level t+1 (ghost rows included, NaN = no value).
 template <int VW>
@@ -1093,8 +1135,8 @@ constexpr int SMALL_DEG = 8;                     // register-resident records: f
 template <int RPT, bool REGS>
 __global__ void __launch_bounds__(SMALL_THREADS) k_small_jacobi(
     int n, int K, const int32_t* __restrict__ ptr, const FaceRec* __restrict__ rec, const double* __restrict__ diag,
-    const double* __restrict__ bhat, double* __restrict__ x, double tol2, int max_sweeps, int check_every,
-    double* __restrict__ info /* [K][3]: sweeps, ||x'-x||^2, ||bhat||^2 */) {
+    const double* __restrict__ bhat, double* __restrict__ x, double tol2, double ew_rel, double ew_abs, int max_sweeps,
+    int check_every, double* __restrict__ info /* [K][5]: sweeps, ||x'-x||^2, ||bhat||^2, max(|dx| - ew_rel |x'|), max |x'| */) {
   extern __shared__ double s_x[];                // n doubles, then reduction scratch
   double* s_red = s_x + n;
   const int k = blockIdx.x;
@@ -1137,12 +1179,21 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_small_jacobi(
     for (int w = 0; w < SMALL_THREADS / 64; ++w) t += s_red[w];
     return t;
   };
+  auto block_max = [&](double v) -> double {
+    for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    __syncthreads();
+    if (lane == 0) s_red[wave] = v;
+    __syncthreads();
+    double t = s_red[0];
+    for (int w = 1; w < SMALL_THREADS / 64; ++w) t = fmax(t, s_red[w]);
+    return t;
+  };
   bb = block_sum(bb);
   int sweep = 0;
-  double rr = 0.0;
+  double rr = 0.0, m1 = 0.0, m2 = 0.0;
   for (;;) {
     double xn[RPT];
-    double dx2 = 0.0;
+    double dx2 = 0.0, e1 = -INFINITY, e2 = 0.0;
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
       const int c = tid + i * SMALL_THREADS;
@@ -1163,6 +1214,8 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_small_jacobi(
         xn[i] = bh[i] + sum;
         const double dx = xn[i] - s_x[c];
         dx2 += dx * dx;
+        e1 = fmax(e1, fabs(dx) - ew_rel * fabs(xn[i]));
+        e2 = fmax(e2, fabs(xn[i]));
       }
     }
     __syncthreads();                             // every read of the old column is done
@@ -1175,7 +1228,8 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_small_jacobi(
     const bool check = (sweep % check_every == 0) || sweep >= max_sweeps;
     if (check) {                                 // uniform
       rr = block_sum(dx2);                       // (its barriers also publish the new column)
-      if (!(rr > tol2 * bb) || sweep >= max_sweeps) break;    // converged, NaN, or out of sweeps
+      m1 = block_max(e1); m2 = block_max(e2);    // element-wise measures of this sweep (see k_apply MODE 4)
+      if (!(rr == rr) || (!(rr > tol2 * bb) && !(m1 > ew_abs * m2)) || sweep >= max_sweeps) break;    // NaN, converged, or out of sweeps
     } else {
       __syncthreads();
     }
@@ -1185,7 +1239,7 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_small_jacobi(
     const int c = tid + i * SMALL_THREADS;
     if (c < n) x[(size_t)c * K + k] = s_x[c];
   }
-  if (tid == 0) { info[k * 3 + 0] = (double)sweep; info[k * 3 + 1] = rr; info[k * 3 + 2] = bb; }
+  if (tid == 0) { info[k * 5 + 0] = (double)sweep; info[k * 5 + 1] = rr; info[k * 5 + 2] = bb; info[k * 5 + 3] = m1; info[k * 5 + 4] = m2; }
 }
 
 // ------------------------------------------------------------------------------------------------ a-8 on device

@@ -30,11 +30,14 @@ STEP_FORCE_BICGSTAB = 4
 STEP_FORCE_JACOBI = 8
 STEP_MASS_BALANCE = 16
 
+INFO_LOOSE_RESIDUAL = 1        # BiCGSTAB stagnated within 100 x tol and was accepted
+INFO_ELEMENTWISE_MISSED = 2    # the element-wise rule was still violated after the tightened BiCGSTAB rounds
+
 # every symbol include/cwr_transport.h declares (tests check that the library exports them all)
 ABI_SYMBOLS = (
     'cwr_abi_version', 'cwr_create', 'cwr_destroy', 'cwr_last_error', 'cwr_load_flow_field',
     'cwr_load_coefficients', 'cwr_get_coefficients', 'cwr_load_boundary', 'cwr_set_boundary_level',
-    'cwr_set_state', 'cwr_get_state', 'cwr_react_linear', 'cwr_state_device_ptr', 'cwr_apply', 'cwr_rhs', 'cwr_step', 'cwr_get_mass_flux',
+    'cwr_set_state', 'cwr_get_state', 'cwr_load_real_inputs', 'cwr_react_linear', 'cwr_state_device_ptr', 'cwr_apply', 'cwr_rhs', 'cwr_step', 'cwr_get_mass_flux',
     'cwr_time_apply', 'cwr_profile_read', 'cwr_synchronize', 'cwr_apply_bytes',
     'cwr_comm_unique_id', 'cwr_attach_comm',
     'cwr_set_boundary_lines', 'cwr_reset_mass_balance', 'cwr_get_mass_balance', 'cwr_domain_mass',
@@ -49,7 +52,7 @@ class SolverNotConverged(RuntimeError):
 class StepInfo(C.Structure):
     _fields_ = [('iterations', C.c_int32), ('sweeps', C.c_int32), ('restarts', C.c_int32), ('status', C.c_int32),
                 ('operator_launches', C.c_int32), ('solver', C.c_int32), ('max_rel_residual', C.c_double),
-                ('solve_ms', C.c_double), ('sweep_kernel', C.c_int32), ('reserved', C.c_int32)]
+                ('solve_ms', C.c_double), ('sweep_kernel', C.c_int32), ('flags', C.c_int32)]
 
 
 @dataclass
@@ -62,6 +65,7 @@ class StepResult:
     max_rel_residual: float
     solve_ms: float
     sweep_kernel: int = 0    # 4 plain sweep, 5 J^2 pass, 6 tiled J^2 pass, 7 one-launch small-mesh solver
+    flags: int = 0           # INFO_* bits: tolerance decisions that were not met exactly (0 in a clean step)
 
 
 _lib = None
@@ -95,6 +99,7 @@ def load_library(path: str | None = None) -> C.CDLL:
         'cwr_set_boundary_level': [vp, i32, vp],
         'cwr_set_state': [vp, vp],
         'cwr_get_state': [vp, vp],
+        'cwr_load_real_inputs': [vp, i32, vp, vp, vp],
         'cwr_react_linear': [vp, vp],
         'cwr_state_device_ptr': [vp, P(vp), P(vp)],
         'cwr_apply': [vp, i32, vp, vp],
@@ -271,6 +276,29 @@ class TransportEngine:
             return ref
         return out
 
+    def load_real_inputs(self, levels, cells, values):
+        """Non-zero input_array entries on real cells at levels >= 1 (transport.py:258-264): ``levels`` (m,), ``cells`` (m,)
+        reference cell ids, ``values`` (m, K) with 0 = no input for that constituent.  Sorted by level here."""
+        lv = _arr(levels, np.int32).ravel()
+        ce = _arr(cells, np.int64).ravel()
+        va = _arr(np.asarray(values, dtype=np.float64).reshape(len(lv), -1), np.float64, (len(lv), self.K), 'values')
+        if len(ce) != len(lv):
+            raise ValueError('levels and cells must have the same length')
+        if len(ce) and (ce.min() < 0 or ce.max() >= self.n_core):
+            raise ValueError('real-cell inputs must address real cells of this engine')
+        if self._order is not None:
+            inv = np.empty(self.n_owned, dtype=np.int64)
+            inv[self._order] = np.arange(self.n_owned)
+            ce = inv[ce]
+        o = np.argsort(lv, kind='stable')
+        lv, ce, va = np.ascontiguousarray(lv[o]), np.ascontiguousarray(ce[o].astype(np.int32)), np.ascontiguousarray(va[o])
+        self._check(self._lib.cwr_load_real_inputs(self._h, len(lv), _ptr(lv), _ptr(ce), _ptr(va)))
+
+    def state_row_order(self):
+        """order[device row] = reference cell id of the real cells behind state_device_ptr() (None: rows are the
+        reference's ids)."""
+        return None if self._order is None else self._order.copy()
+
     def react_linear(self, reaction_matrix):
         """c[cell, :] <- M c[cell, :] on every owned cell, on the device (the in-HBM stand-in for the host
         reaction callback of transport.py:233-236)."""
@@ -317,8 +345,16 @@ class TransportEngine:
         flags |= STEP_MASS_BALANCE if mass_balance else 0
         flags |= {'auto': 0, 'jacobi': STEP_FORCE_JACOBI, 'bicgstab': STEP_FORCE_BICGSTAB}[solver]
         self._check(self._lib.cwr_step(self._h, int(t), float(tol), int(max_iter), flags, C.byref(info)))
+        if info.flags:
+            import warnings
+            what = []
+            if info.flags & INFO_LOOSE_RESIDUAL:
+                what.append(f'BiCGSTAB stagnated at a relative residual of {info.max_rel_residual:.2e} (> tol = {tol:.1e}) and was accepted')
+            if info.flags & INFO_ELEMENTWISE_MISSED:
+                what.append('the element-wise convergence rule was not met (the norm criterion holds)')
+            warnings.warn(f'transport step {t}: ' + '; '.join(what), RuntimeWarning, stacklevel=2)
         return StepResult(info.iterations, info.sweeps, info.restarts, info.operator_launches, info.solver,
-                          info.max_rel_residual, info.solve_ms, info.sweep_kernel)
+                          info.max_rel_residual, info.solve_ms, info.sweep_kernel, info.flags)
 
     def get_mass_flux(self):
         shape = (self.n_edges, self.K)

@@ -228,6 +228,15 @@ class ClearwaterRiverine:
         for c in self.constituents:
             rows = np.nonzero(np.any(self.constituent_dict[c].input_array[:, :n] != 0, axis=1))[0]
             self._real_input_rows.update(int(r) for r in rows)
+        # levels >= 1: the reference also writes them into the SOLVED level t+1 before the mass fluxes are taken
+        # (transport.py:258-264); the engine does that on the device from these sparse entries
+        lv, ce, va = [], [], []
+        for r in sorted(self._real_input_rows - {0}):
+            inp = np.stack([self.constituent_dict[c].input_array[r, :n] for c in self.constituents], axis=1)
+            cells = np.nonzero(np.any(inp != 0, axis=1))[0]
+            lv.append(np.full(len(cells), r, dtype=np.int32)); ce.append(cells); va.append(inp[cells])
+        if lv:
+            self.engine.load_real_inputs(np.concatenate(lv), np.concatenate(ce), np.concatenate(va))
         self._device_level = -1
         self.last_step: Optional[StepResult] = None
 
@@ -276,7 +285,8 @@ class ClearwaterRiverine:
                     vals = np.asarray(getattr(vals, 'values', vals), dtype=np.float64)
                     self._row(cname, t)[0:n] = vals[0:n]
                     overridden = True
-        if overridden or self._device_level != t or t in self._real_input_rows:
+        # (real-cell inputs of levels >= 1 are already in the device state: the engine applied them when it solved level t)
+        if overridden or self._device_level != t or (t == 0 and t in self._real_input_rows):
             x = np.stack([self._row(c, t)[0:n] for c in self.constituents], axis=1)
             if t in self._real_input_rows:                       # linalg.py:199-200
                 inp = np.stack([self.constituent_dict[c].input_array[t, :n] for c in self.constituents], axis=1)
@@ -294,6 +304,8 @@ class ClearwaterRiverine:
                 for cname in self.constituents:
                     self._stream.writer.write_level(cname, t, np.ascontiguousarray(self._row(cname, t), dtype=np.float64))
         want_flux = self.store_history or (self._stream is not None and self._stream.with_flux)
+        # (a step that raises leaves the device state at level t -- the engine restores it -- and time_step unchanged:
+        # update() may simply be called again, e.g. with a larger max_iter)
         self.last_step = self.engine.step(t, tol=self.tol, max_iter=self.max_iter, mass_flux=want_flux,
                                           solver=self.solver, mass_balance=bool(self._lines))
         self._device_level = t + 1

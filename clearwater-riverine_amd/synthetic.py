@@ -217,6 +217,21 @@ def make_mesh(nx: int, ny: int, n_steps: int, *, seed: int = 0, n_merge: int = 0
     }
 
 
+BENCH_SEED = 4
+BENCH_GRID = (1026, 1026)
+BENCH_MERGES = 52676            # 5.0 % of the 1 052 676 base quads fused into 6-sided cells: exactly 10^6 real cells
+
+
+def bench_mesh(n_steps: int, *, dt: float = 40.0, diffusion_coefficient: float = 0.5, scale: int = 1) -> dict:
+    """BASELINE config 4 / the bench workload: the unstructured 1 M-cell floodplain mesh --
+    jittered quads with 5 % of the cells merged into 6-sided cells (duplicate faces between the same two cells
+    included), locally shuffled cell and face numbering, seed 4, CFL ~ 2.5 at dt = 40 s, D = 0.5.
+    scale = 2 gives config 5's 4 M-cell mesh (2052 x 2052 base quads, seed 5)."""
+    nx, ny = BENCH_GRID[0] * scale, BENCH_GRID[1] * scale
+    return make_mesh(nx, ny, n_steps, seed=BENCH_SEED if scale == 1 else BENCH_SEED + scale - 1,
+                     n_merge=BENCH_MERGES * scale * scale, dt=dt, diffusion_coefficient=diffusion_coefficient)
+
+
 def boundary_input_array(mesh: dict, n_const: int, *, ic: float | np.ndarray = 1.0,
                          inlet_base: float = 60.0, inlet_amp: float = 40.0,
                          inlet_period_s: float = 600.0, outlet_value: float = 5.0) -> np.ndarray:
@@ -238,4 +253,55 @@ def boundary_input_array(mesh: dict, n_const: int, *, ic: float | np.ndarray = 1
     if outlet_value:
         out = mesh['outlet_ghost_cells']
         arr[:, out[::2], :] = outlet_value * scale[None]   # every other outlet ghost: the rest have "no BC"
+    return arr
+
+
+def distinct_input_array(mesh: dict, n_const: int, *, seed: int = 0) -> np.ndarray:
+    """(T, ncell, K) input array (constituents.py:78-164 convention, as boundary_input_array) in which every
+    constituent has its own initial field and its own boundary series, so that the K batched systems have
+    different right-hand sides, fronts and convergence histories.  Four families by k % 4:
+      0  smooth field  A (1 + 0.5 sin(2 pi p x / Lx + phi) cos(2 pi q y / Ly)), sinusoidal inlet (period, phase by k)
+      1  uniform field, inlet = base + a Gaussian pulse in time (a spill / E. coli spike)
+      2  linear gradient along x, constant inlet, no outlet value
+      3  plume: EXACTLY zero outside a disc (so the implicit solution has fronts decaying to 1e-300), small
+         constant inlet value -- the case an element-wise parity check exists for
+    Every value is >= 0; zero on a ghost cell keeps its reference meaning "no boundary value"."""
+    rng = np.random.default_rng(seed)
+    T = len(mesh['time_seconds'])
+    ncell = len(mesh['face_x'])
+    n = mesh['nreal'] + 1
+    x = np.asarray(mesh['face_x'][:n], dtype=np.float64)
+    y = np.asarray(mesh['face_y'][:n], dtype=np.float64)
+    x0, x1, y0, y1 = x.min(), x.max(), y.min(), y.max()
+    Lx, Ly = max(x1 - x0, 1.0), max(y1 - y0, 1.0)
+    xs, ys = (x - x0) / Lx, (y - y0) / Ly
+    tsec = np.asarray(mesh['time_seconds'], dtype=np.float64)
+    span = max(tsec[-1] - tsec[0], 1.0)
+    inlet = np.asarray(mesh['inlet_ghost_cells'], dtype=np.int64)
+    outlet = np.asarray(mesh['outlet_ghost_cells'], dtype=np.int64)
+    arr = np.zeros((T, ncell, n_const))
+    for k in range(n_const):
+        fam = k % 4
+        amp = 1.0 + 0.75 * k
+        phi = 2 * np.pi * rng.random()
+        if fam == 0:
+            p, q = 1 + (k // 4) % 3, 1 + (k // 8) % 2
+            arr[0, :n, k] = amp * (1.0 + 0.5 * np.sin(2 * np.pi * p * xs + phi) * np.cos(2 * np.pi * q * ys))
+            series = amp * (60.0 + 40.0 * np.sin(2 * np.pi * tsec / (600.0 * (1 + 0.25 * k)) + phi))
+            arr[:, outlet[::2], k] = 5.0 * amp
+        elif fam == 1:
+            arr[0, :n, k] = amp
+            tc = tsec[0] + (0.3 + 0.4 * rng.random()) * span
+            series = amp * (2.0 + 80.0 * np.exp(-0.5 * ((tsec - tc) / (0.15 * span)) ** 2))
+            arr[:, outlet[1::2], k] = 0.5 * amp
+        elif fam == 2:
+            arr[0, :n, k] = amp * (0.2 + 2.0 * xs)
+            series = np.full(T, 0.2 * amp)
+        else:
+            cx, cy = 0.2 + 0.6 * rng.random(), 0.2 + 0.6 * rng.random()
+            r2 = ((xs - cx) * Lx) ** 2 + ((ys - cy) * Ly) ** 2
+            rad = 0.08 * min(Lx, Ly)
+            arr[0, :n, k] = np.where(r2 < rad * rad, 50.0 * amp * np.exp(-4.0 * r2 / (rad * rad)), 0.0)
+            series = np.full(T, 1e-3 * amp)
+        arr[:, inlet, k] = series[:, None]
     return arr

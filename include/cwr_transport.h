@@ -65,8 +65,15 @@ typedef struct cwr_step_info {
   double solve_ms;             /* host wall time of the step, for information only */
   int32_t sweep_kernel;        /* which Jacobi kernel ran: 4 plain sweep, 5 J^2 pass, 6 tiled J^2 pass (x tile in LDS),
                                   7 one-launch small-mesh solver, 0 none (BiCGSTAB only) */
-  int32_t reserved;
+  int32_t flags;               /* CWR_INFO_* bits: tolerance decisions that were NOT met exactly (0 in a clean step) */
 } cwr_step_info;
+
+/* bits of cwr_step_info.flags */
+enum {
+  CWR_INFO_LOOSE_RESIDUAL = 1,     /* BiCGSTAB stagnated within 100 x tol after 6 verified restarts and was accepted */
+  CWR_INFO_ELEMENTWISE_MISSED = 2  /* the element-wise rule |x'-x| <= 1e6 tol |x| + tol max|x| (scaled, see cwr_step) was still
+                                      violated after 3 tightened BiCGSTAB rounds; the norm criterion holds */
+};
 
 int32_t cwr_abi_version(void);
 
@@ -123,6 +130,12 @@ int32_t cwr_set_boundary_level(cwr_engine* e, int32_t t, const double* ghost_con
  * halo rows hold the neighbours' values of the last exchange. */
 int32_t cwr_set_state(cwr_engine* e, const double* conc_owned);
 int32_t cwr_get_state(cwr_engine* e, double* conc_all_cells);
+/* Non-zero entries of input_array[level >= 1] on REAL cells (point sources / fixed concentrations inside the domain):
+ * the reference overwrites the solved level t+1 with them before the mass fluxes are taken (transport.py:258-264) and
+ * uses them as x_t of the next step (linalg.py:199-200).  Sparse triplets sorted by level: level[i], row[i] (an owned real
+ * cell), values[i*K .. i*K+K) with 0 = "no input for this constituent".  Replaces every earlier call. */
+int32_t cwr_load_real_inputs(cwr_engine* e, int32_t n_entries, const int32_t* level, const int32_t* row,
+                             const double* values);
 
 /* ---- device-resident reaction hook (callers: examples/02_...tsm.ipynb cell[39] run_n_timesteps) -----
  * The reference's coupling loop overrides c[t, 0:n] per constituent from a host reaction model before update()
@@ -130,7 +143,12 @@ int32_t cwr_get_state(cwr_engine* e, double* conc_all_cells);
  * cwr_react_linear: c[cell, :] <- M c[cell, :] on every owned cell, M (K, K) row-major host array (first-order
  *   decay on the diagonal, pairwise exchange off it) -- the built-in stand-in for a TSM/NSM kinetics kernel;
  * cwr_state_device_ptr: the device pointer of the (n_cells, K) float64 state and the engine's hipStream_t, for a
- *   caller-supplied HIP reaction kernel launched between two cwr_step() calls (rows [0, n_owned) are the real cells). */
+ *   caller-supplied HIP reaction kernel launched between two cwr_step() calls.  Rows are in the cell numbering this
+ *   engine was CREATED with: rows [0, n_owned) are the real cells face1/face2 of cwr_create refer to (a host wrapper that
+ *   renumbers cells before cwr_create -- engine.py's cell_order -- must hand its row map to the kernel's author:
+ *   TransportEngine.state_row_order()).  The pointer never changes; once it has been handed out the engine assumes the
+ *   state may have been rewritten before every later step (partitioned engines then never skip the start-of-step halo
+ *   exchange).  Work enqueued on the returned stream is ordered with the engine's own kernels. */
 int32_t cwr_react_linear(cwr_engine* e, const double* reaction_matrix);
 int32_t cwr_state_device_ptr(cwr_engine* e, void** state, void** stream);
 
@@ -150,6 +168,12 @@ int32_t cwr_rhs(cwr_engine* e, int32_t t, const double* x_t, double* b);
  * optional mass flux.  State advances from level t to t+1.
  * tol: target for ||D^-1 (b - A x)||_2 / ||D^-1 b||_2 per constituent (e.g. 1e-12); max_iter bounds
  * sweeps and BiCGSTAB iterations each.  info may be NULL.
+ * On top of the norm criterion every cell and constituent must satisfy |x'_i - x_i| <= s (1e6 tol |x'_i| + tol max|x'|)
+ * for one more Jacobi sweep x -> x', s = 0.3 (1 - rho) / rho from the measured contraction rho (clamped to
+ * [1e-3, 0.1]): with Jacobi's a-posteriori bound the forward error then stays within 1e-6 |x_i| + 1e-12 max|x| at
+ * tol = 1e-12 -- also for plume fronts many decades below the peak, which a 2-norm cannot see.
+ * A step that fails (CWR_ERR_NOT_CONVERGED, CWR_ERR_NONFINITE, CWR_ERR_GHOST_COEFF) leaves the state exactly as it
+ * found it: it may be retried with another tolerance, iteration budget or solver.
  * The call returns as soon as convergence is known: the ghost write-back and flux kernels that close the step may still
  * be running on the engine's stream.  Every read-out (cwr_get_state, cwr_get_mass_flux, ...), every later step and
  * cwr_synchronize are ordered behind them; cwr_step_info.solve_ms is the time until convergence was known. */

@@ -5,6 +5,7 @@
 // Semantics kept: stream ordering (the stream is drained before data is read, copies complete before returning),
 // grouped send/recv, in-place all-reduce summed in rank order (identical result on every rank).
 // Build: hipcc -O2 -fPIC -shared tests/mock_rccl/mock_rccl.cpp -o tests/mock_rccl/libmock_rccl.so -lrt
+#include <cmath>
 #include <hip/hip_runtime.h>
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -135,7 +136,7 @@ int ncclRecv(void* buf, size_t count, int dt, int peer, void* comm, hipStream_t 
 
 int ncclAllReduce(const void* sendbuf, void* recvbuf, size_t count, int dt, int op, void* comm, hipStream_t s) {
   Comm* c = static_cast<Comm*>(comm);
-  if (dt != 8 || op != 0 || count * 8 > REDUCE_BYTES) return 4;             // float64 sum only
+  if (dt != 8 || (op != 0 && op != 2) || count * 8 > REDUCE_BYTES) return 4;   // float64 sum (0) and max (2) only
   if (hipStreamSynchronize(s) != hipSuccess) return 1;
   const uint64_t round = ++c->red_round;
   // wait until every rank has finished reading the previous round before overwriting our slot
@@ -145,10 +146,10 @@ int ncclAllReduce(const void* sendbuf, void* recvbuf, size_t count, int dt, int 
   c->sh->red_seq[c->rank].store(round);
   for (int r = 0; r < c->world; ++r)
     if (!spin_until([&] { return c->sh->red_seq[r].load() >= round; })) return 6;
-  std::vector<double> acc(count, 0.0);
+  std::vector<double> acc(count, op == 2 ? -INFINITY : 0.0);
   for (int r = 0; r < c->world; ++r) {
     const double* src = reinterpret_cast<const double*>(c->sh->reduce[r]);
-    for (size_t i = 0; i < count; ++i) acc[i] += src[i];
+    for (size_t i = 0; i < count; ++i) acc[i] = (op == 2) ? std::fmax(acc[i], src[i]) : acc[i] + src[i];
   }
   c->sh->red_done[c->rank].store(round);
   if (hipMemcpy(recvbuf, acc.data(), count * 8, hipMemcpyHostToDevice) != hipSuccess) return 1;

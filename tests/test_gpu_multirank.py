@@ -8,13 +8,14 @@ and the convergence decisions taken identically on every rank.
 """
 import multiprocessing as mp
 import os
+import queue
 import subprocess
 
 import numpy as np
 import pytest
 
 import cwr_oracle as oracle
-from util import rel_err
+from util import flux_err, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -75,6 +76,37 @@ def _rank_main(rank, world, K, solver, depth, uid_pipe, out_queue):
         out_queue.put((rank, 0, 0, None, None, None, None, repr(exc), None, None, None))
 
 
+def run_ranks(world, target, args):
+    """Spawn `world` rank processes, collect one result per rank, and ALWAYS reap the children: a rank that dies without
+    posting a result (segfault, mock-RCCL timeout) must not leave its peers alive on the GPU box."""
+    ctx = mp.get_context('spawn')
+    uid_pipe, out_queue = ctx.Queue(), ctx.Queue()
+    procs = [ctx.Process(target=target, args=(r, world) + tuple(args) + (uid_pipe, out_queue)) for r in range(world)]
+    results = []
+    try:
+        for p in procs:
+            p.start()
+        for _ in range(world):
+            try:
+                results.append(out_queue.get(timeout=240))
+            except queue.Empty:
+                break
+    finally:
+        for p in procs:
+            p.join(5 if len(results) < world else 60)
+            if p.is_alive():
+                p.terminate()
+                p.join(10)
+            if p.is_alive():
+                p.kill()
+                p.join(10)
+    assert len(results) == world, f'{world - len(results)} rank(s) posted no result; exit codes {[p.exitcode for p in procs]}'
+    errs = [r[7] for r in results if r[7]]
+    assert not errs, errs
+    results.sort(key=lambda r: r[0])
+    return results
+
+
 @pytest.mark.parametrize('world,K,solver,depth', [(2, 3, 'jacobi', 1), (2, 3, 'bicgstab', 1), (3, 16, 'auto', 1), (4, 1, 'auto', 1),
                                                   (2, 3, 'jacobi', 4), (3, 2, 'bicgstab', 3), (4, 16, 'auto', 8), (3, 1, 'auto', 2),
                                                   (2, 16, 'jacobi', 8), (3, 8, 'jacobi', 2), (2, 12, 'jacobi', 5)])
@@ -86,19 +118,7 @@ def test_partitioned_step_matches_single_rank_and_oracle(gpu_lib, world, K, solv
         monkeypatch.setenv('CWR_LOCAL_REPS', '1')   # exact Jacobi passes (spawned ranks inherit the environment)
     elif solver == 'bicgstab' or depth < 2:
         pytest.skip('block-asynchronous passes only exist in J^2 sweeps (halo depth >= 2)')
-    ctx = mp.get_context('spawn')
-    uid_pipe, out_queue = ctx.Queue(), ctx.Queue()
-    procs = [ctx.Process(target=_rank_main, args=(r, world, K, solver, depth, uid_pipe, out_queue)) for r in range(world)]
-    for p in procs:
-        p.start()
-    results = [out_queue.get(timeout=240) for _ in range(world)]
-    for p in procs:
-        p.join(60)
-        if p.is_alive():
-            p.terminate()
-    errs = [r[7] for r in results if r[7]]
-    assert not errs, errs
-    results.sort(key=lambda r: r[0])
+    results = run_ranks(world, _rank_main, (K, solver, depth))
     mesh, inputs3 = make_case(K)
     n = mesh['nreal'] + 1
     state = np.full((n, K), np.nan)
@@ -139,7 +159,7 @@ def test_partitioned_step_matches_single_rank_and_oracle(gpu_lib, world, K, solv
     for r in results:
         tot[r[4]] = r[5]
     want_flux = np.stack([ref.constituent_dict[f'c{k}'].total_mass_flux[2] for k in range(K)], axis=1)
-    assert rel_err(tot, want_flux) <= 1e-8
+    assert flux_err(tot, want_flux) <= 1e-8
 
 
 @pytest.mark.parametrize('world,K,depth', [(2, 4, 8), (4, 16, 8), (3, 1, 6), (2, 16, 14), (4, 4, 16)])
@@ -150,18 +170,7 @@ def test_partitioned_block_asynchronous_passes_keep_the_single_rank_sweep_count(
     build_mock()
     monkeypatch.setenv('CWR_NO_SMALL', '1')
     monkeypatch.setenv('CWR_TEST_BIG', '1')
-    ctx = mp.get_context('spawn')
-    uid_pipe, out_queue = ctx.Queue(), ctx.Queue()
-    procs = [ctx.Process(target=_rank_main, args=(r, world, K, 'jacobi', depth, uid_pipe, out_queue)) for r in range(world)]
-    for p in procs:
-        p.start()
-    results = [out_queue.get(timeout=240) for _ in range(world)]
-    for p in procs:
-        p.join(60)
-        if p.is_alive():
-            p.terminate()
-    errs = [r[7] for r in results if r[7]]
-    assert not errs, errs
+    results = run_ranks(world, _rank_main, (K, 'jacobi', depth))
     from clearwater_riverine_amd.distributed import PartitionedTransport
     mesh, inputs3 = make_case(K)
     single = PartitionedTransport(mesh, inputs3, 0, 1)

@@ -1,0 +1,155 @@
+"""GPU tests of the solver's acceptance rules and failure behaviour (through the C ABI):
+element-wise parity at plume fronts, retry after a failed step, the small-mesh solver's hand-over to BiCGSTAB,
+real-cell inputs at levels >= 1 (transport.py:258-264), tolerance flags."""
+import numpy as np
+import pytest
+
+import cwr_oracle as oracle
+from util import flux_err, oracle_run, rel_err
+from test_gpu_parity import make_engine
+
+pytestmark = pytest.mark.gpu
+
+
+def distinct_case(K, **kw):
+    import clearwater_riverine_amd as cw
+    mesh = cw.synthetic.make_mesh(**kw)
+    oracle.derive_coefficients(mesh)
+    return mesh, cw.synthetic.distinct_input_array(mesh, K, seed=kw.get('seed', 0))
+
+
+@pytest.mark.parametrize('path,nx,ny', [('one-launch small-mesh solver', 70, 30), ('tiled block-asynchronous passes', 200, 40)])
+@pytest.mark.parametrize('solver', ['auto', 'bicgstab'])
+def test_plume_fronts_match_the_direct_solve_element_by_element(gpu_lib, path, nx, ny, solver):
+    """Constituents 3 and 7 of distinct_input_array are EXACTLY zero outside a disc: the implicit solution then
+    decays through every decade down to 1e-300 ahead of the front, and a 2-norm stopping rule cannot see those
+    cells.  rel_err asserts |a-b| <= 1e-6 |b| + 1e-12 max|b| for every cell, level and constituent."""
+    import clearwater_riverine_amd as cw
+    K, steps = 8, 4
+    mesh, inputs3 = distinct_case(K, nx=nx, ny=ny, n_steps=steps, seed=3, n_merge=nx * ny // 20, dt=40.0,
+                                  diffusion_coefficient=0.5)
+    names = [f'c{k}' for k in range(K)]
+    ref = oracle_run(mesh, inputs3, steps)
+    model = cw.ClearwaterRiverine(mesh=dict(mesh), input_arrays={nm: inputs3[:, :, k].copy() for k, nm in enumerate(names)},
+                                  solver=solver)
+    for _ in range(steps):
+        model.update()
+        assert model.last_step.flags == 0
+    assert model.last_step.sweep_kernel == ((7 if nx == 70 else 6) if solver == 'auto' else 0)
+    n = mesh['nreal'] + 1
+    plume = ref.constituent_dict['c3'].state[steps, :n]
+    if nx == 200:                                          # (the short mesh is filled by diffusion within four steps)
+        assert np.count_nonzero((plume > 0) & (plume < 1e-9 * plume.max())) > 100      # the fronts are really there
+    for nm in names:
+        assert rel_err(model.mesh[nm], ref.constituent_dict[nm].state) <= 1e-9
+        assert flux_err(model.constituent_dict[nm].total_mass_flux[:steps], ref.constituent_dict[nm].total_mass_flux[:steps]) <= 1e-8
+
+
+def test_element_wise_rule_is_what_holds_the_fronts(gpu_lib, monkeypatch):
+    """A/B of the rule itself: with it switched off (CWR_NO_ELEMENTWISE=1) the same run still satisfies the norm
+    criterion but needs fewer sweeps -- and with it on the sweeps rise, i.e. the rule is the binding one here."""
+    import clearwater_riverine_amd as cw
+    monkeypatch.setenv('CWR_NO_SMALL', '1')
+    mesh, inputs3 = distinct_case(4, nx=200, ny=40, n_steps=2, seed=3, n_merge=400, dt=40.0, diffusion_coefficient=0.5)
+    n = mesh['nreal'] + 1
+    sweeps = {}
+    for off in ('1', '0'):
+        monkeypatch.setenv('CWR_NO_ELEMENTWISE', off)
+        eng = make_engine(mesh, inputs3)
+        eng.set_state(inputs3[0, :n, :])
+        r = [eng.step(t, tol=1e-12) for t in range(2)]
+        assert all(x.max_rel_residual <= 1e-12 for x in r)
+        sweeps[off] = r[-1].sweeps
+        eng.close()
+    assert sweeps['0'] >= sweeps['1']
+
+
+@pytest.mark.parametrize('nx,ny', [(30, 12), (120, 50)])
+@pytest.mark.parametrize('solver', ['auto', 'jacobi', 'bicgstab'])
+def test_a_failed_step_leaves_the_state_untouched_and_can_be_retried(gpu_lib, nx, ny, solver):
+    """The solver iterates in place in the state vector; a step that fails (here: max_iter = 3) must put x_t and the
+    ghost rows back, so that a caller who catches SolverNotConverged and calls update() again gets the reference's
+    result -- through the facade, whose _device_level still says `t`."""
+    import clearwater_riverine_amd as cw
+    K = 3
+    mesh, inputs3 = distinct_case(K, nx=nx, ny=ny, n_steps=4, seed=5, n_merge=20, dt=60.0, diffusion_coefficient=0.3)
+    names = [f'c{k}' for k in range(K)]
+    ref = oracle_run(mesh, inputs3, 4)
+    model = cw.ClearwaterRiverine(mesh=dict(mesh), input_arrays={nm: inputs3[:, :, k].copy() for k, nm in enumerate(names)},
+                                  solver=solver)
+    model.update()
+    model.update()
+    before = model.engine.get_state()
+    model.max_iter = 3
+    with pytest.raises(cw.SolverNotConverged):
+        model.update()
+    assert model.time_step == 2
+    assert np.array_equal(model.engine.get_state(), before, equal_nan=True)      # bitwise: real cells AND ghost rows
+    model.max_iter = 5000
+    model.update()                                                               # the retry
+    model.update()
+    for nm in names:
+        assert rel_err(model.mesh[nm], ref.constituent_dict[nm].state) <= 1e-9
+
+
+def test_nan_failure_restores_the_state_too(gpu_lib):
+    import clearwater_riverine_amd as cw
+    mesh, inputs3 = distinct_case(2, nx=40, ny=16, n_steps=2, seed=6, n_merge=10)
+    n = mesh['nreal'] + 1
+    eng = make_engine(mesh, inputs3)
+    x = inputs3[0, :n, :].copy()
+    x[5, 1] = np.nan
+    eng.set_state(x)
+    with pytest.raises(FloatingPointError):
+        eng.step(0)
+    assert np.array_equal(eng.get_state()[:n], x, equal_nan=True)
+    eng.set_state(inputs3[0, :n, :])
+    eng.step(0)                                                                  # and the engine is still usable
+
+
+def test_stiff_small_mesh_hands_over_to_bicgstab_in_auto_mode(gpu_lib):
+    """A mesh that fits the one-launch LDS solver, stiff enough (dt = 20 000 s on 10 m cells) that the sweeps run out of
+    a small budget: in 'auto' mode BiCGSTAB must continue from the iterate -- scipy's spsolve simply succeeds there --
+    while 'jacobi' (forced) reports SolverNotConverged."""
+    import clearwater_riverine_amd as cw
+    mesh = cw.synthetic.make_mesh(24, 10, 3, seed=3, dt=20000.0, breathing=0.0, n_merge=6)
+    oracle.derive_coefficients(mesh)
+    inputs3 = cw.synthetic.distinct_input_array(mesh, 2, seed=1)
+    n = mesh['nreal'] + 1
+    eng = make_engine(mesh, inputs3)
+    eng.set_state(inputs3[0, :n, :])
+    with pytest.raises(cw.SolverNotConverged):
+        eng.step(0, max_iter=40, solver='jacobi')
+    res = eng.step(0, max_iter=40, solver='auto')
+    assert res.sweep_kernel == 7 and res.solver == 2 and res.iterations > 0 and res.flags == 0
+    ref = oracle.OracleModel(mesh, {f'c{k}': inputs3[:, :, k].copy() for k in range(2)})
+    ref.update()
+    got = eng.get_state()
+    for k in range(2):
+        assert rel_err(got[:, k], ref.constituent_dict[f'c{k}'].state[1]) <= 1e-9
+
+
+@pytest.mark.parametrize('nx,ny', [(30, 12), (110, 50)])
+def test_real_cell_inputs_at_later_levels_follow_the_reference(gpu_lib, nx, ny):
+    """input_array rows t >= 1 with non-zero entries on REAL cells (a point source held at a fixed concentration):
+    the reference writes them into the solved level before _mass_flux (transport.py:258-264) and starts the next step
+    from them (linalg.py:199-200).  State AND fluxes of every level must match the oracle."""
+    import clearwater_riverine_amd as cw
+    K, steps = 3, 5
+    mesh, inputs3 = distinct_case(K, nx=nx, ny=ny, n_steps=steps, seed=8, n_merge=15, dt=30.0, diffusion_coefficient=0.2)
+    n = mesh['nreal'] + 1
+    rng = np.random.default_rng(0)
+    src = rng.choice(n, size=7, replace=False)
+    inputs3[1:4, src[:4], 0] = 250.0                      # constituent 0: four cells held for levels 1-3
+    inputs3[2, src[3:], 2] = 40.0 + rng.random(4)         # constituent 2: one level, overlapping cell src[3]
+    names = [f'c{k}' for k in range(K)]
+    ref = oracle_run(mesh, inputs3, steps)
+    model = cw.ClearwaterRiverine(mesh=dict(mesh), input_arrays={nm: inputs3[:, :, k].copy() for k, nm in enumerate(names)})
+    for _ in range(steps):
+        model.update()
+    assert model.mesh['c0'][2, src[0]] == 250.0
+    for nm in names:
+        assert rel_err(model.mesh[nm], ref.constituent_dict[nm].state) <= 1e-9
+        for got, want in ((model.constituent_dict[nm].advection_mass_flux, ref.constituent_dict[nm].advection_mass_flux),
+                          (model.constituent_dict[nm].total_mass_flux, ref.constituent_dict[nm].total_mass_flux)):
+            assert flux_err(got[:steps], want[:steps]) <= 1e-8
