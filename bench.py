@@ -7,11 +7,13 @@
 
 A "step" is one ClearwaterRiverine.update()-equivalent pass (transport.py:201-276) over all cells and
 constituents: operator set-up, right-hand side, implicit solve, write-back, per-face mass flux.
-Workload: BASELINE.json's 1 M-cell synthetic floodplain mesh (1000 x 1000 cells, 2 002 000 faces,
-4 000 ghost cells, CFL ~ 2.5, D = 0.5) with 16 constituents (the north-star roofline target case);
---constituents 1 gives configs[3] literally.  The whole flow field, boundary values and state are
-resident in HBM before the timed region; nothing is copied to the host inside it.
-Rank 0 prints ONE JSON line.
+Workload: BASELINE.json's 1 M-cell synthetic UNSTRUCTURED floodplain mesh (synthetic.bench_mesh: 1026 x 1026 jittered
+quads of which 5 % are merged into 6-sided cells = exactly 1 000 000 real cells, 2 054 728 faces, 4 104 ghost cells,
+locally shuffled cell and face numbering, CFL ~ 2.5, D = 0.5) with 16 DISTINCT constituents (own initial field,
+fronts and boundary series each: synthetic.distinct_input_array) -- the north-star roofline target case;
+--constituents 1 gives configs[3] literally, --mesh quad the structured 1000 x 1000 grid of round 1.
+The whole flow field, boundary values and state are resident in HBM before the timed region; nothing is copied to
+the host inside it.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -30,23 +32,30 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, ch
 HBM_MEASURED_GBS = 6290.0      # measured float4 copy, same guide
 
 
-def cpu_baseline(nx: int, steps: int, dt: float, D: float, seed: int):
-    """The oracle (numpy COO assembly + scipy spsolve per constituent, the reference algorithm) timed on
-    this host, single process, on a bounded sample of the same generator."""
+def cpu_baseline(mesh: dict, input_col: np.ndarray, budget_s: float, max_steps: int):
+    """The oracle (numpy COO assembly + scipy spsolve per constituent = the reference algorithm without its xarray
+    overhead) timed on this host, single process, on the SAME mesh as the GPU run with one constituent.
+    Imports and allocator are warmed on a tiny mesh; then steps of the full mesh are timed one by one until
+    `max_steps` are done or `budget_s` seconds are used (at least one step)."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import copy
     import cwr_oracle as oracle
     from clearwater_riverine_amd import synthetic
-    mesh = synthetic.make_mesh(nx, nx, steps + 1, seed=seed, dt=dt, diffusion_coefficient=D)
-    oracle.derive_coefficients(mesh)
-    inp = synthetic.boundary_input_array(mesh, 1)[:, :, 0]
-    model = oracle.OracleModel(mesh, {'c': inp})
-    model.update()                                    # warm-up step (imports, allocator)
-    t0 = time.perf_counter()
-    for _ in range(steps):
+    tiny = synthetic.make_mesh(20, 10, 2, seed=1)
+    oracle.derive_coefficients(tiny)
+    oracle.OracleModel(tiny, {'c': synthetic.boundary_input_array(tiny, 1)[:, :, 0]}).update()
+    m = copy.copy(mesh)
+    oracle.derive_coefficients(m)
+    model = oracle.OracleModel(m, {'c': np.ascontiguousarray(input_col)})
+    n = m['nreal'] + 1
+    times = []
+    t_all = time.perf_counter()
+    while len(times) < max_steps and (not times or time.perf_counter() - t_all + times[-1] <= budget_s):
+        t0 = time.perf_counter()
         model.update()
-    el = time.perf_counter() - t0
-    n = mesh['nreal'] + 1
-    return n * steps / el / 1e6, el, n
+        times.append(time.perf_counter() - t0)
+    el = float(np.sum(times))
+    return n * len(times) / el / 1e6, el, n, len(times)
 
 
 def main():
@@ -54,8 +63,13 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--nx', type=int, default=1000)
-    ap.add_argument('--ny', type=int, default=1000)
+    ap.add_argument('--mesh', default='merged', choices=['merged', 'quad'],
+                    help='merged: the unstructured bench mesh (5 %% of the quads merged into 6-sided cells, 10^6 cells); '
+                         'quad: the structured 1000 x 1000 grid')
+    ap.add_argument('--nx', type=int, default=0, help='custom grid (with --ny): nx x ny base quads, 5 %% merged unless --mesh quad')
+    ap.add_argument('--ny', type=int, default=0)
+    ap.add_argument('--inputs', default='distinct', choices=['distinct', 'scaled'],
+                    help='distinct: every constituent has its own field / fronts / boundary series; scaled: multiples of one')
     ap.add_argument('--constituents', type=int, default=16)
     ap.add_argument('--tol', type=float, default=1e-12)
     ap.add_argument('--dt', type=float, default=40.0)
@@ -67,8 +81,8 @@ def main():
     ap.add_argument('--halo-depth', type=int, default=0,
                     help='N > 1: halo layers = Jacobi sweeps between two exchanges (0: from the per-rank size, distributed.auto_halo_depth)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample-nx', type=int, default=640)
-    ap.add_argument('--cpu-sample-steps', type=int, default=3)
+    ap.add_argument('--cpu-budget-s', type=float, default=100.0, help='wall-clock budget of the CPU baseline leg')
+    ap.add_argument('--cpu-steps', type=int, default=3)
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -98,9 +112,20 @@ def main():
 
     K = args.constituents
     n_levels = args.warmup + args.steps + 1
-    mesh = synthetic.make_mesh(args.nx, args.ny, n_levels, seed=args.seed, dt=args.dt,
-                               diffusion_coefficient=args.diffusion)
-    inputs3 = synthetic.boundary_input_array(mesh, K)
+    if args.nx and args.ny:
+        mesh = synthetic.make_mesh(args.nx, args.ny, n_levels, seed=args.seed, dt=args.dt, diffusion_coefficient=args.diffusion,
+                                   n_merge=0 if args.mesh == 'quad' else int(round(0.05 * args.nx * args.ny)))
+        mesh_name = f'{args.nx}x{args.ny} ' + ('quad grid' if args.mesh == 'quad' else 'quads, 5 % merged into 6-sided cells')
+        mesh_key = f'{args.nx}x{args.ny}' + ('' if args.mesh == 'quad' else '_merged')
+    elif args.mesh == 'quad':
+        mesh = synthetic.make_mesh(1000, 1000, n_levels, seed=args.seed, dt=args.dt, diffusion_coefficient=args.diffusion)
+        mesh_name, mesh_key = 'structured 1000x1000 quad grid', '1000x1000'
+    else:
+        mesh = synthetic.bench_mesh(n_levels, dt=args.dt, diffusion_coefficient=args.diffusion)
+        mesh_name = 'unstructured floodplain mesh: 1026x1026 jittered quads, 5 % merged into 6-sided cells, shuffled numbering'
+        mesh_key = 'bench_merged_1m'
+    inputs3 = (synthetic.distinct_input_array(mesh, K, seed=synthetic.BENCH_SEED) if args.inputs == 'distinct'
+               else synthetic.boundary_input_array(mesh, K))
     n = mesh['nreal'] + 1
 
     uid = None
@@ -150,7 +175,7 @@ def main():
         traffic = traffic_rw = None
         try:                                             # PMC-measured HBM bytes per launch of this exact config, if profiled
             with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as fh:
-                ent = json.load(fh).get(f'{args.nx}x{args.ny}', {}).get(str(K)) if world == 1 and args.solver == 'auto' else None
+                ent = json.load(fh).get(mesh_key, {}).get(str(K)) if world == 1 and args.solver == 'auto' else None
             if ent:
                 traffic_rw = (int(ent['read']), int(ent['written']))
                 traffic = sum(traffic_rw)
@@ -189,12 +214,11 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        v, el, nn = cpu_baseline(args.cpu_sample_nx, args.cpu_sample_steps, args.dt, args.diffusion, args.seed)
+        v, el, nn, done = cpu_baseline(mesh, inputs3[:, :, 0], args.cpu_budget_s, args.cpu_steps)
         cpu = {'value': round(v, 5), 'unit': 'Mcell-updates/s', 'cores': 1, 'kind': 'port',
-               'sample': f'{args.cpu_sample_nx}x{args.cpu_sample_nx}-cell mesh of the same generator ({nn} cells), '
-                         f'1 constituent, {args.cpu_sample_steps} steps after 1 warm-up, {el:.1f} s; numpy COO '
-                         f'assembly + scipy.sparse.linalg.spsolve per constituent (single-threaded SuperLU); '
-                         f'host has {os.cpu_count()} cores',
+               'sample': f'the same mesh ({nn} cells, {mesh_name}), constituent 0 only, {done} step(s) of {el / done:.1f} s each '
+                         f'(budget {args.cpu_budget_s:.0f} s; imports warmed on a 200-cell mesh); numpy COO assembly + '
+                         f'scipy.sparse.linalg.spsolve per constituent (single-threaded SuperLU); host has {os.cpu_count()} cores',
                'host_cores': os.cpu_count()}
 
     if rank == 0:
@@ -204,8 +228,8 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1000.0 * elapsed / args.steps, 3), 'higher_is_better': True,
             'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': f'synthetic {args.nx}x{args.ny} floodplain mesh ({n} cells, '
-                                   f'{len(mesh["edges_face1"])} faces), {K} constituents, implicit upwind '
+            'config': {'workload': f'synthetic {mesh_name} ({n} cells, {len(mesh["edges_face1"])} faces), {K} '
+                                   f'{"distinct " if args.inputs == "distinct" and K > 1 else ""}constituents, implicit upwind '
                                    f'advection-diffusion step, dt={args.dt} s, D={args.diffusion}',
                        'cells': n, 'faces': int(len(mesh['edges_face1'])), 'constituents': K,
                        'numbering': args.renumber, 'partition': f'contiguous cell ranges x{world}' + (f', halo depth {pt.local.depth}' if world > 1 else ''),

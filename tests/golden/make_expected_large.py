@@ -45,41 +45,83 @@ def main():
     n = mesh['nreal'] + 1
     E = len(mesh['edges_face1'])
     oracle.derive_coefficients(mesh)
-    model = oracle.OracleModel(mesh, {f'c{k}': inputs3[:, :, k].copy() for k in COLS})
-    for s in range(STEPS):
-        model.update()
-        print(f'step {s + 1}/{STEPS} done, {time.time() - t0:.0f} s', flush=True)
+    raw_path = os.environ.get('CWR_LARGE_RAW', '/tmp/cwr_large_raw.npz')   # the oracle's full columns, kept between runs
+    if os.path.exists(raw_path):
+        raw = np.load(raw_path)
+        states, fluxes = raw['states'], raw['fluxes']
+    else:
+        model = oracle.OracleModel(mesh, {f'c{k}': inputs3[:, :, k].copy() for k in COLS})
+        for s in range(STEPS):
+            model.update()
+            print(f'step {s + 1}/{STEPS} done, {time.time() - t0:.0f} s', flush=True)
+        states = np.stack([model.constituent_dict[f'c{k}'].state[1:STEPS + 1] for k in COLS], axis=1)          # (STEPS, C, ncell)
+        fluxes = np.stack([model.constituent_dict[f'c{k}'].total_mass_flux[:STEPS] for k in COLS], axis=1)     # (STEPS, C, E)
+        np.savez(raw_path, states=states, fluxes=fluxes)
     rng = np.random.default_rng(20251004)
-    cells = set(rng.choice(n, size=N_SAMPLE - 8192, replace=False).tolist())
-    # stratify: the plume column's tiny values (fronts) must be in the sample -- add cells from every decade of |c|
-    plume = np.abs(model.constituent_dict[f'c{COLS[1]}'].state[STEPS, :n])
+    # stratified part: the plume column's tiny values (fronts) must be in the sample -- cells from every decade of |c|
+    plume = np.abs(states[STEPS - 1, 1, :n])
     dec = np.floor(np.log10(np.maximum(plume, 1e-320))).astype(int)
+    strat = []
     for d in np.unique(dec):
         idx = np.nonzero(dec == d)[0]
-        take = rng.choice(idx, size=min(len(idx), 96), replace=False)
-        cells.update(take.tolist())
-    rest = np.setdiff1d(np.arange(n), np.fromiter(cells, dtype=np.int64))
-    cells = np.sort(np.concatenate([np.fromiter(cells, dtype=np.int64),
-                                    rng.choice(rest, size=N_SAMPLE - len(cells), replace=False)]))
+        strat.append(rng.choice(idx, size=min(len(idx), 48), replace=False))
+    strat = np.unique(np.concatenate(strat))[:N_SAMPLE // 2]
+    rest = np.setdiff1d(np.arange(n), strat)
+    cells = np.sort(np.concatenate([strat, rng.choice(rest, size=N_SAMPLE - len(strat), replace=False)]))
+    print(f'{len(strat)} stratified + {N_SAMPLE - len(strat)} uniform sample cells; plume decades {dec.min()}..{dec.max()}')
     faces = np.sort(rng.choice(E, size=N_FACES, replace=False))
-    C = len(COLS)
-    state = np.empty((STEPS, C, len(cells)))
-    ghost = np.empty((STEPS, C, len(mesh['face_x']) - n))
-    norms = np.empty((STEPS, C, 3))
-    flux = np.empty((STEPS, C, len(faces)))
-    for ci, k in enumerate(COLS):
-        con = model.constituent_dict[f'c{k}']
-        for s in range(STEPS):
-            col = con.state[s + 1]
-            state[s, ci] = col[cells]
-            ghost[s, ci] = col[n:]
-            norms[s, ci] = (np.linalg.norm(col[:n]), np.sum(col[:n]), np.max(np.abs(col[:n])))
-            flux[s, ci] = con.total_mass_flux[s][faces]
+    state = np.ascontiguousarray(states[:, :, cells])
+    ghost = np.ascontiguousarray(states[:, :, n:])
+    norms = np.stack([np.linalg.norm(states[:, :, :n], axis=2), np.sum(states[:, :, :n], axis=2),
+                      np.max(np.abs(states[:, :, :n]), axis=2)], axis=2)
+    flux = np.ascontiguousarray(fluxes[:, :, faces])
     out = os.path.join(HERE, 'config4_1m_expected.npz')
     np.savez_compressed(out, cells=cells, state=state, ghost=ghost, norms=norms, flux_faces=faces, total_flux=flux,
                         cols=np.asarray(COLS), steps=STEPS, K=K)
     print(f'wrote {out} ({os.path.getsize(out) / 1e6:.1f} MB) in {time.time() - t0:.0f} s')
 
 
+def reaction_matrix(K: int, dt: float) -> np.ndarray:
+    """Config 5's per-step reaction: first-order decay on the diagonal, pairwise exchange
+    c_k -> c_(k+1) off it -- the stand-in for the TSM/NSM kinetics.  tests/test_gpu_fullsize.py imports it."""
+    lam = 1.0e-4 * (1.0 + np.arange(K) % 5)
+    M = np.diag(np.exp(-lam * dt))
+    for k in range(0, K - 1, 2):
+        M[k + 1, k] += 0.002
+        M[k, k] -= 0.002
+    return M
+
+
+def main_config5():
+    """BASELINE config 5: the 4 M-cell mesh (synthetic.bench_mesh(scale=2)), 16 constituents, reaction before the step.
+    One oracle step for the columns COLS5: the override x_t' = (M x_0)[:, k] needs only the known initial fields, so the
+    other columns do not have to be solved.  -> tests/golden/config5_4m_expected.npz"""
+    t0 = time.time()
+    COLS5 = (0, 7)
+    dt = 40.0
+    mesh = synthetic.bench_mesh(1, scale=2)
+    inputs3 = synthetic.distinct_input_array(mesh, K, seed=synthetic.BENCH_SEED + 1)
+    n = mesh['nreal'] + 1
+    oracle.derive_coefficients(mesh)
+    M = reaction_matrix(K, dt)
+    x0 = inputs3[0, :n, :]
+    override = {f'c{k}': x0 @ M[k] for k in COLS5}
+    model = oracle.OracleModel(mesh, {f'c{k}': inputs3[:, :, k].copy() for k in COLS5})
+    model.update(override)
+    print(f'config 5: one oracle step for {len(COLS5)} columns on {n} cells, {time.time() - t0:.0f} s', flush=True)
+    rng = np.random.default_rng(20251005)
+    cells = np.sort(rng.choice(n, size=N_SAMPLE, replace=False))
+    states = np.stack([model.constituent_dict[f'c{k}'].state[1] for k in COLS5], axis=0)
+    out = os.path.join(HERE, 'config5_4m_expected.npz')
+    np.savez_compressed(out, cells=cells, state=np.ascontiguousarray(states[:, cells]),
+                        norms=np.stack([np.linalg.norm(states[:, :n], axis=1), np.sum(states[:, :n], axis=1),
+                                        np.max(np.abs(states[:, :n]), axis=1)], axis=1),
+                        cols=np.asarray(COLS5), K=K, dt=dt)
+    print(f'wrote {out} ({os.path.getsize(out) / 1e6:.1f} MB) in {time.time() - t0:.0f} s')
+
+
 if __name__ == '__main__':
-    main()
+    if '--config5' in sys.argv:
+        main_config5()
+    else:
+        main()

@@ -1,0 +1,127 @@
+"""GPU tests at BASELINE.json's full sizes (through the facade / C ABI).
+
+Config 4 / the bench workload -- the 1 M-cell merged floodplain mesh, K = 1 and K = 16 with distinct constituents --
+is compared ELEMENT-WISE with committed oracle output (tests/golden/config4_1m_expected.npz: a 65 536-cell sample
+stratified over the plume's decades, every ghost cell, column norms and sampled face fluxes, produced by
+tests/golden/make_expected_large.py from the oracle's spsolve on the full mesh).
+Config 5 -- 4 M cells x 16 constituents + a per-step reaction -- is compared with an oracle sample of its first step
+and, beyond that, through size-independent properties: device reaction == host callback, exact scaling by two,
+the true residual through the exported operator.
+Meshes and inputs are regenerated from seeds on the GPU box (nothing under /root/reference is read).
+"""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+from util import GOLDEN, flux_err, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _large():
+    spec = importlib.util.spec_from_file_location('make_expected_large', os.path.join(GOLDEN, 'make_expected_large.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.fixture(scope='module')
+def config4():
+    import clearwater_riverine_amd as cw
+    exp = np.load(os.path.join(GOLDEN, 'config4_1m_expected.npz'))
+    steps, K = int(exp['steps']), int(exp['K'])
+    mesh = cw.synthetic.bench_mesh(steps + 1)
+    inputs3 = cw.synthetic.distinct_input_array(mesh, K, seed=cw.synthetic.BENCH_SEED)
+    assert mesh['nreal'] + 1 == 1_000_000
+    return mesh, inputs3, exp, steps, K
+
+
+def _check_column(model, name, exp, ci, steps, n):
+    cells, faces = exp['cells'], exp['flux_faces']
+    for s in range(steps):
+        col = model.mesh[name][s + 1]
+        assert rel_err(col[cells], exp['state'][s, ci]) <= 1e-9                 # element-wise 1e-6 |b| + 1e-12 peak inside
+        assert rel_err(col[n:], exp['ghost'][s, ci]) <= 1e-12                   # boundary values / NaN pattern
+        got = np.array([np.linalg.norm(col[:n]), np.sum(col[:n]), np.max(np.abs(col[:n]))])
+        assert np.allclose(got, exp['norms'][s, ci], rtol=1e-9, atol=0.0)       # the WHOLE column, not only the sample
+        assert flux_err(model.constituent_dict[name].total_mass_flux[s][faces], exp['total_flux'][s, ci]) <= 1e-8
+
+
+def test_config4_one_tracer_on_the_1m_cell_mesh_matches_the_oracle(gpu_lib, config4):
+    """BASELINE config 4 literally: K = 1 (column 0 of the distinct inputs)."""
+    import clearwater_riverine_amd as cw
+    mesh, inputs3, exp, steps, K = config4
+    n = mesh['nreal'] + 1
+    model = cw.ClearwaterRiverine(mesh=dict(mesh), input_arrays={'c0': inputs3[:, :, 0].copy()})
+    for _ in range(steps):
+        model.update()
+        assert model.last_step.sweep_kernel == 6 and model.last_step.flags == 0 and model.last_step.iterations == 0
+    _check_column(model, 'c0', exp, 0, steps, n)
+
+
+def test_bench_workload_16_distinct_constituents_on_the_1m_cell_mesh_matches_the_oracle(gpu_lib, config4):
+    """The bench workload: 16 batched constituents with different fields, fronts and boundary series; the oracle solved
+    columns 0 (smooth), 7 (plume with fronts down to 1e-300) and 13 (pulse)."""
+    import clearwater_riverine_amd as cw
+    mesh, inputs3, exp, steps, K = config4
+    n = mesh['nreal'] + 1
+    names = [f'c{k}' for k in range(K)]
+    model = cw.ClearwaterRiverine(mesh=dict(mesh), input_arrays={nm: inputs3[:, :, k] for k, nm in enumerate(names)})
+    for _ in range(steps):
+        model.update()
+        assert model.last_step.sweep_kernel == 6 and model.last_step.flags == 0 and model.last_step.iterations == 0
+        assert model.last_step.max_rel_residual <= 1e-12
+    for ci, k in enumerate(exp['cols']):
+        _check_column(model, names[int(k)], exp, ci, steps, n)
+    # the batched columns do not influence each other: column 0 equals the K = 1 run's fixture too (checked above via ci = 0)
+
+
+def test_config5_4m_cells_16_constituents_with_a_per_step_reaction(gpu_lib):
+    """BASELINE config 5: 2052 x 2052 base quads (4 M cells after the merges), 16 constituents, a K x K reaction applied to
+    the level-t state before every transport step -- on the device (cwr_react_linear) and, for one step, through the
+    reference's host callback contract (update_concentration, transport.py:233-236)."""
+    import clearwater_riverine_amd as cw
+    large = _large()
+    exp = np.load(os.path.join(GOLDEN, 'config5_4m_expected.npz'))
+    K, dt = int(exp['K']), float(exp['dt'])
+    steps = 3
+    mesh = cw.synthetic.bench_mesh(steps, scale=2)
+    inputs3 = cw.synthetic.distinct_input_array(mesh, K, seed=cw.synthetic.BENCH_SEED + 1)
+    n = mesh['nreal'] + 1
+    assert n == 4_000_000
+    M = large.reaction_matrix(K, dt)
+    names = [f'c{k}' for k in range(K)]
+    arrays = {nm: inputs3[:, :, k] for k, nm in enumerate(names)}
+    dev = cw.ClearwaterRiverine(mesh=dict(mesh), input_arrays=arrays, store_history=False)
+    dev.update(reaction_matrix=M)
+    assert dev.last_step.sweep_kernel == 6 and dev.last_step.flags == 0 and dev.last_step.max_rel_residual <= 1e-12
+    first = dev.engine.get_state()
+    # (a) the oracle's first step (sample + whole-column norms), columns 0 and 7
+    for ci, k in enumerate(exp['cols']):
+        col = first[:, int(k)]
+        assert rel_err(col[exp['cells']], exp['state'][ci]) <= 1e-9
+        got = np.array([np.linalg.norm(col[:n]), np.sum(col[:n]), np.max(np.abs(col[:n]))])
+        assert np.allclose(got, exp['norms'][ci], rtol=1e-9, atol=0.0)
+    # (b) the host callback route gives the same level: override = (M c_0)[:, k] per constituent
+    host = cw.ClearwaterRiverine(mesh=dict(mesh), input_arrays=arrays, store_history=False)
+    x0 = inputs3[0, :n, :]
+    host.update({nm: x0 @ M[k] for k, nm in enumerate(names)})
+    assert rel_err(host.engine.get_state(), first) <= 1e-12
+    host.engine.close()
+    del host
+    # (c) two more steps with the device reaction; then the true residual of the last step through the exported
+    # operator and right-hand side (b - A x, all 4 M x 16 entries)
+    dev.update(reaction_matrix=M)
+    x_t = dev.engine.get_state()[:n].copy()
+    x_t = x_t @ M.T                                                   # what the device reaction makes of level 2
+    dev.update(reaction_matrix=M)
+    x_n = dev.engine.get_state()[:n]
+    b = dev.engine.rhs(2, x_t)
+    r = b - dev.engine.apply(2, x_n)
+    assert np.max(np.linalg.norm(r, axis=0) / np.linalg.norm(b, axis=0)) <= 1e-10
+    # (d) exact linearity: every input scaled by 2 (a power of two: no rounding anywhere) gives bitwise 2 x the state
+    twice = cw.ClearwaterRiverine(mesh=dict(mesh), input_arrays={nm: 2.0 * a for nm, a in arrays.items()}, store_history=False)
+    twice.update(reaction_matrix=M)
+    assert np.array_equal(twice.engine.get_state(), 2.0 * first, equal_nan=True)
