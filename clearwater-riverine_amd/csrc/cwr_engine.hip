@@ -77,6 +77,7 @@ struct cwr_engine {
   // static topology
   int32_t *d_f1 = nullptr, *d_f2 = nullptr, *d_ptr = nullptr, *d_ent_edge = nullptr, *d_ent_nb = nullptr;
   int32_t* d_face_orig = nullptr;          // internal face index -> reference face id (k_faces_in / k_faces_out)
+  int32_t* d_face_pos = nullptr;           // reference face id -> internal face index
   uint8_t* d_row_ghost = nullptr;          // 1 where a computed row has a boundary (ghost) face
   std::vector<int32_t> bad_level;          // per time level: the zero-coefficient precondition is violated (k_check_ghost_levels)
   std::vector<int32_t> h_face_pos;         // reference face id -> internal face index
@@ -165,6 +166,7 @@ struct cwr_engine {
   int32_t *d_ptr2 = nullptr, *d_col2 = nullptr, *d_row2 = nullptr, *d_pair_ptr = nullptr;
   uint8_t* d_slots = nullptr;
   bool sq_rowwise = false;
+  size_t sqn_lds = 0;              // dynamic LDS of k_sq_numeric: the entries of the fullest 128-row block
   int sq_max_row = 0;              // longest J^2 row
   // tiled J^2 pass: per tile the distinct x rows it touches, and per J^2 entry the row's index in that list
   bool use_tcl = true, tcl_ready = false;
@@ -173,6 +175,10 @@ struct cwr_engine {
   int n_tcl = 0, tcl_TR = 0, tcl_ntiles = 0, tcl_max_cols = 0, tcl_stage_cap = 0, tcl_grid = 0;
   size_t tcl_lds = 0, tcl_total_cols = 0;
   int32_t *d_tcl_ptr = nullptr, *d_tcl_cols = nullptr;
+  int32_t *d_trow = nullptr, *d_vptr = nullptr;   // rows and virtual items (chunks 1.. of long rows) of every tile
+  int tcl_nvmax = 0;                              // virtual items a tile may hold (LDS for their partial sums)
+  int tcl_seg = 1 << 20;                          // J^2 entries per work item of the tiled pass (rows are summed in chunks of it)
+  int32_t* d_meta = nullptr;                      // per tile: its rows' ptr2 entries, then the codes of its virtual items
   uint16_t* d_loc2 = nullptr;    // local (in-tile) column of every J^2 entry: 16 bits (a tile holds < 65 536 x rows)
   double* d_w2 = nullptr;
   std::map<int, hipGraphExec_t> batch_exec;   // whole-batch graphs by number of passes (see solve_jacobi)
@@ -283,10 +289,10 @@ int launch_apply(cwr_engine* e, const double* xin, double* yout, const double* r
   }
   if (e->VW == 2)
     k_apply<2, MODE><<<grid, BLOCK, lds, e->stream>>>(row0, rows, e->n_core, e->K, e->G, e->U, ntiles, cap, e->nt_stream,
-        ptr, rec, e->d_diag, xin, yout, r0, bhat, r0_out, p_out, e->d_partial, e->ew_rel);
+        ptr, rec, e->d_diag, xin, yout, r0, bhat, r0_out, p_out, e->d_partial, e->ew_rel, e->tcl_seg);
   else
     k_apply<1, MODE><<<grid, BLOCK, lds, e->stream>>>(row0, rows, e->n_core, e->K, e->G, e->U, ntiles, cap, e->nt_stream,
-        ptr, rec, e->d_diag, xin, yout, r0, bhat, r0_out, p_out, e->d_partial, e->ew_rel);
+        ptr, rec, e->d_diag, xin, yout, r0, bhat, r0_out, p_out, e->d_partial, e->ew_rel, e->tcl_seg);
   e->last_apply_grid = grid;
   HIP_TRY(e, hipGetLastError());
   if (e1) HIP_TRY(e, hipEventRecord(e1, e->stream));
@@ -453,9 +459,12 @@ int check_ghost_levels(cwr_engine* e) {
 #define CWR_TCL_K(VWv, Q) k_sq_tiled<VWv, TCL_CFG[Q].wrn, TCL_CFG[Q].ut, TCL_CFG[Q].xr>
 const void* tcl_kernel(int vw, int cfg) {
   if (vw == 4) return cfg == 3 ? reinterpret_cast<const void*>(&CWR_TCL_K(4, 3)) : cfg == 4 ? reinterpret_cast<const void*>(&CWR_TCL_K(4, 4))
-                    : cfg == 5 ? reinterpret_cast<const void*>(&CWR_TCL_K(4, 5)) : reinterpret_cast<const void*>(&CWR_TCL_K(4, 6));
-  if (vw == 2) return cfg == 0 ? reinterpret_cast<const void*>(&CWR_TCL_K(2, 0)) : cfg == 1 ? reinterpret_cast<const void*>(&CWR_TCL_K(2, 1)) : reinterpret_cast<const void*>(&CWR_TCL_K(2, 2));
-  return cfg == 0 ? reinterpret_cast<const void*>(&CWR_TCL_K(1, 0)) : cfg == 1 ? reinterpret_cast<const void*>(&CWR_TCL_K(1, 1)) : reinterpret_cast<const void*>(&CWR_TCL_K(1, 2));
+                    : cfg == 5 ? reinterpret_cast<const void*>(&CWR_TCL_K(4, 5)) : cfg == 6 ? reinterpret_cast<const void*>(&CWR_TCL_K(4, 6))
+                    : cfg == 7 ? reinterpret_cast<const void*>(&CWR_TCL_K(4, 7)) : reinterpret_cast<const void*>(&CWR_TCL_K(4, 8));
+  if (vw == 2) return cfg == 0 ? reinterpret_cast<const void*>(&CWR_TCL_K(2, 0)) : cfg == 1 ? reinterpret_cast<const void*>(&CWR_TCL_K(2, 1))
+                    : cfg == 9 ? reinterpret_cast<const void*>(&CWR_TCL_K(2, 9)) : reinterpret_cast<const void*>(&CWR_TCL_K(2, 2));
+  return cfg == 0 ? reinterpret_cast<const void*>(&CWR_TCL_K(1, 0)) : cfg == 1 ? reinterpret_cast<const void*>(&CWR_TCL_K(1, 1))
+       : cfg == 9 ? reinterpret_cast<const void*>(&CWR_TCL_K(1, 9)) : reinterpret_cast<const void*>(&CWR_TCL_K(1, 2));
 }
 
 // Symbolic J^2 (once): row c of J^2 has the columns reachable in two face steps.  Numeric values per step on
@@ -519,6 +528,15 @@ int ensure_sq_pattern(cwr_engine* e) {
   TRY(dev_alloc(e, &e->d_rec2, (size_t)e->nnz2));
   TRY(upload(e, e->d_ptr2, ptr2.data(), (size_t)n + 1));
   TRY(upload(e, e->d_col2, col2.data(), (size_t)e->nnz2));
+  {
+    int most = 1;
+    for (int b = 0; b * SQN_THREADS < n; ++b) most = std::max(most, ptr2[std::min((b + 1) * SQN_THREADS, n)] - ptr2[b * SQN_THREADS]);
+    e->sqn_lds = (size_t)most * sizeof(double);
+    if (e->sqn_lds > 64 * 1024) rowwise = false;
+    else if (e->sqn_lds > 48 * 1024)
+      for (const void* fn : {reinterpret_cast<const void*>(&k_sq_numeric<4>), reinterpret_cast<const void*>(&k_sq_numeric<6>), reinterpret_cast<const void*>(&k_sq_numeric<8>)})
+        HIP_TRY(e, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->sqn_lds));
+  }
   if (rowwise && slots.size() < 2000000000u) {
     TRY(dev_alloc(e, &e->d_pair_ptr, (size_t)n + 1));
     TRY(dev_alloc(e, &e->d_slots, slots.size()));
@@ -550,19 +568,55 @@ int ensure_sq_pattern(cwr_engine* e) {
     int tr = tr_target;
     while (tr > Rt && (tr % Rt) != 0) --tr;
     tr = std::max(tr, Rt);
-    if (want4) tr = Rt;                                          // (the four-wide configuration holds one row per lane group)
+    if (want4) {
+      // four-wide mapping: one row per lane group.  Two rows per lane group (84-102-row tiles at K = 20-24, 64-row tiles at
+      // K = 32; configurations 7 and 8) were measured SLOWER on the merged 1 M-cell mesh: 191 / 222 / 271 us per pass against
+      // 148 / 169 / 202 us at K = 20 / 24 / 32 (profiles/r02_b_per_K.txt) -- the extra prefetch registers cost a block per CU
+      int ut = 1;
+      if (const char* v = getenv("CWR_TCL_UT")) ut = std::max(1, std::min(2, atoi(v)));
+      tr = Rt * ut;
+    }
     // a tile that holds too many entries or distinct rows for every compiled configuration (dense adjacency: many 5-8-face
     // cells; narrow rows use 256-row tiles) is retried at half the rows -- part of the lanes then idle in the compute phase,
     // which still beats the un-tiled exact pass by far
     for (int shrink = 0; shrink < 3 && !e->tcl_ready; ++shrink, tr = std::max(16, tr / 2)) {
-    const int nt = cdiv(n_t, tr);
+    // tiles of work items (see k_sq_tiled): a row of more than TCL_SEG entries occupies one lane group per chunk, so a tile
+    // takes rows while rows + extra chunks fit the tr lane-group slots of a pass (CWR_TCL_SEG=0: one item per row)
+    // splitting pays where the LDS compute phase bounds the pass -- narrow rows (one or two constituents per lane, three
+    // tile-local applications): 43 -> 38 us per pass at K = 1 on the merged mesh; with four constituents per lane the phase
+    // hides behind the HBM stream and the extra barrier and the smaller tiles cost 110 -> 119 us at K = 16, 202 -> 259 at 32
+    // (measured, merged 1 M-cell mesh, us per pass split / not: K = 1: 38.5 / 43.3, 2: 46.1 / 44.6, 3: 83 / 73, 4: 70 / 64,
+    // 6: 76 / 69, 16: 119 / 110; profiles/r02_f_split_sweep.txt)
+    bool split = e->K == 1;
+    if (const char* v = getenv("CWR_TCL_SPLIT")) split = atoi(v) != 0;
+    split = split && e->VW == 1 && !want4;                       // (only the one-constituent-per-lane kernels carry the item logic)
+    const int seg = split ? TCL_SEG : (1 << 20);
+    const int nvmax = split ? TCL_NVMAX : 0;
+    std::vector<int32_t> trow(1, 0), vptr(1, 0);
+    std::vector<uint16_t> vtab;
+    bool tile_ok = true;
+    for (int c = 0; c < n_t && tile_ok;) {
+      int rows = 0, virt = 0;
+      while (c + rows < n_t && rows < 256) {
+        const int len = ptr2[c + rows + 1] - ptr2[c + rows];
+        const int extra = (len > seg) ? (len - 1) / seg : 0;
+        if (rows + 1 + virt + extra > tr || virt + extra > nvmax || extra > 255) break;
+        for (int ch = 1; ch <= extra; ++ch) vtab.push_back((uint16_t)(rows | (ch << 8)));
+        ++rows; virt += extra;
+      }
+      if (rows == 0) { tile_ok = false; break; }                 // a single row needs more slots than a tile has
+      c += rows;
+      trow.push_back(c); vptr.push_back((int32_t)vtab.size());
+    }
+    if (!tile_ok) continue;
+    const int nt = (int)trow.size() - 1;
     std::vector<int32_t> tptr((size_t)nt + 1, 0), tcols;
     std::vector<uint16_t> loc2((size_t)e->nnz2, 0);
     tcols.reserve((size_t)n_t * 3);
     std::vector<int32_t> stamp((size_t)e->n_real, -1), pos((size_t)e->n_real, 0), others;
     int max_cols = 0, cap2 = 1;
     for (int t = 0; t < nt; ++t) {
-      const int c0 = t * tr, c1 = std::min(c0 + tr, n_t);
+      const int c0 = trow[t], c1 = trow[t + 1];
       const int base = (int)tcols.size();
       for (int c = c0; c < c1; ++c) { stamp[c] = t; pos[c] = c - c0; tcols.push_back(c); }
       others.clear();
@@ -575,30 +629,48 @@ int ensure_sq_pattern(cwr_engine* e) {
       cap2 = std::max(cap2, ptr2[c1] - ptr2[c0]);
     }
     cap2 += cap2 & 1;                                            // even: the 16-bit index array keeps what follows 4-byte aligned
-    const size_t lds = ((size_t)max_cols * e->K * sizeof(double) + (size_t)cap2 * (sizeof(double) + sizeof(uint16_t)) +
-                        (size_t)(tr + 1) * sizeof(int32_t) + 15) & ~(size_t)15;
+    const size_t lds = ((size_t)(max_cols + nvmax) * e->K * sizeof(double) + (size_t)cap2 * (sizeof(double) + sizeof(uint16_t)) +
+                        (size_t)(tr + 1 + nvmax) * sizeof(int32_t) + 15) & ~(size_t)15;
     // the kernel's compile-time prefetch depths bound what a tile may hold; otherwise the plain J^2 pass stays
     e->tcl_cfg = -1;
     int q0 = 0;
-    if (const char* v = getenv("CWR_TCL_CFG")) q0 = std::max(0, std::min(2, atoi(v)));
+    if (const char* v = getenv("CWR_TCL_CFG")) q0 = std::max(0, std::min(3, atoi(v)));       // (index into TCL_NARROW)
     e->tcl_vw = e->VW;
     // (fetch mapping: K/2 lanes per row; compute mapping: K/4 lanes per row)
     int q4 = 3;
-    if (const char* v = getenv("CWR_TCL_CFG")) q4 = std::max(3, std::min(TCL_NCFG - 1, atoi(v)));
-    for (int q = q4; q < TCL_NCFG && want4 && e->tcl_cfg < 0; ++q)
+    if (const char* v = getenv("CWR_TCL_CFG")) q4 = std::max(3, std::min(8, atoi(v)));
+    for (int q = q4; q < 9 && want4 && e->tcl_cfg < 0; ++q)
       if (max_cols <= TCL_CFG[q].xr * (BLOCK / (e->K / 2)) && cap2 <= TCL_CFG[q].wrn * BLOCK && tr <= TCL_CFG[q].ut * R4) { e->tcl_cfg = q; e->tcl_vw = 4; }
-    for (int q = q0; q < 3 && e->tcl_cfg < 0; ++q)
+    for (int qi = q0; qi < 4 && e->tcl_cfg < 0; ++qi) {
+      const int q = TCL_NARROW[qi];
       if (max_cols <= TCL_CFG[q].xr * e->R && cap2 <= TCL_CFG[q].wrn * BLOCK && tr <= TCL_CFG[q].ut * e->R) e->tcl_cfg = q;
+    }
     if (lds <= 64 * 1024 && e->tcl_cfg >= 0 && tr <= BLOCK) {
       const void* fn6 = tcl_kernel(e->tcl_vw, e->tcl_cfg);
       int pc = 1;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, fn6, BLOCK, lds) != hipSuccess || pc < 1) pc = 1;
       pc = std::min(pc, 8);
       e->n_tcl = n_t;
+      e->tcl_seg = seg; e->tcl_nvmax = nvmax;
       e->tcl_TR = tr; e->tcl_ntiles = nt; e->tcl_max_cols = max_cols; e->tcl_stage_cap = cap2; e->tcl_lds = lds;
       e->tcl_total_cols = tcols.size();
       e->tcl_grid = std::max(N_XCD, std::min(cdiv(nt, N_XCD) * N_XCD, (n_cu * pc / N_XCD) * N_XCD));
       TRY(dev_alloc(e, &e->d_tcl_ptr, (size_t)nt + 1));
+      TRY(dev_alloc(e, &e->d_trow, (size_t)nt + 1));
+      TRY(dev_alloc(e, &e->d_vptr, (size_t)nt + 1));
+      {
+        // per tile: the ptr2 entries of its rows, then the codes of its virtual items (one prefetch stream in the kernel)
+        std::vector<int32_t> meta((size_t)n_t + vtab.size());
+        for (int t = 0; t < nt; ++t) {
+          int32_t* m = meta.data() + trow[t] + vptr[t];
+          for (int c = trow[t]; c < trow[t + 1]; ++c) *m++ = ptr2[c];
+          for (int v = vptr[t]; v < vptr[t + 1]; ++v) *m++ = (int32_t)vtab[(size_t)v];
+        }
+        TRY(dev_alloc(e, &e->d_meta, meta.size()));
+        TRY(upload(e, e->d_meta, meta.data(), meta.size()));
+      }
+      TRY(upload(e, e->d_trow, trow.data(), (size_t)nt + 1));
+      TRY(upload(e, e->d_vptr, vptr.data(), (size_t)nt + 1));
       TRY(dev_alloc(e, &e->d_tcl_cols, tcols.size()));
       TRY(dev_alloc(e, &e->d_loc2, (size_t)e->nnz2));
       TRY(dev_alloc(e, &e->d_w2, (size_t)e->nnz2));
@@ -606,11 +678,11 @@ int ensure_sq_pattern(cwr_engine* e) {
       TRY(upload(e, e->d_tcl_cols, tcols.data(), tcols.size()));
       TRY(upload(e, e->d_loc2, loc2.data(), (size_t)e->nnz2));
       e->tcl_ready = true;
-      if (getenv("CWR_VERBOSE")) fprintf(stderr, "[cwr] tiled J^2: tile=%d rows, %.2f distinct x rows per row, max %d per tile, lds=%zu, grid=%d\n",
-                                         tr, (double)tcols.size() / n_t, max_cols, lds, e->tcl_grid);
+      if (getenv("CWR_VERBOSE")) fprintf(stderr, "[cwr] tiled J^2: %d tiles of <= %d items (%.1f rows + %.2f extra chunks of long rows each), cfg %d, %.2f distinct x rows per row, max %d per tile, lds=%zu, grid=%d\n",
+                                         nt, tr, (double)n_t / nt, (double)vtab.size() / nt, e->tcl_cfg, (double)tcols.size() / n_t, max_cols, lds, e->tcl_grid);
     } else if (getenv("CWR_VERBOSE")) {
       fprintf(stderr, "[cwr] tiled J^2 not used over %d rows: tile=%d rows, max %d distinct x rows per tile (limit %d), %d entries per tile (limit %d), lds=%zu\n",
-              n_t, tr, max_cols, TCL_CFG[2].xr * e->R, cap2, TCL_CFG[2].wrn * BLOCK, lds);
+              n_t, tr, max_cols, TCL_CFG[2].xr * e->R, cap2, TCL_CFG[9].wrn * BLOCK, lds);
     }
     }
     }
@@ -628,12 +700,10 @@ int prepare_sq(cwr_engine* e, bool& active) {
   if (!e->sq_pattern) return CWR_OK;
   // (the entry weights w were written by k_prep_step)
   const bool need_rec2 = !e->tcl_ready || e->n_sq > e->n_tcl;      // the un-tiled pass reads FaceRec-format rows
-  if (e->sq_rowwise && e->sq_max_row <= 16)
-    k_sq_numeric<16><<<cdiv(e->n_sq, SQN_THREADS), SQN_THREADS, 0, e->stream>>>(e->n_sq, e->d_ptr, e->d_ent_nb, e->d_w, e->d_ptr2, e->d_col2,
-        e->d_pair_ptr, e->d_slots, need_rec2 ? e->d_rec2 : nullptr, e->tcl_ready ? e->d_w2 : nullptr);
-  else if (e->sq_rowwise)
-    k_sq_numeric<SQN_MAXC><<<cdiv(e->n_sq, SQN_THREADS), SQN_THREADS, 0, e->stream>>>(e->n_sq, e->d_ptr, e->d_ent_nb, e->d_w, e->d_ptr2, e->d_col2,
-        e->d_pair_ptr, e->d_slots, need_rec2 ? e->d_rec2 : nullptr, e->tcl_ready ? e->d_w2 : nullptr);
+#define CWR_SQN(DEGv) k_sq_numeric<DEGv><<<cdiv(e->n_sq, SQN_THREADS), SQN_THREADS, e->sqn_lds, e->stream>>>(e->n_sq, e->d_ptr, e->d_ent_nb, \
+        e->d_w, e->d_ptr2, e->d_col2, e->d_pair_ptr, e->d_slots, e->d_row_ghost, need_rec2 ? e->d_rec2 : nullptr, e->tcl_ready ? e->d_w2 : nullptr)
+  if (e->sq_rowwise) { if (e->max_degree <= 4) CWR_SQN(4); else if (e->max_degree <= 6) CWR_SQN(6); else CWR_SQN(8); }
+#undef CWR_SQN
   else
     k_build_sq<<<cdiv(e->nnz2, BLOCK), BLOCK, 0, e->stream>>>(e->nnz2, e->d_ptr, e->d_ent_nb, e->d_w, e->d_row2, e->d_col2, e->d_rec2, e->tcl_ready ? e->d_w2 : nullptr);
   HIP_TRY(e, hipGetLastError());
@@ -645,21 +715,27 @@ int prepare_sq(cwr_engine* e, bool& active) {
   return CWR_OK;
 }
 
-int launch_sq_tiled(cwr_engine* e, const double* xin, double* yout) {
+// tile_list (device, optional): the launch covers only these `n_list` tiles (interior / cut tiles of a partitioned engine)
+int launch_sq_tiled(cwr_engine* e, const double* xin, double* yout, const int32_t* tile_list = nullptr, int n_list = 0, bool tail = true) {
+  const int ntiles = tile_list ? n_list : e->tcl_ntiles;
+  if (ntiles <= 0) return CWR_OK;
+  const int grid = std::max(N_XCD, std::min(e->tcl_grid, cdiv(ntiles, N_XCD) * N_XCD));
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (e->profiling && e->dominant_mode == 6 && e->ev_used + 2 <= e->ev.size()) {
     e0 = e->ev[e->ev_used++]; e1 = e->ev[e->ev_used++];
     HIP_TRY(e, hipEventRecord(e0, e->stream));
   }
-#define CWR_TILED(VWv, Q) CWR_TCL_K(VWv, Q)<<<e->tcl_grid, BLOCK, e->tcl_lds, e->stream>>>(e->n_tcl, e->K, e->K / VWv, e->tcl_TR,    \
-      e->tcl_ntiles, e->d_ptr2, e->d_loc2, e->d_w2, e->d_tcl_ptr, e->d_tcl_cols, e->tcl_max_cols, e->tcl_stage_cap, e->local_reps, xin, e->d_t, yout)
-  if (e->tcl_vw == 4) { if (e->tcl_cfg == 3) CWR_TILED(4, 3); else if (e->tcl_cfg == 4) CWR_TILED(4, 4); else if (e->tcl_cfg == 5) CWR_TILED(4, 5); else CWR_TILED(4, 6); }
-  else if (e->VW == 2) { if (e->tcl_cfg == 0) CWR_TILED(2, 0); else if (e->tcl_cfg == 1) CWR_TILED(2, 1); else CWR_TILED(2, 2); }
-  else            { if (e->tcl_cfg == 0) CWR_TILED(1, 0); else if (e->tcl_cfg == 1) CWR_TILED(1, 1); else CWR_TILED(1, 2); }
+#define CWR_TILED(VWv, Q) CWR_TCL_K(VWv, Q)<<<grid, BLOCK, e->tcl_lds, e->stream>>>(e->K, e->K / VWv, e->tcl_TR, ntiles, tile_list,    \
+      e->d_trow, e->d_ptr2, e->d_loc2, e->d_w2, e->d_tcl_ptr, e->d_tcl_cols, e->d_vptr, e->d_meta, e->tcl_max_cols, e->tcl_stage_cap,    \
+      e->local_reps, e->tcl_seg, e->tcl_nvmax, xin, e->d_t, yout)
+  if (e->tcl_vw == 4) { if (e->tcl_cfg == 3) CWR_TILED(4, 3); else if (e->tcl_cfg == 4) CWR_TILED(4, 4); else if (e->tcl_cfg == 5) CWR_TILED(4, 5);
+                        else if (e->tcl_cfg == 6) CWR_TILED(4, 6); else if (e->tcl_cfg == 7) CWR_TILED(4, 7); else CWR_TILED(4, 8); }
+  else if (e->VW == 2) { if (e->tcl_cfg == 0) CWR_TILED(2, 0); else if (e->tcl_cfg == 1) CWR_TILED(2, 1); else if (e->tcl_cfg == 9) CWR_TILED(2, 9); else CWR_TILED(2, 2); }
+  else            { if (e->tcl_cfg == 0) CWR_TILED(1, 0); else if (e->tcl_cfg == 1) CWR_TILED(1, 1); else if (e->tcl_cfg == 9) CWR_TILED(1, 9); else CWR_TILED(1, 2); }
 #undef CWR_TILED
   HIP_TRY(e, hipGetLastError());
   if (e1) HIP_TRY(e, hipEventRecord(e1, e->stream));
-  if (e->n_sq > e->n_tcl)                             // replayed halo layers (partitioned engines): un-tiled J^2 rows
+  if (tail && e->n_sq > e->n_tcl)                     // replayed halo layers (partitioned engines): un-tiled J^2 rows
     TRY(launch_apply<5>(e, xin, yout, nullptr, e->d_t, nullptr, nullptr, e->n_sq, e->n_tcl));
   return CWR_OK;
 }
@@ -694,8 +770,8 @@ int step_tail(cwr_engine* e, int t, int flags) {
     const int grid = std::max(1, std::min(cdiv(e->E, e->R), 256 * 8));
     const float* adv_t = e->d_adv + (size_t)t * e->E;
     const double* dif_t = e->d_dif + (size_t)t * e->E;
-    if (e->VW == 2) k_mass_flux<2><<<grid, BLOCK, 0, e->stream>>>(e->E, e->n_core, K, e->G, e->d_f1, e->d_f2, adv_t, dif_t, e->dt[t], e->d_c, e->d_face_orig, e->d_fadv, e->d_fdif, e->d_ftot);
-    else            k_mass_flux<1><<<grid, BLOCK, 0, e->stream>>>(e->E, e->n_core, K, e->G, e->d_f1, e->d_f2, adv_t, dif_t, e->dt[t], e->d_c, e->d_face_orig, e->d_fadv, e->d_fdif, e->d_ftot);
+    if (e->VW == 2) k_mass_flux<2><<<grid, BLOCK, 0, e->stream>>>(e->E, e->n_core, K, e->G, e->d_f1, e->d_f2, adv_t, dif_t, e->dt[t], e->d_c, e->d_fadv, e->d_fdif, e->d_ftot);
+    else            k_mass_flux<1><<<grid, BLOCK, 0, e->stream>>>(e->E, e->n_core, K, e->G, e->d_f1, e->d_f2, adv_t, dif_t, e->dt[t], e->d_c, e->d_fadv, e->d_fdif, e->d_ftot);
     HIP_TRY(e, hipGetLastError());
     e->flux_valid = true;
     e->halo_fresh = true;
@@ -1207,6 +1283,8 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   CREATE_TRY(dev_alloc(eng, &eng->d_face_orig, (size_t)std::max(n_edges, 1)));
   CREATE_TRY(upload(eng, eng->d_face_orig, face_orig.data(), (size_t)n_edges));
   eng->h_face_pos = face_pos;
+  CREATE_TRY(dev_alloc(eng, &eng->d_face_pos, (size_t)std::max(n_edges, 1)));
+  CREATE_TRY(upload(eng, eng->d_face_pos, face_pos.data(), (size_t)n_edges));
   {
     std::vector<uint8_t> row_ghost((size_t)n_owned, 0);
     for (int c = 0; c < n_owned; ++c)
@@ -1245,7 +1323,7 @@ void cwr_destroy(cwr_engine* e) {
   for (hipEvent_t ev : e->ev) hipEventDestroy(ev);
   void* ptrs[] = {e->d_f1, e->d_f2, e->d_ptr, e->d_ent_edge, e->d_ent_nb, e->d_adv, e->d_vel, e->d_vol, e->d_dif,
                   e->d_bc, e->d_rec, e->d_diag, e->d_c, e->d_r, e->d_r0, e->d_p, e->d_v, e->d_s, e->d_t, e->d_b,
-                  e->d_scal, e->d_counters, e->d_partial, e->d_fadv, e->d_fdif, e->d_ftot, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf, e->d_ptr2, e->d_col2, e->d_row2, e->d_rec2, e->d_w, e->d_react, e->d_info, e->d_tcl_ptr, e->d_tcl_cols, e->d_loc2, e->d_w2, e->d_pair_ptr, e->d_slots, e->d_line_ptr, e->d_line_faces, e->d_ledger, e->d_mass_out, e->d_chk, e->d_face_orig, e->d_row_ghost, e->d_keep, e->d_in_rows, e->d_in_vals};
+                  e->d_scal, e->d_counters, e->d_partial, e->d_fadv, e->d_fdif, e->d_ftot, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf, e->d_ptr2, e->d_col2, e->d_row2, e->d_rec2, e->d_w, e->d_react, e->d_info, e->d_tcl_ptr, e->d_tcl_cols, e->d_loc2, e->d_w2, e->d_pair_ptr, e->d_slots, e->d_line_ptr, e->d_line_faces, e->d_ledger, e->d_mass_out, e->d_chk, e->d_face_orig, e->d_row_ghost, e->d_keep, e->d_in_rows, e->d_in_vals, e->d_face_pos, e->d_trow, e->d_vptr, e->d_meta};
   for (void* p : ptrs) if (p) hipFree(p);
   if (e->stream) hipStreamDestroy(e->stream);
   delete e;
@@ -1575,9 +1653,18 @@ int32_t cwr_get_mass_flux(cwr_engine* e, double* adv, double* dif, double* tot) 
   if (!e->flux_valid) return fail(e, CWR_ERR_STATE, "cwr_get_mass_flux: the last step was not taken with CWR_STEP_MASS_FLUX");
   HIP_TRY(e, hipSetDevice(e->dev));
   const size_t cnt = (size_t)e->E * e->K;
-  if (adv) TRY(download(e, adv, e->d_fadv, cnt));
-  if (dif) TRY(download(e, dif, e->d_fdif, cnt));
-  if (tot) TRY(download(e, tot, e->d_ftot, cnt));
+  if (cnt == 0) return CWR_OK;
+  DevTmp<double> tmp;                                   // internal face order -> reference face order, on the device
+  TRY(dev_alloc(e, &tmp.p, cnt));
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv((int64_t)cnt, BLOCK), 256 * 16));
+  double* outs[3] = {adv, dif, tot};
+  const double* srcs[3] = {e->d_fadv, e->d_fdif, e->d_ftot};
+  for (int q = 0; q < 3; ++q) {
+    if (!outs[q]) continue;
+    k_face_rows_out<<<grid, BLOCK, 0, e->stream>>>((int64_t)cnt, e->K, e->d_face_orig, srcs[q], tmp.p);
+    HIP_TRY(e, hipGetLastError());
+    TRY(download(e, outs[q], tmp.p, cnt));
+  }
   return CWR_OK;
 }
 
@@ -1774,9 +1861,10 @@ int32_t cwr_output_push(cwr_engine* e, int32_t* slot) {
   if (e->out_flux) {
     const int gridf = std::max(1, std::min(cdiv(e->E, SNAP_ROWS), 256 * 8));
     const size_t EK = (size_t)e->E * e->K;
-    k_snapshot_t<<<gridf, BLOCK, lds, e->stream>>>(e->E, e->K, nullptr, e->d_fadv, e->d_snap + e->out_state_cnt);
-    k_snapshot_t<<<gridf, BLOCK, lds, e->stream>>>(e->E, e->K, nullptr, e->d_fdif, e->d_snap + e->out_state_cnt + EK);
-    k_snapshot_t<<<gridf, BLOCK, lds, e->stream>>>(e->E, e->K, nullptr, e->d_ftot, e->d_snap + e->out_state_cnt + 2 * EK);
+    // (output index = the reference's face id; its row sits at the face's internal position)
+    k_snapshot_t<<<gridf, BLOCK, lds, e->stream>>>(e->E, e->K, e->d_face_pos, e->d_fadv, e->d_snap + e->out_state_cnt);
+    k_snapshot_t<<<gridf, BLOCK, lds, e->stream>>>(e->E, e->K, e->d_face_pos, e->d_fdif, e->d_snap + e->out_state_cnt + EK);
+    k_snapshot_t<<<gridf, BLOCK, lds, e->stream>>>(e->E, e->K, e->d_face_pos, e->d_ftot, e->d_snap + e->out_state_cnt + 2 * EK);
   }
   HIP_TRY(e, hipGetLastError());
   HIP_TRY(e, hipEventRecord(e->out_snap_ready, e->stream));

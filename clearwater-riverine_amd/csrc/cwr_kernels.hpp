@@ -237,6 +237,14 @@ __global__ void __launch_bounds__(BLOCK) k_faces_in(int64_t total, int E, const 
     dst[i] = src[t * E + orig[p]];
   }
 }
+// rows of K values: dst[orig[p], :] = src[p, :] (per-face K-vectors from the internal face order to the reference's)
+__global__ void __launch_bounds__(BLOCK) k_face_rows_out(int64_t total, int K, const int32_t* __restrict__ orig,
+                                                       const double* __restrict__ src, double* __restrict__ dst) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * BLOCK) {
+    const int64_t p = i / K; const int k = (int)(i - p * K);
+    dst[(size_t)orig[p] * K + k] = src[i];
+  }
+}
 template <typename T>
 __global__ void __launch_bounds__(BLOCK) k_faces_out(int E, const int32_t* __restrict__ orig, const T* __restrict__ src,
                                                    T* __restrict__ dst) {
@@ -417,6 +425,8 @@ __host__ __device__ inline int red_doubles(int G, int VW) {     // scratch of bl
 #ifndef CWR_FACE_BATCH
 #define CWR_FACE_BATCH 4          // faces whose neighbour gathers are in flight together (tuning knob)
 #endif
+constexpr int TCL_SEG = 12;         // J^2 entries per work item of the tiled pass (see k_sq_tiled); rows are summed in chunks of it
+constexpr int TCL_NVMAX = 48;       // virtual items (chunks 1.. of long rows) per tile
 #ifndef CWR_APPLY_MIN_WAVES
 #define CWR_APPLY_MIN_WAVES 1     // __launch_bounds__ second argument: waves per SIMD the allocator must allow
 #endif
@@ -425,7 +435,7 @@ __global__ void __launch_bounds__(BLOCK, CWR_APPLY_MIN_WAVES) k_apply(
     int row0, int n_owned, int n_dot, int K, int G, int U, int ntiles, int stage_cap, int nt, const int32_t* __restrict__ ptr,
     const FaceRec* __restrict__ rec, const double* __restrict__ diag, const double* __restrict__ xin,
     double* __restrict__ yout, const double* __restrict__ r0, const double* __restrict__ bhat,
-    double* __restrict__ r0_out, double* __restrict__ p_out, double* __restrict__ partial, double ew_rel) {
+    double* __restrict__ r0_out, double* __restrict__ p_out, double* __restrict__ partial, double ew_rel, int seg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
   FaceRec* s_rec = reinterpret_cast<FaceRec*>(s_dyn);
   double* s_red = reinterpret_cast<double*>(s_dyn + (size_t)stage_cap * sizeof(FaceRec));
@@ -482,7 +492,19 @@ __global__ void __launch_bounds__(BLOCK, CWR_APPLY_MIN_WAVES) k_apply(
         for (int w = 0; w < VW; ++w) sum[w] = 0.0;
         const int j0 = s_ptr[c - c0] - jb, j1 = s_ptr[c - c0 + 1] - jb;
         constexpr int FB = CWR_FACE_BATCH;
+        double tot[VW];                               // MODE 5: closed chunks of `seg` entries (the tiled pass's association)
+#pragma unroll
+        for (int w = 0; w < VW; ++w) tot[w] = 0.0;
+        int until = seg;                              // (seg is a multiple of FB: a chunk closes at a batch boundary)
         for (int j = j0; j < j1; j += FB) {
+          if constexpr (MODE == 5) {
+            if (until == 0) {
+#pragma unroll
+              for (int w = 0; w < VW; ++w) { tot[w] += sum[w]; sum[w] = 0.0; }
+              until = seg;
+            }
+            until -= FB;
+          }
           // up to FB faces at a time, branch-free: a slot past the row's end or a ghost face re-reads the row's own x
           // with a zero coefficient; every neighbour-row gather is issued before the first is consumed
           double coef[FB];
@@ -501,6 +523,10 @@ __global__ void __launch_bounds__(BLOCK, CWR_APPLY_MIN_WAVES) k_apply(
 #pragma unroll
             for (int w = 0; w < VW; ++w) sum[w] += coef[u] * xn[u][w];
           }
+        }
+        if constexpr (MODE == 5) {
+#pragma unroll
+          for (int w = 0; w < VW; ++w) sum[w] = tot[w] + sum[w];
         }
         double y[VW];
         if constexpr (MODE == 0) {
@@ -605,35 +631,92 @@ __global__ void __launch_bounds__(BLOCK) k_scatter_faces(int E, int n_owned, int
 // accumulates into its own LDS row (strided: conflict-free) and writes the row out.  Same summation order as
 // k_build_sq (which stays for rows longer than SQN_MAXC): bitwise the same values.
 constexpr int SQN_THREADS = 128;
-constexpr int SQN_MAXC = 40;            // longest J^2 row the row-wise kernel takes (MAXC = 16: the common case, 2.5 x the waves per CU)
-template <int MAXC>
+constexpr int SQN_MAXC = 255;           // longest J^2 row the row-wise kernel takes (slots are 8-bit)
+// The accumulators of a block's 128 rows sit in LDS in the rows' own CSR layout (entry q of row c at ptr2[c] - ptr2[c0] + q;
+// the host sizes the dynamic LDS to the fullest block), so a block holds ~10 KB and 32 waves per CU hide the dependent
+// L2 latencies of the walk (the first version gave every thread a fixed 40-slot column: 40 KB per block, 6 waves per CU,
+// 192 us on the merged 1 M-cell mesh); the finished rows leave as ONE contiguous, coalesced stream per block.
+// DEG: compile-time bound of the fast path.  The generic walk is a chain of ~25 DEPENDENT global loads per row (row pointer ->
+// neighbour id -> its row pointer -> its entries, one at a time: 135 us on the 1 M-cell mesh, pure latency).  A row all of
+// whose faces and whose neighbours' faces number <= DEG, none of the neighbours touching a boundary, is walked branch-free in
+// three waves of independent loads instead (padded slots re-read a valid entry with a zero weight; +0.0 leaves an accumulator
+// unchanged, so both paths give bitwise the same sums in the same order).
+template <int DEG>
 __global__ void __launch_bounds__(SQN_THREADS) k_sq_numeric(
     int n, const int32_t* __restrict__ ptr, const int32_t* __restrict__ ent_nb, const double* __restrict__ w,
     const int32_t* __restrict__ ptr2, const int32_t* __restrict__ col2, const int32_t* __restrict__ pair_ptr,
-    const uint8_t* __restrict__ slots, FaceRec* __restrict__ rec2, double* __restrict__ w2) {
-  __shared__ double s_acc[SQN_THREADS * MAXC];
-  const int c = blockIdx.x * SQN_THREADS + threadIdx.x;
-  if (c >= n) return;
-  double* acc = s_acc + threadIdx.x;
-  const int o = ptr2[c], len = ptr2[c + 1] - o;
-  for (int q = 0; q < len; ++q) acc[q * SQN_THREADS] = 0.0;
-  int pi = pair_ptr[c];
-  const int j1 = ptr[c + 1];
-  for (int j = ptr[c]; j < j1; ++j) {
-    const int m = ent_nb[j];
-    if (m < 0) continue;
-    const double wj = w[j];
-    const int i1 = ptr[m + 1];
-    for (int i = ptr[m]; i < i1; ++i) {
-      if (ent_nb[i] < 0) continue;
-      acc[(int)slots[pi] * SQN_THREADS] += wj * w[i];
-      ++pi;
+    const uint8_t* __restrict__ slots, const uint8_t* __restrict__ row_ghost, FaceRec* __restrict__ rec2, double* __restrict__ w2) {
+  extern __shared__ double s_acc[];
+  const int c0 = blockIdx.x * SQN_THREADS, c1 = min(c0 + SQN_THREADS, n);
+  const int base = ptr2[c0], nloc = ptr2[c1] - base;
+  for (int i = threadIdx.x; i < nloc; i += SQN_THREADS) s_acc[i] = 0.0;
+  __syncthreads();
+  const int c = c0 + threadIdx.x;
+  if (c < c1) {
+    const int o2 = ptr2[c], len2 = ptr2[c + 1] - o2;
+    double* acc = s_acc + (o2 - base);
+    const int pi0 = pair_ptr[c];
+    const int j0 = ptr[c], deg = ptr[c + 1] - j0;
+    bool fast = deg <= DEG && deg > 0 && len2 > 0;
+    if (fast) {
+      int mm[DEG], p0[DEG], ln[DEG], off[DEG];
+      double wj[DEG];
+#pragma unroll
+      for (int q = 0; q < DEG; ++q) {
+        const int jj = j0 + min(q, deg - 1);
+        const int m = ent_nb[jj];
+        const bool live = (q < deg) & (m >= 0);
+        wj[q] = live ? w[jj] : 0.0;
+        mm[q] = live ? m : -1;
+      }
+      int run = 0;
+#pragma unroll
+      for (int q = 0; q < DEG; ++q) {
+        const int m = mm[q] >= 0 ? mm[q] : c;
+        p0[q] = ptr[m];
+        ln[q] = ptr[m + 1] - p0[q];
+        if (mm[q] >= 0) { fast = fast & (ln[q] <= DEG) & (row_ghost[m] == 0); off[q] = run; run += ln[q]; }
+        else { off[q] = 0; ln[q] = 1; p0[q] = j0; }                       // dead slot: own first entry, zero weight
+      }
+      if (fast && run > 0) {
+#pragma unroll
+        for (int q = 0; q < DEG; ++q) {
+          double ww[DEG]; int sl[DEG];
+#pragma unroll
+          for (int r = 0; r < DEG; ++r) {
+            const int rr = min(r, ln[q] - 1);
+            ww[r] = w[p0[q] + rr];
+            sl[r] = (int)slots[pi0 + off[q] + rr];
+          }
+#pragma unroll
+          for (int r = 0; r < DEG; ++r) {
+            const double v = (r < ln[q]) ? wj[q] * ww[r] : 0.0;
+            acc[min(sl[r], len2 - 1)] += v;
+          }
+        }
+      }
+    }
+    if (!fast) {
+      int pi = pi0;
+      const int j1 = j0 + deg;
+      for (int j = j0; j < j1; ++j) {
+        const int m = ent_nb[j];
+        if (m < 0) continue;
+        const double wj = w[j];
+        const int i1 = ptr[m + 1];
+        for (int i = ptr[m]; i < i1; ++i) {
+          if (ent_nb[i] < 0) continue;
+          acc[(int)slots[pi]] += wj * w[i];             // (products of one row in a fixed order: deterministic)
+          ++pi;
+        }
+      }
     }
   }
-  for (int q = 0; q < len; ++q) {
-    const double v = acc[q * SQN_THREADS];
-    if (w2) w2[o + q] = v;
-    if (rec2) { FaceRec out; out.nb = col2[o + q]; out.a_c = 0.0f; out.d = v; rec2[o + q] = out; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nloc; i += SQN_THREADS) {
+    const double v = s_acc[i];
+    if (w2) w2[base + i] = v;
+    if (rec2) { FaceRec out; out.nb = col2[base + i]; out.a_c = 0.0f; out.d = v; rec2[base + i] = out; }
   }
 }
 
@@ -673,7 +756,7 @@ __global__ void __launch_bounds__(BLOCK) k_build_sq(int nnz2, const int32_t* __r
 // XR x rows per lane group (distinct x rows per tile <= XR * R), WRN J^2 entries per thread (entries per tile <= WRN * BLOCK),
 // UT rows of the tile per lane group (tile rows <= UT * R).  The engine picks the cheapest configuration that fits.
 struct TclCfg { int wrn, ut, xr; };
-constexpr int TCL_NCFG = 7;
+constexpr int TCL_NCFG = 10;
 constexpr TclCfg TCL_CFG[TCL_NCFG] = {{4, 2, 6},      // wide rows (K = 16: 64-row tiles)
                                {10, 1, 3},     // narrow rows (K <= 8: one row per lane group, 64-256-row tiles)
                                {10, 4, 8},     // large tiles
@@ -681,18 +764,36 @@ constexpr TclCfg TCL_CFG[TCL_NCFG] = {{4, 2, 6},      // wide rows (K = 16: 64-r
                                                // row, 64 rows per pass); x rows fetched 8 lanes per row, 6 per lane group
                                {4, 1, 7},      // the same with 7 x rows per lane group: halo tiles of partitioned engines may touch
                                                // a few more than 192 distinct rows (200 on one of 8 ranks of the 1 M-cell mesh)
-                               {5, 1, 6},      // room for 1280 entries per tile (K = 8: 128-row tiles)
-                               {5, 1, 8}};     // both, 8 x rows per lane group: last resort before the un-tiled pass
+                               {6, 1, 6},      // room for 1536 entries per tile (K = 8: 128-row tiles; 1280 overflow on meshes with 6-sided cells)
+                               {6, 1, 8},      // both, 8 x rows per lane group: last resort before the un-tiled pass
+                               {5, 2, 9},      // K = 20 ... 28 with TWO rows per lane group (84-102-row tiles instead of 42-51)
+                               {5, 2, 12},     // K = 32: 64-row tiles (two passes of 32 rows); 16 lanes fetch a row, 12 rows each
+                               {12, 1, 3}};    // narrow rows on meshes with 5-8-face cells: 256-row tiles hold up to 3 072 J^2 entries
+constexpr int TCL_NARROW[4] = {0, 1, 9, 2};    // narrow-row configurations (VW <= 2), cheapest first
+// Work items (long rows).  Unstructured meshes have a few cells with 5-8 faces whose J^2 rows hold 15-40 entries among
+// rows of 9-10: with one lane group per ROW every wave waits for its longest row (at one constituent per lane a wave
+// covers 64 rows, and 96 % of the waves of the 5 %-merged 1 M-cell mesh contain an 18-entry row: 43 us per pass against
+// 27 us on the quad grid).  So a lane group works on an ITEM of at most TCL_SEG entries: item r < NR is the first
+// TCL_SEG entries of the tile's row r; the remaining chunks of longer rows are extra ("virtual") items NR .. NR+NV-1 listed
+// by the host (vtab: row | chunk << 8, the chunks of a row consecutive).  A virtual item leaves its partial sum in LDS
+// (s_part), and after one more barrier the row's own lane group adds the partials in chunk order:
+//     y = c2 + ((chunk_0 + chunk_1) + chunk_2 ...)        -- k_apply<.,5> sums in the same association (bitwise equal rows).
+// Tiles therefore hold a variable number of rows (trow[t] .. trow[t+1]): rows + virtual items <= the lane groups of a pass.
+static_assert(TCL_SEG % CWR_FACE_BATCH == 0, "k_apply<.,5> closes a chunk only at a face-batch boundary");
 template <int VW, int WRN, int TCL_U, int TCL_XR>
 __global__ void __launch_bounds__(BLOCK) k_sq_tiled(
-    int n_rows, int K, int G, int TR, int ntiles, const int32_t* __restrict__ ptr2, const uint16_t* __restrict__ loc2,
+    int K, int G, int TR, int ntiles, const int32_t* __restrict__ tile_list, const int32_t* __restrict__ trow,
+    const int32_t* __restrict__ ptr2, const uint16_t* __restrict__ loc2,
     const double* __restrict__ w2, const int32_t* __restrict__ tcl_ptr, const int32_t* __restrict__ tcl_cols,
-    int max_cols, int stage_cap, int reps, const double* __restrict__ xin, const double* __restrict__ c2, double* __restrict__ yout) {
+    const int32_t* __restrict__ vptr, const int32_t* __restrict__ meta,
+    int max_cols, int stage_cap, int reps, int seg, int nvmax, const double* __restrict__ xin, const double* __restrict__ c2, double* __restrict__ yout) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
   double* s_xt = reinterpret_cast<double*>(s_dyn);                                  // [max_cols][K]
-  double* s_w = s_xt + (size_t)max_cols * K;                                         // [stage_cap]
+  double* s_part = s_xt + (size_t)max_cols * K;                                      // [nvmax][K] partial sums of virtual items
+  double* s_w = s_part + (size_t)nvmax * K;                                          // [stage_cap]
   uint16_t* s_loc = reinterpret_cast<uint16_t*>(s_w + stage_cap);                    // [stage_cap] (stage_cap is even)
   int32_t* s_ptr = reinterpret_cast<int32_t*>(s_loc + stage_cap);                    // [TR + 1]
+  // (the codes of the tile's virtual items follow the row pointers in s_ptr: s_ptr[NR + 1 + v], sorted by row)
   const int R = BLOCK / G;
   const int tid = threadIdx.x;
   const int r = tid / G, g = tid - r * G;
@@ -722,6 +823,9 @@ __global__ void __launch_bounds__(BLOCK) k_sq_tiled(
       *reinterpret_cast<double2*>(rowp + offB) = make_double2(v[2], v[3]);
     } else stv<VW>(rowp + col, v);
   };
+  // SPLIT: the work-item logic is compiled into the one-constituent-per-lane variants only (it costs 12 VGPRs, which takes
+  // the wide-row variants from 4 to 3 blocks per CU, and it only pays where the LDS compute phase bounds the pass)
+  constexpr bool SPLIT = (VW == 1);
   const bool rowlane = r < R;
   // x rows are FETCHED (global -> registers -> LDS) one whole 128-byte row per 8 lanes whatever VW is: with VW == 4 the
   // compute mapping above would fetch half rows (measured +6 us per pass)
@@ -735,27 +839,34 @@ __global__ void __launch_bounds__(BLOCK) k_sq_tiled(
     const int i = lidx + it * bpx;
     if (i >= tpx) return -1;
     const int t = xcd * tpx + i;
-    return t < ntiles ? t : -1;
+    if (t >= ntiles) return -1;
+    return __builtin_amdgcn_readfirstlane(tile_list ? tile_list[t] : t);   // (a launch may cover a subset of the tiles: interior / cut tiles)
   };
   // prefetch registers
   int cn[TCL_XR];                                  // row list of the tile after next (global x row ids)
   double xr[TCL_XR][XW];                           // x rows of the next tile (fetch mapping)
   double wr[WRN]; int lr[WRN];               // weights / local indices of the next tile
   double q0[TCL_U][VW];                            // c2 rows of the next tile
-  int pr = 0;                                      // row pointer slice of the next tile
+  int pr = 0;                                      // row pointer slice of the next tile (then the codes of its virtual items)
+  // (row range, virtual-item range) of: the tile after next (a: loaded with its row list), the next tile (n), the current (c)
+  int a_c0 = 0, a_c1 = 0, a_v0 = 0, a_v1 = 0, n_c0 = 0, n_c1 = 0, n_v0 = 0, n_v1 = 0;
   auto load_cols = [&](int t) {
 #pragma unroll
     for (int u = 0; u < TCL_XR; ++u) cn[u] = -1;
-    if (t < 0 || !loadlane) return;
+    a_c0 = a_c1 = a_v0 = a_v1 = 0;
+    if (t < 0) return;
+    a_c0 = __builtin_amdgcn_readfirstlane(trow[t]); a_c1 = __builtin_amdgcn_readfirstlane(trow[t + 1]);     // (wave-uniform: SGPRs)
+    a_v0 = __builtin_amdgcn_readfirstlane(vptr[t]); a_v1 = __builtin_amdgcn_readfirstlane(vptr[t + 1]);
+    if (!loadlane) return;
     const int cb = tcl_ptr[t], ce = tcl_ptr[t + 1];
 #pragma unroll
     for (int u = 0; u < TCL_XR; ++u) { const int q = rl + u * RL; if (q < ce - cb) cn[u] = tcl_cols[cb + q]; }
   };
-  auto load_rows = [&](int t) {                    // uses cn (the row list loaded one tile earlier)
+  auto load_rows = [&](int t) {                    // uses cn and (n_c0, n_c1, n_v0, n_v1), loaded one tile earlier
     if (t < 0) return;
 #pragma unroll
     for (int u = 0; u < TCL_XR; ++u) if (cn[u] >= 0) ldv<XW>(xin + (size_t)cn[u] * K + gl * XW, xr[u]);
-    const int c0 = t * TR, c1 = min(c0 + TR, n_rows);
+    const int c0 = n_c0, c1 = n_c1;
     const int jb = ptr2[c0], je = ptr2[c1];
 #pragma unroll
     for (int u = 0; u < WRN; ++u) { const int j = jb + tid + u * BLOCK; if (j < je) {
@@ -764,8 +875,11 @@ __global__ void __launch_bounds__(BLOCK) k_sq_tiled(
       if constexpr (VW == 4) { wr[u] = __builtin_nontemporal_load(w2 + j); lr[u] = __builtin_nontemporal_load(loc2 + j); }
       else { wr[u] = w2[j]; lr[u] = loc2[j]; }
     } }
-    if (tid < c1 - c0) pr = ptr2[c0 + tid];         // raw: rebased when it is stored to LDS (a subtraction here would wait
-                                                    // for this load, and with it for every prefetch issued before it)
+    // raw: rebased when it is stored to LDS (a subtraction here would wait for this load, and with it for every prefetch
+    // issued before it).  The threads behind the tile's rows fetch the codes of its virtual items through the same load.
+    // (`meta`: per tile its rows' ptr2 entries followed by the codes of its virtual items, tiles back to back -- one
+    // uniform base + tid, exactly the shape of the row-pointer prefetch it replaces)
+    if (tid < (c1 - c0) + (n_v1 - n_v0)) pr = meta[c0 + n_v0 + tid];
     if (rowlane) {
 #pragma unroll
       for (int u = 0; u < TCL_U; ++u) { const int c = c0 + r + u * R; if (c < c1) ld_row_nt(c2 + (size_t)c * K, q0[u]); }
@@ -773,16 +887,19 @@ __global__ void __launch_bounds__(BLOCK) k_sq_tiled(
   };
   int t_cur = tile_of(0);
   load_cols(t_cur);
+  n_c0 = a_c0; n_c1 = a_c1; n_v0 = a_v0; n_v1 = a_v1;
   load_rows(t_cur);                                // (the first tile's chain is not hidden)
+  int c_c0 = n_c0, c_c1 = n_c1, c_nv = n_v1 - n_v0;
   int t_next = tile_of(1);
   load_cols(t_next);
+  n_c0 = a_c0; n_c1 = a_c1; n_v0 = a_v0; n_v1 = a_v1;
   // Results are stored one tile LATE, right before the next tile's prefetch is issued: on gfx9 stores count in vmcnt like
   // loads, so a store issued at the end of a tile would be the youngest entry the next tile's `wait for the prefetch` has
   // to drain (a full write latency per tile); deferred, it has the whole compute phase to retire.
   double y[TCL_U][VW];
   int pc0 = 0, pc1 = 0;                            // rows of the tile whose results y still holds
   for (int it = 0; t_cur >= 0; ++it) {
-    const int c0 = t_cur * TR, c1 = min(c0 + TR, n_rows);
+    const int c0 = c_c0, c1 = c_c1, NR = c1 - c0, nv = c_nv;
     const int ncol = tcl_ptr[t_cur + 1] - tcl_ptr[t_cur];
     const int jb0 = ptr2[c0];
     const int nent = ptr2[c1] - jb0;
@@ -793,8 +910,10 @@ __global__ void __launch_bounds__(BLOCK) k_sq_tiled(
     }
 #pragma unroll
     for (int u = 0; u < WRN; ++u) { const int j = tid + u * BLOCK; if (j < nent) { s_w[j] = wr[u]; s_loc[j] = (uint16_t)lr[u]; } }
-    if (tid < c1 - c0) s_ptr[tid] = pr - jb0;
-    if (tid == 0) s_ptr[c1 - c0] = nent;
+    // one store for both kinds: row pointers rebased to the tile, virtual-item codes as they are, behind the terminator
+    // (a second, separate store for the codes cost this kernel 26 VGPRs -- a block per CU -- in hipcc's allocation)
+    if (tid < NR + nv) s_ptr[tid + (tid >= NR ? 1 : 0)] = pr - (tid < NR ? jb0 : 0);
+    if (tid == 0) s_ptr[NR] = nent;
     double qc[TCL_U][VW];
 #pragma unroll
     for (int u = 0; u < TCL_U; ++u)
@@ -808,7 +927,9 @@ __global__ void __launch_bounds__(BLOCK) k_sq_tiled(
     // start the next tile's loads (x rows by the list already in registers) and the list of the tile after it
     const int t_after = tile_of(it + 2);
     load_rows(t_next);
+    const int x_c0 = n_c0, x_c1 = n_c1, x_nv = n_v1 - n_v0;      // (the next tile's ranges, before load_cols overwrites a_*)
     load_cols(t_after);
+    n_c0 = a_c0; n_c1 = a_c1; n_v0 = a_v0; n_v1 = a_v1;
     // reps > 1 (block-asynchronous Jacobi): the tile applies J^2 again to its own freshly computed rows, which sit first
     // in the LDS x tile, while rows of other tiles keep the values of the pass's input.  A chaotic relaxation in the
     // sense of Chazan-Miranker: it converges whenever rho(|J|) < 1 (always here: A is a strictly diagonally dominant
@@ -818,19 +939,48 @@ __global__ void __launch_bounds__(BLOCK) k_sq_tiled(
         __syncthreads();                             // every reader of the previous round is done
         if (rowlane) {
 #pragma unroll
-          for (int u = 0; u < TCL_U; ++u) { const int c = c0 + r + u * R; if (c < c1) st_row(s_xt + (size_t)(c - c0) * K, y[u]); }
+          for (int u = 0; u < TCL_U; ++u) { const int i = r + u * R; if (i < NR) st_row(s_xt + (size_t)i * K, y[u]); }
         }
         __syncthreads();
       }
+      if constexpr (!SPLIT) {
+        // one lane group per row (every item is a whole row: the host lists no virtual items for these variants)
+        if (rowlane) {
+#pragma unroll
+          for (int u = 0; u < TCL_U; ++u) {
+            const int i = r + u * R;
+            if (i < NR) {
+              double sum[VW];                          // same association as k_apply<.,5>: (sum of w x) first, + c2 last,
+#pragma unroll
+              for (int w = 0; w < VW; ++w) sum[w] = 0.0;  // so both J^2 kernels give bitwise equal rows
+              const int j0 = s_ptr[i], j1 = s_ptr[i + 1];
+              for (int j = j0; j < j1; ++j) {
+                double xn[VW];
+                ld_row(s_xt + (size_t)(int)s_loc[j] * K, xn);
+                const double wj = s_w[j];
+#pragma unroll
+                for (int w = 0; w < VW; ++w) sum[w] += wj * xn[w];
+              }
+#pragma unroll
+              for (int w = 0; w < VW; ++w) y[u][w] = qc[u][w] + sum[w];
+            }
+          }
+        }
+      } else {
+      int jfull[TCL_U];                              // entries of the item's whole row (real items)
       if (rowlane) {
 #pragma unroll
         for (int u = 0; u < TCL_U; ++u) {
-          const int c = c0 + r + u * R;
-          if (c < c1) {
-            double sum[VW];                          // same association as k_apply<.,5>: (sum of w x) first, + c2 last,
+          const int i = r + u * R;                   // item
+          jfull[u] = 0;
+          if (i < NR + nv) {
+            int row = i, j0, jend;
+            if (i < NR) { j0 = s_ptr[i]; jend = s_ptr[i + 1]; jfull[u] = jend - j0; }
+            else { const int code = s_ptr[i + 1]; row = code & 255; j0 = s_ptr[row] + (code >> 8) * seg; jend = s_ptr[row + 1]; }
+            const int j1 = min(jend, j0 + seg);
+            double sum[VW];                          // same association as k_apply<.,5>: (sum of w x) per chunk, + c2 last,
 #pragma unroll
             for (int w = 0; w < VW; ++w) sum[w] = 0.0;  // so both J^2 kernels give bitwise equal rows
-            const int j0 = s_ptr[c - c0], j1 = s_ptr[c - c0 + 1];
             for (int j = j0; j < j1; ++j) {
               double xn[VW];
               ld_row(s_xt + (size_t)(int)s_loc[j] * K, xn);
@@ -838,15 +988,42 @@ __global__ void __launch_bounds__(BLOCK) k_sq_tiled(
 #pragma unroll
               for (int w = 0; w < VW; ++w) sum[w] += wj * xn[w];
             }
+            if (i < NR) {
 #pragma unroll
-            for (int w = 0; w < VW; ++w) y[u][w] = qc[u][w] + sum[w];
+              for (int w = 0; w < VW; ++w) y[u][w] = sum[w];
+            } else st_row(s_part + (size_t)(i - NR) * K, sum);
           }
         }
       }
+      if (nv > 0) __syncthreads();                   // (uniform per tile) the partial sums of the long rows are in LDS
+      if (rowlane) {
+#pragma unroll
+        for (int u = 0; u < TCL_U; ++u) {
+          const int i = r + u * R;
+          if (i < NR) {
+            if (jfull[u] > seg) {
+              const int nc = (jfull[u] - 1) / seg;
+              int lo = 0, hi = nv;                     // first virtual item of row i (the codes are sorted by row)
+              while (lo < hi) { const int mid = (lo + hi) >> 1; if ((s_ptr[NR + 1 + mid] & 255) < i) lo = mid + 1; else hi = mid; }
+              const int fv = lo;
+              for (int q = 0; q < nc; ++q) {
+                double t[VW];
+                ld_row(s_part + (size_t)(fv + q) * K, t);
+#pragma unroll
+                for (int w = 0; w < VW; ++w) y[u][w] += t[w];
+              }
+            }
+#pragma unroll
+            for (int w = 0; w < VW; ++w) y[u][w] = qc[u][w] + y[u][w];
+          }
+        }
+      }
+          }
     }
     pc0 = c0; pc1 = c1;
     t_cur = t_next;
     t_next = t_after;
+    c_c0 = x_c0; c_c1 = x_c1; c_nv = x_nv;
   }
   if (rowlane) {                                   // the last tile's results
 #pragma unroll
@@ -989,14 +1166,17 @@ template <int VW>
 __global__ void __launch_bounds__(BLOCK) k_mass_flux(
     int E, int n_owned, int K, int G, const int32_t* __restrict__ f1, const int32_t* __restrict__ f2,
     const float* __restrict__ adv_t, const double* __restrict__ dif_t, double dt,
-    const double* __restrict__ c, const int32_t* __restrict__ face_orig, double* __restrict__ fadv,
+    const double* __restrict__ c, double* __restrict__ fadv,
     double* __restrict__ fdif, double* __restrict__ ftot) {
   const int R = BLOCK / G;
   const int r = threadIdx.x / G, g = threadIdx.x - r * G;
   if (r >= R) return;
   for (int e = blockIdx.x * R + r; e < E; e += gridDim.x * R) {   // e: internal face index (faces sorted along the cell order)
     const int P = f1[e], N = f2[e];
-    const size_t o = (size_t)face_orig[e] * K + g * VW;           // the outputs keep the reference's face order
+    // the three arrays are written in the INTERNAL face order: 3 x 8 K E bytes leave as one sequential stream (written at the
+    // reference's face ids they were a scatter of 128-byte rows: 233 vs 150 us at 1 M cells x 16); every reader
+    // (cwr_get_mass_flux, the output snapshot) goes through the face map
+    const size_t o = (size_t)e * K + g * VW;
     double oa[VW], od[VW], ot[VW];
     if (P >= n_owned) {                 // face owned by another rank
 #pragma unroll
