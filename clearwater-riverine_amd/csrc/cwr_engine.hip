@@ -140,6 +140,15 @@ struct cwr_engine {
   int32_t *d_send_cells = nullptr, *d_recv_cells = nullptr;
   double *d_sendbuf = nullptr, *d_recvbuf = nullptr;
   int n_send = 0, n_recv = 0;
+  // overlap of a halo exchange with the interior tiles of the pass that needs it: the exchange runs on its own
+  // stream between two events; `inner` tiles read core rows only, `outer` tiles read (or are) rows an exchange refreshes
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_packed = nullptr, ev_halo = nullptr;
+  bool overlap = true;
+  int n_tile_inner = 0, n_tile_outer = 0;
+  int32_t *d_tile_inner = nullptr, *d_tile_outer = nullptr;
+  std::map<int, hipGraphExec_t> stretch_exec;   // exchange-free runs of passes of a partitioned engine, by (first parity, length)
+  int64_t n_overlapped = 0;                     // exchanges that ran beside interior tiles (diagnostic, cwr_comm_stats)
   // measurement
   std::vector<hipEvent_t> ev;
   size_t ev_used = 0;
@@ -326,6 +335,39 @@ int exchange_halo(cwr_engine* e, double* vec, double* vec2 = nullptr) {
     k_unpack_rows<<<cdiv(rtotal, BLOCK), BLOCK, 0, e->stream>>>(rtotal, e->K, e->d_recv_cells, e->d_recvbuf, vec, vec2);
     HIP_TRY(e, hipGetLastError());
   }
+  return CWR_OK;
+}
+
+// The same exchange in two halves, for overlap: exchange_begin packs on the engine's stream and marks the spot; whatever the
+// caller enqueues next on that stream (the interior tiles) runs beside exchange_finish, which sends / receives / unpacks
+// on the communication stream and makes the engine's stream wait for the unpacked rows.
+int exchange_begin(cwr_engine* e, const double* vec) {
+  const int64_t total = (int64_t)e->n_send * e->K;
+  if (total > 0) {
+    k_pack_rows<<<cdiv(total, BLOCK), BLOCK, 0, e->stream>>>(total, e->K, e->d_send_cells, vec, e->d_sendbuf);
+    HIP_TRY(e, hipGetLastError());
+  }
+  HIP_TRY(e, hipEventRecord(e->ev_packed, e->stream));
+  return CWR_OK;
+}
+int exchange_finish(cwr_engine* e, double* vec, double* vec2) {
+  HIP_TRY(e, hipStreamWaitEvent(e->comm_stream, e->ev_packed, 0));
+  NCCL_TRY(e, g_rccl.GroupStart());
+  for (size_t i = 0; i < e->peers.size(); ++i) {
+    const size_t ns = (size_t)(e->send_ptr[i + 1] - e->send_ptr[i]) * e->K;
+    const size_t nr = (size_t)(e->recv_ptr[i + 1] - e->recv_ptr[i]) * e->K;
+    if (ns) NCCL_TRY(e, g_rccl.Send(e->d_sendbuf + (size_t)e->send_ptr[i] * e->K, ns, NCCL_FLOAT64, e->peers[i], e->comm, e->comm_stream));
+    if (nr) NCCL_TRY(e, g_rccl.Recv(e->d_recvbuf + (size_t)e->recv_ptr[i] * e->K, nr, NCCL_FLOAT64, e->peers[i], e->comm, e->comm_stream));
+  }
+  NCCL_TRY(e, g_rccl.GroupEnd());
+  const int64_t rtotal = (int64_t)e->n_recv * e->K;
+  if (rtotal > 0) {
+    k_unpack_rows<<<cdiv(rtotal, BLOCK), BLOCK, 0, e->comm_stream>>>(rtotal, e->K, e->d_recv_cells, e->d_recvbuf, vec, vec2);
+    HIP_TRY(e, hipGetLastError());
+  }
+  HIP_TRY(e, hipEventRecord(e->ev_halo, e->comm_stream));
+  HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_halo, 0));
+  ++e->n_overlapped;
   return CWR_OK;
 }
 
@@ -677,6 +719,21 @@ int ensure_sq_pattern(cwr_engine* e) {
       TRY(upload(e, e->d_tcl_ptr, tptr.data(), (size_t)nt + 1));
       TRY(upload(e, e->d_tcl_cols, tcols.data(), tcols.size()));
       TRY(upload(e, e->d_loc2, loc2.data(), (size_t)e->nnz2));
+      if (e->comm) {
+        // interior tiles: every row they hold and every x row they read is a core row -- no exchange touches them
+        std::vector<int32_t> inner, outer;
+        for (int t = 0; t < nt; ++t) {
+          bool in = trow[t + 1] <= e->n_core;
+          for (int q = tptr[t]; q < tptr[t + 1] && in; ++q) in = tcols[(size_t)q] < e->n_core;
+          (in ? inner : outer).push_back(t);
+        }
+        e->n_tile_inner = (int)inner.size(); e->n_tile_outer = (int)outer.size();
+        TRY(dev_alloc(e, &e->d_tile_inner, inner.size()));
+        TRY(dev_alloc(e, &e->d_tile_outer, outer.size()));
+        TRY(upload(e, e->d_tile_inner, inner.data(), inner.size()));
+        TRY(upload(e, e->d_tile_outer, outer.data(), outer.size()));
+        if (getenv("CWR_VERBOSE")) fprintf(stderr, "[cwr] rank %d: %d interior tiles overlap the exchange, %d cut tiles wait for it\n", e->rank, e->n_tile_inner, e->n_tile_outer);
+      }
       e->tcl_ready = true;
       if (getenv("CWR_VERBOSE")) fprintf(stderr, "[cwr] tiled J^2: %d tiles of <= %d items (%.1f rows + %.2f extra chunks of long rows each), cfg %d, %.2f distinct x rows per row, max %d per tile, lds=%zu, grid=%d\n",
                                          nt, tr, (double)n_t / nt, (double)vtab.size() / nt, e->tcl_cfg, (double)tcols.size() / n_t, max_cols, lds, e->tcl_grid);
@@ -876,12 +933,56 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
         while (exec && doubles >= cwr_engine::GRAPH_SWEEPS) { HIP_TRY(e, hipGraphLaunch(exec, e->stream)); doubles -= cwr_engine::GRAPH_SWEEPS; }
       }
       // a J^2 pass uses up two halo layers of validity, a plain sweep one
-      for (int i = 0; i < doubles; ++i) {
+      const bool can_overlap = e->comm && tiled && e->overlap && e->comm_stream && e->n_tile_inner > 0 && !e->peers.empty();
+      for (int i = 0; i < doubles;) {
         double* src = (i & 1) ? e->d_p : e->d_c;
-        if (since_exchange + 2 > e->exch_every) { TRY(exchange_halo(e, src, (i & 1) ? e->d_c : e->d_p)); since_exchange = 0; }
-        if (tiled) TRY(launch_sq_tiled(e, src, (i & 1) ? e->d_c : e->d_p));
-        else TRY(launch_apply<5>(e, src, (i & 1) ? e->d_c : e->d_p, nullptr, e->d_t, nullptr, nullptr, e->n_sq));
-        since_exchange += 2;
+        double* dst = (i & 1) ? e->d_c : e->d_p;
+        if (since_exchange + 2 > e->exch_every) {
+          if (can_overlap) {
+            // pack the cut rows, start the interior tiles (they read core rows only), exchange beside them on the
+            // communication stream, then the tiles that read or are refreshed rows, and the un-tiled tail
+            TRY(exchange_begin(e, src));
+            TRY(launch_sq_tiled(e, src, dst, e->d_tile_inner, e->n_tile_inner, false));
+            TRY(exchange_finish(e, src, dst));
+            TRY(launch_sq_tiled(e, src, dst, e->d_tile_outer, e->n_tile_outer, true));
+            if (e->n_tile_outer == 0 && e->n_sq > e->n_tcl) TRY(launch_apply<5>(e, src, dst, nullptr, e->d_t, nullptr, nullptr, e->n_sq, e->n_tcl));
+            since_exchange = 2; ++i;
+            continue;
+          }
+          TRY(exchange_halo(e, src, dst)); since_exchange = 0;
+        }
+        // exchange-free stretch: as many passes as the halo depth still covers, replayed as one hipGraph per (parity, length)
+        int run = std::min(doubles - i, std::max(1, (e->exch_every - since_exchange) / 2));
+        if (!e->comm) run = doubles - i;
+        if (e->comm && tiled && run >= 3 && e->use_graphs && !e->profiling) {
+          const int key = (i & 1) * 4096 + run;
+          auto it = e->stretch_exec.find(key);
+          if (it == e->stretch_exec.end() && e->stretch_exec.size() < 16) {
+            hipGraphExec_t ex = nullptr;
+            if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+              int rc = CWR_OK;
+              for (int q = 0; q < run && rc == CWR_OK; ++q)
+                rc = launch_sq_tiled(e, ((i + q) & 1) ? e->d_p : e->d_c, ((i + q) & 1) ? e->d_c : e->d_p);
+              hipGraph_t g = nullptr;
+              const hipError_t ec = hipStreamEndCapture(e->stream, &g);
+              if (!(rc == CWR_OK && ec == hipSuccess && g && hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess)) { ex = nullptr; (void)hipGetLastError(); }
+              if (g) hipGraphDestroy(g);
+            }
+            it = e->stretch_exec.emplace(key, ex).first;
+          }
+          if (it != e->stretch_exec.end() && it->second) {
+            HIP_TRY(e, hipGraphLaunch(it->second, e->stream));
+            since_exchange += 2 * run; i += run;
+            continue;
+          }
+        }
+        for (int q = 0; q < run; ++q, ++i) {
+          double* s2 = (i & 1) ? e->d_p : e->d_c;
+          double* d2 = (i & 1) ? e->d_c : e->d_p;
+          if (tiled) TRY(launch_sq_tiled(e, s2, d2));
+          else TRY(launch_apply<5>(e, s2, d2, nullptr, e->d_t, nullptr, nullptr, e->n_sq));
+          since_exchange += 2;
+        }
       }
       // block-asynchronous passes leave the replayed halo layers only approximately equal to their owners' rows: refresh
       // them so that the two plain sweeps below are exact on the core and the check is the true residual
@@ -1312,7 +1413,12 @@ void cwr_destroy(cwr_engine* e) {
   hipSetDevice(e->dev);
   if (e->stream) hipStreamSynchronize(e->stream);
   cwr_output_close(e);
+  if (e->comm_stream) hipStreamSynchronize(e->comm_stream);
   if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
+  for (auto& kv : e->stretch_exec) if (kv.second) hipGraphExecDestroy(kv.second);
+  if (e->ev_packed) hipEventDestroy(e->ev_packed);
+  if (e->ev_halo) hipEventDestroy(e->ev_halo);
+  if (e->comm_stream) hipStreamDestroy(e->comm_stream);
   if (e->sweep_exec) hipGraphExecDestroy(e->sweep_exec);
   if (e->sweep_graph) hipGraphDestroy(e->sweep_graph);
   if (e->sq_exec) hipGraphExecDestroy(e->sq_exec);
@@ -1323,7 +1429,7 @@ void cwr_destroy(cwr_engine* e) {
   for (hipEvent_t ev : e->ev) hipEventDestroy(ev);
   void* ptrs[] = {e->d_f1, e->d_f2, e->d_ptr, e->d_ent_edge, e->d_ent_nb, e->d_adv, e->d_vel, e->d_vol, e->d_dif,
                   e->d_bc, e->d_rec, e->d_diag, e->d_c, e->d_r, e->d_r0, e->d_p, e->d_v, e->d_s, e->d_t, e->d_b,
-                  e->d_scal, e->d_counters, e->d_partial, e->d_fadv, e->d_fdif, e->d_ftot, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf, e->d_ptr2, e->d_col2, e->d_row2, e->d_rec2, e->d_w, e->d_react, e->d_info, e->d_tcl_ptr, e->d_tcl_cols, e->d_loc2, e->d_w2, e->d_pair_ptr, e->d_slots, e->d_line_ptr, e->d_line_faces, e->d_ledger, e->d_mass_out, e->d_chk, e->d_face_orig, e->d_row_ghost, e->d_keep, e->d_in_rows, e->d_in_vals, e->d_face_pos, e->d_trow, e->d_vptr, e->d_meta};
+                  e->d_scal, e->d_counters, e->d_partial, e->d_fadv, e->d_fdif, e->d_ftot, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf, e->d_ptr2, e->d_col2, e->d_row2, e->d_rec2, e->d_w, e->d_react, e->d_info, e->d_tcl_ptr, e->d_tcl_cols, e->d_loc2, e->d_w2, e->d_pair_ptr, e->d_slots, e->d_line_ptr, e->d_line_faces, e->d_ledger, e->d_mass_out, e->d_chk, e->d_face_orig, e->d_row_ghost, e->d_keep, e->d_in_rows, e->d_in_vals, e->d_face_pos, e->d_trow, e->d_vptr, e->d_meta, e->d_tile_inner, e->d_tile_outer};
   for (void* p : ptrs) if (p) hipFree(p);
   if (e->stream) hipStreamDestroy(e->stream);
   delete e;
@@ -1977,6 +2083,40 @@ int32_t cwr_attach_comm(cwr_engine* e, int32_t rank, int32_t world, const uint8_
   TRY(dev_alloc(e, &e->d_recvbuf, (size_t)n_recv * e->K));
   TRY(upload(e, e->d_send_cells, send_cells, (size_t)n_send));
   TRY(upload(e, e->d_recv_cells, recv_cells, (size_t)n_recv));
+  if (const char* v = getenv("CWR_NO_OVERLAP")) e->overlap = atoi(v) == 0;
+  HIP_TRY(e, hipStreamCreateWithFlags(&e->comm_stream, hipStreamNonBlocking));
+  HIP_TRY(e, hipEventCreateWithFlags(&e->ev_packed, hipEventDisableTiming));
+  HIP_TRY(e, hipEventCreateWithFlags(&e->ev_halo, hipEventDisableTiming));
+  return CWR_OK;
+}
+
+int32_t cwr_comm_selftest(cwr_engine* e, int32_t count, int64_t* overlapped_exchanges) {
+  if (!e) return CWR_ERR_BAD_ARG;
+  if (overlapped_exchanges) *overlapped_exchanges = e->n_overlapped;
+  if (count <= 0) return CWR_OK;                               // (statistics only)
+  if (!e->comm) return fail(e, CWR_ERR_STATE, "cwr_comm_selftest: no communicator attached");
+  HIP_TRY(e, hipSetDevice(e->dev));
+  // a grouped ncclSend / ncclRecv of this rank to ITSELF on the communication stream, bracketed by the two events of
+  // the overlapped exchange: the call signatures and the stream / event plumbing of exchange_begin / exchange_finish,
+  // executable with a single rank (the one-GPU box cannot host two RCCL ranks)
+  DevTmp<double> a, b;
+  TRY(dev_alloc(e, &a.p, (size_t)count));
+  TRY(dev_alloc(e, &b.p, (size_t)count));
+  std::vector<double> h((size_t)count), back((size_t)count, -1.0);
+  for (int i = 0; i < count; ++i) h[(size_t)i] = 1.5 * i - 7.0;
+  TRY(upload(e, a.p, h.data(), (size_t)count));
+  HIP_TRY(e, hipMemsetAsync(b.p, 0, (size_t)count * sizeof(double), e->stream));
+  HIP_TRY(e, hipEventRecord(e->ev_packed, e->stream));
+  HIP_TRY(e, hipStreamWaitEvent(e->comm_stream, e->ev_packed, 0));
+  NCCL_TRY(e, g_rccl.GroupStart());
+  NCCL_TRY(e, g_rccl.Send(a.p, (size_t)count, NCCL_FLOAT64, e->rank, e->comm, e->comm_stream));
+  NCCL_TRY(e, g_rccl.Recv(b.p, (size_t)count, NCCL_FLOAT64, e->rank, e->comm, e->comm_stream));
+  NCCL_TRY(e, g_rccl.GroupEnd());
+  HIP_TRY(e, hipEventRecord(e->ev_halo, e->comm_stream));
+  HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_halo, 0));
+  TRY(download(e, back.data(), b.p, (size_t)count));
+  for (int i = 0; i < count; ++i)
+    if (back[(size_t)i] != h[(size_t)i]) return fail(e, CWR_ERR_RCCL, "cwr_comm_selftest: self send/recv returned different data");
   return CWR_OK;
 }
 

@@ -14,7 +14,7 @@ import numpy as np
 
 from .engine import TransportEngine
 from .model import face_to_face_distance, change_in_time
-from .ordering import hilbert_order, renumber_mesh
+from .ordering import hilbert_order
 from .partition import LocalMesh, partition_mesh, slice_fields
 
 
@@ -46,6 +46,25 @@ def auto_halo_depth(n_real_cells: int, world: int) -> int:
     return int(min(16, max(8, d)))
 
 
+def shared_hilbert_order(mesh: dict, n: int, rank: int, world: int) -> np.ndarray:
+    """order[new id] = reference id along the Hilbert curve: computed by rank 0 and broadcast when a torch.distributed
+    group is up (the sort is the only global O(n log n) step of the set-up), computed locally otherwise."""
+    if world > 1:
+        try:
+            import torch
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() == world:
+                dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+                t = torch.empty(n, dtype=torch.int64, device=dev)
+                if dist.get_rank() == 0:
+                    t.copy_(torch.from_numpy(hilbert_order(mesh['face_x'], mesh['face_y'], n)))
+                dist.broadcast(t, src=0)
+                return t.cpu().numpy()
+        except ImportError:
+            pass
+    return hilbert_order(mesh['face_x'], mesh['face_y'], n)
+
+
 class PartitionedTransport:
     """The transport engine of one rank of a domain-decomposed run.  With world == 1 it is exactly the
     single-GPU engine (no halo, no communicator)."""
@@ -58,26 +77,33 @@ class PartitionedTransport:
         n = int(np.asarray(mesh['edges_face1']).max()) + 1
         if halo_depth == 0:
             halo_depth = auto_halo_depth(n, world)
+        ncell = len(mesh['face_x'])
         self.order = None
-        if renumber == 'hilbert':
-            self.order = hilbert_order(mesh['face_x'], mesh['face_y'], n)
-            mesh = renumber_mesh(mesh, self.order)
-            inputs3 = np.concatenate([inputs3[:, self.order, :], inputs3[:, n:, :]], axis=1)
-        elif renumber is not None:
-            raise ValueError(f'unknown renumbering {renumber!r}')
         f1 = np.asarray(mesh['edges_face1'])
         f2 = np.asarray(mesh['edges_face2'])
+        if renumber == 'hilbert':
+            # the curve order is computed ONCE (rank 0) and broadcast over the control plane; no rank materialises a
+            # renumbered copy of the global mesh: only the face tables are mapped (2 E integers), every field is sliced
+            # straight from the reference arrays through the composed index maps below
+            self.order = shared_hilbert_order(mesh, n, rank, world)
+            inv = np.arange(ncell, dtype=np.int64)
+            inv[self.order] = np.arange(n)
+            f1, f2 = inv[f1], inv[f2]
+        elif renumber is not None:
+            raise ValueError(f'unknown renumbering {renumber!r}')
         self.n_global = n
         self.K = int(inputs3.shape[2])
         self.local: LocalMesh = partition_mesh(f1, f2, n, world, rank, depth=halo_depth)
         lm = self.local
+        # reference id of every local cell (ghost ids are never renumbered)
+        ref_cells = lm.cell_global if self.order is None else np.where(lm.cell_global < n, self.order[np.minimum(lm.cell_global, n - 1)], lm.cell_global)
         dist_e = mesh.get('face_to_face_dist')
         if dist_e is None:
-            dist_e = face_to_face_distance(mesh)
+            dist_e = face_to_face_distance(mesh)                 # (reference numbering: a face keeps its two cells)
         dt = mesh.get('dt')
         if dt is None:
             dt = change_in_time(mesh['time_seconds'] if 'time_seconds' in mesh else mesh['time'])
-        fields = slice_fields(lm, mesh, np.asarray(dist_e))
+        fields = slice_fields(lm, mesh, np.asarray(dist_e), ref_cells)
         self.engine = TransportEngine(lm.face1, lm.face2, lm.n_cells, self.K, n_owned=lm.n_rows,
                                       n_halo=lm.n_halo, device=device)
         self.engine.load_flow_field(fields['face_flow'], fields['edge_velocity'], fields['volume'], dt,
@@ -90,7 +116,7 @@ class PartitionedTransport:
             self.engine.attach_comm(rank, world, unique_id, lm.peers, lm.send_ptr, lm.send_cells, lm.recv_ptr,
                                     lm.recv_cells, n_core=lm.n_core, exchange_every=lm.depth)
         # initial condition of the owned cells (row 0 of input_array, constituents.py:94-98)
-        self.engine.set_state(np.ascontiguousarray(inputs3[0, lm.lo:lm.hi, :]))
+        self.engine.set_state(np.ascontiguousarray(inputs3[0, ref_cells[:lm.n_core], :]))
 
     def step(self, t: int, **kw):
         return self.engine.step(t, **kw)

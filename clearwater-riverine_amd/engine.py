@@ -39,7 +39,7 @@ ABI_SYMBOLS = (
     'cwr_load_coefficients', 'cwr_get_coefficients', 'cwr_load_boundary', 'cwr_set_boundary_level',
     'cwr_set_state', 'cwr_get_state', 'cwr_load_real_inputs', 'cwr_react_linear', 'cwr_state_device_ptr', 'cwr_apply', 'cwr_rhs', 'cwr_step', 'cwr_get_mass_flux',
     'cwr_time_apply', 'cwr_profile_read', 'cwr_synchronize', 'cwr_apply_bytes',
-    'cwr_comm_unique_id', 'cwr_attach_comm',
+    'cwr_comm_unique_id', 'cwr_attach_comm', 'cwr_comm_selftest',
     'cwr_set_boundary_lines', 'cwr_reset_mass_balance', 'cwr_get_mass_balance', 'cwr_domain_mass',
     'cwr_output_open', 'cwr_output_push', 'cwr_output_wait', 'cwr_output_release', 'cwr_output_close',
 )
@@ -112,6 +112,7 @@ def load_library(path: str | None = None) -> C.CDLL:
         'cwr_apply_bytes': [vp, P(C.c_int64), P(C.c_int64)],
         'cwr_comm_unique_id': [vp],
         'cwr_attach_comm': [vp, i32, i32, vp, i32, i32, i32, vp, vp, vp, vp, vp],
+        'cwr_comm_selftest': [vp, i32, P(C.c_int64)],
         'cwr_set_boundary_lines': [vp, i32, vp, vp],
         'cwr_reset_mass_balance': [vp],
         'cwr_get_mass_balance': [vp, vp],
@@ -470,6 +471,13 @@ class TransportEngine:
                                               int(exchange_every), int(len(pe)), _ptr(pe), _ptr(sp), _ptr(sc),
                                               _ptr(rp), _ptr(rc)))
         self.n_core = n_core
+
+    def comm_selftest(self, count: int = 4096) -> int:
+        """Grouped RCCL send / recv of this rank to itself on the communication stream (count doubles, compared bit for
+        bit); returns the number of halo exchanges that have run beside interior tiles so far.  count = 0: statistics only."""
+        n = C.c_int64(0)
+        self._check(self._lib.cwr_comm_selftest(self._h, int(count), C.byref(n)))
+        return n.value
 
     # ------------------------------------------------------------------ lifetime
     def close(self):

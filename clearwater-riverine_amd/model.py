@@ -294,6 +294,12 @@ class ClearwaterRiverine:
             self.engine.set_state(x)
         if reaction_matrix is not None:
             self.engine.react_linear(reaction_matrix)
+            if t in self._real_input_rows:
+                # as with the host override, non-zero input_array[t] entries on real cells win over the reaction's result
+                # (linalg.py:199-200) -- at level 0 that is the whole initial condition
+                x = self.engine.get_state()[:n]
+                inp = np.stack([self.constituent_dict[c].input_array[t, :n] for c in self.constituents], axis=1)
+                self.engine.set_state(np.where(inp != 0, inp, x))
             if self.store_history:                               # keep mesh[name][t] consistent, as the override does
                 c_now = self.engine.get_state()
                 for k, cname in enumerate(self.constituents):

@@ -161,10 +161,11 @@ def partition_mesh(face1, face2, n_real_cells: int, world: int, rank: int, depth
         recv_cells=(np.concatenate(recv_cells) if recv_cells else np.zeros(0, np.int64)).astype(np.int32))
 
 
-def slice_fields(local: LocalMesh, mesh: dict, dist: np.ndarray) -> dict:
-    """Per-rank slices of the flow field in local numbering (what the rank uploads to its GPU)."""
+def slice_fields(local: LocalMesh, mesh: dict, dist: np.ndarray, ref_cells: np.ndarray | None = None) -> dict:
+    """Per-rank slices of the flow field in local numbering (what the rank uploads to its GPU).  `mesh` is in the
+    reference numbering; ref_cells[i] = reference id of local cell i (default: the partition was made in it)."""
     eg = local.edge_global
-    cg = local.cell_global
+    cg = local.cell_global if ref_cells is None else ref_cells
     return {
         'face_flow': np.ascontiguousarray(np.asarray(mesh['face_flow'])[:, eg]),
         'edge_velocity': np.ascontiguousarray(np.asarray(mesh['edge_velocity'])[:, eg]),

@@ -213,6 +213,11 @@ int32_t cwr_comm_unique_id(uint8_t id_out[128]);
 int32_t cwr_attach_comm(cwr_engine* e, int32_t rank, int32_t world, const uint8_t unique_id[128], int32_t n_core,
                         int32_t exchange_every, int32_t n_peers, const int32_t* peers, const int32_t* send_ptr,
                         const int32_t* send_cells, const int32_t* recv_ptr, const int32_t* recv_cells);
+/* Diagnostics of the communication path.  count > 0: a grouped ncclSend / ncclRecv of `count` doubles from this rank to
+ * itself on the engine's communication stream, bracketed by the two events of the overlapped exchange, compared bit for
+ * bit -- the RCCL point-to-point signatures and the stream / event plumbing, executable with ONE rank.  count = 0: only
+ * the statistics.  overlapped_exchanges (may be NULL): halo exchanges that ran beside the interior tiles of a pass so far. */
+int32_t cwr_comm_selftest(cwr_engine* e, int32_t count, int64_t* overlapped_exchanges);
 
 /* ------------------------------------------------------------------ output side
  * Mass balance on the device (replaces the host post-processing of postproc_util.py:21-166, which needs the whole

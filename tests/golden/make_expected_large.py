@@ -83,40 +83,47 @@ def main():
 
 def reaction_matrix(K: int, dt: float) -> np.ndarray:
     """Config 5's per-step reaction: first-order decay on the diagonal, pairwise exchange
-    c_k -> c_(k+1) off it -- the stand-in for the TSM/NSM kinetics.  tests/test_gpu_fullsize.py imports it."""
+    c_(k+1) -> c_k (k even) off it -- the stand-in for the TSM/NSM kinetics.  tests/test_gpu_fullsize.py imports it.
+    Odd constituents lose to their even partner and receive nothing, so their override needs only their own column."""
     lam = 1.0e-4 * (1.0 + np.arange(K) % 5)
     M = np.diag(np.exp(-lam * dt))
     for k in range(0, K - 1, 2):
-        M[k + 1, k] += 0.002
-        M[k, k] -= 0.002
+        M[k, k + 1] += 0.002
+        M[k + 1, k + 1] -= 0.002
     return M
+
+
+CONFIG5_STEPS = 3          # time steps of the config-5 test (the mesh and the pulse inputs depend on the number of levels)
 
 
 def main_config5():
     """BASELINE config 5: the 4 M-cell mesh (synthetic.bench_mesh(scale=2)), 16 constituents, reaction before the step.
-    One oracle step for the columns COLS5: the override x_t' = (M x_0)[:, k] needs only the known initial fields, so the
-    other columns do not have to be solved.  -> tests/golden/config5_4m_expected.npz"""
+    The oracle takes step 0 plain (at level 0 the reference lets the initial condition overwrite any override,
+    linalg.py:199-200) and step 1 with the override x' = (M c_1)[:, k], for the odd columns COLS5 -- whose rows of M
+    touch only their own column, so the other 14 columns need not be solved.  -> tests/golden/config5_4m_expected.npz"""
     t0 = time.time()
-    COLS5 = (0, 7)
+    COLS5 = (5, 7)            # pulse, plume
     dt = 40.0
-    mesh = synthetic.bench_mesh(1, scale=2)
+    mesh = synthetic.bench_mesh(CONFIG5_STEPS, scale=2)
     inputs3 = synthetic.distinct_input_array(mesh, K, seed=synthetic.BENCH_SEED + 1)
     n = mesh['nreal'] + 1
     oracle.derive_coefficients(mesh)
     M = reaction_matrix(K, dt)
-    x0 = inputs3[0, :n, :]
-    override = {f'c{k}': x0 @ M[k] for k in COLS5}
+    for k in COLS5:
+        assert np.count_nonzero(M[k]) == 1
     model = oracle.OracleModel(mesh, {f'c{k}': inputs3[:, :, k].copy() for k in COLS5})
-    model.update(override)
-    print(f'config 5: one oracle step for {len(COLS5)} columns on {n} cells, {time.time() - t0:.0f} s', flush=True)
+    model.update()
+    print(f'config 5: step 1/2 (plain), {time.time() - t0:.0f} s', flush=True)
+    model.update({f'c{k}': M[k, k] * model.constituent_dict[f'c{k}'].state[1][:n] for k in COLS5})
+    print(f'config 5: step 2/2 (reaction override), {len(COLS5)} columns on {n} cells, {time.time() - t0:.0f} s', flush=True)
     rng = np.random.default_rng(20251005)
-    cells = np.sort(rng.choice(n, size=N_SAMPLE, replace=False))
-    states = np.stack([model.constituent_dict[f'c{k}'].state[1] for k in COLS5], axis=0)
+    cells = np.sort(rng.choice(n, size=N_SAMPLE // 2, replace=False))
+    states = np.stack([model.constituent_dict[f'c{k}'].state[1:3] for k in COLS5], axis=1)       # (2 levels, C, ncell)
     out = os.path.join(HERE, 'config5_4m_expected.npz')
-    np.savez_compressed(out, cells=cells, state=np.ascontiguousarray(states[:, cells]),
-                        norms=np.stack([np.linalg.norm(states[:, :n], axis=1), np.sum(states[:, :n], axis=1),
-                                        np.max(np.abs(states[:, :n]), axis=1)], axis=1),
-                        cols=np.asarray(COLS5), K=K, dt=dt)
+    np.savez_compressed(out, cells=cells, state=np.ascontiguousarray(states[:, :, cells]),
+                        norms=np.stack([np.linalg.norm(states[:, :, :n], axis=2), np.sum(states[:, :, :n], axis=2),
+                                        np.max(np.abs(states[:, :, :n]), axis=2)], axis=2),
+                        cols=np.asarray(COLS5), K=K, dt=dt, steps=CONFIG5_STEPS)
     print(f'wrote {out} ({os.path.getsize(out) / 1e6:.1f} MB) in {time.time() - t0:.0f} s')
 
 

@@ -209,6 +209,9 @@ def test_single_rank_rccl_communicator(gpu_lib, monkeypatch):
             uid = cw.TransportEngine.comm_unique_id()
             assert len(uid) == 128
             eng.attach_comm(0, 1, uid, [], [0], [], [0], [])
+            # the real librccl's point-to-point entry points (ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd) on the
+            # communication stream, this rank to itself: the signatures and the event plumbing of the overlapped exchange
+            assert eng.comm_selftest(4096) == 0
         eng.set_state(inputs3[0, :n, :])
         eng.step(0, solver='jacobi')
         eng.step(1, solver='bicgstab')

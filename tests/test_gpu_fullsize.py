@@ -81,12 +81,12 @@ def test_bench_workload_16_distinct_constituents_on_the_1m_cell_mesh_matches_the
 def test_config5_4m_cells_16_constituents_with_a_per_step_reaction(gpu_lib):
     """BASELINE config 5: 2052 x 2052 base quads (4 M cells after the merges), 16 constituents, a K x K reaction applied to
     the level-t state before every transport step -- on the device (cwr_react_linear) and, for one step, through the
-    reference's host callback contract (update_concentration, transport.py:233-236)."""
+    reference's host callback contract (update_concentration, transport.py:233-236).  Step 0 is taken plain: at level 0
+    the reference lets the initial condition overwrite any override (linalg.py:199-200)."""
     import clearwater_riverine_amd as cw
     large = _large()
     exp = np.load(os.path.join(GOLDEN, 'config5_4m_expected.npz'))
-    K, dt = int(exp['K']), float(exp['dt'])
-    steps = 3
+    K, dt, steps = int(exp['K']), float(exp['dt']), int(exp['steps'])
     mesh = cw.synthetic.bench_mesh(steps, scale=2)
     inputs3 = cw.synthetic.distinct_input_array(mesh, K, seed=cw.synthetic.BENCH_SEED + 1)
     n = mesh['nreal'] + 1
@@ -94,28 +94,34 @@ def test_config5_4m_cells_16_constituents_with_a_per_step_reaction(gpu_lib):
     M = large.reaction_matrix(K, dt)
     names = [f'c{k}' for k in range(K)]
     arrays = {nm: inputs3[:, :, k] for k, nm in enumerate(names)}
+
+    def check_level(state, level):
+        # the oracle's columns (pulse, plume): 32 768-cell sample element-wise + whole-column norms
+        for ci, k in enumerate(exp['cols']):
+            col = state[:, int(k)]
+            assert rel_err(col[exp['cells']], exp['state'][level, ci]) <= 1e-9
+            got = np.array([np.linalg.norm(col[:n]), np.sum(col[:n]), np.max(np.abs(col[:n]))])
+            assert np.allclose(got, exp['norms'][level, ci], rtol=1e-9, atol=0.0)
+
     dev = cw.ClearwaterRiverine(mesh=dict(mesh), input_arrays=arrays, store_history=False)
-    dev.update(reaction_matrix=M)
+    dev.update()
     assert dev.last_step.sweep_kernel == 6 and dev.last_step.flags == 0 and dev.last_step.max_rel_residual <= 1e-12
-    first = dev.engine.get_state()
-    # (a) the oracle's first step (sample + whole-column norms), columns 0 and 7
-    for ci, k in enumerate(exp['cols']):
-        col = first[:, int(k)]
-        assert rel_err(col[exp['cells']], exp['state'][ci]) <= 1e-9
-        got = np.array([np.linalg.norm(col[:n]), np.sum(col[:n]), np.max(np.abs(col[:n]))])
-        assert np.allclose(got, exp['norms'][ci], rtol=1e-9, atol=0.0)
-    # (b) the host callback route gives the same level: override = (M c_0)[:, k] per constituent
+    level1 = dev.engine.get_state()
+    check_level(level1, 0)
+    dev.update(reaction_matrix=M)                                     # (a) reaction on the device, then transport
+    level2 = dev.engine.get_state()
+    check_level(level2, 1)
+    # (b) the host callback route gives the same level 2: override = (M c_1)[:, k] per constituent
     host = cw.ClearwaterRiverine(mesh=dict(mesh), input_arrays=arrays, store_history=False)
-    x0 = inputs3[0, :n, :]
-    host.update({nm: x0 @ M[k] for k, nm in enumerate(names)})
-    assert rel_err(host.engine.get_state(), first) <= 1e-12
+    host.update()
+    c1 = host.engine.get_state()[:n]
+    host.update({nm: c1 @ M[k] for k, nm in enumerate(names)})
+    assert rel_err(host.engine.get_state(), level2) <= 1e-12
     host.engine.close()
     del host
-    # (c) two more steps with the device reaction; then the true residual of the last step through the exported
-    # operator and right-hand side (b - A x, all 4 M x 16 entries)
-    dev.update(reaction_matrix=M)
-    x_t = dev.engine.get_state()[:n].copy()
-    x_t = x_t @ M.T                                                   # what the device reaction makes of level 2
+    # (c) a third step with the device reaction; the true residual of that step through the exported operator and
+    # right-hand side (b - A x over all 4 M x 16 entries)
+    x_t = level2[:n] @ M.T                                            # what the device reaction makes of level 2
     dev.update(reaction_matrix=M)
     x_n = dev.engine.get_state()[:n]
     b = dev.engine.rhs(2, x_t)
@@ -123,5 +129,6 @@ def test_config5_4m_cells_16_constituents_with_a_per_step_reaction(gpu_lib):
     assert np.max(np.linalg.norm(r, axis=0) / np.linalg.norm(b, axis=0)) <= 1e-10
     # (d) exact linearity: every input scaled by 2 (a power of two: no rounding anywhere) gives bitwise 2 x the state
     twice = cw.ClearwaterRiverine(mesh=dict(mesh), input_arrays={nm: 2.0 * a for nm, a in arrays.items()}, store_history=False)
+    twice.update()
     twice.update(reaction_matrix=M)
-    assert np.array_equal(twice.engine.get_state(), 2.0 * first, equal_nan=True)
+    assert np.array_equal(twice.engine.get_state(), 2.0 * level2, equal_nan=True)

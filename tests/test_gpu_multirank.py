@@ -69,11 +69,12 @@ def _rank_main(rank, world, K, solver, depth, uid_pipe, out_queue):
             infos.append((r.sweeps, r.iterations))
         adv, dif, tot = pt.engine.get_mass_flux()
         owned_faces = pt.local.face1 < pt.local.n_core
+        overlapped = pt.engine.comm_selftest(257)             # self send/recv through the stand-in + the overlap counter
         out_queue.put((rank, pt.owned_reference_ids(), pt.local.hi, pt.owned_state(), pt.local.edge_global[owned_faces],
-                       tot[owned_faces], infos, None, pt.engine.get_mass_balance(), mass0, pt.engine.domain_mass(3)))
+                       tot[owned_faces], infos, None, pt.engine.get_mass_balance(), mass0, pt.engine.domain_mass(3), overlapped))
         pt.engine.close()
     except Exception as exc:                                  # surface the failure in the parent
-        out_queue.put((rank, 0, 0, None, None, None, None, repr(exc), None, None, None))
+        out_queue.put((rank, 0, 0, None, None, None, None, repr(exc), None, None, None, 0))
 
 
 def run_ranks(world, target, args):
@@ -184,3 +185,74 @@ def test_partitioned_block_asynchronous_passes_keep_the_single_rank_sweep_count(
         got = [s for s, _ in r[6]]
         assert all(g <= s + 4 for g, s in zip(got[1:], single_sweeps[1:])), (got, single_sweeps)
     assert min(single_sweeps) >= 20                           # the case really iterates
+    # the exchanges inside the pass loop ran beside the interior tiles (second stream + events), on every rank
+    assert all(r[11] > 0 for r in results), [r[11] for r in results]
+
+
+def _hip():
+    """hipMemcpyAsync / hipStreamSynchronize of the HIP runtime the ENGINE is linked against (resolved through the engine
+    library's own handle: a second copy of libamdhip64 in the process would not know the engine's stream)."""
+    import ctypes
+    import clearwater_riverine_amd as cw
+    lib = cw.load_library()
+    lib.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+    lib.hipMemcpyAsync.restype = ctypes.c_int
+    lib.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+    lib.hipStreamSynchronize.restype = ctypes.c_int
+    return lib
+
+
+def _rank_hook(rank, world, K, route, uid_pipe, out_queue):
+    """Three steps with the state rewritten between them -- through cwr_set_state, or through the device pointer of
+    cwr_state_device_ptr fetched ONCE before the first step (what a device reaction kernel does)."""
+    try:
+        os.environ['CWR_RCCL_LIB'] = MOCK_LIB
+        import clearwater_riverine_amd as cw
+        from clearwater_riverine_amd.distributed import PartitionedTransport
+        mesh, inputs3 = make_case(K)
+        if rank == 0:
+            uid = cw.TransportEngine.comm_unique_id()
+            for _ in range(world - 1):
+                uid_pipe.put(uid)
+        else:
+            uid = uid_pipe.get(timeout=120)
+        pt = PartitionedTransport(mesh, inputs3, rank, world, device=0, unique_id=uid, halo_depth=6, renumber='hilbert')
+        ptr, stream = pt.engine.state_device_ptr()
+        hip = _hip()
+        nc = pt.local.n_core
+        for t in range(3):
+            pt.step(t, tol=1e-12, mass_flux=True)            # (a mass-flux step leaves the halo rows "fresh")
+            new = np.ascontiguousarray(pt.owned_state() * (1.0 + 0.1 * (t + 1)) + 0.25)
+            if route == 'pointer':
+                rc = hip.hipMemcpyAsync(ptr, new.ctypes.data, new.nbytes, 1, stream)
+                rc2 = hip.hipStreamSynchronize(stream)
+                if rc or rc2:
+                    raise RuntimeError(f'hipMemcpyAsync -> {rc}, hipStreamSynchronize -> {rc2}')
+            else:
+                pt.engine.set_state(new)
+        pt.step(3, tol=1e-12, mass_flux=True)
+        out_queue.put((rank, pt.owned_reference_ids(), nc, pt.owned_state(), None, None, None, None))
+        pt.engine.close()
+    except Exception as exc:
+        out_queue.put((rank, 0, 0, None, None, None, None, repr(exc)))
+
+
+def test_state_rewritten_through_the_device_pointer_between_partitioned_steps(gpu_lib, monkeypatch):
+    """the pointer of cwr_state_device_ptr never changes, so a caller fetches it once and writes through it
+    between steps; after a mass-flux step the engine used to skip the next start-of-step halo exchange, and the replayed
+    halo layers then built their right-hand sides from the pre-reaction state.  The pointer route must equal the
+    cwr_set_state route bit for bit."""
+    build_mock()
+    monkeypatch.setenv('CWR_NO_SMALL', '1')
+    monkeypatch.setenv('CWR_TEST_BIG', '1')
+    K = 4
+    outs = {}
+    for route in ('set_state', 'pointer'):
+        results = run_ranks(2, _rank_hook, (K, route))
+        mesh, _ = make_case(K)
+        state = np.full((mesh['nreal'] + 1, K), np.nan)
+        for r in results:
+            state[r[1]] = r[3]
+        assert not np.isnan(state).any()
+        outs[route] = state
+    assert np.array_equal(outs['set_state'], outs['pointer'])
