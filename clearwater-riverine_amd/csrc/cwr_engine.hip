@@ -145,6 +145,7 @@ struct cwr_engine {
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_packed = nullptr, ev_halo = nullptr;
   bool overlap = true;
+  int overlap_reserve = 8 * N_XCD;              // block slots an overlapped interior launch leaves to the communication kernels
   int n_tile_inner = 0, n_tile_outer = 0;
   int32_t *d_tile_inner = nullptr, *d_tile_outer = nullptr;
   std::map<int, hipGraphExec_t> stretch_exec;   // exchange-free runs of passes of a partitioned engine, by (first parity, length)
@@ -776,7 +777,10 @@ int prepare_sq(cwr_engine* e, bool& active) {
 int launch_sq_tiled(cwr_engine* e, const double* xin, double* yout, const int32_t* tile_list = nullptr, int n_list = 0, bool tail = true) {
   const int ntiles = tile_list ? n_list : e->tcl_ntiles;
   if (ntiles <= 0) return CWR_OK;
-  const int grid = std::max(N_XCD, std::min(e->tcl_grid, cdiv(ntiles, N_XCD) * N_XCD));
+  int grid = std::max(N_XCD, std::min(e->tcl_grid, cdiv(ntiles, N_XCD) * N_XCD));
+  // an interior launch that runs beside an exchange leaves a few block slots free: the grid is persistent (every resident
+  // slot taken until the launch ends), so RCCL's copy kernels could otherwise only start when it is over
+  if (tile_list && !tail && grid > 4 * e->overlap_reserve) grid -= e->overlap_reserve;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (e->profiling && e->dominant_mode == 6 && e->ev_used + 2 <= e->ev.size()) {
     e0 = e->ev[e->ev_used++]; e1 = e->ev[e->ev_used++];
@@ -2084,6 +2088,7 @@ int32_t cwr_attach_comm(cwr_engine* e, int32_t rank, int32_t world, const uint8_
   TRY(upload(e, e->d_send_cells, send_cells, (size_t)n_send));
   TRY(upload(e, e->d_recv_cells, recv_cells, (size_t)n_recv));
   if (const char* v = getenv("CWR_NO_OVERLAP")) e->overlap = atoi(v) == 0;
+  if (const char* v = getenv("CWR_OVERLAP_RESERVE")) e->overlap_reserve = std::max(0, atoi(v)) / N_XCD * N_XCD;
   HIP_TRY(e, hipStreamCreateWithFlags(&e->comm_stream, hipStreamNonBlocking));
   HIP_TRY(e, hipEventCreateWithFlags(&e->ev_packed, hipEventDisableTiming));
   HIP_TRY(e, hipEventCreateWithFlags(&e->ev_halo, hipEventDisableTiming));

@@ -19,6 +19,31 @@ from .model import Mesh
 _BASE = 'Results/Unsteady/Output/Output Blocks/Base Output/Unsteady Time Series'
 
 
+def _have_pandas() -> bool:
+    try:
+        import pandas  # noqa: F401
+        return True
+    except ImportError:
+        return False
+
+
+def boundary_dataframe(external_faces, attributes, keep):
+    """mesh.attrs['boundary_data'] as the reference builds it (io/hdf.py:355-436): one row per kept boundary face with the
+    columns of 'External Faces' (minus 'Station Start' / 'Station End') followed by the columns of the line 'Attributes'
+    (byte strings decoded), which postproc_util.py:72-90 groups by 'Name' / 'BC Line ID' and reads 'Face Index' from."""
+    import pandas as pd
+    ext = pd.DataFrame(external_faces)
+    att = pd.DataFrame(attributes)
+    for col in att.select_dtypes([object]).columns:
+        att[col] = att[col].str.decode('utf-8')
+    att['BC Line ID'] = att.index
+    df = pd.merge(ext, att, on='BC Line ID', how='left')[np.asarray(keep, dtype=bool)]
+    df = df.drop(columns=[c for c in ('Station Start', 'Station End') if c in df.columns]).drop_duplicates()
+    # the reference concatenates line by line in order of first appearance of the name (io/hdf.py:404-425)
+    first = {nm: i for i, nm in enumerate(pd.unique(df['Name']))}
+    return df.iloc[np.argsort(df['Name'].map(first).to_numpy(), kind='stable')]
+
+
 def _parse_stamps(raw) -> np.ndarray:
     """'%d%b%Y %H:%M:%S' byte strings (io/hdf.py:152-156) -> datetime64[ns]."""
     from datetime import datetime
@@ -70,15 +95,19 @@ def read_ras_hdf(file_path: str, datetime_range: Optional[Union[Tuple[int, int],
             'volume': res['Cell Volume'][sl].astype(np.float32),
         })
         m.attrs['nreal'] = int(faces_cells[:, 0].max())                                  # io/hdf.py:268-269
-        # boundary lines -> faces, keeping only the faces listed in '<name> - Flow per Face'.attrs['Faces']
+        # boundary lines (io/hdf.py:355-436): External Faces joined with the line attributes on 'BC Line ID', keeping of
+        # every line only the faces listed in '<name> - Flow per Face'.attrs['Faces'] (the HEC-RAS bug the reference works
+        # around), 'Station Start' / 'Station End' dropped, duplicates removed -- vectorised over all faces
         ext = f['Geometry/Boundary Condition Lines/External Faces'][()]
         attrs = f['Geometry/Boundary Condition Lines/Attributes'][()]
-        faces = {}
-        for line_id, row in enumerate(attrs):
-            name = row[0].decode('utf-8')
-            orig = [int(r['Face Index']) for r in ext if int(r['BC Line ID']) == line_id]
-            fix = set(int(v) for v in f[f'{_BASE}/Boundary Conditions/{name} - Flow per Face'].attrs['Faces'])
-            faces[name] = sorted(set(x for x in orig if x in fix))
+        names = [row[0].decode('utf-8') for row in attrs]
+        line_of_face = np.asarray(ext['BC Line ID'], dtype=np.int64)
+        face_index = np.asarray(ext['Face Index'], dtype=np.int64)
+        keep = np.zeros(len(face_index), dtype=bool)
+        for line_id, name in enumerate(names):
+            fix = np.asarray(f[f'{_BASE}/Boundary Conditions/{name} - Flow per Face'].attrs['Faces'], dtype=np.int64)
+            keep |= (line_of_face == line_id) & np.isin(face_index, fix)
+        faces = {name: np.unique(face_index[keep & (line_of_face == line_id)]).tolist() for line_id, name in enumerate(names)}
         m.attrs['boundary_faces'] = faces
-        m.attrs['boundary_data'] = faces
+        m.attrs['boundary_data'] = boundary_dataframe(ext, attrs, keep) if _have_pandas() else faces
     return m

@@ -109,13 +109,49 @@ def input_array_from_tables(mesh: Mesh, ic_cell_index, ic_concentration, bc_by_g
     return arr
 
 
+def _boundary_face_table(boundary_faces) -> Dict[str, np.ndarray]:
+    """Name -> face ids from either form of mesh.attrs['boundary_data']: the reference's DataFrame (columns 'Name',
+    'Face Index'; io/hdf.py:355-436) or a plain {name: faces} dict."""
+    if boundary_faces is None:
+        return {}
+    if hasattr(boundary_faces, 'groupby'):                       # pandas DataFrame
+        return {str(name): grp['Face Index'].to_numpy(dtype=np.int64) for name, grp in boundary_faces.groupby('Name', sort=False)}
+    return {str(k): np.asarray(v, dtype=np.int64).ravel() for k, v in boundary_faces.items()}
+
+
+def boundary_series(model_time, bc_frame) -> Dict[str, np.ndarray]:
+    """constituents.py:121-150 per boundary line, without the reference's growing DataFrame: the CSV rows of one line
+    are merged BACKWARD onto the model stamps (pd.merge_asof: the last row at or before each stamp) and gaps are filled
+    by linear interpolation in the row index (Series.interpolate(method='linear'): leading NaNs stay NaN, trailing
+    ones repeat the last value).  Returns {line name: (T,) concentrations}."""
+    import pandas as pd
+    t = pd.DatetimeIndex(np.asarray(model_time)).values.astype('datetime64[ns]').astype(np.int64)
+    out = {}
+    for name, grp in bc_frame.groupby('RAS2D_TS_Name'):
+        grp = grp.sort_values('Datetime', kind='stable')
+        gt = pd.DatetimeIndex(grp['Datetime']).values.astype('datetime64[ns]').astype(np.int64)
+        gv = grp['Concentration'].to_numpy(dtype=np.float64)
+        pos = np.searchsorted(gt, t, side='right') - 1           # merge_asof(direction='backward')
+        vals = np.where(pos >= 0, gv[np.maximum(pos, 0)], np.nan)
+        ok = ~np.isnan(vals)
+        if ok.any() and not ok.all():                             # interpolate(method='linear', limit_direction='forward')
+            idx = np.arange(len(vals), dtype=np.float64)
+            first = int(np.argmax(ok))
+            filled = np.interp(idx, idx[ok], vals[ok])
+            filled[:first] = np.nan
+            vals = filled
+        out[str(name)] = vals
+    return out
+
+
 def input_array_from_csv(mesh: Mesh, initial_conditions_csv: str, boundary_conditions_csv: str,
-                        boundary_faces: Dict[str, list]) -> np.ndarray:
-    """constituents.py:78-164 with pandas: IC CSV (Cell_Index, Concentration) -> row 0; BC CSV
-    (RAS2D_TS_Name, Datetime, Concentration) merged backward onto the model stamps
-    (merge_asof), linearly interpolated, written at [time index, ghost cell of each face of the
-    named boundary line].  ``boundary_faces`` is the Name -> Face Index table of
-    mesh.attrs['boundary_data'] (io/hdf.py:355-436)."""
+                        boundary_faces) -> np.ndarray:
+    """constituents.py:78-164: IC CSV (Cell_Index, Concentration) -> row 0; BC CSV (RAS2D_TS_Name, Datetime,
+    Concentration) time-aligned per boundary line (boundary_series) and written at [every time index, ghost cell of
+    every face of the line] in one vectorised assignment per line.  ``boundary_faces`` is mesh.attrs['boundary_data']
+    (the reference's DataFrame, io/hdf.py:355-436) or a {name: face ids} dict.  The reference builds a (T x faces)-row
+    DataFrame by repeated concat + merge for this (12 s on the Ohio River model, examples/Ohio River.ipynb cell[13]);
+    here it is O(T) per line plus the assignment.  NaN stays NaN, as in the reference."""
     import pandas as pd
     T = len(mesh['time'])
     ncell = len(mesh['face_x'])
@@ -123,14 +159,13 @@ def input_array_from_csv(mesh: Mesh, initial_conditions_csv: str, boundary_condi
     ic = pd.read_csv(initial_conditions_csv)
     arr[0, ic['Cell_Index'].astype(int).to_numpy()] = ic['Concentration'].to_numpy(dtype=np.float64)
     bc = pd.read_csv(boundary_conditions_csv, parse_dates=['Datetime']).dropna(how='all')
-    model_df = pd.DataFrame({'Datetime': pd.DatetimeIndex(np.asarray(mesh['time'])), 'Time Index': range(T)})
     f2 = np.asarray(mesh[EDGES_FACE2])
-    for boundary, group in bc.groupby('RAS2D_TS_Name'):
-        merged = pd.merge_asof(model_df, group.sort_values('Datetime'), on='Datetime')
-        merged['Concentration'] = merged['Concentration'].interpolate(method='linear')
-        for face in boundary_faces.get(boundary, []):
-            vals = merged['Concentration'].to_numpy(dtype=np.float64)
-            arr[merged['Time Index'].to_numpy(), f2[int(face)]] = vals      # NaN stays NaN, as in the reference
+    table = _boundary_face_table(boundary_faces)
+    for name, vals in boundary_series(mesh['time'], bc).items():
+        faces = table.get(name)
+        if faces is None or len(faces) == 0:
+            continue                                             # a CSV line the flow field does not have: the left merge drops it
+        arr[:, f2[faces]] = vals[:, None]
     return arr
 
 
@@ -202,7 +237,9 @@ class ClearwaterRiverine:
             if not isinstance(constituent_dict, dict):
                 raise TypeError('Missing a `config_filepath` or a `constituent_dict` and '
                                 '`flow_field_file_path` to run the model.')
-            bfaces = m.attrs.get('boundary_faces') or {}
+            bfaces = m.attrs.get('boundary_data')
+            if bfaces is None:
+                bfaces = m.attrs.get('boundary_faces') or {}
             input_arrays = {
                 name: input_array_from_csv(m, cfg['initial_conditions'], cfg['boundary_conditions'], bfaces)
                 for name, cfg in constituent_dict.items()}

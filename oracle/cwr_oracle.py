@@ -395,6 +395,29 @@ def build_input_array(mesh: dict, ic_cell_index, ic_concentration, bc_ghost_valu
     return arr
 
 
+def set_boundary_conditions_literal(input_array: np.ndarray, mesh: dict, bc_df, flow_field_boundaries) -> np.ndarray:
+    """constituents.py:100-164 restated statement for statement with pandas (the reference's own tool here): per
+    RAS2D_TS_Name group merge_asof onto the model stamps + linear interpolation, the groups concatenated, a LEFT merge
+    with the flow field's boundary DataFrame on the line name, then the fancy assignment
+    input_array[[Time Index], [Ghost Cell]] = Concentration.  bc_df: DataFrame (RAS2D_TS_Name, Datetime, Concentration);
+    flow_field_boundaries: DataFrame with 'Name' and 'Face Index' (mesh.attrs['boundary_data'], io/hdf.py:355-436);
+    mesh['time'] datetime64 stamps.  Test infrastructure: the product's vectorised pipeline is checked against this."""
+    import pandas as pd
+    xarray_time_index = pd.DatetimeIndex(np.asarray(mesh['time']))                    # :125-127
+    model_dataframe = pd.DataFrame({'Datetime': xarray_time_index,                     # :128-131
+                                    'Time Index': range(len(xarray_time_index))})
+    result_df = pd.DataFrame()                                                         # :133
+    for boundary, group_df in bc_df.groupby('RAS2D_TS_Name'):                          # :134
+        merged_group = pd.merge_asof(model_dataframe, group_df, on='Datetime')         # :136-140
+        merged_group['Concentration'] = merged_group['Concentration'].interpolate(method='linear')   # :142-144
+        result_df = pd.concat([result_df, merged_group], ignore_index=True)            # :146-149
+    boundary_df = pd.merge(result_df, flow_field_boundaries, left_on='RAS2D_TS_Name', right_on='Name', how='left')  # :152-158
+    f2 = np.asarray(mesh[EDGES_FACE2])
+    boundary_df['Ghost Cell'] = f2[boundary_df['Face Index'].to_list()]                # :159
+    input_array[[boundary_df['Time Index']], [boundary_df['Ghost Cell']]] = boundary_df['Concentration']   # :163
+    return input_array
+
+
 class OracleModel:
     """transport.py:68-276 restated over arrays: owns the mesh dict, the LHS, the
     constituents and time_step; update() follows transport.py:201-276."""

@@ -41,6 +41,74 @@ def test_input_array_from_the_reference_csv_data(tmp_path):
     assert np.array_equal(arr, want)
 
 
+def test_vectorised_boundary_pipeline_equals_the_reference_algorithm_and_is_fast():
+    """constituents.py:100-164 (merge_asof per line, interpolate, concat, left merge, fancy assignment)
+    restated literally in the oracle vs the product's vectorised pipeline, on a case of the Ohio River model's size
+    (913 hourly stamps, 3 boundary lines with 40 / 25 / 60 faces; the reference needs 12 s there, Ohio River.ipynb
+    cell[13]): CSV rows at irregular times, gaps (interpolated), rows between stamps, unsorted rows.  (Every line starts
+    at or before the first model stamp: otherwise merge_asof leaves the line NAME empty on the leading stamps and the
+    reference's left merge + fancy index raises; the vectorised pipeline writes NaN there.)"""
+    import time
+    from clearwater_riverine_amd.model import Mesh, input_array_from_csv
+    rng = np.random.default_rng(5)
+    T, nreal, E = 913, 3000, 6500
+    t0 = np.datetime64('2010-05-29T00:00:00')
+    stamps = t0 + (np.arange(T) * 3600).astype('timedelta64[s]')
+    f2 = rng.integers(0, nreal, size=E)
+    lines = {'Upstream Q': np.arange(100, 140), 'Tributary': np.arange(900, 925), 'Downstream Stage': np.arange(5000, 5060)}
+    ghost = nreal
+    for faces in lines.values():
+        f2[faces] = ghost + np.arange(len(faces))
+        ghost += len(faces)
+    mesh = Mesh({'time': stamps.astype('datetime64[ns]'), 'face_x': np.zeros(ghost), 'edges_face2': f2})
+    rows = []
+    for name, start, every in (('Upstream Q', -5, 7200), ('Tributary', -30, 5400), ('Downstream Stage', 0, 86400)):
+        when = t0 + (start * 3600 + np.sort(rng.choice(np.arange(0, T * 3600, every), size=min(120, len(np.arange(0, T * 3600, every))), replace=False))).astype('timedelta64[s]')
+        when[0] = t0 + np.timedelta64(min(start, 0) * 3600, 's')                       # a row at or before the first stamp
+        conc = 50.0 + 40.0 * rng.random(len(when))
+        conc[1 + rng.choice(len(when) - 1, size=len(when) // 10, replace=False)] = np.nan    # gaps in the series
+        rows.append(pd.DataFrame({'RAS2D_TS_Name': name, 'Datetime': when, 'Concentration': conc}))
+    bc_df = pd.concat(rows, ignore_index=True).sample(frac=1.0, random_state=1).reset_index(drop=True)      # unsorted rows
+    boundary_data = pd.DataFrame([{'BC Line ID': i, 'Face Index': int(f), 'Name': nm, 'Type': 'External'}
+                                  for i, (nm, faces) in enumerate(lines.items()) for f in faces])
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        icp, bcp = os.path.join(d, 'ic.csv'), os.path.join(d, 'bc.csv')
+        pd.DataFrame({'Cell_Index': np.arange(nreal), 'Concentration': 1.0 + rng.random(nreal)}).to_csv(icp, index=False)
+        bc_df.to_csv(bcp, index=False)
+        w0 = time.perf_counter()
+        got = input_array_from_csv(mesh, icp, bcp, boundary_data)
+        fast = time.perf_counter() - w0
+        got_dict = input_array_from_csv(mesh, icp, bcp, {k: v.tolist() for k, v in lines.items()})
+        ic = pd.read_csv(icp)
+        bc_read = pd.read_csv(bcp, parse_dates=['Datetime'])
+    want = np.zeros((T, ghost))
+    want[0, ic['Cell_Index'].to_numpy()] = ic['Concentration'].to_numpy()
+    w0 = time.perf_counter()
+    # merge_asof needs each group sorted on the key; the reference's CSVs are (its groupby keeps row order), ours is shuffled
+    oracle.set_boundary_conditions_literal(want, mesh, bc_read.sort_values('Datetime', kind='stable'), boundary_data)
+    slow = time.perf_counter() - w0
+    assert np.array_equal(got, want, equal_nan=True) and np.array_equal(got_dict, want, equal_nan=True)
+    assert np.isfinite(got[-1, nreal:]).all()
+    assert fast < 1.0, f'vectorised boundary pipeline took {fast:.2f} s (literal restatement of the reference: {slow:.2f} s)'
+
+
+def test_boundary_dataframe_has_the_reference_columns():
+    """hdf_reader.boundary_dataframe == io/hdf.py:355-436 on records shaped like the HDF's compound datasets."""
+    from clearwater_riverine_amd.hdf_reader import boundary_dataframe
+    from clearwater_riverine_amd.mass_balance import boundary_lines
+    ext = np.array([(0, 10, 0, 1, 0.0, 5.0), (0, 11, 1, 2, 5.0, 9.0), (1, 40, 0, 1, 0.0, 3.0), (1, 41, 1, 2, 3.0, 6.0), (1, 41, 1, 2, 3.0, 6.0)],
+                   dtype=[('BC Line ID', '<i4'), ('Face Index', '<i4'), ('FP Start Index', '<i4'), ('FP End Index', '<i4'),
+                          ('Station Start', '<f4'), ('Station End', '<f4')])
+    att = np.array([(b'Upstream Q', b'Perimeter 1', b'External', 9.0), (b'Downstream', b'Perimeter 1', b'External', 6.0)],
+                   dtype=[('Name', 'O'), ('SA-2D', 'O'), ('Type', 'O'), ('Length', '<f4')])
+    keep = np.array([True, True, True, False, False])               # face 41 is not in the line's 'Faces' attribute
+    df = boundary_dataframe(ext, att, keep)
+    assert list(df.columns) == ['BC Line ID', 'Face Index', 'FP Start Index', 'FP End Index', 'Name', 'SA-2D', 'Type', 'Length']
+    assert df['Face Index'].tolist() == [10, 11, 40] and df['Name'].tolist() == ['Upstream Q', 'Upstream Q', 'Downstream']
+    assert [(n, f.tolist()) for n, f in boundary_lines(df)] == [('Upstream Q', [10, 11]), ('Downstream', [40])]
+
+
 def test_synthetic_mesh_has_the_reference_surface_and_discrete_continuity():
     import clearwater_riverine_amd as cw
     m = cw.synthetic.make_mesh(30, 12, 10, seed=2, n_merge=40, n_dry=3)
