@@ -59,7 +59,6 @@ struct Rccl {
 Rccl g_rccl;
 constexpr int NCCL_FLOAT64 = 8;   // ncclDataType_t::ncclFloat64
 constexpr int NCCL_SUM = 0;       // ncclRedOp_t::ncclSum
-constexpr int NCCL_MAX = 2;       // ncclRedOp_t::ncclMax
 
 }  // namespace
 
@@ -97,6 +96,7 @@ struct cwr_engine {
          *d_t = nullptr, *d_b = nullptr;
   double* d_chk = nullptr;       // [4][K] convergence-check scalars of the Jacobi path: ||x'-x||^2, ||bhat||^2 (sums) and the
                                  // element-wise measures max(|x'-x| - ew_rel |x'|), max |x'| (k_apply MODE 4)
+  double* d_chkx = nullptr;      // partitioned engines: [rr | bb | world x (m1 | m2)] -- the one all-reduce of a check (gather_check)
   double* d_keep = nullptr;      // x_t (computed rows, written by k_rhs) and the ghost rows as the step found them: a failed
                                  // step restores the state from here
   // element-wise stopping rule on top of the norm criterion: |x'_i - x_i| <= ew_rel |x'_i| + ew_abs max|x'| for every cell
@@ -378,18 +378,35 @@ int allreduce(cwr_engine* e, double* p, size_t count) {
   return CWR_OK;
 }
 
-int allreduce_max(cwr_engine* e, double* p, size_t count) {
-  if (!e->comm || (e->world == 1 && !e->force_coll)) return CWR_OK;
-  NCCL_TRY(e, g_rccl.AllReduce(p, p, count, NCCL_FLOAT64, NCCL_MAX, e->comm, e->stream));
-  return CWR_OK;
-}
-
 #define TRY(call) do { int _rc = (call); if (_rc != CWR_OK) return _rc; } while (0)
 
 // the closing check of a batch of sweeps: fold the per-block partials of the last MODE 4 launch into d_chk
 int reduce_check(cwr_engine* e) {
   const int K = e->K;
   return reduce_partials(e, e->last_apply_grid, 4, e->d_chk, e->d_chk + K, e->d_chk + 2 * K, e->d_chk + 3 * K, 2);
+}
+
+// The check scalars of every rank, on the host: h = [rr | bb | m1 | m2] with the sums added and the maxima taken over the
+// ranks.  ONE all-reduce (sum) carries both: every rank adds its two maxima in its own slot of a (world x 2K) block that is
+// zero elsewhere, and the host takes the maximum over the slots -- a second (max) collective would cost another 20-40 us of
+// latency per check.  Single GPU: a plain download.
+int gather_check(cwr_engine* e, double* h) {
+  const size_t K = (size_t)e->K;
+  if (!e->comm || (e->world == 1 && !e->force_coll)) return download(e, h, e->d_chk, 4 * K);
+  const size_t W = (size_t)e->world, n = 2 * K + W * 2 * K;
+  HIP_TRY(e, hipMemsetAsync(e->d_chkx, 0, n * sizeof(double), e->stream));
+  HIP_TRY(e, hipMemcpyAsync(e->d_chkx, e->d_chk, 2 * K * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(e->d_chkx + 2 * K + (size_t)e->rank * 2 * K, e->d_chk + 2 * K, 2 * K * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+  TRY(allreduce(e, e->d_chkx, n));
+  std::vector<double> all(n);
+  TRY(download(e, all.data(), e->d_chkx, n));
+  for (size_t k = 0; k < 2 * K; ++k) h[k] = all[k];
+  for (size_t k = 0; k < 2 * K; ++k) {
+    double m = -INFINITY;
+    for (size_t r = 0; r < W; ++r) m = std::max(m, all[2 * K + r * 2 * K + k]);
+    h[2 * K + k] = m;
+  }
+  return CWR_OK;
 }
 
 // element-wise verdict from the downloaded check scalars h = [rr | bb | m1 | m2]; ratio: by how much |x'-x| still has to fall
@@ -855,7 +872,6 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
   need_bicg = false;
   std::vector<double> h(4 * (size_t)K);
   // the reduced check scalars (||x'-x||^2, ||bhat||^2 | element-wise maxima) land side by side: one download per check
-  double* d_rr = e->d_chk;
   double prev_worst = -1.0;
   int prev_sweeps = 0;
   int since_exchange = 0;                     // the caller exchanged the state's halo just before the right-hand side
@@ -1031,10 +1047,10 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
     st.sweeps += batch; st.launches += launches;
     if (!batch_graph) TRY(reduce_check(e));
     bool speculated = false;
-    if (e->spec_t >= 0 && !e->comm) { TRY(step_tail(e, e->spec_t, e->spec_flags)); speculated = true; }
-    TRY(allreduce(e, d_rr, 2 * (size_t)K));
-    TRY(allreduce_max(e, e->d_chk + 2 * (size_t)K, 2 * (size_t)K));
-    TRY(download(e, h.data(), d_rr, 4 * (size_t)K));
+    // (partitioned engines too: every rank takes the same decisions from the all-reduced check, so a speculative tail --
+    // whose exchange is a collective -- is entered and, if the check fails, repeated by all ranks alike)
+    if (e->spec_t >= 0) { TRY(step_tail(e, e->spec_t, e->spec_flags)); speculated = true; }
+    TRY(gather_check(e, h.data()));
     bool ok = true;
     double worst = 0.0;                                                   // max over columns of rr / (tol^2 bb)
     st.max_rel = 0.0;
@@ -1216,9 +1232,7 @@ int solve_bicgstab(cwr_engine* e, double tol2, int max_iter, SolveStats& st) {
     if (rc != CWR_OK) return rc;
     launches += 2; st.sweeps += 2;
     TRY(reduce_check(e));
-    TRY(allreduce(e, e->d_chk, 2 * (size_t)K));
-    TRY(allreduce_max(e, e->d_chk + 2 * (size_t)K, 2 * (size_t)K));
-    TRY(download(e, h.data(), e->d_chk, 4 * (size_t)K));
+    TRY(gather_check(e, h.data()));
     bool finite = true;
     for (int k = 0; k < K; ++k) if (!std::isfinite(h[k])) finite = false;
     if (!finite) { status = CWR_ERR_NONFINITE; break; }
@@ -1433,7 +1447,7 @@ void cwr_destroy(cwr_engine* e) {
   for (hipEvent_t ev : e->ev) hipEventDestroy(ev);
   void* ptrs[] = {e->d_f1, e->d_f2, e->d_ptr, e->d_ent_edge, e->d_ent_nb, e->d_adv, e->d_vel, e->d_vol, e->d_dif,
                   e->d_bc, e->d_rec, e->d_diag, e->d_c, e->d_r, e->d_r0, e->d_p, e->d_v, e->d_s, e->d_t, e->d_b,
-                  e->d_scal, e->d_counters, e->d_partial, e->d_fadv, e->d_fdif, e->d_ftot, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf, e->d_ptr2, e->d_col2, e->d_row2, e->d_rec2, e->d_w, e->d_react, e->d_info, e->d_tcl_ptr, e->d_tcl_cols, e->d_loc2, e->d_w2, e->d_pair_ptr, e->d_slots, e->d_line_ptr, e->d_line_faces, e->d_ledger, e->d_mass_out, e->d_chk, e->d_face_orig, e->d_row_ghost, e->d_keep, e->d_in_rows, e->d_in_vals, e->d_face_pos, e->d_trow, e->d_vptr, e->d_meta, e->d_tile_inner, e->d_tile_outer};
+                  e->d_scal, e->d_counters, e->d_partial, e->d_fadv, e->d_fdif, e->d_ftot, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf, e->d_ptr2, e->d_col2, e->d_row2, e->d_rec2, e->d_w, e->d_react, e->d_info, e->d_tcl_ptr, e->d_tcl_cols, e->d_loc2, e->d_w2, e->d_pair_ptr, e->d_slots, e->d_line_ptr, e->d_line_faces, e->d_ledger, e->d_mass_out, e->d_chk, e->d_face_orig, e->d_row_ghost, e->d_keep, e->d_in_rows, e->d_in_vals, e->d_face_pos, e->d_trow, e->d_vptr, e->d_meta, e->d_tile_inner, e->d_tile_outer, e->d_chkx};
   for (void* p : ptrs) if (p) hipFree(p);
   if (e->stream) hipStreamDestroy(e->stream);
   delete e;
@@ -1694,7 +1708,7 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
     rc_solve = solve_small(e, tol2, max_iter, force_jac, st, handled, need_bicg);
     if (rc_solve != CWR_OK && st.status == CWR_OK) return rc_solve;
     if (!handled) {
-      e->spec_t = (!e->comm && !e->profiling && !has_inputs) ? t : -1; e->spec_flags = flags;
+      e->spec_t = (!e->profiling && !has_inputs) ? t : -1; e->spec_flags = flags;
       rc_solve = solve_jacobi(e, tol2, max_iter, force_jac, st, need_bicg);
       e->spec_t = -1;
       if (rc_solve != CWR_OK && st.status == CWR_OK) return rc_solve;     // HIP / RCCL failure
@@ -2087,6 +2101,7 @@ int32_t cwr_attach_comm(cwr_engine* e, int32_t rank, int32_t world, const uint8_
   TRY(dev_alloc(e, &e->d_recvbuf, (size_t)n_recv * e->K));
   TRY(upload(e, e->d_send_cells, send_cells, (size_t)n_send));
   TRY(upload(e, e->d_recv_cells, recv_cells, (size_t)n_recv));
+  TRY(dev_alloc(e, &e->d_chkx, (size_t)(2 + 2 * world) * e->K));
   if (const char* v = getenv("CWR_NO_OVERLAP")) e->overlap = atoi(v) == 0;
   if (const char* v = getenv("CWR_OVERLAP_RESERVE")) e->overlap_reserve = std::max(0, atoi(v)) / N_XCD * N_XCD;
   HIP_TRY(e, hipStreamCreateWithFlags(&e->comm_stream, hipStreamNonBlocking));
