@@ -58,6 +58,41 @@ def cpu_baseline(mesh: dict, input_col: np.ndarray, budget_s: float, max_steps: 
     return n * len(times) / el / 1e6, el, n, len(times)
 
 
+def pmc_traffic(which: str, K: int, kernel: str = 'k_sq_tiled'):
+    """HBM-side bytes per launch of the dominant kernel, measured NOW: two counter-only rocprofv3 passes (--pmc FETCH_SIZE,
+    --pmc WRITE_SIZE; the guide's HBM section: separate passes, read = 2 x FETCH_SIZE x 1024 on gfx950, written =
+    WRITE_SIZE x 1024) over scratch/pmc_target.py -- two steps of this very workload -- as child processes.  Called before
+    this process touches the GPU.  Returns (read, written) or None when rocprofv3 is not there or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which('rocprofv3') is None:
+        return None
+    out = {}
+    for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+        d = tempfile.mkdtemp(prefix='cwr_pmc_', dir='/tmp')
+        try:
+            env = dict(os.environ, TMPDIR='/tmp')
+            subprocess.run(['rocprofv3', '--pmc', counter, '--output-format', 'csv', '-d', d, '-o', 'pmc', '--',
+                            sys.executable, os.path.join(ROOT, 'scratch', 'pmc_target.py'), which, str(K)],
+                           check=True, capture_output=True, timeout=240, env=env, cwd='/tmp')
+            tot, n = 0.0, 0
+            for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if kernel in r['Kernel_Name'] and r['Counter_Name'] == counter:
+                        tot += float(r['Counter_Value']); n += 1
+            if n == 0:
+                return None
+            out[counter] = tot / n
+        except (subprocess.SubprocessError, OSError, KeyError, ValueError):
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return int(2 * out['FETCH_SIZE'] * 1024), int(out['WRITE_SIZE'] * 1024)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -81,6 +116,7 @@ def main():
     ap.add_argument('--halo-depth', type=int, default=0,
                     help='N > 1: halo layers = Jacobi sweeps between two exchanges (0: from the per-rank size, distributed.auto_halo_depth)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-pmc', action='store_true', help='skip the two rocprofv3 counter passes that measure roofline.traffic')
     ap.add_argument('--cpu-budget-s', type=float, default=100.0, help='wall-clock budget of the CPU baseline leg')
     ap.add_argument('--cpu-steps', type=int, default=3)
     args = ap.parse_args()
@@ -92,6 +128,10 @@ def main():
         if args.gpus > 1:
             sys.exit(f'--gpus {args.gpus} needs one process per GPU: launch with torch.distributed.run '
                      f'--nproc-per-node {args.gpus} (WORLD_SIZE is {world})')
+    # roofline.traffic, measured in this run (children of a process that has NOT initialised the GPU yet)
+    live_traffic = None
+    if rank == 0 and world == 1 and not args.no_pmc and args.solver == 'auto' and not (args.nx or args.ny):
+        live_traffic = pmc_traffic(args.mesh, args.constituents)
     import torch                                       # device plumbing + control plane only
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -173,12 +213,17 @@ def main():
                        7: 'k_small_jacobi: one-launch LDS-resident solve'}.get(r.sweep_kernel, 'k_apply<VW,1>: BiCGSTAB product')
         back_to_back_us = eng.time_apply(args.warmup, reps=50) if world == 1 else None
         traffic = traffic_rw = None
-        try:                                             # PMC-measured HBM bytes per launch of this exact config, if profiled
+        traffic_source = None
+        if live_traffic is not None and r.sweep_kernel == 6:
+            traffic_rw, traffic = live_traffic, sum(live_traffic)
+            traffic_source = 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over scratch/pmc_target.py in this run'
+        try:                                             # otherwise the committed PMC measurement of this exact config, if any
             with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as fh:
                 ent = json.load(fh).get(mesh_key, {}).get(str(K)) if world == 1 and args.solver == 'auto' else None
-            if ent:
+            if ent and traffic is None:
                 traffic_rw = (int(ent['read']), int(ent['written']))
                 traffic = sum(traffic_rw)
+                traffic_source = 'profiles/pmc_traffic.json (committed rocprofv3 --pmc measurement of this configuration)'
         except (OSError, KeyError, TypeError, ValueError):
             pass
         if launches > 0:
@@ -201,7 +246,7 @@ def main():
                 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
                 'traffic_read': None if traffic_rw is None else traffic_rw[0],
-                'traffic_written': None if traffic_rw is None else traffic_rw[1],
+                'traffic_written': None if traffic_rw is None else traffic_rw[1], 'traffic_source': traffic_source,
                 'algorithmic_bytes': alg, 'applies_per_launch': applies, 'survey_bytes_per_apply': survey_apply,
                 'avg_launch_us': round(avg_us, 2), 'launches_timed': launches,
                 # the bytes THIS kernel has to read / write per launch (pre-multiplied J^2 entries: fewer than two applies' worth)

@@ -185,6 +185,20 @@ def _worker(rank, world, port, ok_flags):
         part = torch.tensor((y_local * y_local).sum(axis=0))
         dist.all_reduce(part)
         assert np.allclose(part.numpy(), (want * want).sum(axis=0), rtol=1e-12)
+        # set-up side of a partitioned run (distributed.py): the curve order comes from rank 0 over the control plane, and
+        # a rank's slices are cut straight from the reference arrays through composed index maps -- equal to slicing a
+        # renumbered copy of the global mesh, which no rank builds any more
+        from clearwater_riverine_amd.distributed import shared_hilbert_order
+        from clearwater_riverine_amd.ordering import hilbert_order, renumber_mesh
+        from clearwater_riverine_amd.partition import slice_fields
+        order = shared_hilbert_order(mesh, n, rank, world)
+        assert np.array_equal(order, hilbert_order(mesh['face_x'], mesh['face_y'], n))
+        rm = renumber_mesh(mesh, order)
+        lm2 = partition_mesh(rm['edges_face1'], rm['edges_face2'], n, world, rank, depth=3)
+        want_f = slice_fields(lm2, rm, np.zeros(len(f1)))
+        ref_cells = np.where(lm2.cell_global < n, order[np.minimum(lm2.cell_global, n - 1)], lm2.cell_global)
+        got_f = slice_fields(lm2, mesh, np.zeros(len(f1)), ref_cells)
+        assert all(np.array_equal(got_f[k], want_f[k]) for k in want_f)
         ok_flags[rank] = 1
     finally:
         dist.destroy_process_group()
