@@ -1109,7 +1109,7 @@ int solve_small(cwr_engine* e, double tol2, int max_iter, bool forced, SolveStat
   if (e->comm || !e->use_small || e->n_halo != 0 || e->n_owned > SMALL_THREADS * 4 || e->max_degree > SMALL_DEG) return CWR_OK;
   const int K = e->K, n = e->n_owned;
   if (!e->d_info) TRY(dev_alloc(e, &e->d_info, (size_t)5 * K));
-  const size_t lds = ((size_t)n + 32) * sizeof(double);
+  const size_t lds = ((size_t)n + 64) * sizeof(double);     // the column + the scratch of block_reduce3 (3 x 16 wave results)
   const int limit = forced ? max_iter : std::min(max_iter, e->jacobi_limit);
   const int rpt = cdiv(n, SMALL_THREADS);
 #define CWR_SMALL(RPTv, REGSv) do {                                                                                   \

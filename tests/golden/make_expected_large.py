@@ -118,6 +118,8 @@ def main_config5():
     print(f'config 5: step 2/2 (reaction override), {len(COLS5)} columns on {n} cells, {time.time() - t0:.0f} s', flush=True)
     rng = np.random.default_rng(20251005)
     cells = np.sort(rng.choice(n, size=N_SAMPLE // 2, replace=False))
+    # (level 1 as the model holds it now: the override of the second update() was written into state[1] itself,
+    # transport.py:233-236, i.e. M[k, k] x the solved level for these columns; level 2 is the solved level)
     states = np.stack([model.constituent_dict[f'c{k}'].state[1:3] for k in COLS5], axis=1)       # (2 levels, C, ncell)
     out = os.path.join(HERE, 'config5_4m_expected.npz')
     np.savez_compressed(out, cells=cells, state=np.ascontiguousarray(states[:, :, cells]),

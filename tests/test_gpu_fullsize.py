@@ -4,8 +4,9 @@ Config 4 / the bench workload -- the 1 M-cell merged floodplain mesh, K = 1 and 
 is compared ELEMENT-WISE with committed oracle output (tests/golden/config4_1m_expected.npz: a 65 536-cell sample
 stratified over the plume's decades, every ghost cell, column norms and sampled face fluxes, produced by
 tests/golden/make_expected_large.py from the oracle's spsolve on the full mesh).
-Config 5 -- 4 M cells x 16 constituents + a per-step reaction -- is compared with an oracle sample of its first step
-and, beyond that, through size-independent properties: device reaction == host callback, exact scaling by two,
+Config 5 -- 4 M cells x 16 constituents + a per-step reaction -- is compared with committed oracle output too
+(config5_4m_expected.npz: a plain step and a step behind the reaction override, two columns, 32 768-cell sample + whole-column
+norms) and, beyond that, through size-independent properties: device reaction == host callback, exact scaling by two,
 the true residual through the exported operator.
 Meshes and inputs are regenerated from seeds on the GPU box (nothing under /root/reference is read).
 """
@@ -95,10 +96,10 @@ def test_config5_4m_cells_16_constituents_with_a_per_step_reaction(gpu_lib):
     names = [f'c{k}' for k in range(K)]
     arrays = {nm: inputs3[:, :, k] for k, nm in enumerate(names)}
 
-    def check_level(state, level):
+    def check_level(state, level, scale=None):
         # the oracle's columns (pulse, plume): 32 768-cell sample element-wise + whole-column norms
         for ci, k in enumerate(exp['cols']):
-            col = state[:, int(k)]
+            col = state[:, int(k)] * (1.0 if scale is None else scale[int(k)])
             assert rel_err(col[exp['cells']], exp['state'][level, ci]) <= 1e-9
             got = np.array([np.linalg.norm(col[:n]), np.sum(col[:n]), np.max(np.abs(col[:n]))])
             assert np.allclose(got, exp['norms'][level, ci], rtol=1e-9, atol=0.0)
@@ -107,7 +108,9 @@ def test_config5_4m_cells_16_constituents_with_a_per_step_reaction(gpu_lib):
     dev.update()
     assert dev.last_step.sweep_kernel == 6 and dev.last_step.flags == 0 and dev.last_step.max_rel_residual <= 1e-12
     level1 = dev.engine.get_state()
-    check_level(level1, 0)
+    # (the fixture's level 1 is what the reference holds AFTER its second update() call: the override is written into
+    # mesh[name][t] itself, transport.py:233-236 -- for these columns M[k, k] x the solved level)
+    check_level(level1, 0, scale=np.diag(M))
     dev.update(reaction_matrix=M)                                     # (a) reaction on the device, then transport
     level2 = dev.engine.get_state()
     check_level(level2, 1)
@@ -127,8 +130,13 @@ def test_config5_4m_cells_16_constituents_with_a_per_step_reaction(gpu_lib):
     b = dev.engine.rhs(2, x_t)
     r = b - dev.engine.apply(2, x_n)
     assert np.max(np.linalg.norm(r, axis=0) / np.linalg.norm(b, axis=0)) <= 1e-10
-    # (d) exact linearity: every input scaled by 2 (a power of two: no rounding anywhere) gives bitwise 2 x the state
+    # (d) exact linearity: every input scaled by 2 (a power of two: no rounding anywhere above the subnormal range) gives
+    # bitwise 2 x the state
     twice = cw.ClearwaterRiverine(mesh=dict(mesh), input_arrays={nm: 2.0 * a for nm, a in arrays.items()}, store_history=False)
     twice.update()
     twice.update(reaction_matrix=M)
-    assert np.array_equal(twice.engine.get_state(), 2.0 * level2, equal_nan=True)
+    got2, want2 = twice.engine.get_state(), 2.0 * level2
+    big = ~(np.abs(want2) < 1e-290)                       # (NaN ghosts included)
+    assert np.array_equal(got2[big], want2[big], equal_nan=True)
+    # ahead of the plume fronts the values run into the subnormal range, where a product no longer scales exactly
+    assert np.all(np.abs(got2[~big] - want2[~big]) <= 1e-300)
