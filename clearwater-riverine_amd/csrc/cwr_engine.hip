@@ -683,7 +683,8 @@ int ensure_sq_pattern(cwr_engine* e) {
       for (int q = ptr2[c0]; q < ptr2[c1]; ++q) { const int k = col2[q]; if (stamp[k] != t) { stamp[k] = t; others.push_back(k); } }
       std::sort(others.begin(), others.end());
       for (size_t u = 0; u < others.size(); ++u) { pos[others[u]] = (c1 - c0) + (int)u; tcols.push_back(others[u]); }
-      for (int q = ptr2[c0]; q < ptr2[c1]; ++q) loc2[q] = (uint16_t)pos[col2[q]];
+      // (stored pre-multiplied by K: the entry's double index into the tile's x image, so the kernel's inner loop has no multiply)
+      for (int q = ptr2[c0]; q < ptr2[c1]; ++q) loc2[q] = (uint16_t)(pos[col2[q]] * e->K);
       tptr[t + 1] = (int32_t)tcols.size();
       max_cols = std::max(max_cols, (int)tcols.size() - base);
       cap2 = std::max(cap2, ptr2[c1] - ptr2[c0]);
@@ -705,7 +706,7 @@ int ensure_sq_pattern(cwr_engine* e) {
       const int q = TCL_NARROW[qi];
       if (max_cols <= TCL_CFG[q].xr * e->R && cap2 <= TCL_CFG[q].wrn * BLOCK && tr <= TCL_CFG[q].ut * e->R) e->tcl_cfg = q;
     }
-    if (lds <= 64 * 1024 && e->tcl_cfg >= 0 && tr <= BLOCK) {
+    if (lds <= 64 * 1024 && e->tcl_cfg >= 0 && tr <= BLOCK && (int64_t)max_cols * e->K <= 65535) {
       const void* fn6 = tcl_kernel(e->tcl_vw, e->tcl_cfg);
       int pc = 1;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, fn6, BLOCK, lds) != hipSuccess || pc < 1) pc = 1;

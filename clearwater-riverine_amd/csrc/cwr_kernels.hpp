@@ -824,6 +824,24 @@ __global__ void __launch_bounds__(BLOCK) k_sq_tiled(
       *reinterpret_cast<double2*>(rowp + offB) = make_double2(v[2], v[3]);
     } else stv<VW>(rowp + col, v);
   };
+  // sum over the entries [j0, j1) of (weight x the x row at the entry's in-tile position); s_loc holds the position
+  // pre-multiplied by K (a double index into s_xt: no multiply in the loop).  Entries ascending from 0.0, as k_apply<.,5>.
+  // (Measured and dropped, round 2: a two-entry software pipeline of this loop -- index two entries ahead, row one ahead,
+  // sched_barriers against hipcc's re-sinking -- makes the EXACT pass faster, 97.7 -> 91.4 us at K = 16, because there the
+  // two dependent LDS round trips per entry are exposed; but it re-reads one row per row and pads odd rows, and with two
+  // or three tile-local applications the phase is LDS-bandwidth-bound (LDS busy 50 % of the pass, a quarter of it bank
+  // conflicts of the 64-byte row pieces): 109.7 -> 117.1 us and 135 -> 150 us.  profiles/r02_k_pipelined_loop.txt)
+  auto row_sum = [&](int j0, int j1, double (&sum)[VW]) {
+#pragma unroll
+    for (int w = 0; w < VW; ++w) sum[w] = 0.0;
+    for (int j = j0; j < j1; ++j) {
+      double xn[VW];
+      ld_row(s_xt + (int)s_loc[j], xn);
+      const double wj = s_w[j];
+#pragma unroll
+      for (int w = 0; w < VW; ++w) sum[w] += wj * xn[w];
+    }
+  };
   // SPLIT: the work-item logic is compiled into the one-constituent-per-lane variants only (it costs 12 VGPRs, which takes
   // the wide-row variants from 4 to 3 blocks per CU, and it only pays where the LDS compute phase bounds the pass)
   constexpr bool SPLIT = (VW == 1);
@@ -952,16 +970,7 @@ __global__ void __launch_bounds__(BLOCK) k_sq_tiled(
             const int i = r + u * R;
             if (i < NR) {
               double sum[VW];                          // same association as k_apply<.,5>: (sum of w x) first, + c2 last,
-#pragma unroll
-              for (int w = 0; w < VW; ++w) sum[w] = 0.0;  // so both J^2 kernels give bitwise equal rows
-              const int j0 = s_ptr[i], j1 = s_ptr[i + 1];
-              for (int j = j0; j < j1; ++j) {
-                double xn[VW];
-                ld_row(s_xt + (size_t)(int)s_loc[j] * K, xn);
-                const double wj = s_w[j];
-#pragma unroll
-                for (int w = 0; w < VW; ++w) sum[w] += wj * xn[w];
-              }
+              row_sum(s_ptr[i], s_ptr[i + 1], sum);    // so both J^2 kernels give bitwise equal rows
 #pragma unroll
               for (int w = 0; w < VW; ++w) y[u][w] = qc[u][w] + sum[w];
             }
@@ -980,15 +989,7 @@ __global__ void __launch_bounds__(BLOCK) k_sq_tiled(
             else { const int code = s_ptr[i + 1]; row = code & 255; j0 = s_ptr[row] + (code >> 8) * seg; jend = s_ptr[row + 1]; }
             const int j1 = min(jend, j0 + seg);
             double sum[VW];                          // same association as k_apply<.,5>: (sum of w x) per chunk, + c2 last,
-#pragma unroll
-            for (int w = 0; w < VW; ++w) sum[w] = 0.0;  // so both J^2 kernels give bitwise equal rows
-            for (int j = j0; j < j1; ++j) {
-              double xn[VW];
-              ld_row(s_xt + (size_t)(int)s_loc[j] * K, xn);
-              const double wj = s_w[j];
-#pragma unroll
-              for (int w = 0; w < VW; ++w) sum[w] += wj * xn[w];
-            }
+            row_sum(j0, j1, sum);                    // so both J^2 kernels give bitwise equal rows
             if (i < NR) {
 #pragma unroll
               for (int w = 0; w < VW; ++w) y[u][w] = sum[w];
