@@ -196,6 +196,30 @@ def test_baseline_configs_2_and_3_river_band_mesh(gpu_lib, K, n_target):
         assert flux_err(model.constituent_dict[names[col]].total_mass_flux[:6], ref.constituent_dict[f'c{kk}'].total_mass_flux[:6]) <= 1e-8
 
 
+@pytest.mark.parametrize('K,steps', [(1, 912), (12, 96)])
+def test_baseline_config_2_full_length_run_on_the_ohio_sized_mesh(gpu_lib, K, steps):
+    """BASELINE config 2 at its specified length: 912 hourly steps of one tracer on the 2 943-cell river-band
+    mesh (the Ohio River model's size; its HDF is a missing blob), and 96 steps of the 12-constituent NSM-I state vector
+    (config 3), step by step against the oracle's spsolve: every stored level, element-wise."""
+    import clearwater_riverine_amd as cw
+    mesh = cw.synthetic.make_mesh(109, 28, steps, seed=20100529 % 100000, n_merge=109, dx=75.0, dy=75.0, dt=3600.0, velocity=0.4,
+                                  diffusion_coefficient=0.1, period_steps=24)
+    oracle.derive_coefficients(mesh)
+    n = mesh['nreal'] + 1
+    assert abs(n - 2943) <= 30
+    inputs3 = cw.synthetic.distinct_input_array(mesh, K, seed=7)
+    names = [f'c{k}' for k in range(K)]
+    model = cw.ClearwaterRiverine(mesh=dict(mesh), input_arrays={nm_: inputs3[:, :, k].copy() for k, nm_ in enumerate(names)})
+    ref = oracle_run(mesh, inputs3, steps)
+    for _ in range(steps):
+        model.update()
+        assert model.last_step.flags == 0
+    assert model.time_step == steps and model.last_step.sweep_kernel == 7
+    for k, nm in enumerate(names):
+        assert rel_err(model.mesh[nm], ref.constituent_dict[f'c{k}'].state) <= TOL_CONC
+        assert flux_err(model.constituent_dict[nm].total_mass_flux[:steps], ref.constituent_dict[f'c{k}'].total_mass_flux[:steps]) <= 1e-8
+
+
 @pytest.mark.parametrize('K', [1, 16])
 def test_dense_adjacency_mesh_is_tiled_and_matches_the_oracle(gpu_lib, K, monkeypatch):
     """A third of the cells merged into 5-6-face cells (4.7 faces and 12 J^2 entries per row on average): a 256-row tile
