@@ -516,6 +516,31 @@ int check_ghost_levels(cwr_engine* e) {
   return rc;
 }
 
+// Rows (lane-group slots) of a tile of the tiled pass for K constituents -- also what cwr_tile_rows tells a host wrapper that
+// wants to arrange its cell numbering in tiles (ordering.balance_windows).
+int tile_rows_for(int K, bool* four_wide) {
+  int tr_target = 64;
+  if (const char* v = getenv("CWR_TCL_ROWS")) tr_target = std::max(1, atoi(v));
+  // wide rows: four constituents per lane halve the lanes that re-read every (weight, index) pair from LDS
+  bool want4 = (K % 4 == 0) && K >= 8;
+  if (const char* v = getenv("CWR_TCL_VW")) want4 = atoi(v) == 4 && (K % 4 == 0);
+  const int VW = (K % 2 == 0) ? 2 : 1;
+  const int Rt = want4 ? BLOCK / (K / 4) : BLOCK / (K / VW);     // rows one pass of the compute mapping covers
+  int tr = tr_target;
+  while (tr > Rt && (tr % Rt) != 0) --tr;
+  tr = std::max(tr, Rt);
+  if (want4) {
+    // four-wide mapping: one row per lane group.  Two rows per lane group (84-102-row tiles at K = 20-24, 64-row tiles at
+    // K = 32; configurations 7 and 8) were measured SLOWER on the merged 1 M-cell mesh: 191 / 222 / 271 us per pass against
+    // 148 / 169 / 202 us at K = 20 / 24 / 32 (profiles/r02_b_per_K.txt) -- the extra prefetch registers cost a block per CU
+    int ut = 1;
+    if (const char* v = getenv("CWR_TCL_UT")) ut = std::max(1, std::min(2, atoi(v)));
+    tr = Rt * ut;
+  }
+  if (four_wide) *four_wide = want4;
+  return std::max(1, std::min(tr, BLOCK));
+}
+
 #define CWR_TCL_K(VWv, Q) k_sq_tiled<VWv, TCL_CFG[Q].wrn, TCL_CFG[Q].ut, TCL_CFG[Q].xr>
 const void* tcl_kernel(int vw, int cfg) {
   if (vw == 4) return cfg == 3 ? reinterpret_cast<const void*>(&CWR_TCL_K(4, 3)) : cfg == 4 ? reinterpret_cast<const void*>(&CWR_TCL_K(4, 4))
@@ -618,24 +643,9 @@ int ensure_sq_pattern(cwr_engine* e) {
     for (int attempt = 0; attempt < 2 && !e->tcl_ready; ++attempt) {
     const int n_t = (e->comm && attempt == 1) ? e->n_core : n;
     if (attempt == 1 && (!e->comm || e->n_core == n)) break;
-    int tr_target = 64;
-    if (const char* v = getenv("CWR_TCL_ROWS")) tr_target = std::max(1, atoi(v));
-    // wide rows: four constituents per lane halve the lanes that re-read every (weight, index) pair from LDS
-    bool want4 = (e->K % 4 == 0) && e->K >= 8;
-    if (const char* v = getenv("CWR_TCL_VW")) want4 = atoi(v) == 4 && (e->K % 4 == 0);
+    bool want4 = false;
+    int tr = tile_rows_for(e->K, &want4);
     const int R4 = want4 ? BLOCK / (e->K / 4) : 0;
-    const int Rt = want4 ? R4 : e->R;                            // rows one pass of the compute mapping covers
-    int tr = tr_target;
-    while (tr > Rt && (tr % Rt) != 0) --tr;
-    tr = std::max(tr, Rt);
-    if (want4) {
-      // four-wide mapping: one row per lane group.  Two rows per lane group (84-102-row tiles at K = 20-24, 64-row tiles at
-      // K = 32; configurations 7 and 8) were measured SLOWER on the merged 1 M-cell mesh: 191 / 222 / 271 us per pass against
-      // 148 / 169 / 202 us at K = 20 / 24 / 32 (profiles/r02_b_per_K.txt) -- the extra prefetch registers cost a block per CU
-      int ut = 1;
-      if (const char* v = getenv("CWR_TCL_UT")) ut = std::max(1, std::min(2, atoi(v)));
-      tr = Rt * ut;
-    }
     // a tile that holds too many entries or distinct rows for every compiled configuration (dense adjacency: many 5-8-face
     // cells; narrow rows use 256-row tiles) is retried at half the rows -- part of the lanes then idle in the compute phase,
     // which still beats the un-tiled exact pass by far
@@ -1253,6 +1263,14 @@ int solve_bicgstab(cwr_engine* e, double tol2, int max_iter, SolveStats& st) {
 extern "C" {
 
 int32_t cwr_abi_version(void) { return 3; }
+
+int32_t cwr_tile_rows(int32_t n_constituents) {
+  if (n_constituents < 1 || n_constituents > 256) return 0;
+  // one constituent: the tiled pass splits long rows into work items itself and its tiles hold a variable number of rows, so
+  // a fixed window would straddle tiles (measured: 38 -> 52 us per pass with sorted 256-row windows): no arrangement wanted
+  if (n_constituents == 1 && !(getenv("CWR_TCL_SPLIT") && atoi(getenv("CWR_TCL_SPLIT")) == 0)) return 0;
+  return tile_rows_for(n_constituents, nullptr);
+}
 
 const char* cwr_last_error(const cwr_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
 

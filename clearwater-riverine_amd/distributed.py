@@ -12,9 +12,9 @@ import os
 
 import numpy as np
 
-from .engine import TransportEngine
+from .engine import TransportEngine, tile_rows
 from .model import face_to_face_distance, change_in_time
-from .ordering import hilbert_order
+from .ordering import balance_windows, hilbert_order
 from .partition import LocalMesh, partition_mesh, slice_fields
 
 
@@ -46,7 +46,7 @@ def auto_halo_depth(n_real_cells: int, world: int) -> int:
     return int(min(16, max(8, d)))
 
 
-def shared_hilbert_order(mesh: dict, n: int, rank: int, world: int) -> np.ndarray:
+def shared_hilbert_order(mesh: dict, n: int, rank: int, world: int, K: int = 16) -> np.ndarray:
     """order[new id] = reference id along the Hilbert curve: computed by rank 0 and broadcast when a torch.distributed
     group is up (the sort is the only global O(n log n) step of the set-up), computed locally otherwise."""
     if world > 1:
@@ -57,12 +57,21 @@ def shared_hilbert_order(mesh: dict, n: int, rank: int, world: int) -> np.ndarra
                 dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
                 t = torch.empty(n, dtype=torch.int64, device=dev)
                 if dist.get_rank() == 0:
-                    t.copy_(torch.from_numpy(hilbert_order(mesh['face_x'], mesh['face_y'], n)))
+                    t.copy_(torch.from_numpy(_curve_order(mesh, n, K)))
                 dist.broadcast(t, src=0)
                 return t.cpu().numpy()
         except ImportError:
             pass
-    return hilbert_order(mesh['face_x'], mesh['face_y'], n)
+    return _curve_order(mesh, n, K)
+
+
+def _curve_order(mesh: dict, n: int, K: int) -> np.ndarray:
+    """Hilbert order, the cells of every tile-sized window sorted by their J^2 row length (ordering.balance_windows; the
+    tile size of the engine's sweep kernel depends on K: cwr_tile_rows).  CWR_NO_BALANCE=1: plain Hilbert order (A/B)."""
+    order = hilbert_order(mesh['face_x'], mesh['face_y'], n)
+    if os.environ.get('CWR_NO_BALANCE'):
+        return order
+    return balance_windows(order, mesh['edges_face1'], mesh['edges_face2'], window=tile_rows(K))
 
 
 class PartitionedTransport:
@@ -85,7 +94,7 @@ class PartitionedTransport:
             # the curve order is computed ONCE (rank 0) and broadcast over the control plane; no rank materialises a
             # renumbered copy of the global mesh: only the face tables are mapped (2 E integers), every field is sliced
             # straight from the reference arrays through the composed index maps below
-            self.order = shared_hilbert_order(mesh, n, rank, world)
+            self.order = shared_hilbert_order(mesh, n, rank, world, int(inputs3.shape[2]))
             inv = np.arange(ncell, dtype=np.int64)
             inv[self.order] = np.arange(n)
             f1, f2 = inv[f1], inv[f2]
@@ -93,7 +102,9 @@ class PartitionedTransport:
             raise ValueError(f'unknown renumbering {renumber!r}')
         self.n_global = n
         self.K = int(inputs3.shape[2])
-        self.local: LocalMesh = partition_mesh(f1, f2, n, world, rank, depth=halo_depth)
+        # (rank ranges start at multiples of the tile size when the numbering was arranged in tile-sized windows)
+        align = tile_rows(self.K) if (renumber == 'hilbert' and not os.environ.get('CWR_NO_BALANCE')) else 1
+        self.local: LocalMesh = partition_mesh(f1, f2, n, world, rank, depth=halo_depth, align=max(1, align))
         lm = self.local
         # reference id of every local cell (ghost ids are never renumbered)
         ref_cells = lm.cell_global if self.order is None else np.where(lm.cell_global < n, self.order[np.minimum(lm.cell_global, n - 1)], lm.cell_global)

@@ -35,7 +35,7 @@ INFO_ELEMENTWISE_MISSED = 2    # the element-wise rule was still violated after 
 
 # every symbol include/cwr_transport.h declares (tests check that the library exports them all)
 ABI_SYMBOLS = (
-    'cwr_abi_version', 'cwr_create', 'cwr_destroy', 'cwr_last_error', 'cwr_load_flow_field',
+    'cwr_abi_version', 'cwr_tile_rows', 'cwr_create', 'cwr_destroy', 'cwr_last_error', 'cwr_load_flow_field',
     'cwr_load_coefficients', 'cwr_get_coefficients', 'cwr_load_boundary', 'cwr_set_boundary_level',
     'cwr_set_state', 'cwr_get_state', 'cwr_load_real_inputs', 'cwr_react_linear', 'cwr_state_device_ptr', 'cwr_apply', 'cwr_rhs', 'cwr_step', 'cwr_get_mass_flux',
     'cwr_time_apply', 'cwr_profile_read', 'cwr_synchronize', 'cwr_apply_bytes',
@@ -86,6 +86,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     P = C.POINTER
     lib.cwr_abi_version.restype = i32
     lib.cwr_abi_version.argtypes = []
+    lib.cwr_tile_rows.restype = i32
+    lib.cwr_tile_rows.argtypes = [i32]
     lib.cwr_last_error.restype = C.c_char_p
     lib.cwr_last_error.argtypes = [vp]
     lib.cwr_destroy.restype = None
@@ -142,6 +144,11 @@ def _arr(a, dtype, shape=None, name='array'):
 
 def _ptr(a: np.ndarray | None):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def tile_rows(n_constituents: int) -> int:
+    """Rows of one tile of the engine's sweep kernel for this many constituents (cwr_tile_rows)."""
+    return int(load_library().cwr_tile_rows(int(n_constituents)))
 
 
 class TransportEngine:

@@ -17,8 +17,8 @@ import numpy as np
 
 from .mass_balance import assemble, boundary_lines, volume_columns
 from .outputs import StreamedOutput, ZarrStreamWriter
-from .engine import TransportEngine, StepResult
-from .ordering import hilbert_order
+from .engine import TransportEngine, StepResult, tile_rows
+from .ordering import balance_windows, hilbert_order
 
 # variables.py names used on the path
 EDGES_FACE1 = 'edges_face1'
@@ -253,7 +253,8 @@ class ClearwaterRiverine:
         # engine: topology, flow field and boundary values resident in HBM
         # meshes beyond the one-launch solver (> 4 096 cells): internal space-filling-curve numbering (ordering.py), which
         # is what keeps the 64-row tiles of the sweep kernels compact; reference ids stay at this boundary
-        order = hilbert_order(m["face_x"], m["face_y"], n) if (renumber and n > 4096) else None
+        # (within every tile-sized window of the curve the cells are sorted by their work: ordering.balance_windows)
+        order = balance_windows(hilbert_order(m["face_x"], m["face_y"], n), f1, f2, window=tile_rows(K)) if (renumber and n > 4096) else None
         self.engine = TransportEngine(f1, f2, ncell, K, device=device, cell_order=order)
         self.engine.load_flow_field(m[FLOW_ACROSS_FACE], m[EDGE_VELOCITY], m[VOLUME], m[CHANGE_IN_TIME],
                                     m[FACE_TO_FACE_DISTANCE], m.attrs['diffusion_coefficient'])

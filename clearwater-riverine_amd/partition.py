@@ -29,9 +29,14 @@ from dataclasses import dataclass, field
 import numpy as np
 
 
-def range_bounds(n_real_cells: int, world: int) -> np.ndarray:
-    """lo/hi of every rank: bounds[r] .. bounds[r+1]."""
-    return (np.arange(world + 1, dtype=np.int64) * n_real_cells) // world
+def range_bounds(n_real_cells: int, world: int, align: int = 1) -> np.ndarray:
+    """lo/hi of every rank: bounds[r] .. bounds[r+1].  align > 1: the inner bounds are rounded to multiples of `align` (the
+    tile size of the engine's sweep kernel), so that a rank's tiles coincide with the tile-sized windows the global
+    numbering was arranged in (ordering.balance_windows); ranges then differ by at most `align` cells."""
+    b = (np.arange(world + 1, dtype=np.int64) * n_real_cells) // world
+    if align > 1 and n_real_cells >= 2 * align * world:
+        b[1:-1] = ((b[1:-1] + align // 2) // align) * align
+    return b
 
 
 def halo_layers(f1: np.ndarray, f2: np.ndarray, n_real_cells: int, lo: int, hi: int, depth: int):
@@ -87,7 +92,7 @@ class LocalMesh:
         return self.n_cells - self.n_real
 
 
-def partition_mesh(face1, face2, n_real_cells: int, world: int, rank: int, depth: int = 1) -> LocalMesh:
+def partition_mesh(face1, face2, n_real_cells: int, world: int, rank: int, depth: int = 1, align: int = 1) -> LocalMesh:
     """Local mesh of `rank` for real cells [0, n_real_cells) split into `world` contiguous ranges."""
     f1 = np.asarray(face1, dtype=np.int64)
     f2 = np.asarray(face2, dtype=np.int64)
@@ -95,7 +100,7 @@ def partition_mesh(face1, face2, n_real_cells: int, world: int, rank: int, depth
         raise ValueError('halo depth must be >= 1')
     if f1.max(initial=-1) >= n_real_cells:
         raise ValueError('face1 must be a real cell for every face')
-    bounds = range_bounds(n_real_cells, world)
+    bounds = range_bounds(n_real_cells, world, align)
     lo, hi = int(bounds[rank]), int(bounds[rank + 1])
     n_core = hi - lo
     if n_core <= 0:

@@ -191,8 +191,12 @@ def _worker(rank, world, port, ok_flags):
         from clearwater_riverine_amd.distributed import shared_hilbert_order
         from clearwater_riverine_amd.ordering import hilbert_order, renumber_mesh
         from clearwater_riverine_amd.partition import slice_fields
-        order = shared_hilbert_order(mesh, n, rank, world)
-        assert np.array_equal(order, hilbert_order(mesh['face_x'], mesh['face_y'], n))
+        from clearwater_riverine_amd.ordering import balance_windows
+        from clearwater_riverine_amd.engine import tile_rows
+        order = shared_hilbert_order(mesh, n, rank, world, K=16)
+        assert tile_rows(16) == 64 and tile_rows(1) == 0 and tile_rows(8) == 128 and tile_rows(2) == 256
+        assert np.array_equal(order, balance_windows(hilbert_order(mesh['face_x'], mesh['face_y'], n), f1, f2, window=64))
+        assert np.array_equal(np.sort(order), np.arange(n))
         rm = renumber_mesh(mesh, order)
         lm2 = partition_mesh(rm['edges_face1'], rm['edges_face2'], n, world, rank, depth=3)
         want_f = slice_fields(lm2, rm, np.zeros(len(f1)))
