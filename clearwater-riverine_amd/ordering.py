@@ -61,7 +61,10 @@ def renumber_mesh(mesh: dict, order: np.ndarray) -> dict:
 def two_hop_row_lengths(face1, face2, n_real: int) -> np.ndarray:
     """Entries per row of the squared Jacobi operator J^2 (columns reachable in two face steps; the engine's
     ensure_sq_pattern builds exactly this pattern): the work of a row in the tiled pass."""
-    from scipy.sparse import csr_matrix
+    try:
+        from scipy.sparse import csr_matrix
+    except ImportError:                                   # no scipy: every row counts the same, the order stays as it is
+        return np.zeros(n_real, dtype=np.int64)
     f1 = np.asarray(face1, dtype=np.int64)
     f2 = np.asarray(face2, dtype=np.int64)
     real = (f1 < n_real) & (f2 < n_real)
