@@ -781,8 +781,11 @@ constexpr int TCL_NARROW[4] = {0, 1, 9, 2};    // narrow-row configurations (VW 
 //     y = c2 + ((chunk_0 + chunk_1) + chunk_2 ...)        -- k_apply<.,5> sums in the same association (bitwise equal rows).
 // Tiles therefore hold a variable number of rows (trow[t] .. trow[t+1]): rows + virtual items <= the lane groups of a pass.
 static_assert(TCL_SEG % CWR_FACE_BATCH == 0, "k_apply<.,5> closes a chunk only at a face-batch boundary");
+#ifndef CWR_TCL_WAVES
+#define CWR_TCL_WAVES 1           // __launch_bounds__ second argument of the tiled pass (A/B builds: 5 forces <= 96 VGPRs)
+#endif
 template <int VW, int WRN, int TCL_U, int TCL_XR>
-__global__ void __launch_bounds__(BLOCK) k_sq_tiled(
+__global__ void __launch_bounds__(BLOCK, CWR_TCL_WAVES) k_sq_tiled(
     int K, int G, int TR, int ntiles, const int32_t* __restrict__ tile_list, const int32_t* __restrict__ trow,
     const int32_t* __restrict__ ptr2, const uint16_t* __restrict__ loc2,
     const double* __restrict__ w2, const int32_t* __restrict__ tcl_ptr, const int32_t* __restrict__ tcl_cols,

@@ -175,3 +175,25 @@ def test_hilbert_order_is_a_permutation_with_local_neighbours():
     internal = f2 < n
     d_new = np.abs(r['edges_face1'][internal].astype(np.int64) - r['edges_face2'][internal])
     assert np.median(d_new) <= 8
+
+
+def test_tile_balanced_numbering_is_a_permutation_that_keeps_the_tiles():
+    """ordering.balance_windows: within every tile-sized window of the curve the cells are sorted by their J^2 row length; each
+    window keeps exactly its cells (so a tile's LDS image is unchanged), the mean of the per-wave maximum drops, and a
+    window <= 1 (cwr_tile_rows(1) = 0: the kernel splits long rows itself) leaves the order alone."""
+    import clearwater_riverine_amd as cw
+    from clearwater_riverine_amd.ordering import balance_windows, hilbert_order, two_hop_row_lengths
+    m = cw.synthetic.make_mesh(96, 64, 2, seed=3, n_merge=300)
+    n = m['nreal'] + 1
+    f1, f2 = m['edges_face1'], m['edges_face2']
+    order = hilbert_order(m['face_x'], m['face_y'], n)
+    length = two_hop_row_lengths(f1, f2, n)
+    assert length.min() >= 4 and length.max() >= 15 and np.bincount(length).argmax() in (9, 10)
+    bal = balance_windows(order, f1, f2, window=64)
+    assert np.array_equal(np.sort(bal), np.arange(n))
+    for w0 in range(0, n, 64):
+        assert set(bal[w0:w0 + 64]) == set(order[w0:w0 + 64])
+        assert np.all(np.diff(length[bal[w0:w0 + 64]]) >= 0)
+    waves = lambda o: length[o][: n // 16 * 16].reshape(-1, 16).max(axis=1).mean()
+    assert waves(bal) < waves(order) - 1.0
+    assert np.array_equal(balance_windows(order, f1, f2, window=0), order)
