@@ -833,7 +833,10 @@ __global__ void __launch_bounds__(BLOCK, CWR_TCL_WAVES) k_sq_tiled(
   // sched_barriers against hipcc's re-sinking -- makes the EXACT pass faster, 97.7 -> 91.4 us at K = 16, because there the
   // two dependent LDS round trips per entry are exposed; but it re-reads one row per row and pads odd rows, and with two
   // or three tile-local applications the phase is LDS-bandwidth-bound (LDS busy 50 % of the pass, a quarter of it bank
-  // conflicts of the 64-byte row pieces): 109.7 -> 117.1 us and 135 -> 150 us.  profiles/r02_k_pipelined_loop.txt)
+  // conflicts of the 64-byte row pieces): 109.7 -> 117.1 us and 135 -> 150 us.  profiles/r02_k_pipelined_loop.txt.
+  // Likewise a quad-broadcast fetch -- the four lanes of a row read the (weight, position) pairs of four consecutive entries
+  // and pass them round with DPP, a quarter of the LDS instructions for them: exact pass 95.7 -> 91.6 us, three applications
+  // 135 -> 131 us, but the default two applications 103.5 -> 106.9 us (three DPP moves and an exec branch per entry).)
   auto row_sum = [&](int j0, int j1, double (&sum)[VW]) {
 #pragma unroll
     for (int w = 0; w < VW; ++w) sum[w] = 0.0;
