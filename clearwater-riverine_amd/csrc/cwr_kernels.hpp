@@ -836,7 +836,9 @@ __global__ void __launch_bounds__(BLOCK, CWR_TCL_WAVES) k_sq_tiled(
   // conflicts of the 64-byte row pieces): 109.7 -> 117.1 us and 135 -> 150 us.  profiles/r02_k_pipelined_loop.txt.
   // Likewise a quad-broadcast fetch -- the four lanes of a row read the (weight, position) pairs of four consecutive entries
   // and pass them round with DPP, a quarter of the LDS instructions for them: exact pass 95.7 -> 91.6 us, three applications
-  // 135 -> 131 us, but the default two applications 103.5 -> 106.9 us (three DPP moves and an exec branch per entry).)
+  // 135 -> 131 us, but the default two applications 103.5 -> 106.9 us (three DPP moves and an exec branch per entry).
+  // And two entries per trip without padding (odd entry handled after the loop): 105 -> 139 us at K = 16, 65 -> 89 at K = 8,
+  // 38 -> 57 at K = 1 (same box, alternating libraries, scratch/r02_ab.sh): the one-entry loop stays.)
   auto row_sum = [&](int j0, int j1, double (&sum)[VW]) {
 #pragma unroll
     for (int w = 0; w < VW; ++w) sum[w] = 0.0;
