@@ -650,16 +650,14 @@ int ensure_sq_pattern(cwr_engine* e) {
     // cells; narrow rows use 256-row tiles) is retried at half the rows -- part of the lanes then idle in the compute phase,
     // which still beats the un-tiled exact pass by far
     for (int shrink = 0; shrink < 3 && !e->tcl_ready; ++shrink, tr = std::max(16, tr / 2)) {
-    // tiles of work items (see k_sq_tiled): a row of more than TCL_SEG entries occupies one lane group per chunk, so a tile
-    // takes rows while rows + extra chunks fit the tr lane-group slots of a pass (CWR_TCL_SEG=0: one item per row)
-    // splitting pays where the LDS compute phase bounds the pass -- narrow rows (one or two constituents per lane, three
-    // tile-local applications): 43 -> 38 us per pass at K = 1 on the merged mesh; with four constituents per lane the phase
-    // hides behind the HBM stream and the extra barrier and the smaller tiles cost 110 -> 119 us at K = 16, 202 -> 259 at 32
-    // (measured, merged 1 M-cell mesh, us per pass split / not: K = 1: 38.5 / 43.3, 2: 46.1 / 44.6, 3: 83 / 73, 4: 70 / 64,
-    // 6: 76 / 69, 16: 119 / 110; profiles/r02_f_split_sweep.txt)
-    bool split = e->K == 1;
+    // tiles of work items (see k_sq_tiled; a -DCWR_WORK_ITEMS=1 build with CWR_TCL_SPLIT=1 only): a row of more than TCL_SEG
+    // entries occupies one lane group per chunk, so a tile takes rows while rows + extra chunks fit the tr lane-group slots
+    // of a pass.  Measured on the merged 1 M-cell mesh, us per pass split / not: K = 2: 46.1 / 44.6, 3: 83 / 73, 4: 70 / 64,
+    // 6: 76 / 69, 16: 119 / 110 (profiles/r02_f_split_sweep.txt); K = 1: 38.3 / 37.1 with the tile-balanced numbering the
+    // unsplit tiles allow (profiles/r02_r_k1_ab.txt): off by default everywhere.
+    bool split = false;
     if (const char* v = getenv("CWR_TCL_SPLIT")) split = atoi(v) != 0;
-    split = split && e->VW == 1 && !want4;                       // (only the one-constituent-per-lane kernels carry the item logic)
+    split = split && CWR_WORK_ITEMS && e->VW == 1 && !want4;     // (only the one-constituent-per-lane kernels carry the item logic)
     const int seg = split ? TCL_SEG : (1 << 20);
     const int nvmax = split ? TCL_NVMAX : 0;
     std::vector<int32_t> trow(1, 0), vptr(1, 0);
@@ -721,11 +719,18 @@ int ensure_sq_pattern(cwr_engine* e) {
       int pc = 1;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, fn6, BLOCK, lds) != hipSuccess || pc < 1) pc = 1;
       pc = std::min(pc, 8);
+      // The grid is PERSISTENT: every block must be resident from the start, or the late ones run their share of the tiles
+      // after the others are done.  The occupancy query counts 5 blocks of 32 704 B (K = 1) into the 160 KB of LDS and the
+      // hardware places 4: 1 280 blocks took 44.6 us per pass, 1 024 take 35.7 (profiles/r02_r_grid_sweep.txt).  Leave 2 KB
+      // of the LDS out of the count.
+      pc = std::min(pc, std::max(1, (int)((160 * 1024 - 2048) / ((lds + 511) / 512 * 512))));
+      if (const char* v = getenv("CWR_TCL_BLOCKS_PER_CU")) pc = std::max(1, std::min(pc, atoi(v)));
       e->n_tcl = n_t;
       e->tcl_seg = seg; e->tcl_nvmax = nvmax;
       e->tcl_TR = tr; e->tcl_ntiles = nt; e->tcl_max_cols = max_cols; e->tcl_stage_cap = cap2; e->tcl_lds = lds;
       e->tcl_total_cols = tcols.size();
       e->tcl_grid = std::max(N_XCD, std::min(cdiv(nt, N_XCD) * N_XCD, (n_cu * pc / N_XCD) * N_XCD));
+      if (const char* v = getenv("CWR_TCL_GRID")) e->tcl_grid = std::max(N_XCD, std::min(e->tcl_grid, atoi(v) / N_XCD * N_XCD));
       TRY(dev_alloc(e, &e->d_tcl_ptr, (size_t)nt + 1));
       TRY(dev_alloc(e, &e->d_trow, (size_t)nt + 1));
       TRY(dev_alloc(e, &e->d_vptr, (size_t)nt + 1));
@@ -1266,9 +1271,9 @@ int32_t cwr_abi_version(void) { return 3; }
 
 int32_t cwr_tile_rows(int32_t n_constituents) {
   if (n_constituents < 1 || n_constituents > 256) return 0;
-  // one constituent: the tiled pass splits long rows into work items itself and its tiles hold a variable number of rows, so
-  // a fixed window would straddle tiles (measured: 38 -> 52 us per pass with sorted 256-row windows): no arrangement wanted
-  if (n_constituents == 1 && !(getenv("CWR_TCL_SPLIT") && atoi(getenv("CWR_TCL_SPLIT")) == 0)) return 0;
+  // (a work-item build with CWR_TCL_SPLIT=1 splits long rows itself and its tiles hold a variable number of rows, so a fixed
+  // window would straddle tiles -- measured 38 -> 52 us per pass with sorted 256-row windows: no arrangement wanted then)
+  if (CWR_WORK_ITEMS && n_constituents == 1 && getenv("CWR_TCL_SPLIT") && atoi(getenv("CWR_TCL_SPLIT")) != 0) return 0;
   return tile_rows_for(n_constituents, nullptr);
 }
 

@@ -781,6 +781,9 @@ constexpr int TCL_NARROW[4] = {0, 1, 9, 2};    // narrow-row configurations (VW 
 //     y = c2 + ((chunk_0 + chunk_1) + chunk_2 ...)        -- k_apply<.,5> sums in the same association (bitwise equal rows).
 // Tiles therefore hold a variable number of rows (trow[t] .. trow[t+1]): rows + virtual items <= the lane groups of a pass.
 static_assert(TCL_SEG % CWR_FACE_BATCH == 0, "k_apply<.,5> closes a chunk only at a face-batch boundary");
+#ifndef CWR_WORK_ITEMS
+#define CWR_WORK_ITEMS 0          // 1: compile the work-item (long-row splitting) path of the tiled pass; enable with CWR_TCL_SPLIT=1
+#endif
 #ifndef CWR_TCL_WAVES
 #define CWR_TCL_WAVES 1           // __launch_bounds__ second argument of the tiled pass (A/B builds: 5 forces <= 96 VGPRs)
 #endif
@@ -850,9 +853,11 @@ __global__ void __launch_bounds__(BLOCK, CWR_TCL_WAVES) k_sq_tiled(
       for (int w = 0; w < VW; ++w) sum[w] += wj * xn[w];
     }
   };
-  // SPLIT: the work-item logic is compiled into the one-constituent-per-lane variants only (it costs 12 VGPRs, which takes
-  // the wide-row variants from 4 to 3 blocks per CU, and it only pays where the LDS compute phase bounds the pass)
-  constexpr bool SPLIT = (VW == 1);
+  // SPLIT: the work-item logic, compiled into the one-constituent-per-lane variants of a -DCWR_WORK_ITEMS=1 build only.  It is
+  // NOT part of the default build: once 256-row tiles fit without it (configuration {12, 1, 3}) it gains 1 % at K = 1 in a
+  // same-box comparison, less than the tile-balanced numbering gives for free (3 %), and it costs 12 VGPRs and a barrier
+  // wherever rows share a lane's loop (K = 16: 110 -> 119 us).  profiles/r02_r_k1_ab.txt
+  constexpr bool SPLIT = (VW == 1) && (CWR_WORK_ITEMS != 0);
   const bool rowlane = r < R;
   // x rows are FETCHED (global -> registers -> LDS) one whole 128-byte row per 8 lanes whatever VW is: with VW == 4 the
   // compute mapping above would fetch half rows (measured +6 us per pass)

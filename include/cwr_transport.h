@@ -79,8 +79,8 @@ int32_t cwr_abi_version(void);
 /* Rows of one tile of the engine's dominant sweep kernel for K constituents (64 at K = 16, 256 at K = 1, ...).  A host
  * wrapper that chooses the cell numbering it creates the engine with (engine.py's cell_order: a space-filling curve) may
  * arrange the cells of every tile-sized window by their work (ordering.balance_windows sorts them by the number of cells
- * within two face steps): the kernel's waves loop to the longest of their rows.  0 = no arrangement wanted (K = 1: the
- * kernel splits long rows itself).  Purely a speed matter. */
+ * within two face steps): the kernel's waves loop to the longest of their rows.  0 = no arrangement wanted.  Purely a speed
+ * matter. */
 int32_t cwr_tile_rows(int32_t n_constituents);
 
 /* ---- construction -------------------------------------------------------------------------------

@@ -180,7 +180,7 @@ def test_hilbert_order_is_a_permutation_with_local_neighbours():
 def test_tile_balanced_numbering_is_a_permutation_that_keeps_the_tiles():
     """ordering.balance_windows: within every tile-sized window of the curve the cells are sorted by their J^2 row length; each
     window keeps exactly its cells (so a tile's LDS image is unchanged), the mean of the per-wave maximum drops, and a
-    window <= 1 (cwr_tile_rows(1) = 0: the kernel splits long rows itself) leaves the order alone."""
+    window <= 1 leaves the order alone."""
     import clearwater_riverine_amd as cw
     from clearwater_riverine_amd.ordering import balance_windows, hilbert_order, two_hop_row_lengths
     m = cw.synthetic.make_mesh(96, 64, 2, seed=3, n_merge=300)

@@ -194,7 +194,7 @@ def _worker(rank, world, port, ok_flags):
         from clearwater_riverine_amd.ordering import balance_windows
         from clearwater_riverine_amd.engine import tile_rows
         order = shared_hilbert_order(mesh, n, rank, world, K=16)
-        assert tile_rows(16) == 64 and tile_rows(1) == 0 and tile_rows(8) == 128 and tile_rows(2) == 256
+        assert tile_rows(16) == 64 and tile_rows(1) == 256 and tile_rows(8) == 128 and tile_rows(2) == 256
         assert np.array_equal(order, balance_windows(hilbert_order(mesh['face_x'], mesh['face_y'], n), f1, f2, window=64))
         assert np.array_equal(np.sort(order), np.arange(n))
         rm = renumber_mesh(mesh, order)
