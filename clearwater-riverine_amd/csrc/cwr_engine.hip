@@ -77,6 +77,7 @@ struct cwr_engine {
   int32_t *d_f1 = nullptr, *d_f2 = nullptr, *d_ptr = nullptr, *d_ent_edge = nullptr, *d_ent_nb = nullptr;
   int32_t* d_face_orig = nullptr;          // internal face index -> reference face id (k_faces_in / k_faces_out)
   int32_t* d_face_pos = nullptr;           // reference face id -> internal face index
+  uint8_t* d_sq_fast = nullptr;             // 1 where k_sq_numeric may take a row through its branch-free path
   uint8_t* d_row_ghost = nullptr;          // 1 where a computed row has a boundary (ghost) face
   std::vector<int32_t> bad_level;          // per time level: the zero-coefficient precondition is violated (k_check_ghost_levels)
   std::vector<int32_t> h_face_pos;         // reference face id -> internal face index
@@ -593,6 +594,27 @@ int ensure_sq_pattern(cwr_engine* e) {
     pair_ptr[c + 1] = (int32_t)slots.size();
   }
   e->nnz2 = (int)col2.size();
+  {
+    // rows k_sq_numeric may take through its branch-free path (see there): a property of the topology
+    const int DEGsel = e->max_degree <= 4 ? 4 : (e->max_degree <= 6 ? 6 : 8);
+    std::vector<uint8_t> ghosty((size_t)e->n_owned, 0), fastv((size_t)n, 0);
+    for (int c = 0; c < e->n_owned; ++c)
+      for (int j = e->h_ptr[c]; j < e->h_ptr[c + 1]; ++j) if (e->h_nb[j] < 0) ghosty[(size_t)c] = 1;
+    for (int c = 0; c < n; ++c) {
+      const int deg = e->h_ptr[c + 1] - e->h_ptr[c];
+      bool ok = deg > 0 && deg <= DEGsel && ptr2[c + 1] > ptr2[c];
+      bool any = false;
+      for (int j = e->h_ptr[c]; j < e->h_ptr[c + 1] && ok; ++j) {
+        const int m = e->h_nb[j];
+        if (m < 0) continue;
+        any = true;
+        ok = (e->h_ptr[m + 1] - e->h_ptr[m] <= DEGsel) && !ghosty[(size_t)m];
+      }
+      fastv[(size_t)c] = (ok && any) ? 1 : 0;
+    }
+    TRY(dev_alloc(e, &e->d_sq_fast, (size_t)n));
+    TRY(upload(e, e->d_sq_fast, fastv.data(), (size_t)n));
+  }
   int cap = 1;
   for (int b = 0; b * TR < n; ++b) cap = std::max(cap, ptr2[std::min((b + 1) * TR, n)] - ptr2[b * TR]);
   if (cap > 8192) { e->sq_failed = true; return CWR_OK; }      // would not fit LDS staging: stay with plain sweeps
@@ -624,7 +646,7 @@ int ensure_sq_pattern(cwr_engine* e) {
   }
   if (rowwise && slots.size() < 2000000000u) {
     TRY(dev_alloc(e, &e->d_pair_ptr, (size_t)n + 1));
-    TRY(dev_alloc(e, &e->d_slots, slots.size()));
+    TRY(dev_alloc(e, &e->d_slots, slots.size() + SQN_PAD));
     TRY(upload(e, e->d_pair_ptr, pair_ptr.data(), (size_t)n + 1));
     TRY(upload(e, e->d_slots, slots.data(), slots.size()));
     e->sq_rowwise = true;
@@ -792,7 +814,7 @@ int prepare_sq(cwr_engine* e, bool& active) {
   // (the entry weights w were written by k_prep_step)
   const bool need_rec2 = !e->tcl_ready || e->n_sq > e->n_tcl;      // the un-tiled pass reads FaceRec-format rows
 #define CWR_SQN(DEGv) k_sq_numeric<DEGv><<<cdiv(e->n_sq, SQN_THREADS), SQN_THREADS, e->sqn_lds, e->stream>>>(e->n_sq, e->d_ptr, e->d_ent_nb, \
-        e->d_w, e->d_ptr2, e->d_col2, e->d_pair_ptr, e->d_slots, e->d_row_ghost, need_rec2 ? e->d_rec2 : nullptr, e->tcl_ready ? e->d_w2 : nullptr)
+        e->d_w, e->d_ptr2, e->d_col2, e->d_pair_ptr, e->d_slots, e->d_sq_fast, need_rec2 ? e->d_rec2 : nullptr, e->tcl_ready ? e->d_w2 : nullptr)
   if (e->sq_rowwise) { if (e->max_degree <= 4) CWR_SQN(4); else if (e->max_degree <= 6) CWR_SQN(6); else CWR_SQN(8); }
 #undef CWR_SQN
   else
@@ -1402,10 +1424,10 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   CREATE_TRY(dev_alloc(eng, &eng->d_f2, (size_t)n_edges));
   CREATE_TRY(dev_alloc(eng, &eng->d_ptr, (size_t)n_owned + 1));
   CREATE_TRY(dev_alloc(eng, &eng->d_ent_edge, (size_t)nnz));
-  CREATE_TRY(dev_alloc(eng, &eng->d_ent_nb, (size_t)nnz));
+  CREATE_TRY(dev_alloc(eng, &eng->d_ent_nb, (size_t)nnz + SQN_PAD));
   CREATE_TRY(dev_alloc(eng, &eng->d_rec, (size_t)nnz));
   CREATE_TRY(dev_alloc(eng, &eng->d_diag, (size_t)n_owned));
-  CREATE_TRY(dev_alloc(eng, &eng->d_w, (size_t)nnz));
+  CREATE_TRY(dev_alloc(eng, &eng->d_w, (size_t)nnz + SQN_PAD));
   CREATE_TRY(dev_alloc(eng, &eng->d_chk, 4 * (size_t)K));
   CREATE_TRY(dev_alloc(eng, &eng->d_keep, (size_t)n_cells * K));
   if (const char* v = getenv("CWR_NO_ELEMENTWISE")) eng->ew_enabled = atoi(v) == 0;
@@ -1471,7 +1493,7 @@ void cwr_destroy(cwr_engine* e) {
   for (hipEvent_t ev : e->ev) hipEventDestroy(ev);
   void* ptrs[] = {e->d_f1, e->d_f2, e->d_ptr, e->d_ent_edge, e->d_ent_nb, e->d_adv, e->d_vel, e->d_vol, e->d_dif,
                   e->d_bc, e->d_rec, e->d_diag, e->d_c, e->d_r, e->d_r0, e->d_p, e->d_v, e->d_s, e->d_t, e->d_b,
-                  e->d_scal, e->d_counters, e->d_partial, e->d_fadv, e->d_fdif, e->d_ftot, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf, e->d_ptr2, e->d_col2, e->d_row2, e->d_rec2, e->d_w, e->d_react, e->d_info, e->d_tcl_ptr, e->d_tcl_cols, e->d_loc2, e->d_w2, e->d_pair_ptr, e->d_slots, e->d_line_ptr, e->d_line_faces, e->d_ledger, e->d_mass_out, e->d_chk, e->d_face_orig, e->d_row_ghost, e->d_keep, e->d_in_rows, e->d_in_vals, e->d_face_pos, e->d_trow, e->d_vptr, e->d_meta, e->d_tile_inner, e->d_tile_outer, e->d_chkx};
+                  e->d_scal, e->d_counters, e->d_partial, e->d_fadv, e->d_fdif, e->d_ftot, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf, e->d_ptr2, e->d_col2, e->d_row2, e->d_rec2, e->d_w, e->d_react, e->d_info, e->d_tcl_ptr, e->d_tcl_cols, e->d_loc2, e->d_w2, e->d_pair_ptr, e->d_slots, e->d_line_ptr, e->d_line_faces, e->d_ledger, e->d_mass_out, e->d_chk, e->d_face_orig, e->d_row_ghost, e->d_keep, e->d_in_rows, e->d_in_vals, e->d_face_pos, e->d_trow, e->d_vptr, e->d_meta, e->d_tile_inner, e->d_tile_outer, e->d_chkx, e->d_sq_fast};
   for (void* p : ptrs) if (p) hipFree(p);
   if (e->stream) hipStreamDestroy(e->stream);
   delete e;

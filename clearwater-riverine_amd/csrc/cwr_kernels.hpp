@@ -283,15 +283,52 @@ __global__ void __launch_bounds__(BLOCK) k_prep_step(
     const int32_t* __restrict__ ent_nb, const float* __restrict__ adv_t, const double* __restrict__ dif_t,
     const float* __restrict__ vol_next, double dt, FaceRec* __restrict__ rec, double* __restrict__ diag,
     double* __restrict__ w) {
-  // rows are worked one per thread, but their records and weights leave through LDS as one contiguous, coalesced stream
-  // (a thread's own 16-byte stores at a 64-byte stride cost 2.6 x the bytes at the HBM side: PMC, profiles/r01_k_*)
+  // The block's adjacency entries are gathered ENTRY-parallel (entry i by thread i mod 256: the code and neighbour loads
+  // are coalesced, the two face gathers of all of a thread's entries are in flight together), staged in LDS, reduced per
+  // row by the row's thread, and leave as one contiguous stream (a thread's own 16-byte stores at a 64-byte stride cost
+  // 2.6 x the bytes at the HBM side: PMC, profiles/r01_k_*).  One thread per row walking its own entries -- round 1's
+  // form -- made every load wait for the one before it (65.8 -> 58.1 us per level, profiles/r02_u_set_up_kernels.txt).
   __shared__ FaceRec s_rec[PREP_CAP];
   __shared__ double s_w[PREP_CAP];
   const int c0 = blockIdx.x * BLOCK, c1 = min(c0 + BLOCK, n_owned);
   const int jb = ptr[c0], nent = ptr[c1] - jb;
-  const bool staged = nent <= PREP_CAP;              // uniform per block
   const int c = c0 + threadIdx.x;
-  if (c < n_owned) {
+  if (nent <= PREP_CAP) {                            // uniform per block
+    constexpr int NU = PREP_CAP / BLOCK;
+    int code[NU], nb[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int i = threadIdx.x + u * BLOCK;
+      code[u] = 0; nb[u] = -1;
+      if (i < nent) { code[u] = ent_edge[jb + i]; nb[u] = ent_nb[jb + i]; }
+    }
+    float a[NU]; double d[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      a[u] = 0.f; d[u] = 0.0;
+      if (threadIdx.x + u * BLOCK < nent) { a[u] = adv_t[code[u] >> 1]; d[u] = dif_t[code[u] >> 1]; }
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int i = threadIdx.x + u * BLOCK;
+      if (i < nent) { FaceRec r; r.nb = nb[u]; r.a_c = (code[u] & 1) ? -a[u] : a[u]; r.d = d[u]; s_rec[i] = r; }
+    }
+    __syncthreads();
+    if (c < n_owned) {
+      const double vn = (double)vol_next[c];
+      double dg = vn / dt + (vn == 0.0 ? 1.0 : 0.0);
+      const int j0 = ptr[c] - jb, j1 = ptr[c + 1] - jb;
+      for (int j = j0; j < j1; ++j) dg += s_rec[j].d + fmax((double)s_rec[j].a_c, 0.0);   // (ascending j: the reference's order)
+      diag[c] = dg;
+      // w[j] = -offd_j / diag >= 0: the Jacobi iteration matrix J = I - D^-1 A per adjacency entry (0 on ghost faces)
+      for (int j = j0; j < j1; ++j) {
+        const FaceRec fr = s_rec[j];
+        s_w[j] = (fr.nb >= 0) ? (fr.d - fmin((double)fr.a_c, 0.0)) / dg : 0.0;
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nent; i += BLOCK) { rec[jb + i] = s_rec[i]; w[jb + i] = s_w[i]; }
+  } else if (c < n_owned) {                          // denser adjacency than the stage holds: one thread per row, straight to memory
     const double vn = (double)vol_next[c];
     double dg = vn / dt + (vn == 0.0 ? 1.0 : 0.0);
     const int j0 = ptr[c], j1 = ptr[c + 1];
@@ -303,19 +340,13 @@ __global__ void __launch_bounds__(BLOCK) k_prep_step(
       const float a_c = (code & 1) ? -a : a;
       dg += d + fmax((double)a_c, 0.0);
       FaceRec r; r.nb = ent_nb[j]; r.a_c = a_c; r.d = d;
-      if (staged) s_rec[j - jb] = r; else rec[j] = r;
+      rec[j] = r;
     }
     diag[c] = dg;
-    // w[j] = -offd_j / diag >= 0: the Jacobi iteration matrix J = I - D^-1 A per adjacency entry (0 on ghost faces)
     for (int j = j0; j < j1; ++j) {
-      const FaceRec fr = staged ? s_rec[j - jb] : rec[j];
-      const double wj = (fr.nb >= 0) ? (fr.d - fmin((double)fr.a_c, 0.0)) / dg : 0.0;
-      if (staged) s_w[j - jb] = wj; else w[j] = wj;
+      const FaceRec fr = rec[j];
+      w[j] = (fr.nb >= 0) ? (fr.d - fmin((double)fr.a_c, 0.0)) / dg : 0.0;
     }
-  }
-  if (staged) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < nent; i += BLOCK) { rec[jb + i] = s_rec[i]; w[jb + i] = s_w[i]; }
   }
 }
 
@@ -632,6 +663,10 @@ __global__ void __launch_bounds__(BLOCK) k_scatter_faces(int E, int n_owned, int
 // accumulates into its own LDS row (strided: conflict-free) and writes the row out.  Same summation order as
 // k_build_sq (which stays for rows longer than SQN_MAXC): bitwise the same values.
 constexpr int SQN_THREADS = 128;
+constexpr int SQN_PAD = 8;          // elements the weight and slot arrays are over-allocated by (whole-row vector loads of k_sq_numeric)
+typedef double double2_u __attribute__((ext_vector_type(2), aligned(8)));
+typedef int32_t int2_u __attribute__((ext_vector_type(2), aligned(4)));
+typedef uint32_t uint32_u __attribute__((aligned(1)));
 constexpr int SQN_MAXC = 255;           // longest J^2 row the row-wise kernel takes (slots are 8-bit)
 // The accumulators of a block's 128 rows sit in LDS in the rows' own CSR layout (entry q of row c at ptr2[c] - ptr2[c0] + q;
 // the host sizes the dynamic LDS to the fullest block), so a block holds ~10 KB and 32 waves per CU hide the dependent
@@ -646,7 +681,7 @@ template <int DEG>
 __global__ void __launch_bounds__(SQN_THREADS) k_sq_numeric(
     int n, const int32_t* __restrict__ ptr, const int32_t* __restrict__ ent_nb, const double* __restrict__ w,
     const int32_t* __restrict__ ptr2, const int32_t* __restrict__ col2, const int32_t* __restrict__ pair_ptr,
-    const uint8_t* __restrict__ slots, const uint8_t* __restrict__ row_ghost, FaceRec* __restrict__ rec2, double* __restrict__ w2) {
+    const uint8_t* __restrict__ slots, const uint8_t* __restrict__ fast_ok, FaceRec* __restrict__ rec2, double* __restrict__ w2) {
   extern __shared__ double s_acc[];
   const int c0 = blockIdx.x * SQN_THREADS, c1 = min(c0 + SQN_THREADS, n);
   const int base = ptr2[c0], nloc = ptr2[c1] - base;
@@ -658,36 +693,48 @@ __global__ void __launch_bounds__(SQN_THREADS) k_sq_numeric(
     double* acc = s_acc + (o2 - base);
     const int pi0 = pair_ptr[c];
     const int j0 = ptr[c], deg = ptr[c + 1] - j0;
-    bool fast = deg <= DEG && deg > 0 && len2 > 0;
+    // fast_ok (host, from the topology): 0 < deg <= DEG, a J^2 row of its own, at least one real neighbour, and every real
+    // neighbour's row has <= DEG entries and no ghost face (so that its r-th entry is its r-th product)
+    const bool fast = fast_ok[c] != 0;
     if (fast) {
       int mm[DEG], p0[DEG], ln[DEG], off[DEG];
       double wj[DEG];
 #pragma unroll
-      for (int q = 0; q < DEG; ++q) {
-        const int jj = j0 + min(q, deg - 1);
-        const int m = ent_nb[jj];
-        const bool live = (q < deg) & (m >= 0);
-        wj[q] = live ? w[jj] : 0.0;
-        mm[q] = live ? m : -1;
+      for (int v = 0; v < DEG / 2; ++v) {                                    // the own row, two entries per load
+        const int2_u m2 = *reinterpret_cast<const int2_u*>(ent_nb + j0 + 2 * v);
+        const double2_u w2v = *reinterpret_cast<const double2_u*>(w + j0 + 2 * v);
+        const bool live0 = (2 * v < deg) & (m2.x >= 0), live1 = (2 * v + 1 < deg) & (m2.y >= 0);
+        wj[2 * v] = live0 ? w2v.x : 0.0;     mm[2 * v] = live0 ? m2.x : -1;
+        wj[2 * v + 1] = live1 ? w2v.y : 0.0; mm[2 * v + 1] = live1 ? m2.y : -1;
       }
       int run = 0;
 #pragma unroll
       for (int q = 0; q < DEG; ++q) {
         const int m = mm[q] >= 0 ? mm[q] : c;
-        p0[q] = ptr[m];
-        ln[q] = ptr[m + 1] - p0[q];
-        if (mm[q] >= 0) { fast = fast & (ln[q] <= DEG) & (row_ghost[m] == 0); off[q] = run; run += ln[q]; }
+        const int2_u pp = *reinterpret_cast<const int2_u*>(ptr + m);         // (ptr[m], ptr[m + 1]) in one load
+        p0[q] = pp.x;
+        ln[q] = pp.y - pp.x;
+        if (mm[q] >= 0) { off[q] = run; run += ln[q]; }
         else { off[q] = 0; ln[q] = 1; p0[q] = j0; }                       // dead slot: own first entry, zero weight
       }
-      if (fast && run > 0) {
+      {
 #pragma unroll
         for (int q = 0; q < DEG; ++q) {
+          // the neighbour's whole row in DEG / 2 16-byte loads and its slots in one or two 4-byte loads (8- and 1-byte aligned:
+          // gfx950 global loads need no natural alignment); what lies behind the row's end is read and not used -- both
+          // arrays are allocated SQN_PAD elements longer.  The kernel is bound by the address rate of its gathers (about
+          // 100 scalar loads per row before), not by bytes.
           double ww[DEG]; int sl[DEG];
 #pragma unroll
-          for (int r = 0; r < DEG; ++r) {
-            const int rr = min(r, ln[q] - 1);
-            ww[r] = w[p0[q] + rr];
-            sl[r] = (int)slots[pi0 + off[q] + rr];
+          for (int v = 0; v < DEG / 2; ++v) {
+            const double2_u t = *reinterpret_cast<const double2_u*>(w + p0[q] + 2 * v);
+            ww[2 * v] = t.x; ww[2 * v + 1] = t.y;
+          }
+#pragma unroll
+          for (int v = 0; v < (DEG + 3) / 4; ++v) {
+            const uint32_t t = *reinterpret_cast<const uint32_u*>(slots + pi0 + off[q] + 4 * v);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) if (4 * v + b < DEG) sl[4 * v + b] = (int)((t >> (8 * b)) & 255u);
           }
 #pragma unroll
           for (int r = 0; r < DEG; ++r) {
