@@ -203,6 +203,7 @@ struct cwr_engine {
   hipGraphExec_t sq_exec = nullptr;
   bool sq_graph_tried = false;
   int dominant_mode = 4;
+  bool two_closing = false;      // CWR_TWO_CLOSING=1: round 1's batch shape on one GPU too (even passes + two closing sweeps; A/B)
   bool use_small = true;         // one-workgroup-per-constituent LDS-resident solve for meshes that fit one CU
   double* d_info = nullptr;      // [K][3] results of k_small_jacobi
   int nt_stream = 0;            // nt loads for the streamed operands (records, bhat/c2/r0): pays for wide rows only
@@ -913,7 +914,8 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
   double prev_worst = -1.0;
   int prev_sweeps = 0;
   int since_exchange = 0;                     // the caller exchanged the state's halo just before the right-hand side
-  int batch = (e->last_sweeps > 0) ? std::max(2, (e->last_sweeps + 1) & ~1) : 8;
+  int want = (e->last_sweeps > 0) ? std::max(2, e->last_sweeps) : 8;   // sweeps the next batch should add (prediction, unrounded)
+  int batch = 0;
   const int sweep_limit = forced ? max_iter : std::min(max_iter, e->jacobi_limit);
   bool sq = false;
   TRY(prepare_sq(e, sq));
@@ -926,50 +928,67 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
   e->dominant_mode = tiled ? 6 : (sq ? 5 : 4);
   st.sweep_kernel = e->dominant_mode;
   for (;;) {
-    batch = std::min(batch, std::max(2, (sweep_limit - st.sweeps + 1) & ~1));   // max_iter bounds the first batch too
-    batch = std::max(2, std::min(batch, 4096)) & ~1;                   // even: the result lands in the state vector
+    want = std::min(want, std::max(2, sweep_limit - st.sweeps));       // max_iter bounds the first batch too
+    batch = std::max(2, std::min((want + 1) & ~1, 4096));               // even: the result lands in the state vector
     int launches = batch;
     int todo = batch;
     bool batch_graph = false;
     if (sq) {
-      // batch = 2*doubles + 2 with an even number of J^2 passes, then two plain sweeps: the last one's ||x'-x|| is the
-      // exact scaled residual of its input, so the convergence criterion is unchanged
-      batch += (6 - batch % 4) % 4;                                     // round up to 2 (mod 4)
-      int doubles = (batch - 2) / 2;
+      // One GPU: batch = 2*doubles + 1 -- `doubles` J^2 passes, then ONE plain sweep whose ||x'-x|| is the exact scaled
+      // residual of its input (the convergence criterion) and whose output is the answer.  The launches ping-pong between
+      // the state vector and its partner and must END in the state vector: with an odd number of launches the first pass
+      // reads x_t from the copy k_rhs keeps for a failed step (d_keep: every computed row) and writes the state vector,
+      // which shifts the parity -- first batch of a step only; later batches take one pass more instead.  (Round 1 used an
+      // even number of passes and two closing sweeps: 4-sweep granularity and a plain sweep, 85 us at K = 16, more.)
+      // That shape is still the cheaper one when the sweeps wanted are 2 (mod 4): N passes + 2 sweeps against N + 1 passes +
+      // 1 sweep, and a plain sweep costs less than a pass.  Partitioned engines always use it: their halo layers and
+      // exchanges are counted in pairs of sweeps.
+      const bool one_closing = !e->comm && !e->two_closing && want % 4 != 2;
+      int doubles;
+      if (one_closing) {
+        doubles = std::min(want / 2, 2047);
+        if (!(doubles & 1) && st.sweeps > 0) ++doubles;                 // (a later batch cannot start from the copy: odd, ends in the state vector)
+        batch = 2 * doubles + 1;
+      } else {
+        // batch = 2*doubles + 2 with an even number of J^2 passes, then two plain sweeps
+        batch += (6 - batch % 4) % 4;                                   // round up to 2 (mod 4)
+        doubles = (batch - 2) / 2;
+      }
+      const bool from_keep = one_closing && !(doubles & 1) ;           // doubles + 1 launches, odd: start from the copy
+      auto srcb = [&](int i) -> double* { if (!from_keep) return (i & 1) ? e->d_p : e->d_c; return i == 0 ? e->d_keep : ((i & 1) ? e->d_c : e->d_p); };
+      auto dstb = [&](int i) -> double* { if (!from_keep) return (i & 1) ? e->d_c : e->d_p; return (i & 1) ? e->d_p : e->d_c; };
       const int passes = doubles;
-      launches = doubles + 2;
+      launches = doubles + (one_closing ? 1 : 2);
       todo = 0;
       // steady state (the same batch shape as the previous check): the WHOLE batch -- passes, closing sweeps, reduction --
       // is one hipGraph, captured the second time a shape is seen (the kernel arguments of a batch never change)
       if (!e->comm && !e->profiling && e->use_graphs) {
-        auto it = e->batch_exec.find(doubles);
-        if (it == e->batch_exec.end() && e->batch_last == doubles && e->batch_exec.size() < 6) {
+        const int shape = 2 * doubles + (one_closing ? 1 : 0);
+        auto it = e->batch_exec.find(shape);
+        if (it == e->batch_exec.end() && e->batch_last == shape && e->batch_exec.size() < 6) {
           hipGraphExec_t ex = nullptr;
           if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
             int rc = CWR_OK;
-            for (int i = 0; i < doubles && rc == CWR_OK; ++i) {
-              double* src = (i & 1) ? e->d_p : e->d_c;
-              double* dst = (i & 1) ? e->d_c : e->d_p;
-              rc = tiled ? launch_sq_tiled(e, src, dst) : launch_apply<5>(e, src, dst, nullptr, e->d_t, nullptr, nullptr, e->n_sq);
-            }
-            if (rc == CWR_OK) rc = launch_apply<4>(e, e->d_c, e->d_p, nullptr, e->d_b, nullptr, nullptr);
-            if (rc == CWR_OK) rc = launch_apply<4>(e, e->d_p, e->d_c, nullptr, e->d_b, nullptr, nullptr);
+            for (int i = 0; i < doubles && rc == CWR_OK; ++i)
+              rc = tiled ? launch_sq_tiled(e, srcb(i), dstb(i)) : launch_apply<5>(e, srcb(i), dstb(i), nullptr, e->d_t, nullptr, nullptr, e->n_sq);
+            if (rc == CWR_OK) rc = launch_apply<4>(e, srcb(doubles), dstb(doubles), nullptr, e->d_b, nullptr, nullptr);
+            if (rc == CWR_OK && !one_closing) rc = launch_apply<4>(e, srcb(doubles + 1), dstb(doubles + 1), nullptr, e->d_b, nullptr, nullptr);
             if (rc == CWR_OK) rc = reduce_check(e);
             hipGraph_t g = nullptr;
             const hipError_t ec = hipStreamEndCapture(e->stream, &g);
             if (!(rc == CWR_OK && ec == hipSuccess && g && hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess)) { ex = nullptr; (void)hipGetLastError(); }
             if (g) hipGraphDestroy(g);
           }
-          it = e->batch_exec.emplace(doubles, ex).first;      // (nullptr: capture failed, do not try this shape again)
+          it = e->batch_exec.emplace(shape, ex).first;        // (nullptr: capture failed, do not try this shape again)
         }
-        e->batch_last = doubles;
+        e->batch_last = shape;
         if (it != e->batch_exec.end() && it->second) {
           HIP_TRY(e, hipGraphLaunch(it->second, e->stream));
           batch_graph = true;
         }
       }
       if (!batch_graph) {
-      if (!e->comm && !e->profiling && e->use_graphs) {
+      if (!e->comm && !e->profiling && e->use_graphs && !from_keep) {
         hipGraphExec_t& exec = tiled ? e->tcl_exec : e->sq_exec;
         hipGraph_t& graph = tiled ? e->tcl_graph : e->sq_graph;
         bool& tried = tiled ? e->tcl_graph_tried : e->sq_graph_tried;
@@ -993,8 +1012,8 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
       // a J^2 pass uses up two halo layers of validity, a plain sweep one
       const bool can_overlap = e->comm && tiled && e->overlap && e->comm_stream && e->n_tile_inner > 0 && !e->peers.empty();
       for (int i = 0; i < doubles;) {
-        double* src = (i & 1) ? e->d_p : e->d_c;
-        double* dst = (i & 1) ? e->d_c : e->d_p;
+        double* src = srcb(i);
+        double* dst = dstb(i);
         if (since_exchange + 2 > e->exch_every) {
           if (can_overlap) {
             // pack the cut rows, start the interior tiles (they read core rows only), exchange beside them on the
@@ -1035,8 +1054,8 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
           }
         }
         for (int q = 0; q < run; ++q, ++i) {
-          double* s2 = (i & 1) ? e->d_p : e->d_c;
-          double* d2 = (i & 1) ? e->d_c : e->d_p;
+          double* s2 = srcb(i);
+          double* d2 = dstb(i);
           if (tiled) TRY(launch_sq_tiled(e, s2, d2));
           else TRY(launch_apply<5>(e, s2, d2, nullptr, e->d_t, nullptr, nullptr, e->n_sq));
           since_exchange += 2;
@@ -1044,6 +1063,9 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
       }
       // block-asynchronous passes leave the replayed halo layers only approximately equal to their owners' rows: refresh
       // them so that the two plain sweeps below are exact on the core and the check is the true residual
+      if (one_closing) {
+        TRY(launch_apply<4>(e, srcb(passes), dstb(passes), nullptr, e->d_b, nullptr, nullptr));
+      } else {
       if (e->comm && tiled && e->local_reps > 1 && passes > 0) since_exchange = e->exch_every;
       if (since_exchange + 1 > e->exch_every) { TRY(exchange_halo(e, e->d_c)); since_exchange = 0; }
       TRY(launch_apply<4>(e, e->d_c, e->d_p, nullptr, e->d_b, nullptr, nullptr));
@@ -1051,6 +1073,7 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
       if (since_exchange + 1 > e->exch_every) { TRY(exchange_halo(e, e->d_p)); since_exchange = 0; }
       TRY(launch_apply<4>(e, e->d_p, e->d_c, nullptr, e->d_b, nullptr, nullptr));
       ++since_exchange;
+      }
       }
     } else if (!e->comm && !e->profiling && e->use_graphs) {
       if (!e->graph_tried) {                               // capture GRAPH_SWEEPS sweeps once
@@ -1133,7 +1156,7 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
       }
     }
     prev_worst = worst; prev_sweeps = st.sweeps;
-    batch = std::min(predicted + (predicted & 1), std::max(2, (sweep_limit - st.sweeps) & ~1));
+    want = predicted;
   }
 }
 
@@ -1362,6 +1385,7 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   if (const char* v = getenv("CWR_NO_GRAPHS")) eng->use_graphs = atoi(v) == 0;
   if (const char* v = getenv("CWR_NO_SQ")) eng->use_sq = atoi(v) == 0;
   if (const char* v = getenv("CWR_NO_SMALL")) eng->use_small = atoi(v) == 0;
+  if (const char* v = getenv("CWR_TWO_CLOSING")) eng->two_closing = atoi(v) != 0;
   if (const char* v = getenv("CWR_NO_TCL")) eng->use_tcl = atoi(v) == 0;
   // tile-local J^2 applications per pass: each costs LDS time only (measured 15-25 us at K = 16, 4 us at K = 1 on 1 M cells)
   // and cuts the passes from 46 to 28 (x2) / 24 (x3); narrow rows gain from the third application, wide rows do not

@@ -200,6 +200,7 @@ def test_single_rank_rccl_communicator(gpu_lib, monkeypatch):
     import clearwater_riverine_amd as cw
     monkeypatch.setenv('CWR_FORCE_COLLECTIVES', '1')
     monkeypatch.setenv('CWR_NO_SMALL', '1')          # both engines on the multi-launch path (a communicator rules out the small one)
+    monkeypatch.setenv('CWR_TWO_CLOSING', '1')       # ... and the same batch shape (engines with a communicator count sweeps in pairs)
     mesh, inputs3 = synthetic_case(3, nx=30, ny=14, n_steps=3, seed=12, n_merge=15)
     n = mesh['nreal'] + 1
     outs = []
@@ -340,3 +341,24 @@ def test_block_asynchronous_passes_converge_faster_to_the_same_solution(gpu_lib,
     want = np.stack([ref.constituent_dict[f'c{k}'].state[4, :n] for k in range(K)], axis=1)
     for reps in outs:
         assert rel_err(outs[reps], want) <= 1e-9
+
+
+@pytest.mark.parametrize('K', [1, 16])
+def test_persistent_grid_size_of_the_tiled_pass_does_not_change_the_result(gpu_lib, monkeypatch, K):
+    """The tiled pass is a persistent launch whose blocks walk a static share of the tiles (csrc launch_sq_tiled): with
+    8 blocks, with one resident block per CU and with every slot taken the state is bitwise the same (the pass reads
+    one buffer and writes the other, so which block computes a tile cannot matter)."""
+    from clearwater_riverine_amd.distributed import PartitionedTransport
+    monkeypatch.setenv('CWR_NO_SMALL', '1')
+    mesh, inputs3 = synthetic_case(K, nx=120, ny=60, n_steps=3, seed=29, n_merge=150, dt=40.0, diffusion_coefficient=0.5)
+    outs = []
+    for knob, val in ((None, None), ('CWR_TCL_GRID', '8'), ('CWR_TCL_BLOCKS_PER_CU', '1')):
+        if knob:
+            monkeypatch.setenv(knob, val)
+        pt = PartitionedTransport(mesh, inputs3, 0, 1, renumber='hilbert')
+        res = [pt.step(t, tol=1e-12, solver='jacobi') for t in range(3)]
+        assert res[-1].sweep_kernel == 6 and all(r.max_rel_residual <= 1e-12 for r in res)
+        outs.append(pt.gather_state())
+        if knob:
+            monkeypatch.delenv(knob)
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])

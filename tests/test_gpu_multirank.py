@@ -115,6 +115,7 @@ def run_ranks(world, target, args):
 def test_partitioned_step_matches_single_rank_and_oracle(gpu_lib, world, K, solver, depth, local_reps, monkeypatch):
     build_mock()
     monkeypatch.setenv('CWR_NO_SMALL', '1')      # the single-rank reference run takes the same multi-launch path as the ranks
+    monkeypatch.setenv('CWR_TWO_CLOSING', '1')   # ... and the ranks' batch shape (even passes + two closing sweeps): bitwise comparison
     if local_reps == '1':
         monkeypatch.setenv('CWR_LOCAL_REPS', '1')   # exact Jacobi passes (spawned ranks inherit the environment)
     elif solver == 'bicgstab' or depth < 2:
