@@ -203,6 +203,12 @@ struct cwr_engine {
   hipGraphExec_t sq_exec = nullptr;
   bool sq_graph_tried = false;
   int dominant_mode = 4;
+  // Sweeps added to the previous step's need when the first batch of a step is sized (CWR_SWEEP_MARGIN).  The need drifts by a
+  // sweep or two from step to step with the boundary series; a first batch that falls one sweep short costs a host round
+  // trip, one more pass and another closing sweep (~0.25 ms at K = 16), a sweep of margin 0.05-0.09 ms.  Measured over 32
+  // steps of the bench workload (profiles/r02_v_batch_shape.txt): margin 0: 6 steps with a second batch, 3.322 ms per step;
+  // 1: none, 3.266; 2: none, 3.325.
+  int sweep_margin = 1;
   bool two_closing = false;      // CWR_TWO_CLOSING=1: round 1's batch shape on one GPU too (even passes + two closing sweeps; A/B)
   bool use_small = true;         // one-workgroup-per-constituent LDS-resident solve for meshes that fit one CU
   double* d_info = nullptr;      // [K][3] results of k_small_jacobi
@@ -914,7 +920,7 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
   double prev_worst = -1.0;
   int prev_sweeps = 0;
   int since_exchange = 0;                     // the caller exchanged the state's halo just before the right-hand side
-  int want = (e->last_sweeps > 0) ? std::max(2, e->last_sweeps) : 8;   // sweeps the next batch should add (prediction, unrounded)
+  int want = (e->last_sweeps > 0) ? std::max(2, e->last_sweeps + e->sweep_margin) : 8;   // sweeps the next batch should add (prediction, unrounded)
   int batch = 0;
   const int sweep_limit = forced ? max_iter : std::min(max_iter, e->jacobi_limit);
   bool sq = false;
@@ -1386,6 +1392,7 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   if (const char* v = getenv("CWR_NO_SQ")) eng->use_sq = atoi(v) == 0;
   if (const char* v = getenv("CWR_NO_SMALL")) eng->use_small = atoi(v) == 0;
   if (const char* v = getenv("CWR_TWO_CLOSING")) eng->two_closing = atoi(v) != 0;
+  if (const char* v = getenv("CWR_SWEEP_MARGIN")) eng->sweep_margin = std::max(0, atoi(v));
   if (const char* v = getenv("CWR_NO_TCL")) eng->use_tcl = atoi(v) == 0;
   // tile-local J^2 applications per pass: each costs LDS time only (measured 15-25 us at K = 16, 4 us at K = 1 on 1 M cells)
   // and cuts the passes from 46 to 28 (x2) / 24 (x3); narrow rows gain from the third application, wide rows do not

@@ -1,0 +1,25 @@
+#!/bin/bash
+# copy the outputs of scratch/r02_final.sh (gpurun_out/final) into profiles/ as the set named $1 (e.g. r02_s)
+P=${1:-r02_s}; F=gpurun_out/final
+cp $F/bench_K16_merged.json profiles/${P}_bench_line.json; cp $F/bench_K1_merged.json profiles/${P}_bench_line_K1.json
+cp $F/bench_K16_quad_r01workload.json profiles/${P}_bench_line_quad_r01_workload_K16.json; cp $F/bench_K1_quad_r01workload.json profiles/${P}_bench_line_quad_r01_workload_K1.json
+cp $F/bench_K16_merged_under_rocprof.json profiles/${P}_bench_line_under_rocprof_K16.json; cp $F/bench_K1_merged_under_rocprof.json profiles/${P}_bench_line_under_rocprof_K1.json
+cat $F/config5.txt $F/ohio_like.txt > profiles/${P}_config5_and_small_meshes.txt
+cp $F/kernel_stats_bench_K16_merged.csv profiles/${P}_kernel_stats_bench_K16.csv; cp $F/kernel_stats_bench_K1_merged.csv profiles/${P}_kernel_stats_bench_K1.csv
+cp $F/pmc_raw_summary.txt profiles/${P}_pmc_raw_summary.txt
+python - $P <<'PY'
+import json, sys, csv
+P = sys.argv[1]
+p = 'profiles/pmc_traffic.json'
+d = json.load(open(p))
+b = json.load(open(f'profiles/{P}_bench_line.json'))['roofline']; b1 = json.load(open(f'profiles/{P}_bench_line_K1.json'))['roofline']
+d['bench_merged_1m'] = {'16': {'read': b['traffic_read'], 'written': b['traffic_written']}, '1': {'read': b1['traffic_read'], 'written': b1['traffic_written']}}
+json.dump(d, open(p, 'w'), indent=1)
+for f in ['bench_line', 'bench_line_K1', 'bench_line_quad_r01_workload_K16', 'bench_line_quad_r01_workload_K1']:
+    d = json.load(open(f'profiles/{P}_{f}.json')); r = d['roofline']
+    print(f, d['value'], d['ms_per_step'], r['avg_launch_us'], r['frac'], r.get('traffic_read'), r.get('traffic_written'), r['achieved'], r.get('frac_kernel_bytes_read'), r.get('achieved_read_plus_write'), (d.get('cpu_baseline') or {}).get('value'), [i['sweeps'] for i in d['solver']['iterations_per_step']][-6:])
+for K in (16, 1):
+    rows = list(csv.DictReader(open(f'profiles/{P}_kernel_stats_bench_K{K}.csv')))
+    tot = sum(float(r['TotalDurationNs']) for r in rows)
+    print(K, [(r['Name'][5:28], r['Calls'], round(float(r['TotalDurationNs']) / tot * 100, 1), round(float(r['AverageNs']) / 1e3, 1)) for r in rows[:7]])
+PY
