@@ -32,9 +32,11 @@ def make_mesh(nx: int, ny: int, n_steps: int, *, seed: int = 0, n_merge: int = 0
               shuffle_window: int = 32, dx: float = 10.0, dy: float = 10.0, depth: float = 2.0,
               dt: float = 10.0, velocity: float = 0.5, unsteady: float = 0.1, period_steps: int = 24,
               eddy: float = 0.3, breathing: float = 0.02, jitter: float = 0.2,
-              diffusion_coefficient: float = 0.1, n_dry: int = 0, steady: bool = False) -> dict:
+              diffusion_coefficient: float = 0.1, n_dry: int = 0, steady: bool = False, n_merge4: int = 0) -> dict:
     """Return a mesh dict (reference variable names) with T = n_steps + 1 time levels.
-    steady=True freezes the field in time (then the reference scheme is exactly conservative)."""
+    steady=True freezes the field in time (then the reference scheme is exactly conservative).
+    n_merge pairs of quads become 6-sided cells; n_merge4 blocks of 2 x 2 quads become 8-sided cells (HEC-RAS allows up to
+    8 faces per cell).  Faces between the same two cells stay separate faces, as in HEC-RAS output."""
     rng = np.random.default_rng(seed)
     if steady:
         unsteady = 0.0
@@ -44,10 +46,26 @@ def make_mesh(nx: int, ny: int, n_steps: int, *, seed: int = 0, n_merge: int = 0
     # ---- base grid: cell (i, j) -> base id j*nx + i ; optional pair merges ------------
     nb = nx * ny
     base_to_cell = np.arange(nb, dtype=np.int64)
+    in_block = np.zeros(nb, dtype=bool)
+    if n_merge4 > 0:
+        # 2 x 2 blocks at even (i, j) never overlap; drawn from a generator of their own so that meshes without them
+        # keep the random stream (and every fixture) they had before the option existed
+        rng4 = np.random.default_rng(seed + 7919)
+        i4, j4 = np.meshgrid(np.arange(0, nx - 1, 2), np.arange(0, ny - 1, 2), indexing='xy')
+        cand4 = (j4 * nx + i4).ravel()
+        if n_merge4 > len(cand4):
+            raise ValueError('n_merge4 too large for this grid')
+        pick4 = rng4.choice(cand4, size=n_merge4, replace=False)
+        for off in (1, nx, nx + 1):
+            base_to_cell[pick4 + off] = pick4
+        for off in (0, 1, nx, nx + 1):
+            in_block[pick4 + off] = True
     if n_merge > 0:
         # candidate pairs ((2m, j), (2m+1, j)) never overlap
         ii, jj = np.meshgrid(np.arange(0, nx - 1, 2), np.arange(ny), indexing='xy')
         cand = (jj * nx + ii).ravel()
+        if n_merge4 > 0:
+            cand = cand[~in_block[cand]]
         if n_merge > len(cand):
             raise ValueError('n_merge too large for this grid')
         pick = rng.choice(cand, size=n_merge, replace=False)

@@ -238,3 +238,32 @@ def test_dense_adjacency_mesh_is_tiled_and_matches_the_oracle(gpu_lib, K, monkey
         assert model.last_step.sweep_kernel == 6 and model.last_step.max_rel_residual <= 1e-12
     for kk, col in enumerate(cols):
         assert rel_err(model.mesh[names[col]], ref.constituent_dict[f'c{kk}'].state) <= TOL_CONC
+
+
+@pytest.mark.parametrize('K,small', [(1, False), (4, False), (16, False), (3, True)])
+def test_meshes_with_eight_sided_cells_match_the_oracle(gpu_lib, K, small, monkeypatch):
+    """HEC-RAS cells have up to 8 faces.  2 x 2 blocks of quads merged into 8-sided cells (two faces towards each
+    neighbour pair, J^2 rows of up to ~24 entries) beside 6-sided and plain cells: the 8-face instantiations of the set-up
+    and sweep kernels (k_sq_numeric<8> with its whole-row vector gathers, the tiled pass's long rows, k_small_jacobi's
+    8-face records) against the oracle's spsolve, fluxes included."""
+    import clearwater_riverine_amd as cw
+    if small:
+        kw = dict(nx=40, ny=30, n_steps=3, seed=31, n_merge=60, n_merge4=50, dt=30.0, diffusion_coefficient=0.2)
+    else:
+        monkeypatch.setenv('CWR_NO_SMALL', '1')
+        kw = dict(nx=120, ny=64, n_steps=3, seed=31, n_merge=500, n_merge4=400, dt=40.0, diffusion_coefficient=0.3)
+    mesh, inputs3 = synthetic_case(K, **kw)
+    n = mesh['nreal'] + 1
+    deg = np.bincount(np.concatenate([mesh['edges_face1'], mesh['edges_face2']]), minlength=len(mesh['face_x']))[:n]
+    assert deg.max() == 8
+    names = [f'c{k}' for k in range(K)]
+    model = cw.ClearwaterRiverine(mesh=dict(mesh), input_arrays={nm: inputs3[:, :, k].copy() for k, nm in enumerate(names)})
+    cols = [0, K - 1] if K > 1 else [0]
+    ref = oracle_run(mesh, inputs3[:, :, cols], 3)
+    for _ in range(3):
+        model.update()
+        assert model.last_step.max_rel_residual <= 1e-12
+        assert model.last_step.sweep_kernel == (7 if small else 6)
+    for kk, col in enumerate(cols):
+        assert rel_err(model.mesh[names[col]], ref.constituent_dict[f'c{kk}'].state) <= TOL_CONC
+        assert flux_err(model.constituent_dict[names[col]].total_mass_flux[:3], ref.constituent_dict[f'c{kk}'].total_mass_flux[:3]) <= 1e-8
