@@ -920,7 +920,10 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
   double prev_worst = -1.0;
   int prev_sweeps = 0;
   int since_exchange = 0;                     // the caller exchanged the state's halo just before the right-hand side
-  int want = (e->last_sweeps > 0) ? std::max(2, e->last_sweeps + e->sweep_margin) : 8;   // sweeps the next batch should add (prediction, unrounded)
+  // sweeps the next batch should add (prediction, unrounded; the margin only where batches come in steps of one or two
+  // sweeps: the even-passes shape rounds up to 2 (mod 4) and has its slack built in)
+  const int margin = (e->comm || e->two_closing) ? 0 : e->sweep_margin;
+  int want = (e->last_sweeps > 0) ? std::max(2, e->last_sweeps + margin) : 8;
   int batch = 0;
   const int sweep_limit = forced ? max_iter : std::min(max_iter, e->jacobi_limit);
   bool sq = false;
