@@ -269,6 +269,18 @@ template <typename T> int download(cwr_engine* e, T* dst, const T* src, size_t c
 
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// Blocks of `fn` (BLOCK threads, `lds` bytes of dynamic LDS) that are resident on a CU at once -- the size of a PERSISTENT grid,
+// whose blocks walk a static share of the work: a block that is not resident from the start runs its share after the others
+// are done.  The occupancy query counts 5 blocks of 32 704 B (tiled pass, K = 1) into the 160 KB of LDS and the hardware
+// places 4: 1 280 blocks took 44.6 us per pass, 1 024 take 35.7 (profiles/r02_r_grid_sweep.txt).  So 2 KB of the LDS are left
+// out of the count.
+int resident_blocks(const void* fn, size_t lds) {
+  int pc = 1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, fn, BLOCK, lds) != hipSuccess || pc < 1) pc = 1;
+  if (lds > 0) pc = std::min(pc, std::max(1, (int)((160 * 1024 - 2048) / ((lds + 511) / 512 * 512))));
+  return pc;
+}
+
 // ---- launches ----------------------------------------------------------------------------------------
 int prep_step(cwr_engine* e, int t) {
   if (e->prepared_t == t) return CWR_OK;
@@ -632,7 +644,7 @@ int ensure_sq_pattern(cwr_engine* e) {
   int per_cu = 1, n_cu = 256;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, e->dev) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, BLOCK, e->apply_lds2) != hipSuccess || per_cu < 1) per_cu = 1;
+  per_cu = resident_blocks(fn, e->apply_lds2);
   per_cu = std::min(per_cu, e->cu_cap);
   e->apply_grid2 = std::max(N_XCD, std::min(cdiv(cdiv(n, TR), N_XCD) * N_XCD, (n_cu * per_cu / N_XCD) * N_XCD));
   if (e->apply_grid2 > std::max(e->apply_grid, 256 * 8)) e->apply_grid2 = std::max(e->apply_grid, 256 * 8);   // partials buffer size
@@ -745,14 +757,7 @@ int ensure_sq_pattern(cwr_engine* e) {
     }
     if (lds <= 64 * 1024 && e->tcl_cfg >= 0 && tr <= BLOCK && (int64_t)max_cols * e->K <= 65535) {
       const void* fn6 = tcl_kernel(e->tcl_vw, e->tcl_cfg);
-      int pc = 1;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, fn6, BLOCK, lds) != hipSuccess || pc < 1) pc = 1;
-      pc = std::min(pc, 8);
-      // The grid is PERSISTENT: every block must be resident from the start, or the late ones run their share of the tiles
-      // after the others are done.  The occupancy query counts 5 blocks of 32 704 B (K = 1) into the 160 KB of LDS and the
-      // hardware places 4: 1 280 blocks took 44.6 us per pass, 1 024 take 35.7 (profiles/r02_r_grid_sweep.txt).  Leave 2 KB
-      // of the LDS out of the count.
-      pc = std::min(pc, std::max(1, (int)((160 * 1024 - 2048) / ((lds + 511) / 512 * 512))));
+      int pc = std::min(resident_blocks(fn6, lds), 8);
       if (const char* v = getenv("CWR_TCL_BLOCKS_PER_CU")) pc = std::max(1, std::min(pc, atoi(v)));
       e->n_tcl = n_t;
       e->tcl_seg = seg; e->tcl_nvmax = nvmax;
@@ -1449,7 +1454,7 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
     const void* fn = (eng->VW == 2) ? reinterpret_cast<const void*>(&k_apply<2, 2>) : reinterpret_cast<const void*>(&k_apply<1, 2>);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, BLOCK, eng->apply_lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    per_cu = resident_blocks(fn, eng->apply_lds);
     per_cu = std::min(per_cu, eng->cu_cap);
     eng->apply_grid = std::max(N_XCD, std::min(cdiv(eng->ntiles, N_XCD) * N_XCD, (n_cu * per_cu / N_XCD) * N_XCD));
   }
