@@ -197,3 +197,20 @@ def test_tile_balanced_numbering_is_a_permutation_that_keeps_the_tiles():
     waves = lambda o: length[o][: n // 16 * 16].reshape(-1, 16).max(axis=1).mean()
     assert waves(bal) < waves(order) - 1.0
     assert np.array_equal(balance_windows(order, f1, f2, window=0), order)
+
+
+def test_synthetic_meshes_with_eight_sided_cells():
+    """synthetic.make_mesh(n_merge4=...): 2 x 2 blocks of quads become 8-sided cells (HEC-RAS's maximum), pair merges avoid
+    them, and meshes built without the option are what they were before it existed (their random stream is untouched)."""
+    import clearwater_riverine_amd as cw
+    m = cw.synthetic.make_mesh(40, 30, 3, seed=9, n_merge=60, n_merge4=50)
+    n = m['nreal'] + 1
+    assert n == 40 * 30 - 60 - 3 * 50
+    deg = np.bincount(np.concatenate([m['edges_face1'], m['edges_face2']]), minlength=len(m['face_x']))[:n]
+    assert np.array_equal(np.bincount(deg, minlength=9)[[4, 6, 8]], [n - 110, 60, 50]) and deg.max() == 8
+    # every face has a real cell on side 1, its ghost (or a different real cell) on side 2
+    assert (m['edges_face1'] <= m['nreal']).all() and (m['edges_face1'] != m['edges_face2']).all()
+    a = cw.synthetic.make_mesh(24, 10, 3, seed=9, n_merge=12, n_dry=1)
+    b = cw.synthetic.make_mesh(24, 10, 3, seed=9, n_merge=12, n_dry=1, n_merge4=0)
+    assert all(np.array_equal(a[k], b[k], equal_nan=True) for k in a if isinstance(a[k], np.ndarray))
+    assert int(np.asarray(a['edges_face1']).sum()) == 57280      # pinned: the generator's stream for existing seeds
