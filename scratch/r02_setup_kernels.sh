@@ -9,7 +9,7 @@ import csv,sys,json
 d=json.load(open(sys.argv[3]))
 print(f"K={sys.argv[2]}: {d['ms_per_step']} ms/step (under the profiler)")
 for r in csv.DictReader(open(sys.argv[1])):
-    if any(k in r['Name'] for k in ('k_prep_step','k_sq_numeric','k_rhs','k_mass_flux','k_sq_tiled','k_apply')):
+    if any(k in r['Name'] for k in ('k_prep_step','k_sq_numeric','k_rhs','k_mass_flux','k_sq_tiled','k_apply',"k_reduce")):
         print(f"   {r['Name'][:44]:44s} calls {r['Calls']:>5s} avg {float(r['AverageNs'])/1e3:8.1f} us")
 PY
 done
