@@ -1362,9 +1362,13 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   // internal face order: ascending smaller cell id (stable), so per-face data of neighbouring cells is contiguous
   std::vector<int32_t> face_orig((size_t)n_edges), face_pos((size_t)n_edges);
   for (int e = 0; e < n_edges; ++e) face_orig[(size_t)e] = e;
-  // (narrow rows keep the reference's order: k_mass_flux writes one output row per face in reference order, and rows
-  // shorter than a 64-byte sector would turn that into a scatter -- measured 23 -> 58 us at K = 1)
-  if (!getenv("CWR_NO_FACE_ORDER") && K * 8 >= 64)
+  // (Round 1 kept the reference's order for rows shorter than a 64-byte sector: k_mass_flux then wrote one output row per
+  // face in reference order, a scatter -- 23 -> 58 us at K = 1.  Since the flux arrays are written in the INTERNAL order and
+  // read out through the face map, the sorted order pays at every K: K = 1 1.025 -> 1.003 ms per step, K = 2 1.174 -> 1.153,
+  // K = 4 1.571 -> 1.555; CWR_FACE_ORDER_MIN_K=8 restores the old threshold.)
+  int face_order_min_k = 1;
+  if (const char* v = getenv("CWR_FACE_ORDER_MIN_K")) face_order_min_k = atoi(v);
+  if (!getenv("CWR_NO_FACE_ORDER") && K >= face_order_min_k)
     std::stable_sort(face_orig.begin(), face_orig.end(), [&](int32_t a, int32_t b) {
       const int ka = (face2[a] < n_real) ? std::min(face1[a], face2[a]) : face1[a];
       const int kb = (face2[b] < n_real) ? std::min(face1[b], face2[b]) : face1[b];
