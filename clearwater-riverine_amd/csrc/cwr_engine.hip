@@ -1408,7 +1408,11 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   if (const char* v = getenv("CWR_NO_TCL")) eng->use_tcl = atoi(v) == 0;
   // tile-local J^2 applications per pass: each costs LDS time only (measured 15-25 us at K = 16, 4 us at K = 1 on 1 M cells)
   // and cuts the passes from 46 to 28 (x2) / 24 (x3); narrow rows gain from the third application, wide rows do not
-  eng->local_reps = (K <= 4) ? 3 : 2;
+  // two everywhere (round 1 ran three at K <= 4).  Same box, ms per step at 2 / 3 / 4 applications (profiles/r02_w_local_reps.txt):
+  // K = 1 1.007 / 1.011 / 1.096, K = 2 1.150 / 1.146 / 1.260, K = 4 1.476 / 1.555 / 1.745, K = 8 2.162 / 2.265 / 2.598, K = 16 3.64-3.67 / 3.786 / 4.234
+  // (small meshes at narrow K keep three: their passes are a single round of tiles, bound by its latency, and an application
+  // more is nearly free -- 8 000 cells, K = 1, CFL 18: 110 sweeps and 0.53 ms per step with three, 226 and 0.57 with two)
+  eng->local_reps = (K <= 4 && n_owned < 100000) ? 3 : 2;
   if (const char* v = getenv("CWR_LOCAL_REPS")) eng->local_reps = std::max(1, std::min(16, atoi(v)));
   eng->nt_stream = (K >= 8) ? 1 : 0;
   if (const char* v = getenv("CWR_NT_STREAM")) eng->nt_stream = atoi(v) != 0;
