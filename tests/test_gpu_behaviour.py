@@ -362,3 +362,33 @@ def test_persistent_grid_size_of_the_tiled_pass_does_not_change_the_result(gpu_l
         if knob:
             monkeypatch.delenv(knob)
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
+@pytest.mark.parametrize('K', [1, 16])
+def test_batch_shapes_agree_and_the_one_sweep_shape_never_ends_outside_the_state_vector(gpu_lib, monkeypatch, K):
+    """One GPU: a batch is N J^2 passes + one closing sweep, its parity fixed by starting from the kept copy of x_t
+    (csrc solve_jacobi); CWR_TWO_CLOSING=1 is round 1's shape (even passes + two sweeps).  Both must give the oracle's
+    answer; with exact passes (CWR_LOCAL_REPS=1) every iterate is a plain Jacobi iterate, so the two runs differ only by
+    how many sweeps they took and agree to the solver tolerance; odd and even sweep counts both occur."""
+    from clearwater_riverine_amd.distributed import PartitionedTransport
+    monkeypatch.setenv('CWR_NO_SMALL', '1')
+    monkeypatch.setenv('CWR_LOCAL_REPS', '1')
+    mesh, inputs3 = synthetic_case(K, nx=120, ny=60, n_steps=6, seed=37, n_merge=150, dt=40.0, diffusion_coefficient=0.5)
+    n = mesh['nreal'] + 1
+    runs = {}
+    for shape in ('one', 'two'):
+        if shape == 'two':
+            monkeypatch.setenv('CWR_TWO_CLOSING', '1')
+        pt = PartitionedTransport(mesh, inputs3, 0, 1, renumber='hilbert')
+        res = [pt.step(t, tol=1e-12, solver='jacobi') for t in range(6)]
+        assert all(r.max_rel_residual <= 1e-12 and r.sweep_kernel == 6 for r in res)
+        runs[shape] = (pt.gather_state(), [r.sweeps for r in res])
+    assert all(s % 2 == 0 for s in runs['two'][1])                      # even passes + two sweeps
+    assert any(s % 2 == 1 for s in runs['one'][1])                      # N passes + one sweep
+    assert sum(runs['one'][1]) <= sum(runs['two'][1])
+    ref = oracle.OracleModel(mesh, {f'c{k}': inputs3[:, :, k].copy() for k in range(K)})
+    for _ in range(6):
+        ref.update()
+    want = np.stack([ref.constituent_dict[f'c{k}'].state[6, :n] for k in range(K)], axis=1)
+    for shape in runs:
+        assert rel_err(runs[shape][0], want) <= 1e-9
