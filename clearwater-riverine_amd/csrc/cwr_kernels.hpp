@@ -894,7 +894,10 @@ __global__ void __launch_bounds__(BLOCK, CWR_TCL_WAVES) k_sq_tiled(
   // and pass them round with DPP, a quarter of the LDS instructions for them: exact pass 95.7 -> 91.6 us, three applications
   // 135 -> 131 us, but the default two applications 103.5 -> 106.9 us (three DPP moves and an exec branch per entry).
   // And two entries per trip without padding (odd entry handled after the loop): 105 -> 139 us at K = 16, 65 -> 89 at K = 8,
-  // 38 -> 57 at K = 1 (same box, alternating libraries, scratch/r02_ab.sh): the one-entry loop stays.)
+  // 38 -> 57 at K = 1 (same box, alternating libraries, scratch/r02_ab.sh): the one-entry loop stays.
+  // And the lightest form -- only the NEXT entry's (position, weight) asked for one trip ahead, through inline asm because
+  // hipcc rotates a C version back: 104.2 -> 109.3 us at K = 16, 90.0 -> 92.6 at K = 12, 65.3 -> 67.0 at K = 8, 30.6 -> 31.1
+  // at K = 1.  The two dependent LDS round trips per entry are not what the pass waits for.)
   auto row_sum = [&](int j0, int j1, double (&sum)[VW]) {
 #pragma unroll
     for (int w = 0; w < VW; ++w) sum[w] = 0.0;
