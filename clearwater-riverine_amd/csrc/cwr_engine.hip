@@ -452,7 +452,7 @@ int launch_rhs(cwr_engine* e, int t, const double* x, double* b, bool scale, dou
   const double* bc_n = e->d_bc + (size_t)(t + 1) * e->n_ghost * e->K;
   const int used = (e->D != 0.0) ? 1 : 0;
 #define CWR_RHS(VWv, SC) k_rhs<VWv, SC><<<grid, BLOCK, 0, e->stream>>>(e->n_owned, e->K, e->G, e->d_ptr, e->d_ent_edge, \
-    e->d_ent_nb, vol_t, e->dt[t], vel_n, adv_n, dif_n, used, bc_n, x, e->d_diag, e->d_row_ghost, b, e->d_counters, keep)
+    e->d_ent_nb, vol_t, e->dt[t], vel_n, adv_n, dif_n, used, bc_n, x, e->d_diag, e->d_row_ghost, b, e->d_counters, keep, e->n_real, e->n_ghost)
   if (e->VW == 2) { if (scale) CWR_RHS(2, true); else CWR_RHS(2, false); }
   else            { if (scale) CWR_RHS(1, true); else CWR_RHS(1, false); }
 #undef CWR_RHS
@@ -1486,8 +1486,9 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   CREATE_TRY(dev_alloc(eng, &eng->d_s, nK));
   CREATE_TRY(dev_alloc(eng, &eng->d_t, nK));
   CREATE_TRY(dev_alloc(eng, &eng->d_b, nK));
-  CREATE_TRY(dev_alloc(eng, &eng->d_scal, eng->scal_count()));
-  CREATE_TRY(dev_alloc(eng, &eng->d_counters, (size_t)8));
+  // (the 8 step counters live behind the solver scalars: one memset clears both at the start of a step)
+  CREATE_TRY(dev_alloc(eng, &eng->d_scal, eng->scal_count() + 4));
+  eng->d_counters = reinterpret_cast<int32_t*>(eng->d_scal + eng->scal_count());
   CREATE_TRY(dev_alloc(eng, &eng->d_partial, (size_t)std::max(eng->apply_grid, 256 * 8) * 4 * K));
   if (getenv("CWR_VERBOSE")) fprintf(stderr, "[cwr] K=%d VW=%d G=%d U=%d tiles=%d stage_cap=%d lds=%zu grid=%d\n", K, eng->VW, eng->G, eng->U, eng->ntiles, eng->stage_cap, eng->apply_lds, eng->apply_grid);
   CREATE_TRY(upload(eng, eng->d_f1, f1p.data(), (size_t)n_edges));
@@ -1510,8 +1511,7 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   CREATE_HIP(hipMemsetAsync(eng->d_c, 0, (size_t)n_cells * K * sizeof(double), eng->stream));
   for (double* v : {eng->d_r, eng->d_r0, eng->d_p, eng->d_v, eng->d_s, eng->d_t, eng->d_b})
     CREATE_HIP(hipMemsetAsync(v, 0, nK * sizeof(double), eng->stream));
-  CREATE_HIP(hipMemsetAsync(eng->d_scal, 0, eng->scal_count() * sizeof(double), eng->stream));
-  CREATE_HIP(hipMemsetAsync(eng->d_counters, 0, 8 * sizeof(int32_t), eng->stream));
+  CREATE_HIP(hipMemsetAsync(eng->d_scal, 0, (eng->scal_count() + 4) * sizeof(double), eng->stream));
   CREATE_HIP(hipStreamSynchronize(eng->stream));
 #undef CREATE_TRY
 #undef CREATE_HIP
@@ -1540,7 +1540,7 @@ void cwr_destroy(cwr_engine* e) {
   for (hipEvent_t ev : e->ev) hipEventDestroy(ev);
   void* ptrs[] = {e->d_f1, e->d_f2, e->d_ptr, e->d_ent_edge, e->d_ent_nb, e->d_adv, e->d_vel, e->d_vol, e->d_dif,
                   e->d_bc, e->d_rec, e->d_diag, e->d_c, e->d_r, e->d_r0, e->d_p, e->d_v, e->d_s, e->d_t, e->d_b,
-                  e->d_scal, e->d_counters, e->d_partial, e->d_fadv, e->d_fdif, e->d_ftot, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf, e->d_ptr2, e->d_col2, e->d_row2, e->d_rec2, e->d_w, e->d_react, e->d_info, e->d_tcl_ptr, e->d_tcl_cols, e->d_loc2, e->d_w2, e->d_pair_ptr, e->d_slots, e->d_line_ptr, e->d_line_faces, e->d_ledger, e->d_mass_out, e->d_chk, e->d_face_orig, e->d_row_ghost, e->d_keep, e->d_in_rows, e->d_in_vals, e->d_face_pos, e->d_trow, e->d_vptr, e->d_meta, e->d_tile_inner, e->d_tile_outer, e->d_chkx, e->d_sq_fast};
+                  e->d_scal, e->d_partial, e->d_fadv, e->d_fdif, e->d_ftot, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf, e->d_ptr2, e->d_col2, e->d_row2, e->d_rec2, e->d_w, e->d_react, e->d_info, e->d_tcl_ptr, e->d_tcl_cols, e->d_loc2, e->d_w2, e->d_pair_ptr, e->d_slots, e->d_line_ptr, e->d_line_faces, e->d_ledger, e->d_mass_out, e->d_chk, e->d_face_orig, e->d_row_ghost, e->d_keep, e->d_in_rows, e->d_in_vals, e->d_face_pos, e->d_trow, e->d_vptr, e->d_meta, e->d_tile_inner, e->d_tile_outer, e->d_chkx, e->d_sq_fast};
   for (void* p : ptrs) if (p) hipFree(p);
   if (e->stream) hipStreamDestroy(e->stream);
   delete e;
@@ -1777,18 +1777,14 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
     return fail(e, CWR_ERR_GHOST_COEFF, "active ghost face with a zero advection/diffusion coefficient at level t+1 "
                 "(the reference raises a shape-mismatch ValueError, linalg.py:349-351)");
   TRY(prep_step(e, t));
-  HIP_TRY(e, hipMemsetAsync(e->d_counters, 0, 8 * sizeof(int32_t), e->stream));
-  HIP_TRY(e, hipMemsetAsync(e->d_scal, 0, e->scal_count() * sizeof(double), e->stream));
+  HIP_TRY(e, hipMemsetAsync(e->d_scal, 0, (e->scal_count() + 4) * sizeof(double), e->stream));   // (+ the counters behind them)
   // the inner halo layers need x_t for their right-hand sides; the exchange that closed the previous step (for its face
   // fluxes) already delivered it unless the state was touched in between.  Every rank makes the same calls, so every
   // rank takes the same branch.
   // (a caller holding the state pointer may have rewritten the state since: then the exchange is never skipped)
   if (!e->halo_fresh || e->ptr_exported) TRY(exchange_halo(e, e->d_c));
   e->halo_fresh = false;
-  // keep x_t (k_rhs writes the computed rows aside) and the ghost rows: a failed solve restores them
-  if (e->n_ghost > 0)
-    HIP_TRY(e, hipMemcpyAsync(e->d_keep + (size_t)e->n_real * K, e->d_c + (size_t)e->n_real * K, (size_t)e->n_ghost * K * sizeof(double),
-                              hipMemcpyDeviceToDevice, e->stream));
+  // keep x_t and the ghost rows (k_rhs writes both aside): a failed solve restores them
   TRY(launch_rhs(e, t, e->d_c, e->d_b, true, e->d_keep));
   const bool has_inputs = e->in_levels.count(t + 1) != 0;   // the tail writes real rows then: it must not run speculatively
   SolveStats st;

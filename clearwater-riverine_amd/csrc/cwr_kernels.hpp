@@ -385,7 +385,7 @@ __global__ void __launch_bounds__(BLOCK) k_rhs(
     const float* __restrict__ vel_n, const float* __restrict__ adv_n, const double* __restrict__ dif_n,
     int use_diffusion, const double* __restrict__ bc_n, const double* __restrict__ x,
     const double* __restrict__ diag, const uint8_t* __restrict__ row_ghost, double* __restrict__ b,
-    int32_t* __restrict__ counters, double* __restrict__ x_keep) {
+    int32_t* __restrict__ counters, double* __restrict__ x_keep, int keep_from, int keep_rows) {
   const int R = BLOCK / G;
   const int r = threadIdx.x / G, g = threadIdx.x - r * G;
   if (r >= R) return;
@@ -433,6 +433,15 @@ __global__ void __launch_bounds__(BLOCK) k_rhs(
     if (bad) out[w] = __builtin_nan("");
   }
   stv<VW>(b + (size_t)c * K + col, out);
+  }
+  // the ghost rows of the state as the step found them (rows keep_from ...): kept with x_t for a failed step
+  if (x_keep) {
+    const int col2 = g * VW;
+    for (int c = keep_from + blockIdx.x * R + r; c < keep_from + keep_rows; c += gridDim.x * R) {
+      double v[VW];
+      ldv<VW>(x + (size_t)c * K + col2, v);
+      stv<VW>(x_keep + (size_t)c * K + col2, v);
+    }
   }
 }
 
