@@ -93,6 +93,92 @@ def pmc_traffic(which: str, K: int, kernel: str = 'k_sq_tiled'):
     return int(2 * out['FETCH_SIZE'] * 1024), int(out['WRITE_SIZE'] * 1024)
 
 
+def _profiler_active() -> bool:
+    """True when this process already runs under rocprofv3 (its tool library is preloaded): the counter passes below are
+    themselves rocprofv3 children and must not be nested into a traced run."""
+    pre = os.environ.get('LD_PRELOAD', '')
+    return ('rocprofiler' in pre or 'rocprofv3' in pre or any(k.startswith(('ROCPROFILER_', 'ROCPROF_', 'ROCP_TOOL')) for k in os.environ))
+
+
+def launch_ranks(n: int, argv: list[str], timeout_s: float = 1500.0) -> int:
+    """`python bench.py --gpus N` without a launcher: THIS process (which has not imported torch or touched the GPU) starts
+    N children of the same command line, one per GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set --
+    what `python -m torch.distributed.run --nproc-per-node N` would have set --, relays rank 0's JSON line, reaps every
+    child and returns non-zero when any child failed (the others are then terminated: no orphan waits in a collective).
+    The reference has no launcher to mirror (its K-loop is serial, transport.py:231-249)."""
+    import signal
+    import socket
+    import subprocess
+    with socket.socket() as s:                              # a free loopback port for the control plane
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    script = os.environ.get('CWR_BENCH_CHILD', os.path.abspath(__file__))     # (tests substitute a stub child)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), LOCAL_WORLD_SIZE=str(n), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, script] + argv, env=env, start_new_session=True,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    line, rc = None, 0
+    deadline = time.monotonic() + timeout_s
+
+    def stop_all():
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGTERM)
+                except OSError:
+                    pass
+        t_end = time.monotonic() + 10.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                p.wait()
+
+    try:
+        import selectors
+        sel = selectors.DefaultSelector()
+        sel.register(procs[0].stdout, selectors.EVENT_READ)
+        out_open = True
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad:
+                rc = bad[0] if bad[0] > 0 else 1
+                break
+            if all(c == 0 for c in codes) and not out_open:
+                break
+            if time.monotonic() > deadline:
+                print(f'bench.py: ranks still running after {timeout_s:.0f} s, stopping them', file=sys.stderr)
+                rc = 124
+                break
+            if out_open:
+                for key, _ in sel.select(timeout=0.2):
+                    ln = key.fileobj.readline()
+                    if ln == '':
+                        sel.unregister(key.fileobj)
+                        out_open = False
+                    elif ln.lstrip().startswith('{'):
+                        line = ln.rstrip('\n')
+                    else:
+                        sys.stderr.write(ln)
+            else:
+                time.sleep(0.05)
+    finally:
+        stop_all()
+    if rc == 0 and line is None:
+        print('bench.py: rank 0 ended without a result line', file=sys.stderr)
+        rc = 1
+    if rc == 0:
+        print(line, flush=True)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -119,18 +205,23 @@ def main():
     ap.add_argument('--no-pmc', action='store_true', help='skip the two rocprofv3 counter passes that measure roofline.traffic')
     ap.add_argument('--cpu-budget-s', type=float, default=100.0, help='wall-clock budget of the CPU baseline leg')
     ap.add_argument('--cpu-steps', type=int, default=3)
+    ap.add_argument('--windows', type=int, default=5,
+                    help='the timed region (EXACTLY --steps steps between two barriers) is repeated this many times from the same '
+                         'start state; value / ms_per_step are the MEDIAN window, every window is listed in the line')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher (nothing below has run: no torch import, no GPU call)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     if world != args.gpus:
-        if args.gpus > 1:
-            sys.exit(f'--gpus {args.gpus} needs one process per GPU: launch with torch.distributed.run '
-                     f'--nproc-per-node {args.gpus} (WORLD_SIZE is {world})')
+        sys.exit(f'--gpus {args.gpus} but WORLD_SIZE is {world}: one process per GPU (torch.distributed.run --nproc-per-node '
+                 f'{args.gpus}, or plain `python bench.py --gpus {args.gpus}`, which starts the ranks itself)')
     # roofline.traffic, measured in this run (children of a process that has NOT initialised the GPU yet)
     live_traffic = None
-    if rank == 0 and world == 1 and not args.no_pmc and args.solver == 'auto' and not (args.nx or args.ny):
+    if rank == 0 and world == 1 and not args.no_pmc and args.solver == 'auto' and not (args.nx or args.ny) and not _profiler_active():
         live_traffic = pmc_traffic(args.mesh, args.constituents)
     import torch                                       # device plumbing + control plane only
     import torch.distributed as dist
@@ -185,18 +276,27 @@ def main():
     for t in range(args.warmup):
         pt.step(t, tol=args.tol, mass_flux=True, solver=args.solver)
     saved = eng.get_state()[: pt.local.n_core].copy()       # state at the start of the timed region
-    barrier()
-    t0 = time.perf_counter()
-    for t in range(args.warmup, args.warmup + args.steps):
-        r = pt.step(t, tol=args.tol, mass_flux=True, solver=args.solver)
-        iters.append({'sweeps': r.sweeps, 'bicgstab': r.iterations})
-    barrier()
-    elapsed = time.perf_counter() - t0
+    # The timed region -- barrier, EXACTLY --steps steps, barrier -- is repeated --windows times from the same start state
+    # (restored outside the timed region); every window takes the MAX over the ranks, the line reports the median window.
+    windows = []
+    for w in range(max(1, args.windows)):
+        if w > 0:
+            eng.set_state(saved)
+        iters = []
+        barrier()
+        t0 = time.perf_counter()
+        for t in range(args.warmup, args.warmup + args.steps):
+            r = pt.step(t, tol=args.tol, mass_flux=True, solver=args.solver)
+            iters.append({'sweeps': r.sweeps, 'bicgstab': r.iterations})
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        windows.append(el)
     max_resid = r.max_rel_residual
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = float(np.median(windows))
 
     # ---- roofline of the dominant kernel (the face-flux operator), HIP events on the engine's stream ----
     roofline = None
@@ -272,6 +372,9 @@ def main():
             'metric': 'Mcell-updates/s', 'value': round(value, 2), 'unit': 'Mcell-updates/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1000.0 * elapsed / args.steps, 3), 'higher_is_better': True,
+            'windows': {'n': len(windows), 'statistic': 'median', 'ms_per_step': [round(1000.0 * w / args.steps, 3) for w in windows],
+                        'value_min': round(n * K * args.steps / max(windows) / 1e6, 2),
+                        'value_max': round(n * K * args.steps / min(windows) / 1e6, 2)},
             'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': f'synthetic {mesh_name} ({n} cells, {len(mesh["edges_face1"])} faces), {K} '
                                    f'{"distinct " if args.inputs == "distinct" and K > 1 else ""}constituents, implicit upwind '

@@ -105,6 +105,7 @@ struct cwr_engine {
   // (Jacobi's a-posteriori bound |e| <= rho/(1-rho) |x'-x|), i.e. forward error <= 1e-6 |x| + 1e-12 max|x| at tol = 1e-12
   bool ew_enabled = true;
   double ew_rel = 0.0, ew_abs = 0.0;
+  std::vector<double> jnorm;     // per level t: ||J||_inf of step t's Jacobi iteration matrix (k_jnorm, when the flow field is loaded)
   int info_flags = 0;            // CWR_INFO_* bits of the step in progress
   bool ptr_exported = false;     // cwr_state_device_ptr handed the state out: the caller may rewrite it at any time
   // real-cell entries of input_array (levels >= 1): applied to the solved level before the mass fluxes
@@ -319,10 +320,10 @@ int launch_apply(cwr_engine* e, const double* xin, double* yout, const double* r
   }
   if (e->VW == 2)
     k_apply<2, MODE><<<grid, BLOCK, lds, e->stream>>>(row0, rows, e->n_core, e->K, e->G, e->U, ntiles, cap, e->nt_stream,
-        ptr, rec, e->d_diag, xin, yout, r0, bhat, r0_out, p_out, e->d_partial, e->ew_rel, e->tcl_seg);
+        ptr, rec, e->d_diag, xin, yout, r0, bhat, r0_out, p_out, e->d_partial, e->d_chk + 4 * (size_t)e->K, e->tcl_seg);
   else
     k_apply<1, MODE><<<grid, BLOCK, lds, e->stream>>>(row0, rows, e->n_core, e->K, e->G, e->U, ntiles, cap, e->nt_stream,
-        ptr, rec, e->d_diag, xin, yout, r0, bhat, r0_out, p_out, e->d_partial, e->ew_rel, e->tcl_seg);
+        ptr, rec, e->d_diag, xin, yout, r0, bhat, r0_out, p_out, e->d_partial, e->d_chk + 4 * (size_t)e->K, e->tcl_seg);
   e->last_apply_grid = grid;
   HIP_TRY(e, hipGetLastError());
   if (e1) HIP_TRY(e, hipEventRecord(e1, e->stream));
@@ -452,7 +453,8 @@ int launch_rhs(cwr_engine* e, int t, const double* x, double* b, bool scale, dou
   const double* bc_n = e->d_bc + (size_t)(t + 1) * e->n_ghost * e->K;
   const int used = (e->D != 0.0) ? 1 : 0;
 #define CWR_RHS(VWv, SC) k_rhs<VWv, SC><<<grid, BLOCK, 0, e->stream>>>(e->n_owned, e->K, e->G, e->d_ptr, e->d_ent_edge, \
-    e->d_ent_nb, vol_t, e->dt[t], vel_n, adv_n, dif_n, used, bc_n, x, e->d_diag, e->d_row_ghost, b, e->d_counters, keep, e->n_real, e->n_ghost)
+    e->d_ent_nb, vol_t, e->dt[t], vel_n, adv_n, dif_n, used, bc_n, x, e->d_diag, e->d_row_ghost, b, e->d_counters, keep, e->n_real, e->n_ghost, \
+    e->d_chk + 4 * (size_t)e->K, e->ew_rel)
   if (e->VW == 2) { if (scale) CWR_RHS(2, true); else CWR_RHS(2, false); }
   else            { if (scale) CWR_RHS(1, true); else CWR_RHS(1, false); }
 #undef CWR_RHS
@@ -534,6 +536,52 @@ int check_ghost_levels(cwr_engine* e) {
   }
   if (rc == CWR_OK) rc = download(e, e->bad_level.data(), d_flags, (size_t)T);
   return rc;
+}
+
+int sync_jnorms(cwr_engine* e);
+// ||J||_inf of every step the loaded flow field allows (see k_jnorm); jnorm[T-1] = 0 (no step starts at the last level)
+int compute_jnorms(cwr_engine* e) {
+  const int T = e->T;
+  e->jnorm.assign((size_t)std::max(T, 0), 0.0);
+  if (T < 2) return CWR_OK;
+  DevTmp<unsigned long long> t_jn; DevTmp<double> t_dt;
+  TRY(dev_alloc(e, &t_jn.p, (size_t)T));
+  TRY(dev_alloc(e, &t_dt.p, (size_t)T));
+  HIP_TRY(e, hipMemsetAsync(t_jn.p, 0, (size_t)T * sizeof(unsigned long long), e->stream));
+  TRY(upload(e, t_dt.p, e->dt.data(), (size_t)T));
+  for (int t0 = 0; t0 < T - 1; t0 += 32768) {                   // (gridDim.y <= 65535)
+    const int nt = std::min(32768, T - 1 - t0);
+    k_jnorm<<<dim3((unsigned)cdiv(e->n_owned, BLOCK), (unsigned)nt), BLOCK, 0, e->stream>>>(
+        e->n_owned, e->E, e->n_cells, e->d_ptr, e->d_ent_edge, e->d_ent_nb, e->d_adv + (size_t)t0 * e->E, e->d_dif + (size_t)t0 * e->E,
+        e->d_vol + (size_t)t0 * e->n_cells, t_dt.p + t0, t_jn.p + t0);
+    HIP_TRY(e, hipGetLastError());
+  }
+  static_assert(sizeof(unsigned long long) == sizeof(double), "bit patterns");
+  TRY(download(e, reinterpret_cast<unsigned long long*>(e->jnorm.data()), t_jn.p, (size_t)T));
+  return sync_jnorms(e);
+}
+
+// Partitioned engines: every rank's norms become the maximum over the ranks (the element-wise rule of the GLOBAL matrix, as a
+// single engine would apply it).  One sum all-reduce: every rank adds its values in its own slot of a (world x T) block that is
+// zero elsewhere, and the host takes the maximum over the slots (cf. gather_check).  Collective: every rank calls it at the
+// same point -- when the flow field is loaded with a communicator attached, or when the communicator is attached to an
+// engine that already holds a flow field.
+int sync_jnorms(cwr_engine* e) {
+  if (!e->comm || e->world <= 1 || e->T <= 0 || e->jnorm.size() != (size_t)e->T) return CWR_OK;
+  const size_t T = (size_t)e->T, W = (size_t)e->world;
+  DevTmp<double> buf;
+  TRY(dev_alloc(e, &buf.p, W * T));
+  HIP_TRY(e, hipMemsetAsync(buf.p, 0, W * T * sizeof(double), e->stream));
+  HIP_TRY(e, hipMemcpyAsync(buf.p + (size_t)e->rank * T, e->jnorm.data(), T * sizeof(double), hipMemcpyHostToDevice, e->stream));
+  TRY(allreduce(e, buf.p, W * T));
+  std::vector<double> all(W * T);
+  TRY(download(e, all.data(), buf.p, W * T));
+  for (size_t t = 0; t < T; ++t) {
+    double m = 0.0;
+    for (size_t r = 0; r < W; ++r) { const double v = all[r * T + t]; m = (v != v) ? INFINITY : std::max(m, v); }
+    e->jnorm[t] = m;
+  }
+  return CWR_OK;
 }
 
 // Rows (lane-group slots) of a tile of the tiled pass for K constituents -- also what cwr_tile_rows tells a host wrapper that
@@ -1326,7 +1374,7 @@ int solve_bicgstab(cwr_engine* e, double tol2, int max_iter, SolveStats& st) {
 // ====================================================================================================
 extern "C" {
 
-int32_t cwr_abi_version(void) { return 3; }
+int32_t cwr_abi_version(void) { return 4; }
 
 int32_t cwr_tile_rows(int32_t n_constituents) {
   if (n_constituents < 1 || n_constituents > 256) return 0;
@@ -1475,7 +1523,8 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   CREATE_TRY(dev_alloc(eng, &eng->d_rec, (size_t)nnz));
   CREATE_TRY(dev_alloc(eng, &eng->d_diag, (size_t)n_owned));
   CREATE_TRY(dev_alloc(eng, &eng->d_w, (size_t)nnz + SQN_PAD));
-  CREATE_TRY(dev_alloc(eng, &eng->d_chk, 4 * (size_t)K));
+  CREATE_TRY(dev_alloc(eng, &eng->d_chk, 4 * (size_t)K + 2));      // (+ ew_rel, read by k_apply MODE 4)
+  CREATE_HIP(hipMemset(eng->d_chk, 0, (4 * (size_t)K + 2) * sizeof(double)));
   CREATE_TRY(dev_alloc(eng, &eng->d_keep, (size_t)n_cells * K));
   if (const char* v = getenv("CWR_NO_ELEMENTWISE")) eng->ew_enabled = atoi(v) == 0;
   CREATE_TRY(dev_alloc(eng, &eng->d_c, (size_t)n_cells * K));
@@ -1577,7 +1626,8 @@ int32_t cwr_load_flow_field(cwr_engine* e, int32_t T, const float* face_flow, co
   if (rc != CWR_OK) { e->T = 0; return rc; }
   e->dt.assign(dt, dt + T);
   e->D = D;
-  return check_ghost_levels(e);
+  TRY(check_ghost_levels(e));
+  return compute_jnorms(e);
 }
 
 int32_t cwr_load_coefficients(cwr_engine* e, int32_t T, const float* adv, const double* dif, const float* vel,
@@ -1604,7 +1654,8 @@ int32_t cwr_load_coefficients(cwr_engine* e, int32_t T, const float* adv, const 
   TRY(upload(e, e->d_vol, volume, (size_t)T * e->n_cells));
   e->dt.assign(dt, dt + T);
   e->D = D;
-  return check_ghost_levels(e);
+  TRY(check_ghost_levels(e));
+  return compute_jnorms(e);
 }
 
 int32_t cwr_get_coefficients(cwr_engine* e, int32_t t, float* adv, double* dif) {
@@ -1762,10 +1813,17 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
   e->tail_done = false;
   e->info_flags = 0;
   {
-    // element-wise rule: targets (1e6 tol, tol) = (1e-6, 1e-12) at the default tolerance, scaled by s = 0.3 (1-rho)/rho
-    // (clamped to [1e-3, 0.1]) so that Jacobi's a-posteriori bound |e| <= rho/(1-rho) |x'-x| keeps the forward error inside them
-    const double rho = (e->last_rate > 0.0 && e->last_rate < 1.0) ? e->last_rate : 0.9;
-    const double sc = std::min(0.1, std::max(1.0e-3, 0.3 * (1.0 - rho) / rho));
+    // element-wise rule: targets (1e6 tol, tol) = (1e-6, 1e-12) at the default tolerance, scaled by s = 0.3 (1 - rho) / rho with
+    // rho = ||J||_inf of THIS step's iteration matrix (exact, from the flow field: k_jnorm) -- Jacobi's a-posteriori bound
+    // ||x* - x'||_inf <= rho / (1 - rho) ||x' - x||_inf then keeps the forward error within 0.3 (1e6 tol + tol) max|x| in the
+    // max norm, rigorously.  (Round 2 used the measured 2-norm contraction of an earlier check, which is not a bound.)
+    // s is kept within [1e-3, 0.1]: below 1e-3 (rho > 0.9967, CFL of several hundred) |x' - x| would have to fall under the
+    // rounding of a sweep; the step then runs at s = 1e-3 and says so: CWR_INFO_ELEMENTWISE_CLAMPED.
+    double rho = ((size_t)t < e->jnorm.size()) ? e->jnorm[(size_t)t] : 1.0;
+    if (!(rho >= 0.0) || rho >= 1.0) rho = 1.0 - 1.0e-9;
+    const double s_raw = (rho > 0.0) ? 0.3 * (1.0 - rho) / rho : 0.1;
+    const double sc = std::min(0.1, std::max(1.0e-3, s_raw));
+    if (e->ew_enabled && s_raw < 1.0e-3) e->info_flags |= CWR_INFO_ELEMENTWISE_CLAMPED;
     e->ew_rel = sc * std::min(1.0e-2, 1.0e6 * tol);
     e->ew_abs = sc * tol;
   }
@@ -1878,6 +1936,20 @@ int32_t cwr_get_mass_flux(cwr_engine* e, double* adv, double* dif, double* tot) 
     HIP_TRY(e, hipGetLastError());
     TRY(download(e, outs[q], tmp.p, cnt));
   }
+  return CWR_OK;
+}
+
+int32_t cwr_get_jacobi_norms(cwr_engine* e, int32_t n_times, double* norms) {
+  if (!e || !norms) return e ? fail(e, CWR_ERR_BAD_ARG, "cwr_get_jacobi_norms: NULL") : CWR_ERR_BAD_ARG;
+  if (n_times != e->T || e->jnorm.size() != (size_t)e->T) return fail(e, CWR_ERR_STATE, "cwr_get_jacobi_norms: n_times must be the number of loaded levels");
+  std::copy(e->jnorm.begin(), e->jnorm.end(), norms);
+  return CWR_OK;
+}
+
+int32_t cwr_set_jacobi_norms(cwr_engine* e, int32_t n_times, const double* norms) {
+  if (!e || !norms) return e ? fail(e, CWR_ERR_BAD_ARG, "cwr_set_jacobi_norms: NULL") : CWR_ERR_BAD_ARG;
+  if (n_times != e->T || e->T <= 0) return fail(e, CWR_ERR_STATE, "cwr_set_jacobi_norms: n_times must be the number of loaded levels");
+  e->jnorm.assign(norms, norms + n_times);
   return CWR_OK;
 }
 
@@ -2196,7 +2268,7 @@ int32_t cwr_attach_comm(cwr_engine* e, int32_t rank, int32_t world, const uint8_
   HIP_TRY(e, hipStreamCreateWithFlags(&e->comm_stream, hipStreamNonBlocking));
   HIP_TRY(e, hipEventCreateWithFlags(&e->ev_packed, hipEventDisableTiming));
   HIP_TRY(e, hipEventCreateWithFlags(&e->ev_halo, hipEventDisableTiming));
-  return CWR_OK;
+  return sync_jnorms(e);
 }
 
 int32_t cwr_comm_selftest(cwr_engine* e, int32_t count, int64_t* overlapped_exchanges) {

@@ -374,6 +374,46 @@ __global__ void __launch_bounds__(BLOCK) k_check_ghost_levels(
   }
 }
 
+// ||J||_inf of every loaded level: jn[t] = max over the computed rows of sum_j w[j] = (sum over faces with a real neighbour of
+// (d - min(a_c, 0))) / diag, the coefficients k_prep_step forms for step t (a, d of level t; V of level t+1).  The exact
+// max-norm contraction of the Jacobi iteration x <- J x + bhat, so ||x* - x'||_inf <= jn / (1 - jn) ||x' - x||_inf: what the
+// element-wise stopping rule is scaled by (cwr_step).  A property of the flow field: evaluated once when it is loaded.
+// grid (row blocks, T - 1); non-negative doubles order like their bit patterns, so the fold is an integer atomicMax.
+__global__ void __launch_bounds__(BLOCK) k_jnorm(
+    int n_owned, int E, int n_cells, const int32_t* __restrict__ ptr, const int32_t* __restrict__ ent_edge,
+    const int32_t* __restrict__ ent_nb, const float* __restrict__ adv, const double* __restrict__ dif,
+    const float* __restrict__ vol, const double* __restrict__ dt, unsigned long long* __restrict__ jn) {
+  __shared__ double s_m[BLOCK / 64];
+  const int t = blockIdx.y;
+  const int c = blockIdx.x * BLOCK + threadIdx.x;
+  double rho = 0.0;
+  if (c < n_owned) {
+    const float* adv_t = adv + (size_t)t * E;
+    const double* dif_t = dif + (size_t)t * E;
+    const double vn = (double)vol[(size_t)(t + 1) * n_cells + c];
+    double dg = vn / dt[t] + (vn == 0.0 ? 1.0 : 0.0), off = 0.0;
+    const int j1 = ptr[c + 1];
+    for (int j = ptr[c]; j < j1; ++j) {
+      const int code = ent_edge[j];
+      const float a = adv_t[code >> 1];
+      const double d = dif_t[code >> 1];
+      const double a_c = (code & 1) ? -(double)a : (double)a;
+      dg += d + fmax(a_c, 0.0);
+      if (ent_nb[j] >= 0) off += d - fmin(a_c, 0.0);
+    }
+    rho = off / dg;
+    if (!(rho >= 0.0)) rho = INFINITY;               // NaN in the field: no bound
+  }
+  for (int o = 32; o >= 1; o >>= 1) rho = fmax(rho, __shfl_xor(rho, o, 64));
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = rho;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double m = s_m[0];
+    for (int w = 1; w < BLOCK / 64; ++w) m = fmax(m, s_m[w]);
+    atomicMax(jn + t, (unsigned long long)__double_as_longlong(m));
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ a-3
 // b[c,k] = V[t,c]*x[c,k]/dt + G_in[c,k] + G_out[c,k]; boundary terms from level t+1, selected by the
 // sign of edge_velocity[t+1]; the highest active ghost-face id of a cell wins in each set
@@ -385,9 +425,11 @@ __global__ void __launch_bounds__(BLOCK) k_rhs(
     const float* __restrict__ vel_n, const float* __restrict__ adv_n, const double* __restrict__ dif_n,
     int use_diffusion, const double* __restrict__ bc_n, const double* __restrict__ x,
     const double* __restrict__ diag, const uint8_t* __restrict__ row_ghost, double* __restrict__ b,
-    int32_t* __restrict__ counters, double* __restrict__ x_keep, int keep_from, int keep_rows) {
+    int32_t* __restrict__ counters, double* __restrict__ x_keep, int keep_from, int keep_rows, double* __restrict__ ew_out, double ew_val) {
   const int R = BLOCK / G;
   const int r = threadIdx.x / G, g = threadIdx.x - r * G;
+  // this step's relative element-wise tolerance, for every MODE 4 sweep that follows (k_apply reads it from memory)
+  if (ew_out && blockIdx.x == 0 && threadIdx.x == 0) ew_out[0] = ew_val;
   if (r >= R) return;
   const int col = g * VW;
   for (int c = blockIdx.x * R + r; c < n_owned; c += gridDim.x * R) {      // grid-stride: a block works many row groups
@@ -482,8 +524,11 @@ __global__ void __launch_bounds__(BLOCK, CWR_APPLY_MIN_WAVES) k_apply(
     int row0, int n_owned, int n_dot, int K, int G, int U, int ntiles, int stage_cap, int nt, const int32_t* __restrict__ ptr,
     const FaceRec* __restrict__ rec, const double* __restrict__ diag, const double* __restrict__ xin,
     double* __restrict__ yout, const double* __restrict__ r0, const double* __restrict__ bhat,
-    double* __restrict__ r0_out, double* __restrict__ p_out, double* __restrict__ partial, double ew_rel, int seg) {
+    double* __restrict__ r0_out, double* __restrict__ p_out, double* __restrict__ partial, const double* __restrict__ ew_p, int seg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+  // ew_rel lives in device memory (written by k_rhs at the start of every step): these launches are captured into hipGraphs
+  // that later steps replay, and a by-value argument would freeze the value of the step that captured them
+  const double ew_rel = (MODE == 4) ? ew_p[0] : 0.0;
   FaceRec* s_rec = reinterpret_cast<FaceRec*>(s_dyn);
   double* s_red = reinterpret_cast<double*>(s_dyn + (size_t)stage_cap * sizeof(FaceRec));
   int32_t* s_ptr = reinterpret_cast<int32_t*>(s_red + red_doubles(G, VW));

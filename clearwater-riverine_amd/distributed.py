@@ -48,21 +48,42 @@ def auto_halo_depth(n_real_cells: int, world: int) -> int:
 
 def shared_hilbert_order(mesh: dict, n: int, rank: int, world: int, K: int = 16) -> np.ndarray:
     """order[new id] = reference id along the Hilbert curve: computed by rank 0 and broadcast when a torch.distributed
-    group is up (the sort is the only global O(n log n) step of the set-up), computed locally otherwise."""
+    group is up (the sort is the only global O(n log n) step of the set-up), computed locally otherwise.
+    A failure on rank 0 (out of memory in the sparse product, library not built, bad mesh) reaches every rank: a status
+    word travels first, so the others raise instead of waiting in the broadcast."""
+    group_up = False
     if world > 1:
         try:
             import torch
             import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size() == world:
-                dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
-                t = torch.empty(n, dtype=torch.int64, device=dev)
-                if dist.get_rank() == 0:
-                    t.copy_(torch.from_numpy(_curve_order(mesh, n, K)))
-                dist.broadcast(t, src=0)
-                return t.cpu().numpy()
-        except ImportError:
-            pass
-    return _curve_order(mesh, n, K)
+            group_up = dist.is_available() and dist.is_initialized() and dist.get_world_size() == world
+        except ImportError:                                   # (no torch on ANY rank of this job: all compute locally)
+            group_up = False
+    if not group_up:
+        return _curve_order(mesh, n, K)
+    if dist.get_rank() != rank:
+        raise ValueError(f'shared_hilbert_order: rank argument {rank} is not this process\'s rank {dist.get_rank()}')
+    dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+    status = torch.zeros(1, dtype=torch.int64, device=dev)
+    order, err = None, None
+    if rank == 0:
+        try:
+            order = np.ascontiguousarray(_curve_order(mesh, n, K), dtype=np.int64)
+            if order.shape != (n,):
+                raise ValueError(f'curve order has shape {order.shape}, expected {(n,)}')
+            status[0] = 1
+        except Exception as ex:                               # noqa: BLE001 -- whatever it was, the other ranks must hear of it
+            err = ex
+    dist.broadcast(status, src=0)
+    if int(status.item()) != 1:
+        if err is not None:
+            raise err
+        raise RuntimeError('shared_hilbert_order: rank 0 failed to compute the cell order (see its traceback)')
+    t = torch.empty(n, dtype=torch.int64, device=dev)
+    if rank == 0:
+        t.copy_(torch.from_numpy(order))
+    dist.broadcast(t, src=0)
+    return t.cpu().numpy()
 
 
 def _curve_order(mesh: dict, n: int, K: int) -> np.ndarray:
@@ -126,8 +147,24 @@ class PartitionedTransport:
                 raise ValueError('world > 1 needs the RCCL unique id broadcast from rank 0')
             self.engine.attach_comm(rank, world, unique_id, lm.peers, lm.send_ptr, lm.send_cells, lm.recv_ptr,
                                     lm.recv_cells, n_core=lm.n_core, exchange_every=lm.depth)
+            # (attach_comm also makes every rank's ||J||_inf values the maximum over the ranks: the element-wise stopping rule
+            # is then the one of the global matrix, as on one GPU -- cwr_get_jacobi_norms)
         # initial condition of the owned cells (row 0 of input_array, constituents.py:94-98)
-        self.engine.set_state(np.ascontiguousarray(inputs3[0, ref_cells[:lm.n_core], :]))
+        core_ref = ref_cells[:lm.n_core]
+        self.engine.set_state(np.ascontiguousarray(inputs3[0, core_ref, :]))
+        # non-zero input_array entries on REAL cells at levels >= 1 (point sources / fixed concentrations inside the domain):
+        # the reference writes them into the solved level before the mass fluxes and uses them as x_t of the next step
+        # (transport.py:258-264, linalg.py:199-200); every rank loads the entries of the cells it owns
+        lvs, ces, vas = [], [], []
+        for t in range(1, inputs3.shape[0]):
+            if not inputs3[t, :n].any():                          # (one contiguous scan per level; the usual case: nothing)
+                continue
+            blk = np.asarray(inputs3[t, core_ref, :])
+            ce = np.nonzero(np.any(blk != 0, axis=1))[0]
+            if len(ce):
+                lvs.append(np.full(len(ce), t, dtype=np.int32)); ces.append(ce); vas.append(blk[ce])
+        if lvs:
+            self.engine.load_real_inputs(np.concatenate(lvs), np.concatenate(ces), np.concatenate(vas))
 
     def step(self, t: int, **kw):
         return self.engine.step(t, **kw)

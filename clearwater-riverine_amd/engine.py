@@ -32,12 +32,14 @@ STEP_MASS_BALANCE = 16
 
 INFO_LOOSE_RESIDUAL = 1        # BiCGSTAB stagnated within 100 x tol and was accepted
 INFO_ELEMENTWISE_MISSED = 2    # the element-wise rule was still violated after the tightened BiCGSTAB rounds
+INFO_ELEMENTWISE_CLAMPED = 4   # ||J||_inf so close to 1 that the rule's scale was held at 1e-3 (bound weaker by 1e-3 / s)
 
 # every symbol include/cwr_transport.h declares (tests check that the library exports them all)
 ABI_SYMBOLS = (
     'cwr_abi_version', 'cwr_tile_rows', 'cwr_create', 'cwr_destroy', 'cwr_last_error', 'cwr_load_flow_field',
     'cwr_load_coefficients', 'cwr_get_coefficients', 'cwr_load_boundary', 'cwr_set_boundary_level',
     'cwr_set_state', 'cwr_get_state', 'cwr_load_real_inputs', 'cwr_react_linear', 'cwr_state_device_ptr', 'cwr_apply', 'cwr_rhs', 'cwr_step', 'cwr_get_mass_flux',
+    'cwr_get_jacobi_norms', 'cwr_set_jacobi_norms',
     'cwr_time_apply', 'cwr_profile_read', 'cwr_synchronize', 'cwr_apply_bytes',
     'cwr_comm_unique_id', 'cwr_attach_comm', 'cwr_comm_selftest',
     'cwr_set_boundary_lines', 'cwr_reset_mass_balance', 'cwr_get_mass_balance', 'cwr_domain_mass',
@@ -108,6 +110,8 @@ def load_library(path: str | None = None) -> C.CDLL:
         'cwr_rhs': [vp, i32, vp, vp],
         'cwr_step': [vp, i32, f64, i32, i32, P(StepInfo)],
         'cwr_get_mass_flux': [vp, vp, vp, vp],
+        'cwr_get_jacobi_norms': [vp, i32, vp],
+        'cwr_set_jacobi_norms': [vp, i32, vp],
         'cwr_time_apply': [vp, i32, i32, i32, P(f64)],
         'cwr_profile_read': [vp, P(C.c_int64), P(f64)],
         'cwr_synchronize': [vp],
@@ -360,9 +364,22 @@ class TransportEngine:
                 what.append(f'BiCGSTAB stagnated at a relative residual of {info.max_rel_residual:.2e} (> tol = {tol:.1e}) and was accepted')
             if info.flags & INFO_ELEMENTWISE_MISSED:
                 what.append('the element-wise convergence rule was not met (the norm criterion holds)')
+            if info.flags & INFO_ELEMENTWISE_CLAMPED:
+                what.append('||J||_inf of this step is above 0.9967: the scale of the element-wise rule was held at 1e-3, its '
+                            'max-norm error bound is weaker by 1e-3 / (0.3 (1 - ||J||) / ||J||)')
             warnings.warn(f'transport step {t}: ' + '; '.join(what), RuntimeWarning, stacklevel=2)
         return StepResult(info.iterations, info.sweeps, info.restarts, info.operator_launches, info.solver,
                           info.max_rel_residual, info.solve_ms, info.sweep_kernel, info.flags)
+
+    def jacobi_norms(self) -> np.ndarray:
+        """(T,) ||J||_inf of the Jacobi iteration matrix of every step of the loaded flow field (last entry 0)."""
+        out = np.empty(self.n_times, np.float64)
+        self._check(self._lib.cwr_get_jacobi_norms(self._h, self.n_times, _ptr(out)))
+        return out
+
+    def set_jacobi_norms(self, norms):
+        v = _arr(norms, np.float64, (self.n_times,), 'norms')
+        self._check(self._lib.cwr_set_jacobi_norms(self._h, self.n_times, _ptr(v)))
 
     def get_mass_flux(self):
         shape = (self.n_edges, self.K)

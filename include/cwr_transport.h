@@ -71,8 +71,11 @@ typedef struct cwr_step_info {
 /* bits of cwr_step_info.flags */
 enum {
   CWR_INFO_LOOSE_RESIDUAL = 1,     /* BiCGSTAB stagnated within 100 x tol after 6 verified restarts and was accepted */
-  CWR_INFO_ELEMENTWISE_MISSED = 2  /* the element-wise rule |x'-x| <= 1e6 tol |x| + tol max|x| (scaled, see cwr_step) was still
+  CWR_INFO_ELEMENTWISE_MISSED = 2, /* the element-wise rule |x'-x| <= 1e6 tol |x| + tol max|x| (scaled, see cwr_step) was still
                                       violated after 3 tightened BiCGSTAB rounds; the norm criterion holds */
+  CWR_INFO_ELEMENTWISE_CLAMPED = 4 /* ||J||_inf of this step is so close to 1 (> 0.9967: CFL of several hundred) that the scale of the
+                                      element-wise rule, s = 0.3 (1 - ||J||_inf) / ||J||_inf, fell below 1e-3 and was held there: the
+                                      max-norm forward-error bound of cwr_step is then 0.3 (1e6 tol + tol) max|x| x (1e-3 / s) */
 };
 
 int32_t cwr_abi_version(void);
@@ -175,9 +178,13 @@ int32_t cwr_rhs(cwr_engine* e, int32_t t, const double* x_t, double* b);
  * tol: target for ||D^-1 (b - A x)||_2 / ||D^-1 b||_2 per constituent (e.g. 1e-12); max_iter bounds
  * sweeps and BiCGSTAB iterations each.  info may be NULL.
  * On top of the norm criterion every cell and constituent must satisfy |x'_i - x_i| <= s (1e6 tol |x'_i| + tol max|x'|)
- * for one more Jacobi sweep x -> x', s = 0.3 (1 - rho) / rho from the measured contraction rho (clamped to
- * [1e-3, 0.1]): with Jacobi's a-posteriori bound the forward error then stays within 1e-6 |x_i| + 1e-12 max|x| at
- * tol = 1e-12 -- also for plume fronts many decades below the peak, which a 2-norm cannot see.
+ * for one more Jacobi sweep x -> x', s = 0.3 (1 - rho) / rho with rho = ||J||_inf of this step's Jacobi iteration matrix
+ * (exact, from the flow field: cwr_get_jacobi_norms), kept within [1e-3, 0.1].  Jacobi's a-posteriori bound
+ * ||x* - x'||_inf <= rho / (1 - rho) ||x' - x||_inf then gives a RIGOROUS max-norm forward error of 0.3 (1e6 tol + tol) max|x|
+ * (3e-7 of the largest concentration at tol = 1e-12); that every cell is also within 1e-6 of ITS OWN value down to the
+ * 1e-12 max|x| floor -- plume fronts many decades below the peak, which a 2-norm cannot see -- is what the per-cell form of
+ * the rule buys empirically (tests: element-wise against spsolve output up to CFL 180).  When s would fall below 1e-3 the
+ * step runs at 1e-3 and sets CWR_INFO_ELEMENTWISE_CLAMPED.
  * A step that fails (CWR_ERR_NOT_CONVERGED, CWR_ERR_NONFINITE, CWR_ERR_GHOST_COEFF) leaves the state exactly as it
  * found it: it may be retried with another tolerance, iteration budget or solver.
  * The call returns as soon as convergence is known: the ghost write-back and flux kernels that close the step may still
@@ -188,6 +195,15 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
 /* The three (n_edges, K) arrays of the last step taken with CWR_STEP_MASS_FLUX
  * (advection, diffusion, total: transport.py:419-429).  Any pointer may be NULL. */
 int32_t cwr_get_mass_flux(cwr_engine* e, double* advection, double* diffusion, double* total);
+/* ||J||_inf of the Jacobi iteration matrix J = I - D^-1 A of every step the loaded flow field allows: norms[t] for step t
+ * (t = 0 .. T-2; norms[T-1] = 0), the largest row sum of |offd| / diag over this engine's computed rows -- evaluated on the
+ * device when the flow field is loaded.  It scales the element-wise stopping rule of cwr_step (see there).  A partitioned
+ * engine holds the MAXIMUM over the ranks (one all-reduce when the communicator is attached / a flow field is loaded with
+ * a communicator attached: collective calls), so that all ranks apply the rule of the global matrix -- the one a single
+ * engine would apply.  cwr_set_jacobi_norms overrides the values (a caller with bounds of its own).
+ * (No reference counterpart: spsolve is direct, transport.py:249.) */
+int32_t cwr_get_jacobi_norms(cwr_engine* e, int32_t n_times, double* norms);
+int32_t cwr_set_jacobi_norms(cwr_engine* e, int32_t n_times, const double* norms);
 
 /* ---- measurement --------------------------------------------------------------------------------
  * cwr_time_apply: `reps` back-to-back launches of the operator of level t on device-resident vectors,

@@ -3,10 +3,10 @@
 set -o pipefail
 tag=$1; shift
 export TMPDIR=/tmp
-CWR_VERBOSE=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline "$@" > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
+CWR_VERBOSE=1 python bench.py --no-pmc --steps 10 --warmup 3 --no-cpu-baseline "$@" > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 grep '\[cwr\]' gpurun_out/${tag}_bench.err | sort | uniq -c > gpurun_out/${tag}_verbose.txt
 rm -rf /tmp/prof_$tag
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o run -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline "$@" > gpurun_out/${tag}_bench_under_rocprof.json 2> /tmp/prof_$tag.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o run -- python3 bench.py --no-pmc --steps 10 --warmup 3 --no-cpu-baseline "$@" > gpurun_out/${tag}_bench_under_rocprof.json 2> /tmp/prof_$tag.err
 find /tmp/prof_$tag -type f | head -20
 f=$(find /tmp/prof_$tag -name '*kernel_stats*' | head -1)
 [ -n "$f" ] && cp "$f" gpurun_out/${tag}_kernel_stats.csv && head -14 gpurun_out/${tag}_kernel_stats.csv | cut -c1-230

@@ -38,6 +38,12 @@ def make_case(K):
     else:
         mesh = cw.synthetic.make_mesh(48, 20, 4, seed=21, n_merge=60, shuffle_window=16, n_dry=2)
     inputs3 = cw.synthetic.boundary_input_array(mesh, K)
+    if os.environ.get('CWR_TEST_SOURCES'):       # point sources: non-zero input_array entries on REAL cells at levels >= 1
+        n = mesh['nreal'] + 1
+        rng = np.random.default_rng(11)
+        src = rng.choice(n, size=9, replace=False)
+        inputs3[1:3, src[:5], 0] = 250.0
+        inputs3[2, src[4:], K - 1] = 40.0 + rng.random(5)
     return mesh, inputs3
 
 
@@ -257,3 +263,37 @@ def test_state_rewritten_through_the_device_pointer_between_partitioned_steps(gp
         assert not np.isnan(state).any()
         outs[route] = state
     assert np.array_equal(outs['set_state'], outs['pointer'])
+
+
+@pytest.mark.parametrize('world,K,depth', [(1, 3, 1), (2, 3, 4), (3, 16, 8)])
+def test_partitioned_real_cell_inputs_follow_the_reference(gpu_lib, world, K, depth, monkeypatch):
+    """PartitionedTransport (the class bench.py and every multi-rank run go through) used to drop non-zero
+    input_array entries on real cells at levels >= 1 (transport.py:258-264, linalg.py:199-200) without a word -- also with one
+    rank.  Every rank now loads the entries of the cells it owns; state and fluxes must match the oracle."""
+    build_mock()
+    monkeypatch.setenv('CWR_NO_SMALL', '1')
+    monkeypatch.setenv('CWR_TEST_SOURCES', '1')
+    mesh, inputs3 = make_case(K)
+    n = mesh['nreal'] + 1
+    assert np.count_nonzero(inputs3[1:, :n, :]) > 0
+    state = np.full((n, K), np.nan)
+    tot = np.full((len(mesh['edges_face1']), K), np.nan)
+    if world == 1:
+        from clearwater_riverine_amd.distributed import PartitionedTransport
+        pt = PartitionedTransport(mesh, inputs3, 0, 1)
+        for t in range(3):
+            pt.step(t, tol=1e-12, mass_flux=True)
+        state[:] = pt.gather_state()
+        tot[:] = pt.engine.get_mass_flux()[2]
+    else:
+        for r in run_ranks(world, _rank_main, (K, 'auto', depth)):
+            state[r[1]] = r[3]
+            tot[r[4]] = r[5]
+    oracle.derive_coefficients(mesh)
+    ref = oracle.OracleModel(mesh, {f'c{k}': inputs3[:, :, k].copy() for k in range(K)})
+    for _ in range(3):
+        ref.update()
+    want = np.stack([ref.constituent_dict[f'c{k}'].state[3, :n] for k in range(K)], axis=1)
+    assert rel_err(state, want) <= 1e-9
+    want_flux = np.stack([ref.constituent_dict[f'c{k}'].total_mass_flux[2] for k in range(K)], axis=1)
+    assert flux_err(tot, want_flux) <= 1e-8

@@ -153,3 +153,89 @@ def test_real_cell_inputs_at_later_levels_follow_the_reference(gpu_lib, nx, ny):
         for got, want in ((model.constituent_dict[nm].advection_mass_flux, ref.constituent_dict[nm].advection_mass_flux),
                           (model.constituent_dict[nm].total_mass_flux, ref.constituent_dict[nm].total_mass_flux)):
             assert flux_err(got[:steps], want[:steps]) <= 1e-8
+
+
+def _oracle_jacobi_norm(mesh, t):
+    """||J||_inf of step t from the oracle's literal matrix: max over rows of sum_{j != i} |A_ij| / A_ii."""
+    lhs = oracle.LHS(mesh)
+    lhs.update_values(mesh, t)
+    A = lhs.csr().tocsr()
+    d = A.diagonal()
+    off = abs(A).sum(axis=1).A1 - np.abs(d)
+    return float(np.max(off / d))
+
+
+def test_jacobi_norms_of_the_loaded_flow_field_match_the_oracle_matrix(gpu_lib):
+    """cwr_get_jacobi_norms (k_jnorm, evaluated when the flow field is loaded) against the duplicate-bearing COO matrix of
+    linalg.py:34-156 assembled by the oracle: the number that scales the element-wise rule is the exact max-norm
+    contraction of the Jacobi iteration, not a measured rate."""
+    import clearwater_riverine_amd as cw
+    mesh, inputs3 = distinct_case(2, nx=60, ny=24, n_steps=5, seed=4, n_merge=70, n_dry=2, dt=120.0, diffusion_coefficient=0.4)
+    eng = make_engine(mesh, inputs3)
+    got = eng.jacobi_norms()
+    assert got.shape == (6,) and got[-1] == 0.0
+    for t in range(5):
+        want = _oracle_jacobi_norm(mesh, t)
+        assert 0.0 < want < 1.0
+        assert got[t] == pytest.approx(want, rel=1e-12)
+    eng.close()
+
+
+@pytest.mark.parametrize('dt,expect_clamp', [(2000.0, False), (20000.0, True)])
+def test_plume_fronts_in_the_stiff_regime_and_the_clamp_flag(gpu_lib, dt, expect_clamp):
+    """the element-wise rule at CFL >= 100.  dt = 2000 s on 10 m cells at 0.5 m/s is CFL 100 (||J||_inf ~ 0.99):
+    the scale s = 0.3 (1 - rho) / rho is inside [1e-3, 0.1], no flag, and every cell of the plume constituents -- fronts
+    many decades below the peak included -- is within 1e-6 of ITS OWN spsolve value.  dt = 20 000 s (CFL 1000,
+    ||J||_inf > 0.9967): the scale is held at 1e-3 and the step says so (CWR_INFO_ELEMENTWISE_CLAMPED -> RuntimeWarning)."""
+    import warnings
+    import clearwater_riverine_amd as cw
+    K, steps = 4, 2
+    mesh, inputs3 = distinct_case(K, nx=200, ny=40, n_steps=steps, seed=3, n_merge=400, dt=dt, diffusion_coefficient=0.5,
+                                  breathing=0.0)
+    names = [f'c{k}' for k in range(K)]
+    ref = oracle_run(mesh, inputs3, steps)
+    n = mesh['nreal'] + 1
+    eng = make_engine(mesh, inputs3)
+    rho = eng.jacobi_norms()[:steps]
+    assert (rho > 0.9967).all() if expect_clamp else ((rho > 0.98).all() and (rho < 0.9967).all())
+    eng.set_state(inputs3[0, :n, :])
+    flags = []
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter('always')
+        for t in range(steps):
+            flags.append(eng.step(t, tol=1e-12, max_iter=200000).flags)
+    clamped = [bool(f & cw.engine.INFO_ELEMENTWISE_CLAMPED) for f in flags]
+    assert all(clamped) if expect_clamp else not any(flags)
+    assert bool(seen) == expect_clamp                     # the wrapper never swallows a tolerance decision
+    got = eng.get_state()
+    for k, nm in enumerate(names):
+        want = ref.constituent_dict[nm].state[steps]
+        if expect_clamp:                                  # the rigorous part of the rule: max-norm forward error
+            assert rel_err(got[:, k], want, ew_rtol=1e-4, ew_atol=1e-9) <= 1e-6
+        else:
+            assert rel_err(got[:, k], want) <= 1e-9       # element-wise 1e-6 |b| + 1e-12 max|b|
+    eng.close()
+
+
+def test_tolerance_changed_between_steps_of_one_engine(gpu_lib, monkeypatch):
+    """the batch graphs are captured once and replayed by later steps; the relative element-wise tolerance used to
+    be a by-value kernel argument frozen into them.  Loose steps (tol = 1e-8) capture the graphs, then the same engine is
+    asked for tol = 1e-12 from an exact state: the fronts must meet the element-wise bar against spsolve."""
+    import clearwater_riverine_amd as cw
+    monkeypatch.setenv('CWR_NO_SMALL', '1')
+    K, steps = 4, 5
+    mesh, inputs3 = distinct_case(K, nx=200, ny=40, n_steps=steps, seed=3, n_merge=400, dt=40.0, diffusion_coefficient=0.5)
+    n = mesh['nreal'] + 1
+    ref = oracle_run(mesh, inputs3, steps)
+    eng = make_engine(mesh, inputs3)
+    eng.set_state(inputs3[0, :n, :])
+    for t in range(steps - 1):
+        assert eng.step(t, tol=1e-8).max_rel_residual <= 1e-8
+    exact = np.stack([ref.constituent_dict[f'c{k}'].state[steps - 1, :n] for k in range(K)], axis=1)
+    eng.set_state(exact)
+    r = eng.step(steps - 1, tol=1e-12)
+    assert r.max_rel_residual <= 1e-12 and r.flags == 0
+    got = eng.get_state()
+    for k in range(K):
+        assert rel_err(got[:, k], ref.constituent_dict[f'c{k}'].state[steps]) <= 1e-9
+    eng.close()
