@@ -110,6 +110,7 @@ struct cwr_engine {
   bool ptr_exported = false;     // cwr_state_device_ptr handed the state out: the caller may rewrite it at any time
   // real-cell entries of input_array (levels >= 1): applied to the solved level before the mass fluxes
   std::map<int, std::pair<int, int>> in_levels;   // level -> (first entry, count)
+  std::vector<char> in_any;                       // partitioned engines: level has real-cell inputs on SOME rank (sync_input_levels)
   int32_t* d_in_rows = nullptr;
   double* d_in_vals = nullptr;
   bool tail_done = false;        // the step's tail (step_tail) was enqueued speculatively and the check then passed
@@ -147,6 +148,7 @@ struct cwr_engine {
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_packed = nullptr, ev_halo = nullptr;
   bool overlap = true;
+  bool test_poison_halo = false;                // CWR_TEST_POISON_HALO=1 (tests): NaN every halo row of both vectors in front of an overlapped exchange
   int overlap_reserve = 8 * N_XCD;              // block slots an overlapped interior launch leaves to the communication kernels
   int n_tile_inner = 0, n_tile_outer = 0;
   int32_t *d_tile_inner = nullptr, *d_tile_outer = nullptr;
@@ -193,6 +195,21 @@ struct cwr_engine {
   int32_t* d_meta = nullptr;                      // per tile: its rows' ptr2 entries, then the codes of its virtual items
   uint16_t* d_loc2 = nullptr;    // local (in-tile) column of every J^2 entry: 16 bits (a tile holds < 65 536 x rows)
   double* d_w2 = nullptr;
+  // chained in-place passes (single GPU): a schedule [sched_depth][tcl_grid] of tile ids (-1 = end of a block's list); every
+  // block walks chains of tiles linked along the flow of the level the schedule was built for
+  int32_t* d_sched = nullptr;
+  int sched_depth = 0, sched_cap = 0;
+  bool use_chains = true;
+  bool sched_user = false;                 // installed by cwr_set_tile_schedule: never rebuilt by the engine
+  int sched_level = -1, sched_refresh = 64; // level the schedule was built for; rebuilt when the step is this many levels away
+  int cur_t = 0;                           // level of the step in progress
+  // static link structure of the tiles (built with the tiling): directed links (src tile -> dst tile) with their face entries
+  std::vector<int32_t> h_edge;             // host copy of ent_edge (face index << 1 | side per adjacency entry)
+  std::vector<int32_t> link_src, link_dst;
+  int n_links = 0;
+  int32_t *d_link_ptr = nullptr, *d_link_ent = nullptr;
+  float* d_link_flux = nullptr;
+  int64_t n_sched_builds = 0;
   std::map<int, hipGraphExec_t> batch_exec;   // whole-batch graphs by number of passes (see solve_jacobi)
   int batch_last = -1;
   hipGraph_t tcl_graph = nullptr;
@@ -584,6 +601,25 @@ int sync_jnorms(cwr_engine* e) {
   return CWR_OK;
 }
 
+// Partitioned engines: a level at which ANY rank has real-cell inputs is taken non-speculatively by EVERY rank -- the step's
+// tail holds a collective exchange, so all ranks must take the same path.  One sum all-reduce of a 0/1 vector over the levels;
+// collective (every rank calls cwr_load_real_inputs, also with zero entries; or attaches its communicator afterwards).
+int sync_input_levels(cwr_engine* e) {
+  e->in_any.clear();
+  if (!e->comm || e->world <= 1 || e->T <= 0) return CWR_OK;
+  const size_t T = (size_t)e->T + 1;
+  std::vector<double> flags(T, 0.0);
+  for (const auto& kv : e->in_levels) if (kv.first >= 0 && (size_t)kv.first < T) flags[(size_t)kv.first] = 1.0;
+  DevTmp<double> buf;
+  TRY(dev_alloc(e, &buf.p, T));
+  TRY(upload(e, buf.p, flags.data(), T));
+  TRY(allreduce(e, buf.p, T));
+  TRY(download(e, flags.data(), buf.p, T));
+  e->in_any.assign(T, 0);
+  for (size_t t = 0; t < T; ++t) e->in_any[t] = flags[t] > 0.0 ? 1 : 0;
+  return CWR_OK;
+}
+
 // Rows (lane-group slots) of a tile of the tiled pass for K constituents -- also what cwr_tile_rows tells a host wrapper that
 // wants to arrange its cell numbering in tiles (ordering.balance_windows).
 int tile_rows_for(int K, bool* four_wide) {
@@ -865,6 +901,138 @@ int ensure_sq_pattern(cwr_engine* e) {
   return CWR_OK;
 }
 
+// ---- chained passes: the tile schedule along the flow --------------------------------------------------------------------
+// The tiled pass is a persistent grid whose blocks each walk a list of tiles.  Walked in the default order and ping-ponging
+// between two vectors it is a block-Jacobi iteration between tiles: information crosses a tile per pass.  Here the tiles are
+// linked into CHAINS along the flow of one time level -- tile t -> the neighbour tile u that takes most of t's outflow, kept
+// when u's largest inflow comes from t -- and every block walks chains IN PLACE, so that a tile reads what its upstream
+// neighbour of the same chain has just written: block Gauss-Seidel along the flow, with no block ever waiting for another
+// (the order only decides how fresh the values a tile reads are: a schedule built for another flow direction costs passes,
+// never correctness; Chazan-Miranker: converges whenever rho(|J|) < 1).  tests/models/chain_gs_probe.py is the numpy model,
+// clearwater-riverine_amd/schedule.py the numpy specification of this builder (compared in tests/test_gpu_chains.py).
+// Measured on the 1 M-cell bench mesh x 16: 57 -> 43-47 sweep equivalents per step at CFL 2.5, 502 -> 181 at CFL 25 with four
+// tile-local applications (profiles/r03_c_chained_passes.txt).
+int build_tile_links(cwr_engine* e) {
+  if (e->n_links > 0 || !e->tcl_ready || e->tcl_seg < (1 << 20)) return CWR_OK;     // (fixed-size tiles only: tile = row / TR)
+  const int TR = e->tcl_TR, n = e->n_tcl;
+  struct Ent { int64_t key; int32_t code; };
+  std::vector<Ent> ents;
+  const int nt = e->tcl_ntiles;
+  for (int c = 0; c < n; ++c)
+    for (int j = e->h_ptr[c]; j < e->h_ptr[c + 1]; ++j) {
+      const int m = e->h_nb[j];
+      if (m < 0 || m >= n || m / TR == c / TR) continue;
+      ents.push_back({(int64_t)(c / TR) * nt + (m / TR), e->h_edge[(size_t)j]});       // flow leaving c's side of the face
+    }
+  std::stable_sort(ents.begin(), ents.end(), [](const Ent& a, const Ent& b) { return a.key < b.key; });
+  std::vector<int32_t> lptr(1, 0), lent(ents.size());
+  e->link_src.clear(); e->link_dst.clear();
+  for (size_t i = 0; i < ents.size(); ++i) {
+    if (i == 0 || ents[i].key != ents[i - 1].key) {
+      if (i > 0) lptr.push_back((int32_t)i);
+      e->link_src.push_back((int32_t)(ents[i].key / nt)); e->link_dst.push_back((int32_t)(ents[i].key % nt));
+    }
+    lent[i] = ents[i].code;
+  }
+  lptr.push_back((int32_t)ents.size());
+  e->n_links = (int)e->link_src.size();
+  if (e->n_links == 0) return CWR_OK;
+  TRY(dev_alloc(e, &e->d_link_ptr, lptr.size()));
+  TRY(dev_alloc(e, &e->d_link_ent, lent.size()));
+  TRY(dev_alloc(e, &e->d_link_flux, (size_t)e->n_links));
+  TRY(upload(e, e->d_link_ptr, lptr.data(), lptr.size()));
+  TRY(upload(e, e->d_link_ent, lent.data(), lent.size()));
+  return CWR_OK;
+}
+
+// chains -> schedule [depth][grid], -1 padded (see schedule.py: the same construction)
+void chains_to_schedule(int nt, int grid, const std::vector<int32_t>& nxt, std::vector<int32_t>& sched, int& depth) {
+  std::vector<char> has_prev((size_t)nt, 0), seen((size_t)nt, 0);
+  for (int t = 0; t < nt; ++t) if (nxt[(size_t)t] >= 0) has_prev[(size_t)nxt[(size_t)t]] = 1;
+  std::vector<std::vector<int32_t>> chains;
+  auto walk = [&](int start) {
+    if (seen[(size_t)start]) return;
+    std::vector<int32_t> ch;
+    for (int c = start; c >= 0 && !seen[(size_t)c]; c = nxt[(size_t)c]) { seen[(size_t)c] = 1; ch.push_back(c); }
+    chains.push_back(std::move(ch));
+  };
+  for (int t = 0; t < nt; ++t) if (!has_prev[(size_t)t]) walk(t);           // heads first,
+  for (int t = 0; t < nt; ++t) walk(t);                                      // then whatever sits on a cycle
+  std::stable_sort(chains.begin(), chains.end(), [](const std::vector<int32_t>& a, const std::vector<int32_t>& b) { return a[0] < b[0]; });
+  std::vector<int32_t> seq; seq.reserve((size_t)nt);
+  for (const auto& ch : chains) seq.insert(seq.end(), ch.begin(), ch.end());
+  // the chains, in the order of their first tile (along the cell curve: an XCD keeps a compact region), are cut into 2 * grid
+  // consecutive STREAMS of equal length (+-1); block b = lidx * 8 + xcd walks streams 2 (xcd * grid / 8 + lidx) and + 1
+  // INTERLEAVED (A1 B1 A2 B2 ...): the kernel prefetches a tile's x rows one tile ahead, so a tile's chain successor has to
+  // come two slots later to read its results
+  const int SPB = 2, ns = grid * SPB, bpx = grid / N_XCD;
+  auto bound = [&](int s_) { return (int)(((int64_t)s_ * nt) / ns); };
+  int longest = 0;
+  for (int s_ = 0; s_ < ns; ++s_) longest = std::max(longest, bound(s_ + 1) - bound(s_));
+  depth = longest * SPB;
+  sched.assign((size_t)depth * grid, -1);
+  for (int b = 0; b < grid; ++b) {
+    const int xcd = b % N_XCD, lidx = b / N_XCD;
+    const int s0 = (xcd * bpx + lidx) * SPB;
+    int it = 0;
+    for (int i = 0; i < longest; ++i)
+      for (int q = 0; q < SPB; ++q) {
+        const int lo = bound(s0 + q), hi = bound(s0 + q + 1);
+        if (lo + i < hi) sched[(size_t)(it++) * grid + b] = seq[(size_t)(lo + i)];
+      }
+  }
+}
+
+int install_schedule(cwr_engine* e, const std::vector<int32_t>& sched, int depth) {
+  const size_t cnt = sched.size();
+  if ((int)cnt > e->sched_cap || depth != e->sched_depth) {
+    // (buffer pointer and depth are captured kernel arguments of the batch graphs)
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    for (auto& kv : e->batch_exec) if (kv.second) hipGraphExecDestroy(kv.second);
+    e->batch_exec.clear(); e->batch_last = -1;
+  }
+  if ((int)cnt > e->sched_cap) {
+    hipFree(e->d_sched); e->d_sched = nullptr; e->sched_cap = 0;
+    TRY(dev_alloc(e, &e->d_sched, cnt + 1024));
+    e->sched_cap = (int)(cnt + 1024);
+  }
+  TRY(upload(e, e->d_sched, sched.data(), cnt));
+  e->sched_depth = depth;
+  return CWR_OK;
+}
+
+int build_chain_schedule(cwr_engine* e, int t) {
+  TRY(build_tile_links(e));
+  if (e->n_links == 0) { e->sched_level = t; return CWR_OK; }                // a single tile, or variable tiles: nothing to chain
+  const int nt = e->tcl_ntiles, L = e->n_links;
+  k_link_flux<<<cdiv(L, BLOCK), BLOCK, 0, e->stream>>>(L, e->d_link_ptr, e->d_link_ent, e->d_adv + (size_t)t * e->E, e->d_link_flux);
+  HIP_TRY(e, hipGetLastError());
+  std::vector<float> flux((size_t)L);
+  TRY(download(e, flux.data(), e->d_link_flux, (size_t)L));
+  // tile t -> best_dn[t]: the destination of its largest outflow; best_up[u]: the source of u's largest inflow; ties go to the
+  // smaller tile id (links are sorted by (src, dst))
+  std::vector<int32_t> best_dn((size_t)nt, -1), best_up((size_t)nt, -1), nxt((size_t)nt, -1);
+  std::vector<float> w_dn((size_t)nt, 0.f), w_up((size_t)nt, 0.f);
+  for (int l = 0; l < L; ++l) {
+    const float w = flux[(size_t)l];
+    if (!(w > 0.f)) continue;
+    const int a = e->link_src[(size_t)l], b = e->link_dst[(size_t)l];
+    if (w > w_dn[(size_t)a]) { w_dn[(size_t)a] = w; best_dn[(size_t)a] = b; }
+    if (w > w_up[(size_t)b] || (w == w_up[(size_t)b] && a < best_up[(size_t)b])) { w_up[(size_t)b] = w; best_up[(size_t)b] = a; }
+  }
+  for (int a = 0; a < nt; ++a) { const int b = best_dn[(size_t)a]; if (b >= 0 && best_up[(size_t)b] == a) nxt[(size_t)a] = b; }
+  std::vector<int32_t> sched; int depth = 0;
+  chains_to_schedule(nt, e->tcl_grid, nxt, sched, depth);
+  TRY(install_schedule(e, sched, depth));
+  e->sched_level = t;
+  ++e->n_sched_builds;
+  if (getenv("CWR_VERBOSE")) {
+    int linked = 0; for (int a = 0; a < nt; ++a) linked += nxt[(size_t)a] >= 0;
+    fprintf(stderr, "[cwr] chained passes: schedule for level %d: %d of %d tiles have a chain successor, %d lists x %d slots\n", t, linked, nt, e->tcl_grid, depth);
+  }
+  return CWR_OK;
+}
+
 // numeric J^2 and c2 (into d_t) for the step whose operator is prepared; active = false -> plain sweeps only
 int prepare_sq(cwr_engine* e, bool& active) {
   active = false;
@@ -889,19 +1057,25 @@ int prepare_sq(cwr_engine* e, bool& active) {
 }
 
 // tile_list (device, optional): the launch covers only these `n_list` tiles (interior / cut tiles of a partitioned engine)
-int launch_sq_tiled(cwr_engine* e, const double* xin, double* yout, const int32_t* tile_list = nullptr, int n_list = 0, bool tail = true) {
+// chained = true: every block walks its own list of the schedule e->d_sched (all tiles; single GPU); xin == yout then makes
+// the pass an in-place (block Gauss-Seidel along the chains) relaxation
+int launch_sq_tiled(cwr_engine* e, const double* xin, double* yout, const int32_t* tile_list = nullptr, int n_list = 0, bool tail = true,
+                    bool chained = false) {
   const int ntiles = tile_list ? n_list : e->tcl_ntiles;
   if (ntiles <= 0) return CWR_OK;
   int grid = std::max(N_XCD, std::min(e->tcl_grid, cdiv(ntiles, N_XCD) * N_XCD));
   // an interior launch that runs beside an exchange leaves a few block slots free: the grid is persistent (every resident
   // slot taken until the launch ends), so RCCL's copy kernels could otherwise only start when it is over
   if (tile_list && !tail && grid > 4 * e->overlap_reserve) grid -= e->overlap_reserve;
+  int depth = 0;
+  if (chained) { tile_list = e->d_sched; depth = e->sched_depth; grid = e->tcl_grid; }
+  const int inplace = (xin == yout) ? 1 : 0;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (e->profiling && e->dominant_mode == 6 && e->ev_used + 2 <= e->ev.size()) {
     e0 = e->ev[e->ev_used++]; e1 = e->ev[e->ev_used++];
     HIP_TRY(e, hipEventRecord(e0, e->stream));
   }
-#define CWR_TILED(VWv, Q) CWR_TCL_K(VWv, Q)<<<grid, BLOCK, e->tcl_lds, e->stream>>>(e->K, e->K / VWv, e->tcl_TR, ntiles, tile_list,    \
+#define CWR_TILED(VWv, Q) CWR_TCL_K(VWv, Q)<<<grid, BLOCK, e->tcl_lds, e->stream>>>(e->K, e->K / VWv, e->tcl_TR, ntiles, tile_list, depth, inplace,    \
       e->d_trow, e->d_ptr2, e->d_loc2, e->d_w2, e->d_tcl_ptr, e->d_tcl_cols, e->d_vptr, e->d_meta, e->tcl_max_cols, e->tcl_stage_cap,    \
       e->local_reps, e->tcl_seg, e->tcl_nvmax, xin, e->d_t, yout)
   if (e->tcl_vw == 4) { if (e->tcl_cfg == 3) CWR_TILED(4, 3); else if (e->tcl_cfg == 4) CWR_TILED(4, 4); else if (e->tcl_cfg == 5) CWR_TILED(4, 5);
@@ -982,6 +1156,10 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
   bool sq = false;
   TRY(prepare_sq(e, sq));
   const bool tiled = sq && e->tcl_ready;
+  if (tiled && !e->comm && e->use_chains && !e->two_closing && !e->sched_user && e->tcl_ntiles >= 4 * e->tcl_grid &&
+      (e->sched_level < 0 || std::abs(e->cur_t - e->sched_level) >= e->sched_refresh))
+    // (worth it from four tiles per block up: two interleaved streams of at least two tiles each)
+    TRY(build_chain_schedule(e, e->cur_t));
   if (e->comm && sq && e->n_real > e->n_core)
     // the ping-pong partner starts with this step's halo values too (its never-computed outer layers would otherwise
     // still hold the previous step's): block-asynchronous passes spread what those layers hold four rows per pass
@@ -1005,34 +1183,46 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
       // That shape is still the cheaper one when the sweeps wanted are 2 (mod 4): N passes + 2 sweeps against N + 1 passes +
       // 1 sweep, and a plain sweep costs less than a pass.  Partitioned engines always use it: their halo layers and
       // exchanges are counted in pairs of sweeps.
-      const bool one_closing = !e->comm && !e->two_closing && want % 4 != 2;
+      // Chained passes (one GPU, a tile schedule along the flow is installed): the passes relax IN PLACE in the partner vector
+      // -- the first pass of a step reads x_t from the state vector and writes the partner, every later pass reads and writes
+      // the partner -- and the closing sweep carries the result into the state vector: any number of passes, one closing sweep.
+      // (A later batch of the same step goes on in the partner; the closing sweep's own progress is not used.)
+      const bool chained = tiled && !e->comm && e->use_chains && e->sched_depth > 0 && !e->two_closing;
+      const bool first_batch = st.sweeps == 0;
+      const bool one_closing = chained || (!e->comm && !e->two_closing && want % 4 != 2);
       int doubles;
       if (one_closing) {
-        doubles = std::min(want / 2, 2047);
-        if (!(doubles & 1) && st.sweeps > 0) ++doubles;                 // (a later batch cannot start from the copy: odd, ends in the state vector)
+        doubles = std::max(1, std::min(want / 2, 2047));
+        if (!chained && !(doubles & 1) && st.sweeps > 0) ++doubles;     // (a later batch cannot start from the copy: odd, ends in the state vector)
         batch = 2 * doubles + 1;
       } else {
         // batch = 2*doubles + 2 with an even number of J^2 passes, then two plain sweeps
         batch += (6 - batch % 4) % 4;                                   // round up to 2 (mod 4)
         doubles = (batch - 2) / 2;
       }
-      const bool from_keep = one_closing && !(doubles & 1) ;           // doubles + 1 launches, odd: start from the copy
-      auto srcb = [&](int i) -> double* { if (!from_keep) return (i & 1) ? e->d_p : e->d_c; return i == 0 ? e->d_keep : ((i & 1) ? e->d_c : e->d_p); };
-      auto dstb = [&](int i) -> double* { if (!from_keep) return (i & 1) ? e->d_c : e->d_p; return (i & 1) ? e->d_p : e->d_c; };
+      const bool from_keep = !chained && one_closing && !(doubles & 1);  // doubles + 1 launches, odd: start from the copy
+      auto srcb = [&](int i) -> double* {
+        if (chained) return (i == 0 && first_batch) ? e->d_c : e->d_p;
+        if (!from_keep) return (i & 1) ? e->d_p : e->d_c;
+        return i == 0 ? e->d_keep : ((i & 1) ? e->d_c : e->d_p); };
+      auto dstb = [&](int i) -> double* {
+        if (chained) return i < doubles ? e->d_p : e->d_c;
+        if (!from_keep) return (i & 1) ? e->d_c : e->d_p;
+        return (i & 1) ? e->d_p : e->d_c; };
       const int passes = doubles;
       launches = doubles + (one_closing ? 1 : 2);
       todo = 0;
       // steady state (the same batch shape as the previous check): the WHOLE batch -- passes, closing sweeps, reduction --
       // is one hipGraph, captured the second time a shape is seen (the kernel arguments of a batch never change)
       if (!e->comm && !e->profiling && e->use_graphs) {
-        const int shape = 2 * doubles + (one_closing ? 1 : 0);
+        const int shape = 2 * doubles + (one_closing ? 1 : 0) + (chained ? (first_batch ? (1 << 20) : (1 << 21)) : 0);
         auto it = e->batch_exec.find(shape);
         if (it == e->batch_exec.end() && e->batch_last == shape && e->batch_exec.size() < 6) {
           hipGraphExec_t ex = nullptr;
           if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
             int rc = CWR_OK;
             for (int i = 0; i < doubles && rc == CWR_OK; ++i)
-              rc = tiled ? launch_sq_tiled(e, srcb(i), dstb(i)) : launch_apply<5>(e, srcb(i), dstb(i), nullptr, e->d_t, nullptr, nullptr, e->n_sq);
+              rc = tiled ? launch_sq_tiled(e, srcb(i), dstb(i), nullptr, 0, true, chained) : launch_apply<5>(e, srcb(i), dstb(i), nullptr, e->d_t, nullptr, nullptr, e->n_sq);
             if (rc == CWR_OK) rc = launch_apply<4>(e, srcb(doubles), dstb(doubles), nullptr, e->d_b, nullptr, nullptr);
             if (rc == CWR_OK && !one_closing) rc = launch_apply<4>(e, srcb(doubles + 1), dstb(doubles + 1), nullptr, e->d_b, nullptr, nullptr);
             if (rc == CWR_OK) rc = reduce_check(e);
@@ -1050,7 +1240,7 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
         }
       }
       if (!batch_graph) {
-      if (!e->comm && !e->profiling && e->use_graphs && !from_keep) {
+      if (!e->comm && !e->profiling && e->use_graphs && !from_keep && !chained) {
         hipGraphExec_t& exec = tiled ? e->tcl_exec : e->sq_exec;
         hipGraph_t& graph = tiled ? e->tcl_graph : e->sq_graph;
         bool& tried = tiled ? e->tcl_graph_tried : e->sq_graph_tried;
@@ -1080,6 +1270,14 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
           if (can_overlap) {
             // pack the cut rows, start the interior tiles (they read core rows only), exchange beside them on the
             // communication stream, then the tiles that read or are refreshed rows, and the un-tiled tail
+            if (e->test_poison_halo && e->n_real > e->n_core) {
+              // test hook: every row an exchange refreshes is NaN in BOTH vectors before the pack (and so before ev_packed, which
+              // the unpack on the communication stream waits for).  The result is unchanged only if the interior tiles read
+              // no such row and the cut tiles really wait for the unpacked values (ev_halo)
+              const size_t off = (size_t)e->n_core * K, cnt = (size_t)(e->n_real - e->n_core) * K * sizeof(double);
+              HIP_TRY(e, hipMemsetAsync(src + off, 0xFF, cnt, e->stream));
+              HIP_TRY(e, hipMemsetAsync(dst + off, 0xFF, cnt, e->stream));
+            }
             TRY(exchange_begin(e, src));
             TRY(launch_sq_tiled(e, src, dst, e->d_tile_inner, e->n_tile_inner, false));
             TRY(exchange_finish(e, src, dst));
@@ -1118,7 +1316,7 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
         for (int q = 0; q < run; ++q, ++i) {
           double* s2 = srcb(i);
           double* d2 = dstb(i);
-          if (tiled) TRY(launch_sq_tiled(e, s2, d2));
+          if (tiled) TRY(launch_sq_tiled(e, s2, d2, nullptr, 0, true, chained));
           else TRY(launch_apply<5>(e, s2, d2, nullptr, e->d_t, nullptr, nullptr, e->n_sq));
           since_exchange += 2;
         }
@@ -1438,6 +1636,7 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   eng->h_ptr = cnt;
   for (int c = 0; c < n_owned; ++c) eng->max_degree = std::max(eng->max_degree, cnt[c + 1] - cnt[c]);
   eng->h_nb.assign(ent_nb.begin(), ent_nb.begin() + nnz);
+  eng->h_edge.assign(ent_edge.begin(), ent_edge.begin() + nnz);
   eng->n_core = n_owned;
   eng->n_owned = n_owned; eng->n_halo = n_halo; eng->n_real = n_real; eng->n_cells = n_cells;
   eng->n_ghost = n_cells - n_real; eng->E = n_edges; eng->K = K; eng->nnz = nnz;
@@ -1454,6 +1653,8 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   if (const char* v = getenv("CWR_TWO_CLOSING")) eng->two_closing = atoi(v) != 0;
   if (const char* v = getenv("CWR_SWEEP_MARGIN")) eng->sweep_margin = std::max(0, atoi(v));
   if (const char* v = getenv("CWR_NO_TCL")) eng->use_tcl = atoi(v) == 0;
+  if (const char* v = getenv("CWR_NO_CHAINS")) eng->use_chains = atoi(v) == 0;
+  if (const char* v = getenv("CWR_CHAIN_REFRESH")) eng->sched_refresh = std::max(1, atoi(v));
   // tile-local J^2 applications per pass: each costs LDS time only (measured 15-25 us at K = 16, 4 us at K = 1 on 1 M cells)
   // and cuts the passes from 46 to 28 (x2) / 24 (x3); narrow rows gain from the third application, wide rows do not
   // two everywhere (round 1 ran three at K <= 4).  Same box, ms per step at 2 / 3 / 4 applications (profiles/r02_w_local_reps.txt):
@@ -1589,7 +1790,7 @@ void cwr_destroy(cwr_engine* e) {
   for (hipEvent_t ev : e->ev) hipEventDestroy(ev);
   void* ptrs[] = {e->d_f1, e->d_f2, e->d_ptr, e->d_ent_edge, e->d_ent_nb, e->d_adv, e->d_vel, e->d_vol, e->d_dif,
                   e->d_bc, e->d_rec, e->d_diag, e->d_c, e->d_r, e->d_r0, e->d_p, e->d_v, e->d_s, e->d_t, e->d_b,
-                  e->d_scal, e->d_partial, e->d_fadv, e->d_fdif, e->d_ftot, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf, e->d_ptr2, e->d_col2, e->d_row2, e->d_rec2, e->d_w, e->d_react, e->d_info, e->d_tcl_ptr, e->d_tcl_cols, e->d_loc2, e->d_w2, e->d_pair_ptr, e->d_slots, e->d_line_ptr, e->d_line_faces, e->d_ledger, e->d_mass_out, e->d_chk, e->d_face_orig, e->d_row_ghost, e->d_keep, e->d_in_rows, e->d_in_vals, e->d_face_pos, e->d_trow, e->d_vptr, e->d_meta, e->d_tile_inner, e->d_tile_outer, e->d_chkx, e->d_sq_fast};
+                  e->d_scal, e->d_partial, e->d_fadv, e->d_fdif, e->d_ftot, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf, e->d_ptr2, e->d_col2, e->d_row2, e->d_rec2, e->d_w, e->d_react, e->d_info, e->d_tcl_ptr, e->d_tcl_cols, e->d_loc2, e->d_w2, e->d_pair_ptr, e->d_slots, e->d_line_ptr, e->d_line_faces, e->d_ledger, e->d_mass_out, e->d_chk, e->d_face_orig, e->d_row_ghost, e->d_keep, e->d_in_rows, e->d_in_vals, e->d_face_pos, e->d_trow, e->d_vptr, e->d_meta, e->d_tile_inner, e->d_tile_outer, e->d_chkx, e->d_sq_fast, e->d_sched, e->d_link_ptr, e->d_link_ent, e->d_link_flux};
   for (void* p : ptrs) if (p) hipFree(p);
   if (e->stream) hipStreamDestroy(e->stream);
   delete e;
@@ -1712,7 +1913,7 @@ int32_t cwr_load_real_inputs(cwr_engine* e, int32_t n_entries, const int32_t* le
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   hipFree(e->d_in_rows); hipFree(e->d_in_vals);
   e->d_in_rows = nullptr; e->d_in_vals = nullptr; e->in_levels.clear();
-  if (n_entries == 0) return CWR_OK;
+  if (n_entries == 0) return sync_input_levels(e);
   TRY(dev_alloc(e, &e->d_in_rows, (size_t)n_entries));
   TRY(dev_alloc(e, &e->d_in_vals, (size_t)n_entries * e->K));
   TRY(upload(e, e->d_in_rows, row, (size_t)n_entries));
@@ -1721,7 +1922,7 @@ int32_t cwr_load_real_inputs(cwr_engine* e, int32_t n_entries, const int32_t* le
     auto it = e->in_levels.find(level[i]);
     if (it == e->in_levels.end()) e->in_levels[level[i]] = std::make_pair(i, 1); else it->second.second += 1;
   }
-  return CWR_OK;
+  return sync_input_levels(e);
 }
 
 int32_t cwr_set_state(cwr_engine* e, const double* conc_owned) {
@@ -1812,6 +2013,7 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
   e->flux_valid = false;
   e->tail_done = false;
   e->info_flags = 0;
+  e->cur_t = t;
   {
     // element-wise rule: targets (1e6 tol, tol) = (1e-6, 1e-12) at the default tolerance, scaled by s = 0.3 (1 - rho) / rho with
     // rho = ||J||_inf of THIS step's iteration matrix (exact, from the flow field: k_jnorm) -- Jacobi's a-posteriori bound
@@ -1844,7 +2046,8 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
   e->halo_fresh = false;
   // keep x_t and the ghost rows (k_rhs writes both aside): a failed solve restores them
   TRY(launch_rhs(e, t, e->d_c, e->d_b, true, e->d_keep));
-  const bool has_inputs = e->in_levels.count(t + 1) != 0;   // the tail writes real rows then: it must not run speculatively
+  // the tail writes real rows then: it must not run speculatively (partitioned: on any rank -- the tail is collective)
+  const bool has_inputs = e->in_levels.count(t + 1) != 0 || ((size_t)(t + 1) < e->in_any.size() && e->in_any[(size_t)t + 1]);
   SolveStats st;
   int rc_solve = CWR_OK;
   const bool force_bicg = (flags & CWR_STEP_FORCE_BICGSTAB) != 0;
@@ -1950,6 +2153,54 @@ int32_t cwr_set_jacobi_norms(cwr_engine* e, int32_t n_times, const double* norms
   if (!e || !norms) return e ? fail(e, CWR_ERR_BAD_ARG, "cwr_set_jacobi_norms: NULL") : CWR_ERR_BAD_ARG;
   if (n_times != e->T || e->T <= 0) return fail(e, CWR_ERR_STATE, "cwr_set_jacobi_norms: n_times must be the number of loaded levels");
   e->jnorm.assign(norms, norms + n_times);
+  return CWR_OK;
+}
+
+// Tiling of the dominant sweep kernel: out = {tiled pass ready, tiles, blocks of its persistent grid, rows per tile}
+int32_t cwr_tiling_info(cwr_engine* e, int32_t out[4]) {
+  if (!e || !out) return e ? fail(e, CWR_ERR_BAD_ARG, "cwr_tiling_info: NULL") : CWR_ERR_BAD_ARG;
+  HIP_TRY(e, hipSetDevice(e->dev));
+  if (e->use_sq && !e->sq_failed && e->K >= e->sq_min_k) TRY(ensure_sq_pattern(e));
+  out[0] = e->tcl_ready ? 1 : 0; out[1] = e->tcl_ntiles; out[2] = e->tcl_grid; out[3] = e->tcl_TR;
+  return CWR_OK;
+}
+
+// Install a tile schedule for the chained in-place passes: sched[it * n_lists + b] = it-th tile of block b, -1 = end of its list
+// (n_lists must be the grid of the tiled pass, every tile must appear exactly once).  depth = 0 removes it.
+int32_t cwr_set_tile_schedule(cwr_engine* e, int32_t n_lists, int32_t depth, const int32_t* sched) {
+  if (!e) return CWR_ERR_BAD_ARG;
+  HIP_TRY(e, hipSetDevice(e->dev));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  if (depth <= 0) { e->sched_depth = 0; e->sched_user = false; e->sched_level = -1; return CWR_OK; }
+  if (!sched || !e->tcl_ready || n_lists != e->tcl_grid) return fail(e, CWR_ERR_BAD_ARG, "cwr_set_tile_schedule: n_lists must equal the grid of the tiled pass (cwr_tiling_info)");
+  std::vector<char> seen((size_t)e->tcl_ntiles, 0);
+  int count = 0;
+  for (int b = 0; b < n_lists; ++b) {
+    bool ended = false;
+    for (int it = 0; it < depth; ++it) {
+      const int t = sched[(size_t)it * n_lists + b];
+      if (t < 0) { ended = true; continue; }
+      if (ended || t >= e->tcl_ntiles || seen[(size_t)t]) return fail(e, CWR_ERR_BAD_ARG, "cwr_set_tile_schedule: a tile out of range, listed twice, or behind the end of a list");
+      seen[(size_t)t] = 1; ++count;
+    }
+  }
+  if (count != e->tcl_ntiles) return fail(e, CWR_ERR_BAD_ARG, "cwr_set_tile_schedule: every tile must appear exactly once");
+  TRY(install_schedule(e, std::vector<int32_t>(sched, sched + (size_t)n_lists * depth), depth));
+  e->sched_user = true;
+  return CWR_OK;
+}
+
+// The installed schedule (built by the engine at the first tiled step of a level range, or set by the caller): out is
+// [depth][n_lists]; info = {depth, n_lists, level it was built for (-1: none / the caller's), schedules built so far}
+int32_t cwr_get_tile_schedule(cwr_engine* e, int32_t info[4], int32_t* out, int64_t out_cap) {
+  if (!e || !info) return e ? fail(e, CWR_ERR_BAD_ARG, "cwr_get_tile_schedule: NULL") : CWR_ERR_BAD_ARG;
+  HIP_TRY(e, hipSetDevice(e->dev));
+  info[0] = e->sched_depth; info[1] = e->sched_depth > 0 ? e->tcl_grid : 0; info[2] = e->sched_user ? -1 : e->sched_level; info[3] = (int32_t)e->n_sched_builds;
+  const size_t cnt = (size_t)e->sched_depth * e->tcl_grid;
+  if (out && cnt > 0) {
+    if ((int64_t)cnt > out_cap) return fail(e, CWR_ERR_BAD_ARG, "cwr_get_tile_schedule: buffer too small");
+    TRY(download(e, out, e->d_sched, cnt));
+  }
   return CWR_OK;
 }
 
@@ -2264,11 +2515,13 @@ int32_t cwr_attach_comm(cwr_engine* e, int32_t rank, int32_t world, const uint8_
   TRY(upload(e, e->d_recv_cells, recv_cells, (size_t)n_recv));
   TRY(dev_alloc(e, &e->d_chkx, (size_t)(2 + 2 * world) * e->K));
   if (const char* v = getenv("CWR_NO_OVERLAP")) e->overlap = atoi(v) == 0;
+  if (const char* v = getenv("CWR_TEST_POISON_HALO")) e->test_poison_halo = atoi(v) != 0;
   if (const char* v = getenv("CWR_OVERLAP_RESERVE")) e->overlap_reserve = std::max(0, atoi(v)) / N_XCD * N_XCD;
   HIP_TRY(e, hipStreamCreateWithFlags(&e->comm_stream, hipStreamNonBlocking));
   HIP_TRY(e, hipEventCreateWithFlags(&e->ev_packed, hipEventDisableTiming));
   HIP_TRY(e, hipEventCreateWithFlags(&e->ev_halo, hipEventDisableTiming));
-  return sync_jnorms(e);
+  TRY(sync_jnorms(e));
+  return sync_input_levels(e);
 }
 
 int32_t cwr_comm_selftest(cwr_engine* e, int32_t count, int64_t* overlapped_exchanges) {

@@ -896,7 +896,7 @@ static_assert(TCL_SEG % CWR_FACE_BATCH == 0, "k_apply<.,5> closes a chunk only a
 #endif
 template <int VW, int WRN, int TCL_U, int TCL_XR>
 __global__ void __launch_bounds__(BLOCK, CWR_TCL_WAVES) k_sq_tiled(
-    int K, int G, int TR, int ntiles, const int32_t* __restrict__ tile_list, const int32_t* __restrict__ trow,
+    int K, int G, int TR, int ntiles, const int32_t* __restrict__ tile_list, int sched_depth, int inplace, const int32_t* __restrict__ trow,
     const int32_t* __restrict__ ptr2, const uint16_t* __restrict__ loc2,
     const double* __restrict__ w2, const int32_t* __restrict__ tcl_ptr, const int32_t* __restrict__ tcl_cols,
     const int32_t* __restrict__ vptr, const int32_t* __restrict__ meta,
@@ -978,6 +978,12 @@ __global__ void __launch_bounds__(BLOCK, CWR_TCL_WAVES) k_sq_tiled(
   const int xcd = blockIdx.x % N_XCD, lidx = blockIdx.x / N_XCD, bpx = gridDim.x / N_XCD;
   const int tpx = (ntiles + N_XCD - 1) / N_XCD;
   auto tile_of = [&](int it) -> int {              // it-th tile of this block, or -1
+    if (sched_depth > 0) {
+      // chained pass: tile_list is a SCHEDULE [sched_depth][gridDim.x] -- every block walks its own list of tiles (chains of
+      // tiles linked along the flow, two of them interleaved: see cwr_engine.hip build_chain_schedule), -1 = end of the list
+      if (it >= sched_depth) return -1;
+      return __builtin_amdgcn_readfirstlane(tile_list[(size_t)it * gridDim.x + blockIdx.x]);
+    }
     const int i = lidx + it * bpx;
     if (i >= tpx) return -1;
     const int t = xcd * tpx + i;
@@ -1061,8 +1067,16 @@ __global__ void __launch_bounds__(BLOCK, CWR_TCL_WAVES) k_sq_tiled(
     for (int u = 0; u < TCL_U; ++u)
 #pragma unroll
       for (int w = 0; w < VW; ++w) qc[u][w] = q0[u][w];
+    // in-place passes (xin == yout, chained schedule): the previous tile's results leave BEFORE the barrier, so that every
+    // wave's stores are issued before any wave's prefetch of the next tile's x rows below -- the tile after next in this
+    // block's list is the chain successor of the previous one and must read what it has just written (same CU, same L1:
+    // workgroup-scope ordering needs no cache action on gfx950, and hipcc's barrier carries no vmcnt wait)
+    if (inplace && rowlane) {
+#pragma unroll
+      for (int u = 0; u < TCL_U; ++u) { const int c = pc0 + r + u * R; if (c < pc1) st_row(yout + (size_t)c * K, y[u]); }
+    }
     __syncthreads();
-    if (rowlane) {                                 // the previous tile's results
+    if (!inplace && rowlane) {                     // the previous tile's results
 #pragma unroll
       for (int u = 0; u < TCL_U; ++u) { const int c = pc0 + r + u * R; if (c < pc1) st_row(yout + (size_t)c * K, y[u]); }
     }
@@ -1154,6 +1168,24 @@ __global__ void __launch_bounds__(BLOCK, CWR_TCL_WAVES) k_sq_tiled(
 #pragma unroll
     for (int u = 0; u < TCL_U; ++u) { const int c = pc0 + r + u * R; if (c < pc1) st_row(yout + (size_t)c * K, y[u]); }
   }
+}
+
+// Flow between tiles (chained passes, see cwr_engine.hip build_chain_schedule): one thread per DIRECTED tile link sums, over the
+// faces through which cells of the link's source tile meet cells of its destination tile, the flow LEAVING the source side
+// at this time level (entries: face index << 1 | side; side 1 = the source cell is face2, so its outflow is -advection_coeff).
+// The entries of a link are contiguous and summed in a fixed order: the schedule built from these sums is reproducible.
+__global__ void __launch_bounds__(BLOCK) k_link_flux(int n_links, const int32_t* __restrict__ link_ptr, const int32_t* __restrict__ link_ent,
+                                                   const float* __restrict__ adv_t, float* __restrict__ flux) {
+  const int l = blockIdx.x * BLOCK + threadIdx.x;
+  if (l >= n_links) return;
+  double s = 0.0;
+  const int j1 = link_ptr[l + 1];
+  for (int j = link_ptr[l]; j < j1; ++j) {
+    const int code = link_ent[j];
+    const double a = (double)adv_t[code >> 1];
+    s += fmax((code & 1) ? -a : a, 0.0);
+  }
+  flux[l] = (float)s;
 }
 
 // ------------------------------------------------------------------------------------------------ BiCGSTAB vector kernels

@@ -14,7 +14,7 @@ import numpy as np
 
 from .engine import TransportEngine, tile_rows
 from .model import face_to_face_distance, change_in_time
-from .ordering import balance_windows, hilbert_order
+from .ordering import balance_windows, flow_aligned_order, hilbert_order
 from .partition import LocalMesh, partition_mesh, slice_fields
 
 
@@ -60,7 +60,7 @@ def shared_hilbert_order(mesh: dict, n: int, rank: int, world: int, K: int = 16)
         except ImportError:                                   # (no torch on ANY rank of this job: all compute locally)
             group_up = False
     if not group_up:
-        return _curve_order(mesh, n, K)
+        return _curve_order(mesh, n, K, world)
     if dist.get_rank() != rank:
         raise ValueError(f'shared_hilbert_order: rank argument {rank} is not this process\'s rank {dist.get_rank()}')
     dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
@@ -68,7 +68,7 @@ def shared_hilbert_order(mesh: dict, n: int, rank: int, world: int, K: int = 16)
     order, err = None, None
     if rank == 0:
         try:
-            order = np.ascontiguousarray(_curve_order(mesh, n, K), dtype=np.int64)
+            order = np.ascontiguousarray(_curve_order(mesh, n, K, world), dtype=np.int64)
             if order.shape != (n,):
                 raise ValueError(f'curve order has shape {order.shape}, expected {(n,)}')
             status[0] = 1
@@ -86,10 +86,13 @@ def shared_hilbert_order(mesh: dict, n: int, rank: int, world: int, K: int = 16)
     return t.cpu().numpy()
 
 
-def _curve_order(mesh: dict, n: int, K: int) -> np.ndarray:
+def _curve_order(mesh: dict, n: int, K: int, world: int = 1) -> np.ndarray:
     """Hilbert order, the cells of every tile-sized window sorted by their J^2 row length (ordering.balance_windows; the
     tile size of the engine's sweep kernel depends on K: cwr_tile_rows).  CWR_NO_BALANCE=1: plain Hilbert order (A/B)."""
-    order = hilbert_order(mesh['face_x'], mesh['face_y'], n)
+    # one rank runs the chained passes (tile chains along the flow): tiles short along the flow axis pay there; the ping-pong
+    # passes of partitioned engines lose from it (3.62 -> 4.07 ms per step on the bench mesh) and keep the isotropic curve
+    aspect = float(os.environ.get('CWR_TILE_ASPECT', '2')) if (world == 1 and not os.environ.get('CWR_NO_CHAINS')) else 1.0
+    order = flow_aligned_order(mesh, n, aspect=aspect) if aspect != 1.0 else hilbert_order(mesh['face_x'], mesh['face_y'], n)
     if os.environ.get('CWR_NO_BALANCE'):
         return order
     return balance_windows(order, mesh['edges_face1'], mesh['edges_face2'], window=tile_rows(K))
@@ -165,6 +168,8 @@ class PartitionedTransport:
                 lvs.append(np.full(len(ce), t, dtype=np.int32)); ces.append(ce); vas.append(blk[ce])
         if lvs:
             self.engine.load_real_inputs(np.concatenate(lvs), np.concatenate(ces), np.concatenate(vas))
+        elif world > 1:                                           # (collective for partitioned engines: also with no entries)
+            self.engine.load_real_inputs(np.zeros(0, np.int32), np.zeros(0, np.int64), np.zeros((0, self.K)))
 
     def step(self, t: int, **kw):
         return self.engine.step(t, **kw)

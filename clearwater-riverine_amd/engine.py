@@ -39,7 +39,7 @@ ABI_SYMBOLS = (
     'cwr_abi_version', 'cwr_tile_rows', 'cwr_create', 'cwr_destroy', 'cwr_last_error', 'cwr_load_flow_field',
     'cwr_load_coefficients', 'cwr_get_coefficients', 'cwr_load_boundary', 'cwr_set_boundary_level',
     'cwr_set_state', 'cwr_get_state', 'cwr_load_real_inputs', 'cwr_react_linear', 'cwr_state_device_ptr', 'cwr_apply', 'cwr_rhs', 'cwr_step', 'cwr_get_mass_flux',
-    'cwr_get_jacobi_norms', 'cwr_set_jacobi_norms',
+    'cwr_get_jacobi_norms', 'cwr_set_jacobi_norms', 'cwr_tiling_info', 'cwr_set_tile_schedule', 'cwr_get_tile_schedule',
     'cwr_time_apply', 'cwr_profile_read', 'cwr_synchronize', 'cwr_apply_bytes',
     'cwr_comm_unique_id', 'cwr_attach_comm', 'cwr_comm_selftest',
     'cwr_set_boundary_lines', 'cwr_reset_mass_balance', 'cwr_get_mass_balance', 'cwr_domain_mass',
@@ -111,6 +111,9 @@ def load_library(path: str | None = None) -> C.CDLL:
         'cwr_step': [vp, i32, f64, i32, i32, P(StepInfo)],
         'cwr_get_mass_flux': [vp, vp, vp, vp],
         'cwr_get_jacobi_norms': [vp, i32, vp],
+        'cwr_tiling_info': [vp, vp],
+        'cwr_set_tile_schedule': [vp, i32, i32, vp],
+        'cwr_get_tile_schedule': [vp, vp, vp, C.c_int64],
         'cwr_set_jacobi_norms': [vp, i32, vp],
         'cwr_time_apply': [vp, i32, i32, i32, P(f64)],
         'cwr_profile_read': [vp, P(C.c_int64), P(f64)],
@@ -292,6 +295,9 @@ class TransportEngine:
         """Non-zero input_array entries on real cells at levels >= 1 (transport.py:258-264): ``levels`` (m,), ``cells`` (m,)
         reference cell ids, ``values`` (m, K) with 0 = no input for that constituent.  Sorted by level here."""
         lv = _arr(levels, np.int32).ravel()
+        if len(lv) == 0:                                   # (partitioned engines call this on every rank: it is collective there)
+            self._check(self._lib.cwr_load_real_inputs(self._h, 0, None, None, None))
+            return
         ce = _arr(cells, np.int64).ravel()
         va = _arr(np.asarray(values, dtype=np.float64).reshape(len(lv), -1), np.float64, (len(lv), self.K), 'values')
         if len(ce) != len(lv):
@@ -364,10 +370,12 @@ class TransportEngine:
                 what.append(f'BiCGSTAB stagnated at a relative residual of {info.max_rel_residual:.2e} (> tol = {tol:.1e}) and was accepted')
             if info.flags & INFO_ELEMENTWISE_MISSED:
                 what.append('the element-wise convergence rule was not met (the norm criterion holds)')
-            if info.flags & INFO_ELEMENTWISE_CLAMPED:
+            if info.flags & INFO_ELEMENTWISE_CLAMPED and not getattr(self, '_clamp_warned', False):
+                self._clamp_warned = True                # a property of the flow field and dt: said once per engine, flagged every step
                 what.append('||J||_inf of this step is above 0.9967: the scale of the element-wise rule was held at 1e-3, its '
                             'max-norm error bound is weaker by 1e-3 / (0.3 (1 - ||J||) / ||J||)')
-            warnings.warn(f'transport step {t}: ' + '; '.join(what), RuntimeWarning, stacklevel=2)
+            if what:
+                warnings.warn(f'transport step {t}: ' + '; '.join(what), RuntimeWarning, stacklevel=2)
         return StepResult(info.iterations, info.sweeps, info.restarts, info.operator_launches, info.solver,
                           info.max_rel_residual, info.solve_ms, info.sweep_kernel, info.flags)
 
@@ -380,6 +388,30 @@ class TransportEngine:
     def set_jacobi_norms(self, norms):
         v = _arr(norms, np.float64, (self.n_times,), 'norms')
         self._check(self._lib.cwr_set_jacobi_norms(self._h, self.n_times, _ptr(v)))
+
+    def tiling_info(self):
+        """(tiled pass ready, tiles, blocks of its persistent grid, rows per tile)."""
+        out = np.zeros(4, np.int32)
+        self._check(self._lib.cwr_tiling_info(self._h, _ptr(out)))
+        return bool(out[0]), int(out[1]), int(out[2]), int(out[3])
+
+    def set_tile_schedule(self, sched):
+        """sched (depth, n_lists) int32: the tiles every block of the tiled pass walks, -1 padded; None removes it."""
+        if sched is None:
+            self._check(self._lib.cwr_set_tile_schedule(self._h, 0, 0, None))
+            return
+        sc = _arr(sched, np.int32)
+        self._check(self._lib.cwr_set_tile_schedule(self._h, sc.shape[1], sc.shape[0], _ptr(sc)))
+
+    def get_tile_schedule(self):
+        """(schedule (depth, n_lists) int32 or None, level it was built for (-1: the caller's / none), schedules built so far)."""
+        info = np.zeros(4, np.int32)
+        self._check(self._lib.cwr_get_tile_schedule(self._h, _ptr(info), None, 0))
+        if info[0] <= 0:
+            return None, int(info[2]), int(info[3])
+        out = np.empty((int(info[0]), int(info[1])), np.int32)
+        self._check(self._lib.cwr_get_tile_schedule(self._h, _ptr(info), _ptr(out), out.size))
+        return out, int(info[2]), int(info[3])
 
     def get_mass_flux(self):
         shape = (self.n_edges, self.K)

@@ -87,3 +87,43 @@ def balance_windows(order: np.ndarray, face1, face2, window: int = 64) -> np.nda
     length = two_hop_row_lengths(face1, face2, n)[order]
     win = np.arange(n) // window
     return order[np.lexsort((np.arange(n), length, win))]
+
+
+def flow_axis(mesh: dict, n_real: int, max_levels: int = 8):
+    """Principal axis of the flow field: unit vector (ax, ay) maximising sum over (sampled) levels and internal faces of
+    (face_flow * cos(angle between the axis and the face1 -> face2 direction))^2, and the ratio of the two eigenvalues of that
+    2 x 2 moment matrix (1 = no preferred direction).  Squared flows: a reversing (tidal) field keeps its axis."""
+    f1 = np.asarray(mesh['edges_face1'], dtype=np.int64)
+    f2 = np.asarray(mesh['edges_face2'], dtype=np.int64)
+    x = np.asarray(mesh['face_x'], dtype=np.float64)
+    y = np.asarray(mesh['face_y'], dtype=np.float64)
+    real = f2 < n_real
+    dx, dy = (x[f2] - x[f1])[real], (y[f2] - y[f1])[real]
+    ln = np.maximum(np.hypot(dx, dy), 1e-300)
+    dx, dy = dx / ln, dy / ln
+    flow = np.asarray(mesh['face_flow'])
+    T = flow.shape[0]
+    levels = np.unique(np.linspace(0, T - 1, min(T, max_levels)).astype(np.int64))
+    q2 = np.zeros(int(real.sum()))
+    for t in levels:
+        q2 += np.asarray(flow[t], dtype=np.float64)[real] ** 2
+    M = np.array([[np.sum(q2 * dx * dx), np.sum(q2 * dx * dy)], [np.sum(q2 * dx * dy), np.sum(q2 * dy * dy)]])
+    if not np.all(np.isfinite(M)) or M.trace() <= 0:
+        return (1.0, 0.0), 1.0
+    w, v = np.linalg.eigh(M)
+    return (float(v[0, 1]), float(v[1, 1])), float(w[1] / max(w[0], 1e-300 * w[1]))
+
+
+def flow_aligned_order(mesh: dict, n_real: int, aspect: float = 2.0, min_ratio: float = 1.5) -> np.ndarray:
+    """Hilbert order in coordinates stretched by `aspect` ALONG the principal flow axis and squeezed by it across: the curve's
+    compact 64-cell tiles become ~ 8 / aspect cells long and 8 * aspect wide.  The chained passes (engine: tile chains along the
+    flow, relaxed in place) move information through a whole tile per visit only when two tile-local J^2 applications cross it,
+    i.e. when it is about four cells long: 47 -> 43 sweep equivalents per step on the 1 M-cell bench mesh at aspect 2
+    (profiles/r03_c_chained_passes.txt).  Only for engines that run chained passes: the ping-pong passes lose from it.
+    A field without a preferred axis (eigenvalue ratio < min_ratio) keeps the isotropic curve."""
+    (ax, ay), ratio = flow_axis(mesh, n_real)
+    x = np.asarray(mesh['face_x'], dtype=np.float64)
+    y = np.asarray(mesh['face_y'], dtype=np.float64)
+    if aspect == 1.0 or ratio < min_ratio:
+        return hilbert_order(x, y, n_real)
+    return hilbert_order((x * ax + y * ay) * aspect, (-x * ay + y * ax) / aspect, n_real)

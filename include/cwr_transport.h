@@ -142,7 +142,10 @@ int32_t cwr_get_state(cwr_engine* e, double* conc_all_cells);
 /* Non-zero entries of input_array[level >= 1] on REAL cells (point sources / fixed concentrations inside the domain):
  * the reference overwrites the solved level t+1 with them before the mass fluxes are taken (transport.py:258-264) and
  * uses them as x_t of the next step (linalg.py:199-200).  Sparse triplets sorted by level: level[i], row[i] (an owned real
- * cell), values[i*K .. i*K+K) with 0 = "no input for this constituent".  Replaces every earlier call. */
+ * cell), values[i*K .. i*K+K) with 0 = "no input for this constituent".  Replaces every earlier call.
+ * Partitioned engines: COLLECTIVE -- every rank calls it with the entries of the cells it owns (also with none): the ranks
+ * agree on the levels that carry inputs anywhere, because such a step's closing kernels, which include a halo exchange, must
+ * be taken on the same path by all of them. */
 int32_t cwr_load_real_inputs(cwr_engine* e, int32_t n_entries, const int32_t* level, const int32_t* row,
                              const double* values);
 
@@ -217,6 +220,20 @@ int32_t cwr_profile_read(cwr_engine* e, int64_t* launches, double* total_us);
 int32_t cwr_synchronize(cwr_engine* e);
 /* Algorithmic bytes of one operator launch (read, written), as DESIGN.md defines them. */
 int32_t cwr_apply_bytes(const cwr_engine* e, int64_t* bytes_read, int64_t* bytes_written);
+
+/* ---- tiling and the chained passes (diagnostics / tuning; no reference counterpart: spsolve is direct, transport.py:249) ----
+ * The dominant sweep kernel walks tiles of cwr_tile_rows(K) rows with a persistent grid.  On one GPU the engine links the
+ * tiles into chains along the flow of the level being solved and relaxes IN PLACE along them (block Gauss-Seidel along the
+ * flow without any block waiting for another; rebuilt every CWR_CHAIN_REFRESH = 64 levels; CWR_NO_CHAINS=1: the
+ * deterministic ping-pong passes).
+ * cwr_tiling_info: out = {tiled pass available, tiles, blocks of its grid, rows per tile}.
+ * cwr_set_tile_schedule: install a caller's schedule instead: sched[it * n_lists + b] = it-th tile of block b, -1 = end of
+ *   the list; n_lists must equal the grid, every tile must appear exactly once (checked).  depth = 0: back to the engine's own.
+ * cwr_get_tile_schedule: info = {depth, n_lists, level the engine built it for (-1: none, or the caller's), schedules built
+ *   so far}; out (may be NULL) receives the depth * n_lists entries. */
+int32_t cwr_tiling_info(cwr_engine* e, int32_t out[4]);
+int32_t cwr_set_tile_schedule(cwr_engine* e, int32_t n_lists, int32_t depth, const int32_t* sched);
+int32_t cwr_get_tile_schedule(cwr_engine* e, int32_t info[4], int32_t* out, int64_t out_cap);
 
 /* ---- domain decomposition (one process per GPU, RCCL over xGMI) --------------------------------
  * A partitioned engine is created with n_owned = the rows it COMPUTES (its own core range plus, with deep

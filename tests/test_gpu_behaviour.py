@@ -350,6 +350,9 @@ def test_persistent_grid_size_of_the_tiled_pass_does_not_change_the_result(gpu_l
     one buffer and writes the other, so which block computes a tile cannot matter)."""
     from clearwater_riverine_amd.distributed import PartitionedTransport
     monkeypatch.setenv('CWR_NO_SMALL', '1')
+    # (the ping-pong passes: with 8 blocks for 113 tiles the engine would otherwise chain the tiles along the flow and relax
+    # in place, where which block computes a tile DOES matter in the last bits -- tests/test_gpu_chains.py)
+    monkeypatch.setenv('CWR_NO_CHAINS', '1')
     mesh, inputs3 = synthetic_case(K, nx=120, ny=60, n_steps=3, seed=29, n_merge=150, dt=40.0, diffusion_coefficient=0.5)
     outs = []
     for knob, val in ((None, None), ('CWR_TCL_GRID', '8'), ('CWR_TCL_BLOCKS_PER_CU', '1')):

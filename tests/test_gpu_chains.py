@@ -1,0 +1,158 @@
+"""GPU tests of the chained in-place passes (round 3): tile chains along the flow, relaxed in place by the persistent grid of
+the tiled J^2 pass -- block Gauss-Seidel along the flow in which no block waits for another.  What replaces spsolve
+(transport.py:249) must reach spsolve's answer whatever the schedule; the schedule only decides how many passes that takes.
+
+The engine builds schedules from four tiles per block up (1 M cells x 16 constituents: 15 per block); CWR_TCL_GRID caps the
+grid of the tiled pass so that a 40 000-cell test mesh gets lists of that length."""
+import numpy as np
+import pytest
+
+import cwr_oracle as oracle
+from util import oracle_run, rel_err
+
+pytestmark = pytest.mark.gpu
+
+K = 16
+GRID = 64
+
+
+def case(steps=3, dt=40.0, nx=200, ny=200):
+    import clearwater_riverine_amd as cw
+    mesh = cw.synthetic.make_mesh(nx, ny, steps, seed=11, n_merge=nx * ny // 20, dt=dt, diffusion_coefficient=0.5)
+    inputs3 = cw.synthetic.distinct_input_array(mesh, K, seed=2)
+    return mesh, inputs3
+
+
+def transport(mesh, inputs3, monkeypatch, chains=True, **env):
+    from clearwater_riverine_amd.distributed import PartitionedTransport
+    monkeypatch.setenv('CWR_TCL_GRID', str(GRID))
+    if chains:
+        monkeypatch.delenv('CWR_NO_CHAINS', raising=False)
+    else:
+        monkeypatch.setenv('CWR_NO_CHAINS', '1')
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    return PartitionedTransport(mesh, inputs3, 0, 1)
+
+
+def test_engine_schedule_equals_the_numpy_specification(gpu_lib, monkeypatch):
+    """build_chain_schedule (csrc/cwr_engine.hip: link fluxes on the device, chains and lists on the host) against
+    schedule.py, the numpy statement of the same construction, on the engine's own tiling."""
+    from clearwater_riverine_amd import schedule as sch
+    mesh, inputs3 = case()
+    pt = transport(mesh, inputs3, monkeypatch)
+    eng, lm = pt.engine, pt.local
+    ready, ntiles, grid, TR = eng.tiling_info()
+    assert ready and grid == GRID and ntiles >= 4 * grid and TR == 64
+    assert eng.get_tile_schedule()[0] is None                  # nothing built before the first step
+    r = pt.step(0, tol=1e-12)
+    got, level, built = eng.get_tile_schedule()
+    assert level == 0 and built == 1 and r.sweep_kernel == 6
+    adv = eng.get_coefficients(0)[0]                           # advection_coeff[0] in the faces this engine was created with
+    want = sch.chain_schedule(lm.face1, lm.face2, adv, lm.n_rows, TR, ntiles, grid)
+    assert got.shape == want.shape and np.array_equal(got, want)
+    tiles = got[got >= 0]
+    assert len(tiles) == ntiles and np.array_equal(np.sort(tiles), np.arange(ntiles))     # every tile exactly once
+    assert (np.diff((got >= 0).astype(int), axis=0) <= 0).all()                            # lists are dense prefixes
+    eng.close()
+
+
+def test_chained_passes_reach_the_direct_solve_in_fewer_sweeps(gpu_lib, monkeypatch):
+    """Three steps against the oracle (spsolve), element-wise, with and without chains; the chained run must not need more
+    sweeps, and the two HIP runs agree far inside the tolerance."""
+    steps = 3
+    mesh, inputs3 = case(steps)
+    oracle.derive_coefficients(mesh)
+    ref = oracle_run(mesh, inputs3, steps)
+    n = mesh['nreal'] + 1
+    want = np.stack([ref.constituent_dict[f'c{k}'].state[steps, :n] for k in range(K)], axis=1)
+    out, sweeps = {}, {}
+    for chains in (False, True):
+        pt = transport(mesh, inputs3, monkeypatch, chains)
+        rs = [pt.step(t, tol=1e-12) for t in range(steps)]
+        assert all(r.sweep_kernel == 6 and r.flags == 0 and r.max_rel_residual <= 1e-12 for r in rs)
+        assert (pt.engine.get_tile_schedule()[0] is not None) == chains
+        out[chains], sweeps[chains] = pt.gather_state(), [r.sweeps for r in rs]
+        pt.engine.close()
+        assert rel_err(out[chains], want) <= 1e-9
+    assert rel_err(out[True], out[False]) <= 1e-10
+    assert all(c <= p for c, p in zip(sweeps[True], sweeps[False])), sweeps
+    assert sum(sweeps[True]) < 0.95 * sum(sweeps[False]), sweeps
+
+
+def test_a_schedule_against_the_flow_costs_sweeps_not_correctness(gpu_lib, monkeypatch):
+    """No block waits for another, so ANY complete schedule is safe: the lists of the reversed flow field (every chain walked
+    upstream: the worst order) and a random permutation of the tiles still reach the oracle's answer."""
+    from clearwater_riverine_amd import schedule as sch
+    mesh, inputs3 = case(2)
+    oracle.derive_coefficients(mesh)
+    ref = oracle_run(mesh, inputs3, 2)
+    n = mesh['nreal'] + 1
+    want = np.stack([ref.constituent_dict[f'c{k}'].state[2, :n] for k in range(K)], axis=1)
+    rng = np.random.default_rng(5)
+    for kind in ('reversed', 'random'):
+        pt = transport(mesh, inputs3, monkeypatch)
+        eng, lm = pt.engine, pt.local
+        _, ntiles, grid, TR = eng.tiling_info()
+        if kind == 'reversed':
+            adv = -np.asarray(mesh['face_flow'][0])[lm.edge_global]
+            sc = sch.chain_schedule(lm.face1, lm.face2, adv, lm.n_rows, TR, ntiles, grid)
+        else:
+            perm = rng.permutation(ntiles)
+            depth = -(-ntiles // grid)
+            sc = np.full((depth, grid), -1, np.int32)
+            for b in range(grid):
+                lst = perm[b::grid]
+                sc[:len(lst), b] = lst
+        eng.set_tile_schedule(sc)
+        for t in range(2):
+            assert pt.step(t, tol=1e-12).flags == 0
+        got, level, built = eng.get_tile_schedule()
+        assert level == -1 and built == 0 and np.array_equal(got, sc)        # the caller's schedule is never replaced
+        assert rel_err(pt.gather_state(), want) <= 1e-9
+        eng.close()
+
+
+def test_schedule_is_rebuilt_as_the_levels_advance_and_bad_schedules_are_refused(gpu_lib, monkeypatch):
+    mesh, inputs3 = case(5)
+    pt = transport(mesh, inputs3, monkeypatch, CWR_CHAIN_REFRESH='2')
+    eng = pt.engine
+    for t in range(5):
+        pt.step(t, tol=1e-10)
+    _, level, built = eng.get_tile_schedule()
+    assert built == 3 and level == 4                                         # levels 0, 2, 4
+    _, ntiles, grid, _ = eng.tiling_info()
+    depth = -(-ntiles // grid)
+    sc = np.full((depth, grid), -1, np.int32)
+    for b in range(grid):
+        lst = np.arange(ntiles)[b::grid]
+        sc[:len(lst), b] = lst
+    bad = sc.copy(); bad[0, 0] = bad[0, 1]                                   # a tile twice, another one missing
+    with pytest.raises(ValueError, match='twice|exactly once'):
+        eng.set_tile_schedule(bad)
+    with pytest.raises(ValueError, match='n_lists'):
+        eng.set_tile_schedule(sc[:, :grid - 8])
+    hole = sc.copy(); hole[0, 3], hole[depth - 1, 3] = -1, sc[0, 3]          # a list that goes on behind its end
+    with pytest.raises(ValueError):
+        eng.set_tile_schedule(hole)
+    eng.set_tile_schedule(sc)                                                # a complete one is taken
+    eng.close()
+
+
+def test_without_chains_runs_are_bitwise_reproducible_and_with_them_within_the_tolerance(gpu_lib, monkeypatch):
+    """The ping-pong passes read only what the previous launch wrote: bitwise reproducible run to run (CWR_NO_CHAINS=1).
+    In a chained pass a tile may or may not see a neighbouring chain's update of the same launch (the blocks do not wait
+    for each other), so two runs agree to the solver tolerance, not bit for bit."""
+    mesh, inputs3 = case(2)
+    runs = {}
+    for chains in (False, True):
+        outs = []
+        for _ in range(2):
+            pt = transport(mesh, inputs3, monkeypatch, chains)
+            for t in range(2):
+                pt.step(t, tol=1e-12)
+            outs.append(pt.gather_state())
+            pt.engine.close()
+        runs[chains] = outs
+    assert np.array_equal(runs[False][0], runs[False][1])
+    assert rel_err(runs[True][0], runs[True][1]) <= 1e-10

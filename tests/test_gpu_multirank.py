@@ -5,6 +5,11 @@ Real RCCL refuses two ranks on one device, and the GPU box has one GPU, so the e
 points it uses.  Everything else is the product path: partition.py, the C-ABI engine with halo rows,
 k_pack_rows, the grouped send/recv before every operator launch, the all-reduces of the inner products,
 and the convergence decisions taken identically on every rank.
+
+Round 3: the stand-in is STREAM-ASYNCHRONOUS by default (mock_rccl.cpp: hipStreamWaitValue64 / hipMemcpyAsync /
+hipStreamWriteValue64 on the caller's stream over a page-locked shared segment; no host-side stream drain), so the two-stream /
+two-event plumbing of the overlapped exchange is exercised the way RCCL exercises it.  CWR_MOCK_ASYNC=0 restores the
+host-synchronous form; CWR_MOCK_ASYNC=2 refuses to fall back.
 """
 import multiprocessing as mp
 import os
@@ -26,7 +31,7 @@ MOCK_LIB = os.path.join(HERE, 'mock_rccl', 'libmock_rccl.so')
 
 def build_mock():
     if not os.path.exists(MOCK_LIB) or os.path.getmtime(MOCK_LIB) < os.path.getmtime(MOCK_SRC):
-        subprocess.run(['/opt/rocm/bin/hipcc', '-O2', '-std=c++17', '-fPIC', '-shared', MOCK_SRC, '-o', MOCK_LIB, '-lrt'],
+        subprocess.run(['/opt/rocm/bin/hipcc', '-O2', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-shared', MOCK_SRC, '-o', MOCK_LIB, '-lrt'],
                        check=True)
     return MOCK_LIB
 
@@ -76,11 +81,14 @@ def _rank_main(rank, world, K, solver, depth, uid_pipe, out_queue):
         adv, dif, tot = pt.engine.get_mass_flux()
         owned_faces = pt.local.face1 < pt.local.n_core
         overlapped = pt.engine.comm_selftest(257)             # self send/recv through the stand-in + the overlap counter
+        import ctypes
+        is_async = ctypes.CDLL(MOCK_LIB).mockRcclLastCommAsync()      # 1: the stand-in only enqueued on the engine's streams
         out_queue.put((rank, pt.owned_reference_ids(), pt.local.hi, pt.owned_state(), pt.local.edge_global[owned_faces],
-                       tot[owned_faces], infos, None, pt.engine.get_mass_balance(), mass0, pt.engine.domain_mass(3), overlapped))
+                       tot[owned_faces], infos, None, pt.engine.get_mass_balance(), mass0, pt.engine.domain_mass(3), overlapped,
+                       is_async))
         pt.engine.close()
     except Exception as exc:                                  # surface the failure in the parent
-        out_queue.put((rank, 0, 0, None, None, None, None, repr(exc), None, None, None, 0))
+        out_queue.put((rank, 0, 0, None, None, None, None, repr(exc), None, None, None, 0, -1))
 
 
 def run_ranks(world, target, args):
@@ -93,11 +101,15 @@ def run_ranks(world, target, args):
     try:
         for p in procs:
             p.start()
-        for _ in range(world):
+        import time
+        deadline = time.monotonic() + 240
+        while len(results) < world and time.monotonic() < deadline:
             try:
-                results.append(out_queue.get(timeout=240))
+                results.append(out_queue.get(timeout=1))
             except queue.Empty:
-                break
+                # a rank that died without posting (segfault, abort) will never post: stop waiting for it
+                if any(p.exitcode not in (None, 0) for p in procs):
+                    break
     finally:
         for p in procs:
             p.join(5 if len(results) < world else 60)
@@ -297,3 +309,53 @@ def test_partitioned_real_cell_inputs_follow_the_reference(gpu_lib, world, K, de
     assert rel_err(state, want) <= 1e-9
     want_flux = np.stack([ref.constituent_dict[f'c{k}'].total_mass_flux[2] for k in range(K)], axis=1)
     assert flux_err(tot, want_flux) <= 1e-8
+
+
+@pytest.mark.parametrize('world,K,depth', [(2, 16, 8), (4, 4, 6), (3, 1, 8)])
+def test_overlapped_exchange_with_poisoned_halo_rows_under_the_asynchronous_stand_in(gpu_lib, world, K, depth, monkeypatch):
+    """VERDICT r02 item 3.  Before every overlapped exchange the engine (test hook CWR_TEST_POISON_HALO) writes NaN into the
+    halo rows of BOTH ping-pong vectors; the stand-in only enqueues on the engine's streams (CWR_MOCK_ASYNC=2: asynchronous or
+    fail).  The result stays the bitwise single-rank result only if (i) the interior tiles, which run beside the exchange, read
+    no halo row, (ii) the unpack on the communication stream waits for the pack (ev_packed), and (iii) the cut tiles on the
+    engine's stream wait for the unpacked rows (ev_halo).  A missing wait shows up as NaN or as a stale row."""
+    build_mock()
+    monkeypatch.setenv('CWR_NO_SMALL', '1')
+    monkeypatch.setenv('CWR_TEST_BIG', '1')
+    monkeypatch.setenv('CWR_TWO_CLOSING', '1')
+    monkeypatch.setenv('CWR_LOCAL_REPS', '1')            # exact passes: bitwise independent of the partitioning
+    monkeypatch.setenv('CWR_MOCK_ASYNC', '2')
+    monkeypatch.setenv('CWR_TEST_POISON_HALO', '1')
+    results = run_ranks(world, _rank_main, (K, 'jacobi', depth))
+    assert all(r[12] == 1 for r in results), 'the stand-in fell back to its host-synchronous mode'
+    assert all(r[11] > 0 for r in results), 'no exchange ran beside interior tiles'
+    monkeypatch.delenv('CWR_TEST_POISON_HALO')
+    from clearwater_riverine_amd.distributed import PartitionedTransport
+    mesh, inputs3 = make_case(K)
+    single = PartitionedTransport(mesh, inputs3, 0, 1)
+    for t in range(3):
+        single.step(t, tol=1e-12, mass_flux=True, solver='jacobi')
+    n = mesh['nreal'] + 1
+    state = np.full((n, K), np.nan)
+    for r in results:
+        state[r[1]] = r[3]
+    assert not np.isnan(state).any()
+    assert np.array_equal(state, single.gather_state())
+
+
+def test_the_synchronous_mode_of_the_stand_in_still_works(gpu_lib, monkeypatch):
+    build_mock()
+    monkeypatch.setenv('CWR_NO_SMALL', '1')
+    monkeypatch.setenv('CWR_MOCK_ASYNC', '0')
+    results = run_ranks(2, _rank_main, (3, 'auto', 4))
+    assert all(r[12] == 0 for r in results)
+    mesh, inputs3 = make_case(3)
+    n = mesh['nreal'] + 1
+    state = np.full((n, 3), np.nan)
+    for r in results:
+        state[r[1]] = r[3]
+    oracle.derive_coefficients(mesh)
+    ref = oracle.OracleModel(mesh, {f'c{k}': inputs3[:, :, k].copy() for k in range(3)})
+    for _ in range(3):
+        ref.update()
+    want = np.stack([ref.constituent_dict[f'c{k}'].state[3, :n] for k in range(3)], axis=1)
+    assert rel_err(state, want) <= 1e-9

@@ -120,8 +120,9 @@ def test_stiff_small_mesh_hands_over_to_bicgstab_in_auto_mode(gpu_lib):
     eng.set_state(inputs3[0, :n, :])
     with pytest.raises(cw.SolverNotConverged):
         eng.step(0, max_iter=40, solver='jacobi')
-    res = eng.step(0, max_iter=40, solver='auto')
-    assert res.sweep_kernel == 7 and res.solver == 2 and res.iterations > 0 and res.flags == 0
+    with pytest.warns(RuntimeWarning, match='element-wise'):      # ||J||_inf > 0.9967 at this dt: the rule's scale is clamped, and says so
+        res = eng.step(0, max_iter=40, solver='auto')
+    assert res.sweep_kernel == 7 and res.solver == 2 and res.iterations > 0 and res.flags == cw.engine.INFO_ELEMENTWISE_CLAMPED
     ref = oracle.OracleModel(mesh, {f'c{k}': inputs3[:, :, k].copy() for k in range(2)})
     ref.update()
     got = eng.get_state()
@@ -159,7 +160,8 @@ def _oracle_jacobi_norm(mesh, t):
     """||J||_inf of step t from the oracle's literal matrix: max over rows of sum_{j != i} |A_ij| / A_ii."""
     lhs = oracle.LHS(mesh)
     lhs.update_values(mesh, t)
-    A = lhs.csr().tocsr()
+    n = mesh['nreal'] + 1
+    A = lhs.csr().tocsr()[:n, :n]
     d = A.diagonal()
     off = abs(A).sum(axis=1).A1 - np.abs(d)
     return float(np.max(off / d))
@@ -174,10 +176,16 @@ def test_jacobi_norms_of_the_loaded_flow_field_match_the_oracle_matrix(gpu_lib):
     eng = make_engine(mesh, inputs3)
     got = eng.jacobi_norms()
     assert got.shape == (6,) and got[-1] == 0.0
+    wants = [_oracle_jacobi_norm(mesh, t) for t in range(5)]
     for t in range(5):
-        want = _oracle_jacobi_norm(mesh, t)
-        assert 0.0 < want < 1.0
-        assert got[t] == pytest.approx(want, rel=1e-12)
+        assert got[t] == pytest.approx(wants[t], rel=1e-12)
+    # (the two dry cells of this mesh break continuity for their neighbours -- inflow without the matching outflow -- so some
+    # rows are NOT diagonally dominant and ||J||_inf > 1: no max-norm bound exists there, and a step says so)
+    assert max(wants) > 1.0
+    n = mesh['nreal'] + 1
+    eng.set_state(inputs3[0, :n, :])
+    with pytest.warns(RuntimeWarning, match='element-wise'):
+        assert eng.step(0).flags == cw.engine.INFO_ELEMENTWISE_CLAMPED
     eng.close()
 
 
