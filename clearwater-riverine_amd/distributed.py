@@ -14,7 +14,7 @@ import numpy as np
 
 from .engine import TransportEngine, tile_rows
 from .model import face_to_face_distance, change_in_time
-from .ordering import balance_windows, flow_aligned_order, hilbert_order
+from .ordering import balance_windows, flow_aligned_order, hilbert_order, lane_order
 from .partition import LocalMesh, partition_mesh, slice_fields
 
 
@@ -92,7 +92,10 @@ def _curve_order(mesh: dict, n: int, K: int, world: int = 1) -> np.ndarray:
     # one rank runs the chained passes (tile chains along the flow): tiles short along the flow axis pay there; the ping-pong
     # passes of partitioned engines lose from it (3.62 -> 4.07 ms per step on the bench mesh) and keep the isotropic curve
     aspect = float(os.environ.get('CWR_TILE_ASPECT', '2')) if (world == 1 and not os.environ.get('CWR_NO_CHAINS')) else 1.0
-    order = flow_aligned_order(mesh, n, aspect=aspect) if aspect != 1.0 else hilbert_order(mesh['face_x'], mesh['face_y'], n)
+    if world == 1 and not os.environ.get('CWR_NO_CHAINS') and os.environ.get('CWR_TILE_ORDER', 'lanes') == 'lanes':
+        order = lane_order(mesh, n, tile_rows=tile_rows(K))
+    else:
+        order = flow_aligned_order(mesh, n, aspect=aspect) if aspect != 1.0 else hilbert_order(mesh['face_x'], mesh['face_y'], n)
     if os.environ.get('CWR_NO_BALANCE'):
         return order
     return balance_windows(order, mesh['edges_face1'], mesh['edges_face2'], window=tile_rows(K))

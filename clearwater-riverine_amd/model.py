@@ -18,7 +18,7 @@ import numpy as np
 from .mass_balance import assemble, boundary_lines, volume_columns
 from .outputs import StreamedOutput, ZarrStreamWriter
 from .engine import TransportEngine, StepResult, tile_rows
-from .ordering import balance_windows, flow_aligned_order, hilbert_order
+from .ordering import balance_windows, flow_aligned_order, hilbert_order, lane_order
 
 # variables.py names used on the path
 EDGES_FACE1 = 'edges_face1'
@@ -258,7 +258,11 @@ class ClearwaterRiverine:
         # passes cross in one visit -- ordering.flow_aligned_order)
         import os
         aspect = 1.0 if os.environ.get('CWR_NO_CHAINS') else float(os.environ.get('CWR_TILE_ASPECT', '2'))
-        order = balance_windows(flow_aligned_order(m, n, aspect=aspect), f1, f2, window=tile_rows(K)) if (renumber and n > 4096) else None
+        if os.environ.get('CWR_NO_CHAINS') or os.environ.get('CWR_TILE_ORDER', 'lanes') != 'lanes':
+            curve = flow_aligned_order(m, n, aspect=aspect) if (renumber and n > 4096) else None
+        else:
+            curve = lane_order(m, n, tile_rows=tile_rows(K)) if (renumber and n > 4096) else None
+        order = balance_windows(curve, f1, f2, window=tile_rows(K)) if curve is not None else None
         self.engine = TransportEngine(f1, f2, ncell, K, device=device, cell_order=order)
         self.engine.load_flow_field(m[FLOW_ACROSS_FACE], m[EDGE_VELOCITY], m[VOLUME], m[CHANGE_IN_TIME],
                                     m[FACE_TO_FACE_DISTANCE], m.attrs['diffusion_coefficient'])

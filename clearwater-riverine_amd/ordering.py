@@ -127,3 +127,31 @@ def flow_aligned_order(mesh: dict, n_real: int, aspect: float = 2.0, min_ratio: 
     if aspect == 1.0 or ratio < min_ratio:
         return hilbert_order(x, y, n_real)
     return hilbert_order((x * ax + y * ay) * aspect, (-x * ay + y * ax) / aspect, n_real)
+
+
+def lane_order(mesh: dict, n_real: int, tile_rows: int = 64, tile_len: int = 4, min_ratio: float = 1.5) -> np.ndarray:
+    """Lane-major order for engines that run chained passes: the cells are cut into LANES -- strips along the principal flow
+    axis, tile_rows / tile_len cells wide -- and numbered lane by lane, along the flow inside a lane.  A tile of the engine
+    (tile_rows consecutive cells) is then ~tile_len cells long and a lane wide, and CONSECUTIVE tiles follow each other along
+    the flow: the engine's flux-built chains become whole lanes, a block of the persistent grid streams down a lane segment,
+    the upstream halo of every tile is what the same block has just written (hot in its XCD's L2) and two tile-local J^2
+    applications carry information across the whole tile.  Against the Hilbert curve (compact tiles, chains of ~6 tiles whose
+    concurrently active tiles are scattered over the XCD's region) -- measured in profiles/r03_c_chained_passes.txt.
+    A field without a preferred axis keeps the Hilbert curve."""
+    (ax, ay), ratio = flow_axis(mesh, n_real)
+    x = np.asarray(mesh['face_x'], dtype=np.float64)[:n_real]
+    y = np.asarray(mesh['face_y'], dtype=np.float64)[:n_real]
+    if ratio < min_ratio or n_real < 4 * tile_rows:
+        return hilbert_order(mesh['face_x'], mesh['face_y'], n_real)
+    s_along = x * ax + y * ay
+    q_across = -x * ay + y * ax
+    f1 = np.asarray(mesh['edges_face1'], dtype=np.int64)
+    f2 = np.asarray(mesh['edges_face2'], dtype=np.int64)
+    real = f2 < n_real
+    h = float(np.median(np.hypot(x[f1[real]] - x[f2[real]], y[f1[real]] - y[f2[real]]))) if real.any() else 1.0
+    width = max(1, tile_rows // tile_len) * max(h, 1e-300)
+    lane = np.floor((q_across - q_across.min()) / width).astype(np.int64)
+    # snake: odd lanes run against the axis, so that the end of a lane and the start of the next are neighbours (the tile that
+    # straddles two lanes stays compact); the engine's chains follow the flow whatever the numbering direction
+    key = np.where(lane & 1, -s_along, s_along)
+    return np.lexsort((key, lane)).astype(np.int64)

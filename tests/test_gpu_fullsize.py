@@ -79,7 +79,7 @@ def test_bench_workload_16_distinct_constituents_on_the_1m_cell_mesh_matches_the
     # the batched columns do not influence each other: column 0 equals the K = 1 run's fixture too (checked above via ci = 0)
 
 
-def test_config5_4m_cells_16_constituents_with_a_per_step_reaction(gpu_lib):
+def test_config5_4m_cells_16_constituents_with_a_per_step_reaction(gpu_lib, monkeypatch):
     """BASELINE config 5: 2052 x 2052 base quads (4 M cells after the merges), 16 constituents, a K x K reaction applied to
     the level-t state before every transport step -- on the device (cwr_react_linear) and, for one step, through the
     reference's host callback contract (update_concentration, transport.py:233-236).  Step 0 is taken plain: at level 0
@@ -130,12 +130,27 @@ def test_config5_4m_cells_16_constituents_with_a_per_step_reaction(gpu_lib):
     b = dev.engine.rhs(2, x_t)
     r = b - dev.engine.apply(2, x_n)
     assert np.max(np.linalg.norm(r, axis=0) / np.linalg.norm(b, axis=0)) <= 1e-10
-    # (d) exact linearity: every input scaled by 2 (a power of two: no rounding anywhere above the subnormal range) gives
-    # bitwise 2 x the state
+    # (d) linearity: every input scaled by 2 gives 2 x the state -- to the solver tolerance with the default chained passes (a
+    # tile may or may not see a neighbouring chain's update of the same launch), and BITWISE with the deterministic ping-pong
+    # passes (CWR_NO_CHAINS=1; a power of two: no rounding anywhere above the subnormal range)
     twice = cw.ClearwaterRiverine(mesh=dict(mesh), input_arrays={nm: 2.0 * a for nm, a in arrays.items()}, store_history=False)
     twice.update()
     twice.update(reaction_matrix=M)
-    got2, want2 = twice.engine.get_state(), 2.0 * level2
+    assert rel_err(twice.engine.get_state(), 2.0 * level2) <= 1e-10
+    twice.engine.close()
+    dev.engine.close()
+    del twice, dev
+    monkeypatch.setenv('CWR_NO_CHAINS', '1')
+    outs = []
+    for f in (1.0, 2.0):
+        m = cw.ClearwaterRiverine(mesh=dict(mesh), input_arrays={nm: f * a for nm, a in arrays.items()}, store_history=False)
+        m.update()
+        m.update(reaction_matrix=M)
+        outs.append(m.engine.get_state())
+        m.engine.close()
+        del m
+    got2, want2 = outs[1], 2.0 * outs[0]
+    assert rel_err(outs[0], level2) <= 1e-10
     big = ~(np.abs(want2) < 1e-290)                       # (NaN ghosts included)
     assert np.array_equal(got2[big], want2[big], equal_nan=True)
     # ahead of the plume fronts the values run into the subnormal range, where a product no longer scales exactly
