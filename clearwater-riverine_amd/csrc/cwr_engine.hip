@@ -186,6 +186,8 @@ struct cwr_engine {
   bool use_tcl = true, tcl_ready = false;
   int tcl_cfg = -1, tcl_vw = 0;   // tcl_vw: constituents per lane in the tiled pass (4 = wide rows, else VW)
   int local_reps = 2;              // J^2 applications per tile and pass (1 = exact Jacobi; > 1 = block-asynchronous)
+  bool reps_auto = true;           // chained passes: chosen per step from ||J||_inf (CWR_LOCAL_REPS fixes it)
+  int reps_base = 2;               // the engine's default for ping-pong passes
   int n_tcl = 0, tcl_TR = 0, tcl_ntiles = 0, tcl_max_cols = 0, tcl_stage_cap = 0, tcl_grid = 0;
   size_t tcl_lds = 0, tcl_total_cols = 0;
   int32_t *d_tcl_ptr = nullptr, *d_tcl_cols = nullptr;
@@ -1189,6 +1191,15 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
       // (A later batch of the same step goes on in the partner; the closing sweep's own progress is not used.)
       const bool chained = tiled && !e->comm && e->use_chains && e->sched_depth > 0 && !e->two_closing;
       const bool first_batch = st.sweeps == 0;
+      if (e->reps_auto) {
+        // Tile-local applications per visit.  A chain carries information from tile to tile only as far as the applications
+        // carry it across a tile, and the stiffer the step the more of its sweeps are transport along the flow: measured on the
+        // 1 M-cell mesh x 16 (profiles/r03_c_chained_passes.txt) two applications win at CFL 2.5 (||J||_inf 0.78: 3.19 ms per step
+        // against 3.46 with three), four at CFL 25 and 62 (0.973 / 0.989: 11.8 and 22.4 ms against 15.4 with two and 14.8 / 23.3
+        // with six).  ||J||_inf of the step is known from the flow field (k_jnorm).
+        const double rho = ((size_t)e->cur_t < e->jnorm.size()) ? e->jnorm[(size_t)e->cur_t] : 0.0;
+        e->local_reps = !chained ? e->reps_base : (rho < 0.9 ? 2 : 4);
+      }
       const bool one_closing = chained || (!e->comm && !e->two_closing && want % 4 != 2);
       int doubles;
       if (one_closing) {
@@ -1215,9 +1226,9 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
       // steady state (the same batch shape as the previous check): the WHOLE batch -- passes, closing sweeps, reduction --
       // is one hipGraph, captured the second time a shape is seen (the kernel arguments of a batch never change)
       if (!e->comm && !e->profiling && e->use_graphs) {
-        const int shape = 2 * doubles + (one_closing ? 1 : 0) + (chained ? (first_batch ? (1 << 20) : (1 << 21)) : 0);
+        const int shape = 2 * doubles + (one_closing ? 1 : 0) + (chained ? (first_batch ? (1 << 20) : (1 << 21)) : 0) + (e->local_reps << 24);
         auto it = e->batch_exec.find(shape);
-        if (it == e->batch_exec.end() && e->batch_last == shape && e->batch_exec.size() < 6) {
+        if (it == e->batch_exec.end() && e->batch_last == shape && e->batch_exec.size() < 12) {
           hipGraphExec_t ex = nullptr;
           if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
             int rc = CWR_OK;
@@ -1662,7 +1673,8 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   // (small meshes at narrow K keep three: their passes are a single round of tiles, bound by its latency, and an application
   // more is nearly free -- 8 000 cells, K = 1, CFL 18: 110 sweeps and 0.53 ms per step with three, 226 and 0.57 with two)
   eng->local_reps = (K <= 4 && n_owned < 100000) ? 3 : 2;
-  if (const char* v = getenv("CWR_LOCAL_REPS")) eng->local_reps = std::max(1, std::min(16, atoi(v)));
+  eng->reps_base = eng->local_reps;
+  if (const char* v = getenv("CWR_LOCAL_REPS")) { eng->local_reps = std::max(1, std::min(16, atoi(v))); eng->reps_auto = false; }
   eng->nt_stream = (K >= 8) ? 1 : 0;
   if (const char* v = getenv("CWR_NT_STREAM")) eng->nt_stream = atoi(v) != 0;
   if (const char* v = getenv("CWR_SQ_MIN_K")) eng->sq_min_k = std::max(1, atoi(v));
