@@ -122,7 +122,7 @@ struct cwr_engine {
   int n_lines = 0;
   int32_t *d_line_ptr = nullptr, *d_line_faces = nullptr;
   double *d_ledger = nullptr, *d_mass_out = nullptr;
-  struct OutSlot { double* h = nullptr; hipEvent_t done = nullptr; std::atomic<bool> busy{false}; };
+  struct OutSlot { double* h = nullptr; hipEvent_t done = nullptr; std::atomic<bool> busy{false}; double *dst_state = nullptr, *dst_flux = nullptr; };
   std::vector<OutSlot> out_slots;
   hipStream_t out_stream = nullptr;
   hipEvent_t out_snap_ready = nullptr, out_copy_done = nullptr;
@@ -2390,8 +2390,10 @@ int32_t cwr_output_open(cwr_engine* e, int32_t n_slots, int32_t with_flux, int32
   return CWR_OK;
 }
 
-int32_t cwr_output_push(cwr_engine* e, int32_t* slot) {
-  if (!e || !slot) return e ? fail(e, CWR_ERR_BAD_ARG, "cwr_output_push: NULL") : CWR_ERR_BAD_ARG;
+namespace {
+// snapshot the state (and fluxes) constituent-major and start the copy to the host: into the ring slot, or -- state_dst given --
+// straight into the caller's own (page-locked) arrays
+int output_push_impl(cwr_engine* e, int32_t* slot, double* state_dst, double* flux_dst) {
   if (!e->out_stream) return fail(e, CWR_ERR_STATE, "cwr_output_push: cwr_output_open first");
   if (e->out_flux && !e->flux_valid) return fail(e, CWR_ERR_STATE, "cwr_output_push: the last step was not taken with CWR_STEP_MASS_FLUX");
   HIP_TRY(e, hipSetDevice(e->dev));
@@ -2417,13 +2419,43 @@ int32_t cwr_output_push(cwr_engine* e, int32_t* slot) {
   HIP_TRY(e, hipGetLastError());
   HIP_TRY(e, hipEventRecord(e->out_snap_ready, e->stream));
   HIP_TRY(e, hipStreamWaitEvent(e->out_stream, e->out_snap_ready, 0));
-  HIP_TRY(e, hipMemcpyAsync(sl.h, e->d_snap, e->out_slot_cnt * sizeof(double), hipMemcpyDeviceToHost, e->out_stream));
+  if (state_dst) {
+    HIP_TRY(e, hipMemcpyAsync(state_dst, e->d_snap, e->out_state_cnt * sizeof(double), hipMemcpyDeviceToHost, e->out_stream));
+    if (e->out_flux && flux_dst)
+      HIP_TRY(e, hipMemcpyAsync(flux_dst, e->d_snap + e->out_state_cnt, (e->out_slot_cnt - e->out_state_cnt) * sizeof(double), hipMemcpyDeviceToHost, e->out_stream));
+  } else {
+    HIP_TRY(e, hipMemcpyAsync(sl.h, e->d_snap, e->out_slot_cnt * sizeof(double), hipMemcpyDeviceToHost, e->out_stream));
+  }
+  sl.dst_state = state_dst; sl.dst_flux = flux_dst;
   HIP_TRY(e, hipEventRecord(sl.done, e->out_stream));
   HIP_TRY(e, hipEventRecord(e->out_copy_done, e->out_stream));
   e->out_copy_pending = true;
   sl.busy.store(true, std::memory_order_release);
   e->out_next = (s + 1) % (int)e->out_slots.size();
   *slot = s;
+  return CWR_OK;
+}
+}  // namespace
+
+int32_t cwr_output_push(cwr_engine* e, int32_t* slot) {
+  if (!e || !slot) return e ? fail(e, CWR_ERR_BAD_ARG, "cwr_output_push: NULL") : CWR_ERR_BAD_ARG;
+  return output_push_impl(e, slot, nullptr, nullptr);
+}
+
+int32_t cwr_output_push_into(cwr_engine* e, double* state_dst, double* flux_dst, int32_t* slot) {
+  if (!e || !slot || !state_dst) return e ? fail(e, CWR_ERR_BAD_ARG, "cwr_output_push_into: NULL") : CWR_ERR_BAD_ARG;
+  if (e->out_flux && !flux_dst) return fail(e, CWR_ERR_BAD_ARG, "cwr_output_push_into: the ring was opened with fluxes: flux_dst needed");
+  return output_push_impl(e, slot, state_dst, flux_dst);
+}
+
+int32_t cwr_host_register(void* ptr, int64_t bytes) {
+  if (!ptr || bytes <= 0) return CWR_ERR_BAD_ARG;
+  if (hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return CWR_ERR_HIP; }
+  return CWR_OK;
+}
+int32_t cwr_host_unregister(void* ptr) {
+  if (!ptr) return CWR_ERR_BAD_ARG;
+  if (hipHostUnregister(ptr) != hipSuccess) { (void)hipGetLastError(); return CWR_ERR_HIP; }
   return CWR_OK;
 }
 
@@ -2434,8 +2466,8 @@ int32_t cwr_output_wait(cwr_engine* e, int32_t slot, const double** state, const
   if (!sl.busy.load(std::memory_order_acquire)) return fail(e, CWR_ERR_STATE, "cwr_output_wait: slot holds no snapshot");
   // (no hipSetDevice: events carry their device; this may run on a consumer thread)
   if (hipEventSynchronize(sl.done) != hipSuccess) return fail(e, CWR_ERR_HIP, "cwr_output_wait: event synchronize failed");
-  if (state) *state = sl.h;
-  if (flux) *flux = e->out_flux ? sl.h + e->out_state_cnt : nullptr;
+  if (state) *state = sl.dst_state ? sl.dst_state : sl.h;
+  if (flux) *flux = !e->out_flux ? nullptr : (sl.dst_state ? sl.dst_flux : sl.h + e->out_state_cnt);
   return CWR_OK;
 }
 

@@ -43,7 +43,7 @@ ABI_SYMBOLS = (
     'cwr_time_apply', 'cwr_profile_read', 'cwr_synchronize', 'cwr_apply_bytes',
     'cwr_comm_unique_id', 'cwr_attach_comm', 'cwr_comm_selftest',
     'cwr_set_boundary_lines', 'cwr_reset_mass_balance', 'cwr_get_mass_balance', 'cwr_domain_mass',
-    'cwr_output_open', 'cwr_output_push', 'cwr_output_wait', 'cwr_output_release', 'cwr_output_close',
+    'cwr_output_open', 'cwr_output_push', 'cwr_output_push_into', 'cwr_host_register', 'cwr_host_unregister', 'cwr_output_wait', 'cwr_output_release', 'cwr_output_close',
 )
 
 
@@ -128,6 +128,9 @@ def load_library(path: str | None = None) -> C.CDLL:
         'cwr_domain_mass': [vp, i32, vp],
         'cwr_output_open': [vp, i32, i32, i32, vp],
         'cwr_output_push': [vp, P(i32)],
+        'cwr_output_push_into': [vp, vp, vp, P(i32)],
+        'cwr_host_register': [vp, C.c_int64],
+        'cwr_host_unregister': [vp],
         'cwr_output_wait': [vp, i32, P(vp), P(vp)],
         'cwr_output_release': [vp, i32],
         'cwr_output_close': [vp],
@@ -463,6 +466,22 @@ class TransportEngine:
         slot = C.c_int32(-1)
         self._check(self._lib.cwr_output_push(self._h, C.byref(slot)))
         return slot.value
+
+    def output_push_into(self, state_dst: np.ndarray, flux_dst: np.ndarray | None) -> int:
+        """Snapshot copied straight into the caller's C-contiguous float64 arrays: state_dst (K, n_out), flux_dst (3, K, n_edges)."""
+        for a, shp in ((state_dst, (self.K, self._out_n)), (flux_dst, (3, self.K, self.n_edges))):
+            if a is not None and (a.dtype != np.float64 or not a.flags.c_contiguous or a.shape != shp):
+                raise ValueError(f'output_push_into: expected a C-contiguous float64 array of shape {shp}')
+        slot = C.c_int32(-1)
+        self._check(self._lib.cwr_output_push_into(self._h, _ptr(state_dst), _ptr(flux_dst), C.byref(slot)))
+        return slot.value
+
+    def host_register(self, arr: np.ndarray) -> bool:
+        """Page-lock a numpy array for asynchronous copies (False when the runtime refuses, e.g. a locked-memory limit)."""
+        return self._lib.cwr_host_register(_ptr(arr), arr.nbytes) == CWR_OK
+
+    def host_unregister(self, arr: np.ndarray):
+        self._lib.cwr_host_unregister(_ptr(arr))
 
     def output_wait(self, slot: int):
         """(state (K, n_out), flux (3, K, n_edges) or None): numpy VIEWS of the pinned slot, valid until

@@ -288,6 +288,14 @@ int32_t cwr_domain_mass(cwr_engine* e, int32_t t_level, double* out);
  * cwr_output_wait and cwr_output_release may be called from a second (writer) thread. */
 int32_t cwr_output_open(cwr_engine* e, int32_t n_slots, int32_t with_flux, int32_t n_out, const int32_t* row_order);
 int32_t cwr_output_push(cwr_engine* e, int32_t* slot);
+/* The same snapshot copied straight into the CALLER's arrays instead of the ring slot: state_dst (K, n_out) and flux_dst
+ * (3, K, n_edges; required when the ring was opened with_flux) -- e.g. row t+1 of a (T, K, ncell) history block, so that no host
+ * copy is left between the device and mesh[name][t+1] (transport.py:252-273).  The copies are asynchronous when the
+ * destination is page-locked (cwr_host_register: hipHostRegister with the engine's HIP runtime) and staged by HIP otherwise;
+ * cwr_output_wait(slot) returns the two destinations once they are complete. */
+int32_t cwr_output_push_into(cwr_engine* e, double* state_dst, double* flux_dst, int32_t* slot);
+int32_t cwr_host_register(void* ptr, int64_t bytes);
+int32_t cwr_host_unregister(void* ptr);
 int32_t cwr_output_wait(cwr_engine* e, int32_t slot, const double** state, const double** flux);
 int32_t cwr_output_release(cwr_engine* e, int32_t slot);
 int32_t cwr_output_close(cwr_engine* e);
