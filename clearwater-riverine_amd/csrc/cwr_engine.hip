@@ -154,6 +154,7 @@ struct cwr_engine {
   int32_t *d_tile_inner = nullptr, *d_tile_outer = nullptr;
   std::map<int, hipGraphExec_t> stretch_exec;   // exchange-free runs of passes of a partitioned engine, by (first parity, length)
   int64_t n_overlapped = 0;                     // exchanges that ran beside interior tiles (diagnostic, cwr_comm_stats)
+  int step_exchanges = 0, step_overlapped = 0, step_checks = 0;   // of the step in progress (cwr_step_info)
   // measurement
   std::vector<hipEvent_t> ev;
   size_t ev_used = 0;
@@ -358,6 +359,7 @@ int vec_grid(const cwr_engine* e) {
 // outermost (never computed) layers would otherwise keep the values of an exchange several passes back
 int exchange_halo(cwr_engine* e, double* vec, double* vec2 = nullptr) {
   if (!e->comm || e->peers.empty()) return CWR_OK;
+  ++e->step_exchanges;
   const int64_t total = (int64_t)e->n_send * e->K;
   if (total > 0) {
     k_pack_rows<<<cdiv(total, BLOCK), BLOCK, 0, e->stream>>>(total, e->K, e->d_send_cells, vec, e->d_sendbuf);
@@ -408,7 +410,7 @@ int exchange_finish(cwr_engine* e, double* vec, double* vec2) {
   }
   HIP_TRY(e, hipEventRecord(e->ev_halo, e->comm_stream));
   HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_halo, 0));
-  ++e->n_overlapped;
+  ++e->n_overlapped; ++e->step_exchanges; ++e->step_overlapped;
   return CWR_OK;
 }
 
@@ -432,6 +434,7 @@ int reduce_check(cwr_engine* e) {
 // latency per check.  Single GPU: a plain download.
 int gather_check(cwr_engine* e, double* h) {
   const size_t K = (size_t)e->K;
+  ++e->step_checks;
   if (!e->comm || (e->world == 1 && !e->force_coll)) return download(e, h, e->d_chk, 4 * K);
   const size_t W = (size_t)e->world, n = 2 * K + W * 2 * K;
   HIP_TRY(e, hipMemsetAsync(e->d_chkx, 0, n * sizeof(double), e->stream));
@@ -2026,6 +2029,7 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
   e->tail_done = false;
   e->info_flags = 0;
   e->cur_t = t;
+  e->step_exchanges = e->step_overlapped = e->step_checks = 0;
   {
     // element-wise rule: targets (1e6 tol, tol) = (1e-6, 1e-12) at the default tolerance, scaled by s = 0.3 (1 - rho) / rho with
     // rho = ||J||_inf of THIS step's iteration matrix (exact, from the flow field: k_jnorm) -- Jacobi's a-posteriori bound
@@ -2095,6 +2099,8 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
   local.solver = (st.iterations == 0 && !force_bicg) ? 0 : (st.sweeps == 0 ? 1 : 2);
   local.sweep_kernel = st.sweep_kernel;
   local.flags = e->info_flags;
+  local.exchanges = e->step_exchanges; local.overlapped = e->step_overlapped; local.checks = e->step_checks;
+  local.local_reps = (st.sweep_kernel == 6) ? e->local_reps : 0;
   if (st.status != CWR_OK) {
     e->flux_valid = false; e->halo_fresh = false; e->tail_done = false;   // (a speculative tail may have run)
     // the solver iterated in place: put x_t and the ghost rows back, so that the state is what the step found and the
@@ -2129,6 +2135,7 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
   }
   // no synchronisation here: convergence is known, and the tail kernels are ordered on the engine's stream before
   // everything a later call does (read-outs synchronise themselves), so the host can already enqueue the next step
+  local.exchanges = e->step_exchanges; local.overlapped = e->step_overlapped; local.checks = e->step_checks;   // (incl. the tail's exchange)
   local.solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
   if (info) *info = local;
   return CWR_OK;

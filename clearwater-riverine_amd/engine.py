@@ -54,7 +54,8 @@ class SolverNotConverged(RuntimeError):
 class StepInfo(C.Structure):
     _fields_ = [('iterations', C.c_int32), ('sweeps', C.c_int32), ('restarts', C.c_int32), ('status', C.c_int32),
                 ('operator_launches', C.c_int32), ('solver', C.c_int32), ('max_rel_residual', C.c_double),
-                ('solve_ms', C.c_double), ('sweep_kernel', C.c_int32), ('flags', C.c_int32)]
+                ('solve_ms', C.c_double), ('sweep_kernel', C.c_int32), ('flags', C.c_int32), ('exchanges', C.c_int32),
+                ('overlapped', C.c_int32), ('checks', C.c_int32), ('local_reps', C.c_int32)]
 
 
 @dataclass
@@ -68,6 +69,10 @@ class StepResult:
     solve_ms: float
     sweep_kernel: int = 0    # 4 plain sweep, 5 J^2 pass, 6 tiled J^2 pass, 7 one-launch small-mesh solver
     flags: int = 0           # INFO_* bits: tolerance decisions that were not met exactly (0 in a clean step)
+    exchanges: int = 0       # partitioned: halo exchanges of this step
+    overlapped: int = 0      # ... of which ran beside interior tiles
+    checks: int = 0          # convergence checks (blocking host round trips)
+    local_reps: int = 0      # tile-local J^2 applications per visit
 
 
 _lib = None
@@ -380,7 +385,8 @@ class TransportEngine:
             if what:
                 warnings.warn(f'transport step {t}: ' + '; '.join(what), RuntimeWarning, stacklevel=2)
         return StepResult(info.iterations, info.sweeps, info.restarts, info.operator_launches, info.solver,
-                          info.max_rel_residual, info.solve_ms, info.sweep_kernel, info.flags)
+                          info.max_rel_residual, info.solve_ms, info.sweep_kernel, info.flags, info.exchanges, info.overlapped,
+                          info.checks, info.local_reps)
 
     def jacobi_norms(self) -> np.ndarray:
         """(T,) ||J||_inf of the Jacobi iteration matrix of every step of the loaded flow field (last entry 0)."""

@@ -66,6 +66,10 @@ typedef struct cwr_step_info {
   int32_t sweep_kernel;        /* which Jacobi kernel ran: 4 plain sweep, 5 J^2 pass, 6 tiled J^2 pass (x tile in LDS),
                                   7 one-launch small-mesh solver, 0 none (BiCGSTAB only) */
   int32_t flags;               /* CWR_INFO_* bits: tolerance decisions that were NOT met exactly (0 in a clean step) */
+  int32_t exchanges;           /* partitioned engines: neighbour halo exchanges of this step (0 on one GPU) */
+  int32_t overlapped;          /* ... of which ran on the communication stream beside interior tiles */
+  int32_t checks;              /* convergence checks = blocking host round trips (one all-reduce each when partitioned) */
+  int32_t local_reps;          /* tile-local J^2 applications per visit the passes of this step used (0: no tiled pass) */
 } cwr_step_info;
 
 /* bits of cwr_step_info.flags */

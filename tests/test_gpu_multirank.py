@@ -72,12 +72,13 @@ def _rank_main(rank, world, K, solver, depth, uid_pipe, out_queue):
             uid = uid_pipe.get(timeout=120)
         pt = PartitionedTransport(mesh, inputs3, rank, world, device=0, unique_id=uid, halo_depth=depth,
                                   renumber='hilbert' if depth >= 4 else None)
-        infos = []
+        infos, comm_counts = [], []
         pt.set_boundary_lines(case_lines(mesh))
         mass0 = pt.engine.domain_mass(0)
         for t in range(3):
             r = pt.step(t, tol=1e-12, mass_flux=True, solver=solver, mass_balance=True)
             infos.append((r.sweeps, r.iterations))
+            comm_counts.append((r.exchanges, r.overlapped, r.checks))
         adv, dif, tot = pt.engine.get_mass_flux()
         owned_faces = pt.local.face1 < pt.local.n_core
         overlapped = pt.engine.comm_selftest(257)             # self send/recv through the stand-in + the overlap counter
@@ -85,10 +86,10 @@ def _rank_main(rank, world, K, solver, depth, uid_pipe, out_queue):
         is_async = ctypes.CDLL(MOCK_LIB).mockRcclLastCommAsync()      # 1: the stand-in only enqueued on the engine's streams
         out_queue.put((rank, pt.owned_reference_ids(), pt.local.hi, pt.owned_state(), pt.local.edge_global[owned_faces],
                        tot[owned_faces], infos, None, pt.engine.get_mass_balance(), mass0, pt.engine.domain_mass(3), overlapped,
-                       is_async))
+                       is_async, comm_counts))
         pt.engine.close()
     except Exception as exc:                                  # surface the failure in the parent
-        out_queue.put((rank, 0, 0, None, None, None, None, repr(exc), None, None, None, 0, -1))
+        out_queue.put((rank, 0, 0, None, None, None, None, repr(exc), None, None, None, 0, -1, None))
 
 
 def run_ranks(world, target, args):
@@ -204,6 +205,15 @@ def test_partitioned_block_asynchronous_passes_keep_the_single_rank_sweep_count(
         got = [s for s, _ in r[6]]
         assert all(g <= s + 4 for g, s in zip(got[1:], single_sweeps[1:])), (got, single_sweeps)
     assert min(single_sweeps) >= 20                           # the case really iterates
+    # cwr_step_info of a partitioned step: exchanges, how many of them overlapped, blocking checks.  A step of P J^2 passes at
+    # halo depth d needs one exchange per d / 2 passes, one before each of the two closing sweeps, one in front of the
+    # right-hand side (skipped when the previous step's tail delivered the rows) and the tail's own; in the steady state ONE check
+    for r in results:
+        for (sweeps, _), (exch, over, checks) in list(zip(r[6], r[13]))[1:]:
+            passes = (sweeps - 2) // 2
+            assert 0 < over <= exch <= -(-passes // max(1, depth // 2)) + 5, (sweeps, exch, over, depth)
+            assert 1 <= checks <= 2, checks
+        assert r[13] == results[0][13]                        # every rank made the same calls
     # the exchanges inside the pass loop ran beside the interior tiles (second stream + events), on every rank
     assert all(r[11] > 0 for r in results), [r[11] for r in results]
 
