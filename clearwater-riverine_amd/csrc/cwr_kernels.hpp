@@ -1080,6 +1080,9 @@ __global__ void __launch_bounds__(BLOCK, CWR_TCL_WAVES) k_sq_tiled(
 #pragma unroll
       for (int u = 0; u < TCL_U; ++u) { const int c = pc0 + r + u * R; if (c < pc1) st_row(yout + (size_t)c * K, y[u]); }
     }
+    // (Measured, round 3: an acquire fence in front of this prefetch changes nothing at workgroup scope -- 43-47 sweeps either
+    // way: the chain successor already reads its predecessor's rows fresh -- and at agent scope, which invalidates the L2,
+    // the same sweeps take 3.5 x the time: gpurun_out/r03k_acquire.txt.)
     // start the next tile's loads (x rows by the list already in registers) and the list of the tile after it
     const int t_after = tile_of(it + 2);
     load_rows(t_next);
