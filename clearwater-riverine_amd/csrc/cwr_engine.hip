@@ -202,6 +202,12 @@ struct cwr_engine {
   // block walks chains of tiles linked along the flow of the level the schedule was built for
   int32_t* d_sched = nullptr;
   int sched_depth = 0, sched_cap = 0;
+  // column reuse along a block's list (see k_sq_tiled, REUSE mode): per-schedule copy of the tiles' column lists
+  bool chain_reuse = true;                 // CWR_CHAIN_REUSE=0: fetch every column, two interleaved streams per block (A/B)
+  int32_t* d_scols = nullptr;
+  std::vector<int32_t> h_tcl_ptr, h_tcl_cols, h_trow;     // host copies of the tiling (column lists, rows of every tile)
+  std::vector<int32_t> sched_nxt;          // chain successor of every tile in the installed schedule (unchanged -> no rebuild)
+  int own_cap = 0;                         // rows of the LDS staging area for a tile's results (tile rows when reuse is on)
   bool use_chains = true;
   bool sched_user = false;                 // installed by cwr_set_tile_schedule: never rebuilt by the engine
   int sched_level = -1, sched_refresh = 64; // level the schedule was built for; rebuilt when the step is this many levels away
@@ -828,7 +834,9 @@ int ensure_sq_pattern(cwr_engine* e) {
       cap2 = std::max(cap2, ptr2[c1] - ptr2[c0]);
     }
     cap2 += cap2 & 1;                                            // even: the 16-bit index array keeps what follows 4-byte aligned
-    const size_t lds = ((size_t)(max_cols + nvmax) * e->K * sizeof(double) + (size_t)cap2 * (sizeof(double) + sizeof(uint16_t)) +
+    // (one GPU with chained passes: + a staging area for a tile's results, which the next tile of the block's list carries over)
+    const int own_cap = (!e->comm && e->use_chains && e->chain_reuse && !split && max_cols < 255) ? tr : 0;   // (positions travel as bytes)
+    const size_t lds = ((size_t)(max_cols + nvmax + own_cap) * e->K * sizeof(double) + (size_t)cap2 * (sizeof(double) + sizeof(uint16_t)) +
                         (size_t)(tr + 1 + nvmax) * sizeof(int32_t) + 15) & ~(size_t)15;
     // the kernel's compile-time prefetch depths bound what a tile may hold; otherwise the plain J^2 pass stays
     e->tcl_cfg = -1;
@@ -852,6 +860,8 @@ int ensure_sq_pattern(cwr_engine* e) {
       e->tcl_seg = seg; e->tcl_nvmax = nvmax;
       e->tcl_TR = tr; e->tcl_ntiles = nt; e->tcl_max_cols = max_cols; e->tcl_stage_cap = cap2; e->tcl_lds = lds;
       e->tcl_total_cols = tcols.size();
+      e->own_cap = own_cap;
+      if (own_cap > 0) { e->h_tcl_ptr = tptr; e->h_tcl_cols = tcols; e->h_trow = trow; }
       e->tcl_grid = std::max(N_XCD, std::min(cdiv(nt, N_XCD) * N_XCD, (n_cu * pc / N_XCD) * N_XCD));
       if (const char* v = getenv("CWR_TCL_GRID")) e->tcl_grid = std::max(N_XCD, std::min(e->tcl_grid, atoi(v) / N_XCD * N_XCD));
       TRY(dev_alloc(e, &e->d_tcl_ptr, (size_t)nt + 1));
@@ -951,7 +961,7 @@ int build_tile_links(cwr_engine* e) {
 }
 
 // chains -> schedule [depth][grid], -1 padded (see schedule.py: the same construction)
-void chains_to_schedule(int nt, int grid, const std::vector<int32_t>& nxt, std::vector<int32_t>& sched, int& depth) {
+void chains_to_schedule(int nt, int grid, int SPB, const std::vector<int32_t>& nxt, std::vector<int32_t>& sched, int& depth) {
   std::vector<char> has_prev((size_t)nt, 0), seen((size_t)nt, 0);
   for (int t = 0; t < nt; ++t) if (nxt[(size_t)t] >= 0) has_prev[(size_t)nxt[(size_t)t]] = 1;
   std::vector<std::vector<int32_t>> chains;
@@ -966,11 +976,12 @@ void chains_to_schedule(int nt, int grid, const std::vector<int32_t>& nxt, std::
   std::stable_sort(chains.begin(), chains.end(), [](const std::vector<int32_t>& a, const std::vector<int32_t>& b) { return a[0] < b[0]; });
   std::vector<int32_t> seq; seq.reserve((size_t)nt);
   for (const auto& ch : chains) seq.insert(seq.end(), ch.begin(), ch.end());
-  // the chains, in the order of their first tile (along the cell curve: an XCD keeps a compact region), are cut into 2 * grid
-  // consecutive STREAMS of equal length (+-1); block b = lidx * 8 + xcd walks streams 2 (xcd * grid / 8 + lidx) and + 1
-  // INTERLEAVED (A1 B1 A2 B2 ...): the kernel prefetches a tile's x rows one tile ahead, so a tile's chain successor has to
-  // come two slots later to read its results
-  const int SPB = 2, ns = grid * SPB, bpx = grid / N_XCD;
+  // the chains, in the order of their first tile (along the cell curve: an XCD keeps a compact region), are cut into SPB * grid
+  // consecutive STREAMS of equal length (+-1); block b = lidx * 8 + xcd walks streams SPB (xcd * grid / 8 + lidx) ...
+  // SPB = 1 (column reuse on): a tile's successor takes the rows they share from LDS, so it simply comes next.
+  // SPB = 2 (reuse off): the kernel prefetches a tile's x rows from memory one tile ahead, so a chain successor has to come
+  // two slots later to read its predecessor's results: two streams INTERLEAVED (A1 B1 A2 B2 ...)
+  const int ns = grid * SPB, bpx = grid / N_XCD;
   auto bound = [&](int s_) { return (int)(((int64_t)s_ * nt) / ns); };
   int longest = 0;
   for (int s_ = 0; s_ < ns; ++s_) longest = std::max(longest, bound(s_ + 1) - bound(s_));
@@ -1026,11 +1037,39 @@ int build_chain_schedule(cwr_engine* e, int t) {
     if (w > w_up[(size_t)b] || (w == w_up[(size_t)b] && a < best_up[(size_t)b])) { w_up[(size_t)b] = w; best_up[(size_t)b] = a; }
   }
   for (int a = 0; a < nt; ++a) { const int b = best_dn[(size_t)a]; if (b >= 0 && best_up[(size_t)b] == a) nxt[(size_t)a] = b; }
-  std::vector<int32_t> sched; int depth = 0;
-  chains_to_schedule(nt, e->tcl_grid, nxt, sched, depth);
-  TRY(install_schedule(e, sched, depth));
   e->sched_level = t;
   ++e->n_sched_builds;
+  if (e->sched_depth > 0 && !e->sched_user && nxt == e->sched_nxt) return CWR_OK;       // the same chains: the lists stand
+  const bool reuse = e->own_cap > 0 && !e->h_tcl_ptr.empty();
+  std::vector<int32_t> sched; int depth = 0;
+  chains_to_schedule(nt, e->tcl_grid, reuse ? 1 : 2, nxt, sched, depth);
+  if (reuse) {
+    // per-schedule column lists: a column the PREVIOUS tile of the same list holds in LDS is coded -2 - (its position there)
+    const std::vector<int32_t>& tp = e->h_tcl_ptr; const std::vector<int32_t>& tc = e->h_tcl_cols;
+    std::vector<int32_t> scols(tc);
+    std::vector<int32_t> owner((size_t)e->n_real, -1), pos((size_t)e->n_real, 0);
+    const int grid = e->tcl_grid;
+    for (int b = 0; b < grid; ++b) {
+      int prev = -1;
+      for (int it = 0; it < depth; ++it) {
+        const int tl = sched[(size_t)it * grid + b];
+        if (tl < 0) break;
+        if (prev >= 0) {
+          for (int q = tp[(size_t)prev]; q < tp[(size_t)prev + 1]; ++q) { owner[(size_t)tc[(size_t)q]] = prev; pos[(size_t)tc[(size_t)q]] = q - tp[(size_t)prev]; }
+          for (int q = tp[(size_t)tl]; q < tp[(size_t)tl + 1]; ++q) {
+            const int g = tc[(size_t)q];
+            if (owner[(size_t)g] == prev) scols[(size_t)q] = -2 - pos[(size_t)g];
+          }
+        }
+        prev = tl;
+      }
+    }
+    if (!e->d_scols) TRY(dev_alloc(e, &e->d_scols, scols.size()));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    TRY(upload(e, e->d_scols, scols.data(), scols.size()));
+  }
+  TRY(install_schedule(e, sched, depth));
+  e->sched_nxt = nxt;
   if (getenv("CWR_VERBOSE")) {
     int linked = 0; for (int a = 0; a < nt; ++a) linked += nxt[(size_t)a] >= 0;
     fprintf(stderr, "[cwr] chained passes: schedule for level %d: %d of %d tiles have a chain successor, %d lists x %d slots\n", t, linked, nt, e->tcl_grid, depth);
@@ -1073,7 +1112,8 @@ int launch_sq_tiled(cwr_engine* e, const double* xin, double* yout, const int32_
   // slot taken until the launch ends), so RCCL's copy kernels could otherwise only start when it is over
   if (tile_list && !tail && grid > 4 * e->overlap_reserve) grid -= e->overlap_reserve;
   int depth = 0;
-  if (chained) { tile_list = e->d_sched; depth = e->sched_depth; grid = e->tcl_grid; }
+  const int32_t* scols = nullptr;
+  if (chained) { tile_list = e->d_sched; depth = e->sched_depth; grid = e->tcl_grid; scols = e->d_scols; }
   const int inplace = (xin == yout) ? 1 : 0;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (e->profiling && e->dominant_mode == 6 && e->ev_used + 2 <= e->ev.size()) {
@@ -1082,7 +1122,7 @@ int launch_sq_tiled(cwr_engine* e, const double* xin, double* yout, const int32_
   }
 #define CWR_TILED(VWv, Q) CWR_TCL_K(VWv, Q)<<<grid, BLOCK, e->tcl_lds, e->stream>>>(e->K, e->K / VWv, e->tcl_TR, ntiles, tile_list, depth, inplace,    \
       e->d_trow, e->d_ptr2, e->d_loc2, e->d_w2, e->d_tcl_ptr, e->d_tcl_cols, e->d_vptr, e->d_meta, e->tcl_max_cols, e->tcl_stage_cap,    \
-      e->local_reps, e->tcl_seg, e->tcl_nvmax, xin, e->d_t, yout)
+      e->local_reps, e->tcl_seg, e->tcl_nvmax, xin, e->d_t, yout, scols, e->own_cap)
   if (e->tcl_vw == 4) { if (e->tcl_cfg == 3) CWR_TILED(4, 3); else if (e->tcl_cfg == 4) CWR_TILED(4, 4); else if (e->tcl_cfg == 5) CWR_TILED(4, 5);
                         else if (e->tcl_cfg == 6) CWR_TILED(4, 6); else if (e->tcl_cfg == 7) CWR_TILED(4, 7); else CWR_TILED(4, 8); }
   else if (e->VW == 2) { if (e->tcl_cfg == 0) CWR_TILED(2, 0); else if (e->tcl_cfg == 1) CWR_TILED(2, 1); else if (e->tcl_cfg == 9) CWR_TILED(2, 9); else CWR_TILED(2, 2); }
@@ -1669,6 +1709,7 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   if (const char* v = getenv("CWR_NO_TCL")) eng->use_tcl = atoi(v) == 0;
   if (const char* v = getenv("CWR_NO_CHAINS")) eng->use_chains = atoi(v) == 0;
   if (const char* v = getenv("CWR_CHAIN_REFRESH")) eng->sched_refresh = std::max(1, atoi(v));
+  if (const char* v = getenv("CWR_CHAIN_REUSE")) eng->chain_reuse = atoi(v) != 0;
   // tile-local J^2 applications per pass: each costs LDS time only (measured 15-25 us at K = 16, 4 us at K = 1 on 1 M cells)
   // and cuts the passes from 46 to 28 (x2) / 24 (x3); narrow rows gain from the third application, wide rows do not
   // two everywhere (round 1 ran three at K <= 4).  Same box, ms per step at 2 / 3 / 4 applications (profiles/r02_w_local_reps.txt):
@@ -1805,7 +1846,7 @@ void cwr_destroy(cwr_engine* e) {
   for (hipEvent_t ev : e->ev) hipEventDestroy(ev);
   void* ptrs[] = {e->d_f1, e->d_f2, e->d_ptr, e->d_ent_edge, e->d_ent_nb, e->d_adv, e->d_vel, e->d_vol, e->d_dif,
                   e->d_bc, e->d_rec, e->d_diag, e->d_c, e->d_r, e->d_r0, e->d_p, e->d_v, e->d_s, e->d_t, e->d_b,
-                  e->d_scal, e->d_partial, e->d_fadv, e->d_fdif, e->d_ftot, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf, e->d_ptr2, e->d_col2, e->d_row2, e->d_rec2, e->d_w, e->d_react, e->d_info, e->d_tcl_ptr, e->d_tcl_cols, e->d_loc2, e->d_w2, e->d_pair_ptr, e->d_slots, e->d_line_ptr, e->d_line_faces, e->d_ledger, e->d_mass_out, e->d_chk, e->d_face_orig, e->d_row_ghost, e->d_keep, e->d_in_rows, e->d_in_vals, e->d_face_pos, e->d_trow, e->d_vptr, e->d_meta, e->d_tile_inner, e->d_tile_outer, e->d_chkx, e->d_sq_fast, e->d_sched, e->d_link_ptr, e->d_link_ent, e->d_link_flux};
+                  e->d_scal, e->d_partial, e->d_fadv, e->d_fdif, e->d_ftot, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf, e->d_ptr2, e->d_col2, e->d_row2, e->d_rec2, e->d_w, e->d_react, e->d_info, e->d_tcl_ptr, e->d_tcl_cols, e->d_loc2, e->d_w2, e->d_pair_ptr, e->d_slots, e->d_line_ptr, e->d_line_faces, e->d_ledger, e->d_mass_out, e->d_chk, e->d_face_orig, e->d_row_ghost, e->d_keep, e->d_in_rows, e->d_in_vals, e->d_face_pos, e->d_trow, e->d_vptr, e->d_meta, e->d_tile_inner, e->d_tile_outer, e->d_chkx, e->d_sq_fast, e->d_sched, e->d_link_ptr, e->d_link_ent, e->d_link_flux, e->d_scols};
   for (void* p : ptrs) if (p) hipFree(p);
   if (e->stream) hipStreamDestroy(e->stream);
   delete e;
@@ -2206,6 +2247,9 @@ int32_t cwr_set_tile_schedule(cwr_engine* e, int32_t n_lists, int32_t depth, con
   if (count != e->tcl_ntiles) return fail(e, CWR_ERR_BAD_ARG, "cwr_set_tile_schedule: every tile must appear exactly once");
   TRY(install_schedule(e, std::vector<int32_t>(sched, sched + (size_t)n_lists * depth), depth));
   e->sched_user = true;
+  // (the column lists of the engine's own schedule do not fit another one: plain lists, every column fetched)
+  if (e->d_scols && !e->h_tcl_cols.empty()) TRY(upload(e, e->d_scols, e->h_tcl_cols.data(), e->h_tcl_cols.size()));
+  e->sched_nxt.clear();
   return CWR_OK;
 }
 

@@ -900,10 +900,12 @@ __global__ void __launch_bounds__(BLOCK, CWR_TCL_WAVES) k_sq_tiled(
     const int32_t* __restrict__ ptr2, const uint16_t* __restrict__ loc2,
     const double* __restrict__ w2, const int32_t* __restrict__ tcl_ptr, const int32_t* __restrict__ tcl_cols,
     const int32_t* __restrict__ vptr, const int32_t* __restrict__ meta,
-    int max_cols, int stage_cap, int reps, int seg, int nvmax, const double* __restrict__ xin, const double* __restrict__ c2, double* __restrict__ yout) {
+    int max_cols, int stage_cap, int reps, int seg, int nvmax, const double* __restrict__ xin, const double* __restrict__ c2, double* __restrict__ yout,
+    const int32_t* __restrict__ scols, int own_cap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
   double* s_xt = reinterpret_cast<double*>(s_dyn);                                  // [max_cols][K]
-  double* s_part = s_xt + (size_t)max_cols * K;                                      // [nvmax][K] partial sums of virtual items
+  double* s_own = s_xt + (size_t)max_cols * K;                                       // [own_cap][K] the previous tile's results (reuse mode)
+  double* s_part = s_own + (size_t)own_cap * K;                                      // [nvmax][K] partial sums of virtual items
   double* s_w = s_part + (size_t)nvmax * K;                                          // [stage_cap]
   uint16_t* s_loc = reinterpret_cast<uint16_t*>(s_w + stage_cap);                    // [stage_cap] (stage_cap is even)
   int32_t* s_ptr = reinterpret_cast<int32_t*>(s_loc + stage_cap);                    // [TR + 1]
@@ -992,6 +994,24 @@ __global__ void __launch_bounds__(BLOCK, CWR_TCL_WAVES) k_sq_tiled(
   };
   // prefetch registers
   int cn[TCL_XR];                                  // row list of the tile after next (global x row ids)
+  // REUSE mode (scols != nullptr; chained passes): the column list of a tile comes from a per-schedule copy in which a column that
+  // the PREVIOUS tile of this block's list already holds in LDS is coded -2 - (its position there) instead of its row id.
+  // Such a column is not fetched: it is carried over from the old LDS image -- for the previous tile's own rows from s_own, i.e.
+  // its fresh results.  With lane-major numbering consecutive tiles of a list overlap in 64 of their 152 columns (the upstream
+  // halo = the predecessor's last two columns, and the own rows that were the predecessor's downstream halo).
+  // (positions fit a byte -- a tile holds < 255 columns in every configuration that reuses --, four to a register: the codes of
+  // the current tile cost (XR + 3) / 4 VGPRs instead of XR; 0xFF = fetched, not carried over)
+  constexpr int NCC = (TCL_XR + 3) / 4;
+  uint32_t cc[NCC];                                // the carry-over positions of the CURRENT tile's columns
+  auto save_codes = [&]() {
+#pragma unroll
+    for (int w = 0; w < NCC; ++w) cc[w] = 0xFFFFFFFFu;
+#pragma unroll
+    for (int u = 0; u < TCL_XR; ++u) {
+      const uint32_t b = (cn[u] <= -2) ? (uint32_t)(-2 - cn[u]) : 0xFFu;
+      cc[u >> 2] = (cc[u >> 2] & ~(0xFFu << (8 * (u & 3)))) | (b << (8 * (u & 3)));
+    }
+  };
   double xr[TCL_XR][XW];                           // x rows of the next tile (fetch mapping)
   double wr[WRN]; int lr[WRN];               // weights / local indices of the next tile
   double q0[TCL_U][VW];                            // c2 rows of the next tile
@@ -1007,8 +1027,9 @@ __global__ void __launch_bounds__(BLOCK, CWR_TCL_WAVES) k_sq_tiled(
     a_v0 = __builtin_amdgcn_readfirstlane(vptr[t]); a_v1 = __builtin_amdgcn_readfirstlane(vptr[t + 1]);
     if (!loadlane) return;
     const int cb = tcl_ptr[t], ce = tcl_ptr[t + 1];
+    const int32_t* cols = scols ? scols : tcl_cols;
 #pragma unroll
-    for (int u = 0; u < TCL_XR; ++u) { const int q = rl + u * RL; if (q < ce - cb) cn[u] = tcl_cols[cb + q]; }
+    for (int u = 0; u < TCL_XR; ++u) { const int q = rl + u * RL; if (q < ce - cb) cn[u] = cols[cb + q]; }
   };
   auto load_rows = [&](int t) {                    // uses cn and (n_c0, n_c1, n_v0, n_v1), loaded one tile earlier
     if (t < 0) return;
@@ -1037,6 +1058,7 @@ __global__ void __launch_bounds__(BLOCK, CWR_TCL_WAVES) k_sq_tiled(
   load_cols(t_cur);
   n_c0 = a_c0; n_c1 = a_c1; n_v0 = a_v0; n_v1 = a_v1;
   load_rows(t_cur);                                // (the first tile's chain is not hidden)
+  save_codes();
   int c_c0 = n_c0, c_c1 = n_c1, c_nv = n_v1 - n_v0;
   int t_next = tile_of(1);
   load_cols(t_next);
@@ -1052,6 +1074,18 @@ __global__ void __launch_bounds__(BLOCK, CWR_TCL_WAVES) k_sq_tiled(
     const int jb0 = ptr2[c0];
     const int nent = ptr2[c1] - jb0;
     __syncthreads();                               // the previous tile's readers are done with LDS
+    if (scols) {
+      // carry over what the previous tile left in LDS (its own rows: the results it has just computed, from s_own)
+      const int pNR = pc1 - pc0;
+      if (loadlane) {
+#pragma unroll
+        for (int u = 0; u < TCL_XR; ++u) {
+          const int pos = (int)((cc[u >> 2] >> (8 * (u & 3))) & 0xFFu);
+          if (pos != 0xFF) ldv<XW>((pos < pNR ? s_own : s_xt) + (size_t)pos * K + gl * XW, xr[u]);
+        }
+      }
+      __syncthreads();                             // the old image has been read: it may be overwritten
+    }
     if (loadlane) {
 #pragma unroll
       for (int u = 0; u < TCL_XR; ++u) { const int q = rl + u * RL; if (q < ncol) stv<XW>(s_xt + (size_t)q * K + gl * XW, xr[u]); }
@@ -1071,12 +1105,14 @@ __global__ void __launch_bounds__(BLOCK, CWR_TCL_WAVES) k_sq_tiled(
     // wave's stores are issued before any wave's prefetch of the next tile's x rows below -- the tile after next in this
     // block's list is the chain successor of the previous one and must read what it has just written (same CU, same L1:
     // workgroup-scope ordering needs no cache action on gfx950, and hipcc's barrier carries no vmcnt wait)
-    if (inplace && rowlane) {
+    // (reuse mode needs neither: the successor takes these rows from LDS)
+    const bool early = inplace && !scols;
+    if (early && rowlane) {
 #pragma unroll
       for (int u = 0; u < TCL_U; ++u) { const int c = pc0 + r + u * R; if (c < pc1) st_row(yout + (size_t)c * K, y[u]); }
     }
     __syncthreads();
-    if (!inplace && rowlane) {                     // the previous tile's results
+    if (!early && rowlane) {                       // the previous tile's results
 #pragma unroll
       for (int u = 0; u < TCL_U; ++u) { const int c = pc0 + r + u * R; if (c < pc1) st_row(yout + (size_t)c * K, y[u]); }
     }
@@ -1086,6 +1122,7 @@ __global__ void __launch_bounds__(BLOCK, CWR_TCL_WAVES) k_sq_tiled(
     // start the next tile's loads (x rows by the list already in registers) and the list of the tile after it
     const int t_after = tile_of(it + 2);
     load_rows(t_next);
+    if (scols) save_codes();                                    // (the next tile's carry-over positions, for its LDS image one iteration on)
     const int x_c0 = n_c0, x_c1 = n_c1, x_nv = n_v1 - n_v0;      // (the next tile's ranges, before load_cols overwrites a_*)
     load_cols(t_after);
     n_c0 = a_c0; n_c1 = a_c1; n_v0 = a_v0; n_v1 = a_v1;
@@ -1161,6 +1198,10 @@ __global__ void __launch_bounds__(BLOCK, CWR_TCL_WAVES) k_sq_tiled(
         }
       }
           }
+    }
+    if (scols && rowlane) {                        // the results, where the next tile of this list looks for them
+#pragma unroll
+      for (int u = 0; u < TCL_U; ++u) { const int i = r + u * R; if (i < NR) st_row(s_own + (size_t)i * K, y[u]); }
     }
     pc0 = c0; pc1 = c1;
     t_cur = t_next;
