@@ -1236,12 +1236,12 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
       const bool first_batch = st.sweeps == 0;
       if (e->reps_auto) {
         // Tile-local applications per visit.  A chain carries information from tile to tile only as far as the applications
-        // carry it across a tile, and the stiffer the step the more of its sweeps are transport along the flow: measured on the
-        // 1 M-cell mesh x 16 (profiles/r03_c_chained_passes.txt) two applications win at CFL 2.5 (||J||_inf 0.78: 3.19 ms per step
-        // against 3.46 with three), four at CFL 25 and 62 (0.973 / 0.989: 11.8 and 22.4 ms against 15.4 with two and 14.8 / 23.3
-        // with six).  ||J||_inf of the step is known from the flow field (k_jnorm).
+        // carry it across a tile, and the stiffer the step the more of its sweeps are transport along the flow.  Measured on the
+        // 1 M-cell mesh x 16 with column reuse (profiles/r03_c_chained_passes.txt, E): CFL 2.5 (||J||_inf 0.78): x2 2.77 ms per
+        // step, x3 3.01; CFL 25 (0.973): x2 15.3, x4 10.8, x6 12.0; CFL 62 (0.989): x4 22.1, x6 19.0; CFL 225 (0.9969): x4 39.2,
+        // x8 34.9 (ping-pong x2: 3.69 / 27.4 / 55.7 / 140.8).  ||J||_inf of the step is known from the flow field (k_jnorm).
         const double rho = ((size_t)e->cur_t < e->jnorm.size()) ? e->jnorm[(size_t)e->cur_t] : 0.0;
-        e->local_reps = !chained ? e->reps_base : (rho < 0.9 ? 2 : 4);
+        e->local_reps = !chained ? e->reps_base : (rho < 0.9 ? 2 : (rho < 0.98 ? 4 : (rho < 0.993 ? 6 : 8)));
       }
       const bool one_closing = chained || (!e->comm && !e->two_closing && want % 4 != 2);
       int doubles;
