@@ -204,6 +204,7 @@ struct cwr_engine {
   int sched_depth = 0, sched_cap = 0;
   // column reuse along a block's list (see k_sq_tiled, REUSE mode): per-schedule copy of the tiles' column lists
   bool chain_reuse = true;                 // CWR_CHAIN_REUSE=0: fetch every column, two interleaved streams per block (A/B)
+  int chain_min_tiles = 3;                 // tiles per block of the persistent grid from which schedules are built
   int32_t* d_scols = nullptr;
   std::vector<int32_t> h_tcl_ptr, h_tcl_cols, h_trow;     // host copies of the tiling (column lists, rows of every tile)
   std::vector<int32_t> sched_nxt;          // chain successor of every tile in the installed schedule (unchanged -> no rebuild)
@@ -835,7 +836,7 @@ int ensure_sq_pattern(cwr_engine* e) {
     }
     cap2 += cap2 & 1;                                            // even: the 16-bit index array keeps what follows 4-byte aligned
     // (one GPU with chained passes: + a staging area for a tile's results, which the next tile of the block's list carries over)
-    const int own_cap = (!e->comm && e->use_chains && e->chain_reuse && !split && max_cols < 255) ? tr : 0;   // (positions travel as bytes)
+    const int own_cap = (!e->comm && e->use_chains && e->chain_reuse && !split) ? tr : 0;
     const size_t lds = ((size_t)(max_cols + nvmax + own_cap) * e->K * sizeof(double) + (size_t)cap2 * (sizeof(double) + sizeof(uint16_t)) +
                         (size_t)(tr + 1 + nvmax) * sizeof(int32_t) + 15) & ~(size_t)15;
     // the kernel's compile-time prefetch depths bound what a tile may hold; otherwise the plain J^2 pass stays
@@ -1201,9 +1202,9 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
   bool sq = false;
   TRY(prepare_sq(e, sq));
   const bool tiled = sq && e->tcl_ready;
-  if (tiled && !e->comm && e->use_chains && !e->two_closing && !e->sched_user && e->tcl_ntiles >= 4 * e->tcl_grid &&
+  if (tiled && !e->comm && e->use_chains && !e->two_closing && !e->sched_user && e->tcl_ntiles >= e->chain_min_tiles * e->tcl_grid &&
       (e->sched_level < 0 || std::abs(e->cur_t - e->sched_level) >= e->sched_refresh))
-    // (worth it from four tiles per block up: two interleaved streams of at least two tiles each)
+    // (worth it from a few tiles per block up: CWR_CHAIN_MIN_TILES, default 3)
     TRY(build_chain_schedule(e, e->cur_t));
   if (e->comm && sq && e->n_real > e->n_core)
     // the ping-pong partner starts with this step's halo values too (its never-computed outer layers would otherwise
@@ -1710,6 +1711,7 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   if (const char* v = getenv("CWR_NO_CHAINS")) eng->use_chains = atoi(v) == 0;
   if (const char* v = getenv("CWR_CHAIN_REFRESH")) eng->sched_refresh = std::max(1, atoi(v));
   if (const char* v = getenv("CWR_CHAIN_REUSE")) eng->chain_reuse = atoi(v) != 0;
+  if (const char* v = getenv("CWR_CHAIN_MIN_TILES")) eng->chain_min_tiles = std::max(1, atoi(v));
   // tile-local J^2 applications per pass: each costs LDS time only (measured 15-25 us at K = 16, 4 us at K = 1 on 1 M cells)
   // and cuts the passes from 46 to 28 (x2) / 24 (x3); narrow rows gain from the third application, wide rows do not
   // two everywhere (round 1 ran three at K <= 4).  Same box, ms per step at 2 / 3 / 4 applications (profiles/r02_w_local_reps.txt):

@@ -999,17 +999,17 @@ __global__ void __launch_bounds__(BLOCK, CWR_TCL_WAVES) k_sq_tiled(
   // Such a column is not fetched: it is carried over from the old LDS image -- for the previous tile's own rows from s_own, i.e.
   // its fresh results.  With lane-major numbering consecutive tiles of a list overlap in 64 of their 152 columns (the upstream
   // halo = the predecessor's last two columns, and the own rows that were the predecessor's downstream halo).
-  // (positions fit a byte -- a tile holds < 255 columns in every configuration that reuses --, four to a register: the codes of
-  // the current tile cost (XR + 3) / 4 VGPRs instead of XR; 0xFF = fetched, not carried over)
-  constexpr int NCC = (TCL_XR + 3) / 4;
+  // (positions travel as 16-bit halves, two to a register: the codes of the current tile cost (XR + 1) / 2 VGPRs instead of XR;
+  // 0xFFFF = fetched, not carried over)
+  constexpr int NCC = (TCL_XR + 1) / 2;
   uint32_t cc[NCC];                                // the carry-over positions of the CURRENT tile's columns
   auto save_codes = [&]() {
 #pragma unroll
     for (int w = 0; w < NCC; ++w) cc[w] = 0xFFFFFFFFu;
 #pragma unroll
     for (int u = 0; u < TCL_XR; ++u) {
-      const uint32_t b = (cn[u] <= -2) ? (uint32_t)(-2 - cn[u]) : 0xFFu;
-      cc[u >> 2] = (cc[u >> 2] & ~(0xFFu << (8 * (u & 3)))) | (b << (8 * (u & 3)));
+      const uint32_t b = (cn[u] <= -2) ? (uint32_t)(-2 - cn[u]) : 0xFFFFu;
+      cc[u >> 1] = (cc[u >> 1] & ~(0xFFFFu << (16 * (u & 1)))) | (b << (16 * (u & 1)));
     }
   };
   double xr[TCL_XR][XW];                           // x rows of the next tile (fetch mapping)
@@ -1080,8 +1080,8 @@ __global__ void __launch_bounds__(BLOCK, CWR_TCL_WAVES) k_sq_tiled(
       if (loadlane) {
 #pragma unroll
         for (int u = 0; u < TCL_XR; ++u) {
-          const int pos = (int)((cc[u >> 2] >> (8 * (u & 3))) & 0xFFu);
-          if (pos != 0xFF) ldv<XW>((pos < pNR ? s_own : s_xt) + (size_t)pos * K + gl * XW, xr[u]);
+          const int pos = (int)((cc[u >> 1] >> (16 * (u & 1))) & 0xFFFFu);
+          if (pos != 0xFFFF) ldv<XW>((pos < pNR ? s_own : s_xt) + (size_t)pos * K + gl * XW, xr[u]);
         }
       }
       __syncthreads();                             // the old image has been read: it may be overwritten
