@@ -157,3 +157,26 @@ def test_without_chains_runs_are_bitwise_reproducible_and_with_them_within_the_t
         runs[chains] = outs
     assert np.array_equal(runs[False][0], runs[False][1])
     assert rel_err(runs[True][0], runs[True][1]) <= 1e-10
+
+
+@pytest.mark.parametrize('Kc,grid', [(1, 32), (3, 32), (12, 32)])
+def test_chained_passes_at_other_constituent_counts_match_the_oracle(gpu_lib, monkeypatch, Kc, grid):
+    """The lane mappings of the tiled pass other than K = 16 (one constituent per lane with 256-row tiles, odd K, the four-wide
+    mapping at K = 12) through the chained, column-reusing passes: element-wise against spsolve output."""
+    import clearwater_riverine_amd as cw
+    from clearwater_riverine_amd.distributed import PartitionedTransport
+    steps = 2
+    mesh = cw.synthetic.make_mesh(200, 200, steps, seed=12, n_merge=2000, dt=40.0, diffusion_coefficient=0.5)
+    inputs3 = cw.synthetic.distinct_input_array(mesh, Kc, seed=3)
+    oracle.derive_coefficients(mesh)
+    ref = oracle_run(mesh, inputs3, steps)
+    n = mesh['nreal'] + 1
+    want = np.stack([ref.constituent_dict[f'c{k}'].state[steps, :n] for k in range(Kc)], axis=1)
+    monkeypatch.setenv('CWR_TCL_GRID', str(grid))
+    monkeypatch.delenv('CWR_NO_CHAINS', raising=False)
+    pt = PartitionedTransport(mesh, inputs3, 0, 1)
+    rs = [pt.step(t, tol=1e-12) for t in range(steps)]
+    sched, _, _ = pt.engine.get_tile_schedule()
+    assert sched is not None and all(r.sweep_kernel == 6 and r.flags == 0 for r in rs)
+    assert rel_err(pt.gather_state(), want) <= 1e-9
+    pt.engine.close()
