@@ -70,7 +70,8 @@ def schedule(chain_list, ntiles: int, grid: int, streams_per_block: int = 2) -> 
     compact region), are concatenated and cut into grid * streams_per_block consecutive STREAMS of equal length (+-1); block
     b = lidx * 8 + xcd walks the streams (xcd * (grid / 8) + lidx) * spb .. + spb - 1 INTERLEAVED (A1 B1 A2 B2 ...): the
     kernel prefetches a tile's x rows one tile ahead, so a tile's chain successor must come two slots later to see its
-    results."""
+    results.  With the engine's column reuse (the default) a successor takes the rows it shares with its predecessor from LDS and
+    simply comes next: streams_per_block = 1."""
     seq = np.concatenate([np.asarray(c, dtype=np.int64) for c in chain_list]) if chain_list else np.zeros(0, np.int64)
     assert len(seq) == ntiles
     ns = grid * streams_per_block

@@ -15,7 +15,7 @@ TPS = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 TR = 64
 mesh = cw.synthetic.make_mesh(nx, nx, 3, seed=4, dt=dt, diffusion_coefficient=0.5, n_merge=int(0.05 * nx * nx))
 n = mesh['nreal'] + 1
-for tile_len in (4, 8):
+for tile_len in (int(v) for v in os.environ.get('TILE_LENS', '4,8').split(',')):
     m = renumber_mesh(mesh, lane_order(mesh, n, tile_rows=TR, tile_len=tile_len))
     orc.derive_coefficients(m)
     lhs = orc.LHS(m); lhs.update_values(m, 0)
@@ -81,7 +81,7 @@ for tile_len in (4, 8):
             return x
         return step
     print(f'-- {n} cells, {ntiles} tiles, streams of {TPS}, dt={dt}, ||J||inf={abs(J).sum(axis=1).max():.4f}')
-    for L in (2, 4):
+    for L in (int(v) for v in os.environ.get('REPS', '2,4').split(',')):
         run(f'ping-pong x{L}            ', jac(L))
         run(f'lanes in place x{L}        ', chains(L))
     run('lanes in place, column GS x1', chains(1, True))
