@@ -482,7 +482,7 @@ int launch_rhs(cwr_engine* e, int t, const double* x, double* b, bool scale, dou
   const double* bc_n = e->d_bc + (size_t)(t + 1) * e->n_ghost * e->K;
   const int used = (e->D != 0.0) ? 1 : 0;
 #define CWR_RHS(VWv, SC) k_rhs<VWv, SC><<<grid, BLOCK, 0, e->stream>>>(e->n_owned, e->K, e->G, e->d_ptr, e->d_ent_edge, \
-    e->d_ent_nb, vol_t, e->dt[t], vel_n, adv_n, dif_n, used, bc_n, x, e->d_diag, e->d_row_ghost, b, e->d_counters, keep, e->n_real, e->n_ghost, \
+    e->d_ent_nb, vol_t, e->dt[t], vel_n, adv_n, dif_n, used, bc_n, x, e->d_diag, e->d_row_ghost, b, e->d_counters, keep, e->n_owned, e->n_cells - e->n_owned, \
     e->d_chk + 4 * (size_t)e->K, e->ew_rel)
   if (e->VW == 2) { if (scale) CWR_RHS(2, true); else CWR_RHS(2, false); }
   else            { if (scale) CWR_RHS(1, true); else CWR_RHS(1, false); }
@@ -1195,7 +1195,7 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
   int since_exchange = 0;                     // the caller exchanged the state's halo just before the right-hand side
   // sweeps the next batch should add (prediction, unrounded; the margin only where batches come in steps of one or two
   // sweeps: the even-passes shape rounds up to 2 (mod 4) and has its slack built in)
-  const int margin = (e->comm || e->two_closing) ? 0 : e->sweep_margin;
+  const int margin = e->two_closing ? 0 : e->sweep_margin;
   int want = (e->last_sweeps > 0) ? std::max(2, e->last_sweeps + margin) : 8;
   int batch = 0;
   const int sweep_limit = forced ? max_iter : std::min(max_iter, e->jacobi_limit);
@@ -1244,7 +1244,9 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
         const double rho = ((size_t)e->cur_t < e->jnorm.size()) ? e->jnorm[(size_t)e->cur_t] : 0.0;
         e->local_reps = !chained ? e->reps_base : (rho < 0.9 ? 2 : (rho < 0.98 ? 4 : (rho < 0.993 ? 6 : 8)));
       }
-      const bool one_closing = chained || (!e->comm && !e->two_closing && want % 4 != 2);
+      // (round 3: partitioned engines take the one-closing shape too -- k_rhs keeps the read-only halo rows of x_t beside the
+      // computed rows, so a first pass may start from the copy there as well: one plain sweep and one exchange fewer per step)
+      const bool one_closing = chained || (!e->two_closing && want % 4 != 2);
       int doubles;
       if (one_closing) {
         doubles = std::max(1, std::min(want / 2, 2047));
@@ -1321,6 +1323,12 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
       for (int i = 0; i < doubles;) {
         double* src = srcb(i);
         double* dst = dstb(i);
+        if (e->comm && from_keep && i == 0 && since_exchange + 2 <= e->exch_every) {
+          // the pass that starts from the kept copy of x_t (it shifts the ping-pong parity): on its own, outside the stretch graphs
+          if (tiled) TRY(launch_sq_tiled(e, src, dst)); else TRY(launch_apply<5>(e, src, dst, nullptr, e->d_t, nullptr, nullptr, e->n_sq));
+          since_exchange += 2; ++i;
+          continue;
+        }
         if (since_exchange + 2 > e->exch_every) {
           if (can_overlap) {
             // pack the cut rows, start the interior tiles (they read core rows only), exchange beside them on the
@@ -1347,14 +1355,14 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
         int run = std::min(doubles - i, std::max(1, (e->exch_every - since_exchange) / 2));
         if (!e->comm) run = doubles - i;
         if (e->comm && tiled && run >= 3 && e->use_graphs && !e->profiling) {
-          const int key = (i & 1) * 4096 + run;
+          const int key = (src == e->d_c ? 0 : 1) * 4096 + run;          // (which vector the stretch starts from)
           auto it = e->stretch_exec.find(key);
           if (it == e->stretch_exec.end() && e->stretch_exec.size() < 16) {
             hipGraphExec_t ex = nullptr;
             if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
               int rc = CWR_OK;
               for (int q = 0; q < run && rc == CWR_OK; ++q)
-                rc = launch_sq_tiled(e, ((i + q) & 1) ? e->d_p : e->d_c, ((i + q) & 1) ? e->d_c : e->d_p);
+                rc = launch_sq_tiled(e, srcb(i + q), dstb(i + q));
               hipGraph_t g = nullptr;
               const hipError_t ec = hipStreamEndCapture(e->stream, &g);
               if (!(rc == CWR_OK && ec == hipSuccess && g && hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess)) { ex = nullptr; (void)hipGetLastError(); }
@@ -1379,6 +1387,11 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
       // block-asynchronous passes leave the replayed halo layers only approximately equal to their owners' rows: refresh
       // them so that the two plain sweeps below are exact on the core and the check is the true residual
       if (one_closing) {
+        if (e->comm) {
+          if (tiled && e->local_reps > 1 && passes > 0) since_exchange = e->exch_every;
+          if (since_exchange + 1 > e->exch_every) { TRY(exchange_halo(e, srcb(passes))); since_exchange = 0; }
+          ++since_exchange;
+        }
         TRY(launch_apply<4>(e, srcb(passes), dstb(passes), nullptr, e->d_b, nullptr, nullptr));
       } else {
       if (e->comm && tiled && e->local_reps > 1 && passes > 0) since_exchange = e->exch_every;

@@ -203,15 +203,16 @@ def test_partitioned_block_asynchronous_passes_keep_the_single_rank_sweep_count(
     assert rel_err(state, single.gather_state()) <= 1e-10
     for r in results:
         got = [s for s, _ in r[6]]
-        assert all(g <= s + 4 for g, s in zip(got[1:], single_sweeps[1:])), (got, single_sweeps)
+        assert all(g <= s + 2 for g, s in zip(got[1:], single_sweeps[1:])), (got, single_sweeps)
+        assert any(g % 2 == 1 for g in got), got          # N passes + ONE closing sweep (round 3: partitioned engines too)
     assert min(single_sweeps) >= 20                           # the case really iterates
     # cwr_step_info of a partitioned step: exchanges, how many of them overlapped, blocking checks.  A step of P J^2 passes at
-    # halo depth d needs one exchange per d / 2 passes, one before each of the two closing sweeps, one in front of the
-    # right-hand side (skipped when the previous step's tail delivered the rows) and the tail's own; in the steady state ONE check
+    # halo depth d needs one exchange per d / 2 passes, one before the closing sweep (two with the even-passes shape), one in
+    # front of the right-hand side (skipped when the previous step's tail delivered the rows) and the tail's own; in the steady state ONE check
     for r in results:
         for (sweeps, _), (exch, over, checks) in list(zip(r[6], r[13]))[1:]:
-            passes = (sweeps - 2) // 2
-            assert 0 < over <= exch <= -(-passes // max(1, depth // 2)) + 5, (sweeps, exch, over, depth)
+            passes = (sweeps - 1) // 2
+            assert 0 < over <= exch <= -(-passes // max(1, depth // 2)) + 4, (sweeps, exch, over, depth)
             assert 1 <= checks <= 2, checks
         assert r[13] == results[0][13]                        # every rank made the same calls
     # the exchanges inside the pass loop ran beside the interior tiles (second stream + events), on every rank
