@@ -1074,17 +1074,16 @@ __global__ void __launch_bounds__(BLOCK, CWR_TCL_WAVES) k_sq_tiled(
     const int jb0 = ptr2[c0];
     const int nent = ptr2[c1] - jb0;
     __syncthreads();                               // the previous tile's readers are done with LDS
-    if (scols) {
-      // carry over what the previous tile left in LDS (its own rows: the results it has just computed, from s_own)
+    if (scols && loadlane) {
+      // carry over the previous tile's own rows -- the results it has just computed -- from the staging area (written before the
+      // barrier above; the columns it held as halo were picked up from the old image at the end of its compute phase, below:
+      // nothing reads the old image any more, so no second barrier is needed before it is overwritten)
       const int pNR = pc1 - pc0;
-      if (loadlane) {
 #pragma unroll
-        for (int u = 0; u < TCL_XR; ++u) {
-          const int pos = (int)((cc[u >> 1] >> (16 * (u & 1))) & 0xFFFFu);
-          if (pos != 0xFFFF) ldv<XW>((pos < pNR ? s_own : s_xt) + (size_t)pos * K + gl * XW, xr[u]);
-        }
+      for (int u = 0; u < TCL_XR; ++u) {
+        const int pos = (int)((cc[u >> 1] >> (16 * (u & 1))) & 0xFFFFu);
+        if (pos < pNR) ldv<XW>(s_own + (size_t)pos * K + gl * XW, xr[u]);
       }
-      __syncthreads();                             // the old image has been read: it may be overwritten
     }
     if (loadlane) {
 #pragma unroll
@@ -1199,9 +1198,21 @@ __global__ void __launch_bounds__(BLOCK, CWR_TCL_WAVES) k_sq_tiled(
       }
           }
     }
-    if (scols && rowlane) {                        // the results, where the next tile of this list looks for them
+    if (scols) {
+      if (rowlane) {                               // the results, where the next tile of this list looks for them
 #pragma unroll
-      for (int u = 0; u < TCL_U; ++u) { const int i = r + u * R; if (i < NR) st_row(s_own + (size_t)i * K, y[u]); }
+        for (int u = 0; u < TCL_U; ++u) { const int i = r + u * R; if (i < NR) st_row(s_own + (size_t)i * K, y[u]); }
+      }
+      if (loadlane) {
+        // ... and the halo columns of THIS tile that the next one needs too, from the image while it is still there (those rows
+        // are read-only during the compute phase, so other waves may still be computing): into the free prefetch registers --
+        // a carried-over column was not fetched.  cc holds the next tile's codes since its prefetch was issued.
+#pragma unroll
+        for (int u = 0; u < TCL_XR; ++u) {
+          const int pos = (int)((cc[u >> 1] >> (16 * (u & 1))) & 0xFFFFu);
+          if (pos != 0xFFFF && pos >= NR) ldv<XW>(s_xt + (size_t)pos * K + gl * XW, xr[u]);
+        }
+      }
     }
     pc0 = c0; pc1 = c1;
     t_cur = t_next;
