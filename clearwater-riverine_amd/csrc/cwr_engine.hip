@@ -836,7 +836,7 @@ int ensure_sq_pattern(cwr_engine* e) {
     }
     cap2 += cap2 & 1;                                            // even: the 16-bit index array keeps what follows 4-byte aligned
     // (one GPU with chained passes: + a staging area for a tile's results, which the next tile of the block's list carries over)
-    const int own_cap = (!e->comm && e->use_chains && e->chain_reuse && !split) ? tr : 0;
+    const int own_cap = (e->use_chains && e->chain_reuse && !split) ? tr : 0;
     const size_t lds = ((size_t)(max_cols + nvmax + own_cap) * e->K * sizeof(double) + (size_t)cap2 * (sizeof(double) + sizeof(uint16_t)) +
                         (size_t)(tr + 1 + nvmax) * sizeof(int32_t) + 15) & ~(size_t)15;
     // the kernel's compile-time prefetch depths bound what a tile may hold; otherwise the plain J^2 pass stays
@@ -1202,7 +1202,7 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
   bool sq = false;
   TRY(prepare_sq(e, sq));
   const bool tiled = sq && e->tcl_ready;
-  if (tiled && !e->comm && e->use_chains && !e->two_closing && !e->sched_user && e->tcl_ntiles >= e->chain_min_tiles * e->tcl_grid &&
+  if (tiled && e->use_chains && !e->two_closing && !e->sched_user && e->tcl_ntiles >= e->chain_min_tiles * e->tcl_grid &&
       (e->sched_level < 0 || std::abs(e->cur_t - e->sched_level) >= e->sched_refresh))
     // (worth it from a few tiles per block up: CWR_CHAIN_MIN_TILES, default 3)
     TRY(build_chain_schedule(e, e->cur_t));
@@ -1233,7 +1233,11 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
       // -- the first pass of a step reads x_t from the state vector and writes the partner, every later pass reads and writes
       // the partner -- and the closing sweep carries the result into the state vector: any number of passes, one closing sweep.
       // (A later batch of the same step goes on in the partner; the closing sweep's own progress is not used.)
-      const bool chained = tiled && !e->comm && e->use_chains && e->sched_depth > 0 && !e->two_closing;
+      // Partitioned engines (round 3): the same, between the halo exchanges -- which then run on the engine's stream in front of
+      // the pass that needs them instead of beside its interior tiles (a chained pass walks ALL tiles of a rank in one launch;
+      // chaining the interior and the cut tiles separately is the next step).  A rank chains when ITS lists are long enough, so
+      // ranks may differ: the exchanges, the batch shape and the checks do not depend on it.
+      const bool chained = tiled && e->use_chains && e->sched_depth > 0 && !e->two_closing;
       const bool first_batch = st.sweeps == 0;
       if (e->reps_auto) {
         // Tile-local applications per visit.  A chain carries information from tile to tile only as far as the applications
@@ -1319,7 +1323,7 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
         while (exec && doubles >= cwr_engine::GRAPH_SWEEPS) { HIP_TRY(e, hipGraphLaunch(exec, e->stream)); doubles -= cwr_engine::GRAPH_SWEEPS; }
       }
       // a J^2 pass uses up two halo layers of validity, a plain sweep one
-      const bool can_overlap = e->comm && tiled && e->overlap && e->comm_stream && e->n_tile_inner > 0 && !e->peers.empty();
+      const bool can_overlap = e->comm && tiled && !chained && e->overlap && e->comm_stream && e->n_tile_inner > 0 && !e->peers.empty();
       for (int i = 0; i < doubles;) {
         double* src = srcb(i);
         double* dst = dstb(i);
@@ -1355,14 +1359,14 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
         int run = std::min(doubles - i, std::max(1, (e->exch_every - since_exchange) / 2));
         if (!e->comm) run = doubles - i;
         if (e->comm && tiled && run >= 3 && e->use_graphs && !e->profiling) {
-          const int key = (src == e->d_c ? 0 : 1) * 4096 + run;          // (which vector the stretch starts from)
+          const int key = (src == e->d_c ? 0 : 1) * 4096 + run + (chained ? (1 << 16) + (e->local_reps << 20) : 0);   // (which vector the stretch starts from)
           auto it = e->stretch_exec.find(key);
-          if (it == e->stretch_exec.end() && e->stretch_exec.size() < 16) {
+          if (it == e->stretch_exec.end() && e->stretch_exec.size() < 32) {
             hipGraphExec_t ex = nullptr;
             if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
               int rc = CWR_OK;
               for (int q = 0; q < run && rc == CWR_OK; ++q)
-                rc = launch_sq_tiled(e, srcb(i + q), dstb(i + q));
+                rc = launch_sq_tiled(e, srcb(i + q), dstb(i + q), nullptr, 0, true, chained);
               hipGraph_t g = nullptr;
               const hipError_t ec = hipStreamEndCapture(e->stream, &g);
               if (!(rc == CWR_OK && ec == hipSuccess && g && hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess)) { ex = nullptr; (void)hipGetLastError(); }

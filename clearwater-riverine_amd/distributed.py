@@ -14,7 +14,7 @@ import numpy as np
 
 from .engine import TransportEngine, tile_rows
 from .model import face_to_face_distance, change_in_time
-from .ordering import balance_windows, flow_aligned_order, hilbert_order, lane_order
+from .ordering import balance_windows, hilbert_order, lane_order
 from .partition import LocalMesh, partition_mesh, slice_fields
 
 
@@ -87,15 +87,18 @@ def shared_hilbert_order(mesh: dict, n: int, rank: int, world: int, K: int = 16)
 
 
 def _curve_order(mesh: dict, n: int, K: int, world: int = 1) -> np.ndarray:
-    """Hilbert order, the cells of every tile-sized window sorted by their J^2 row length (ordering.balance_windows; the
-    tile size of the engine's sweep kernel depends on K: cwr_tile_rows).  CWR_NO_BALANCE=1: plain Hilbert order (A/B)."""
-    # one rank runs the chained passes (tile chains along the flow): tiles short along the flow axis pay there; the ping-pong
-    # passes of partitioned engines lose from it (3.62 -> 4.07 ms per step on the bench mesh) and keep the isotropic curve
-    aspect = float(os.environ.get('CWR_TILE_ASPECT', '2')) if (world == 1 and not os.environ.get('CWR_NO_CHAINS')) else 1.0
-    if world == 1 and not os.environ.get('CWR_NO_CHAINS') and os.environ.get('CWR_TILE_ORDER', 'lanes') == 'lanes':
-        order = lane_order(mesh, n, tile_rows=tile_rows(K))
-    else:
-        order = flow_aligned_order(mesh, n, aspect=aspect) if aspect != 1.0 else hilbert_order(mesh['face_x'], mesh['face_y'], n)
+    """Lane-major or Hilbert order (see below), the cells of every tile-sized window sorted by their J^2 row length
+    (ordering.balance_windows; the tile size of the engine's sweep kernel depends on K: cwr_tile_rows).  CWR_NO_BALANCE=1: the
+    plain curve (A/B)."""
+    # Engines that will run the chained passes (tile chains along the flow: from three tiles per resident block up, i.e. about
+    # 200 k cells per rank at K = 16) want lanes along the flow; the ping-pong passes of smaller ranks lose from anisotropic
+    # tiles (3.62 -> 4.07 ms per step on the bench mesh) and keep the isotropic Hilbert curve, which also gives compact rank
+    # ranges (fewer halo rows).  CWR_TILE_ORDER=lanes|hilbert overrides.
+    tr = tile_rows(K)
+    want = os.environ.get('CWR_TILE_ORDER', 'auto')
+    lanes = want == 'lanes' or (want == 'auto' and not os.environ.get('CWR_NO_CHAINS') and
+                                (world == 1 or n // world >= 3 * 1024 * tr))
+    order = lane_order(mesh, n, tile_rows=tr) if lanes else hilbert_order(mesh['face_x'], mesh['face_y'], n)
     if os.environ.get('CWR_NO_BALANCE'):
         return order
     return balance_windows(order, mesh['edges_face1'], mesh['edges_face2'], window=tile_rows(K))

@@ -18,7 +18,7 @@ import numpy as np
 from .mass_balance import assemble, boundary_lines, volume_columns
 from .outputs import StreamedOutput, ZarrStreamWriter
 from .engine import TransportEngine, StepResult, tile_rows
-from .ordering import balance_windows, flow_aligned_order, hilbert_order, lane_order
+from .ordering import balance_windows, hilbert_order, lane_order
 
 # variables.py names used on the path
 EDGES_FACE1 = 'edges_face1'
@@ -281,14 +281,13 @@ class ClearwaterRiverine:
         # meshes beyond the one-launch solver (> 4 096 cells): internal space-filling-curve numbering (ordering.py), which
         # is what keeps the 64-row tiles of the sweep kernels compact; reference ids stay at this boundary
         # (within every tile-sized window of the curve the cells are sorted by their work: ordering.balance_windows)
-        # (the curve runs in coordinates stretched along the principal flow axis: tiles ~4 cells long, which the engine's chained
-        # passes cross in one visit -- ordering.flow_aligned_order)
+        # (lanes along the principal flow axis, which the engine's chained passes walk: ordering.lane_order; CWR_NO_CHAINS=1 or
+        # CWR_TILE_ORDER=hilbert: the isotropic Hilbert curve of round 2)
         import os
-        aspect = 1.0 if os.environ.get('CWR_NO_CHAINS') else float(os.environ.get('CWR_TILE_ASPECT', '2'))
-        if os.environ.get('CWR_NO_CHAINS') or os.environ.get('CWR_TILE_ORDER', 'lanes') != 'lanes':
-            curve = flow_aligned_order(m, n, aspect=aspect) if (renumber and n > 4096) else None
-        else:
-            curve = lane_order(m, n, tile_rows=tile_rows(K)) if (renumber and n > 4096) else None
+        curve = None
+        if renumber and n > 4096:
+            lanes = not os.environ.get('CWR_NO_CHAINS') and os.environ.get('CWR_TILE_ORDER', 'auto') in ('auto', 'lanes')
+            curve = lane_order(m, n, tile_rows=tile_rows(K)) if lanes else hilbert_order(m['face_x'], m['face_y'], n)
         order = balance_windows(curve, f1, f2, window=tile_rows(K)) if curve is not None else None
         self.engine = TransportEngine(f1, f2, ncell, K, device=device, cell_order=order)
         self.engine.load_flow_field(m[FLOW_ACROSS_FACE], m[EDGE_VELOCITY], m[VOLUME], m[CHANGE_IN_TIME],

@@ -86,10 +86,10 @@ def _rank_main(rank, world, K, solver, depth, uid_pipe, out_queue):
         is_async = ctypes.CDLL(MOCK_LIB).mockRcclLastCommAsync()      # 1: the stand-in only enqueued on the engine's streams
         out_queue.put((rank, pt.owned_reference_ids(), pt.local.hi, pt.owned_state(), pt.local.edge_global[owned_faces],
                        tot[owned_faces], infos, None, pt.engine.get_mass_balance(), mass0, pt.engine.domain_mass(3), overlapped,
-                       is_async, comm_counts))
+                       is_async, comm_counts, pt.engine.get_tile_schedule()[0] is not None))
         pt.engine.close()
     except Exception as exc:                                  # surface the failure in the parent
-        out_queue.put((rank, 0, 0, None, None, None, None, repr(exc), None, None, None, 0, -1, None))
+        out_queue.put((rank, 0, 0, None, None, None, None, repr(exc), None, None, None, 0, -1, None, False))
 
 
 def run_ranks(world, target, args):
@@ -370,3 +370,36 @@ def test_the_synchronous_mode_of_the_stand_in_still_works(gpu_lib, monkeypatch):
         ref.update()
     want = np.stack([ref.constituent_dict[f'c{k}'].state[3, :n] for k in range(3)], axis=1)
     assert rel_err(state, want) <= 1e-9
+
+
+@pytest.mark.parametrize('world,K,depth,grid', [(2, 16, 8, 32), (3, 16, 6, 16)])
+def test_partitioned_engines_chain_their_tiles_too(gpu_lib, world, K, depth, grid, monkeypatch):
+    """Round 3: a rank whose lists are long enough (here: the grid of the tiled pass capped at 32 / 16 blocks) links its tiles along
+    the flow and relaxes in place between the halo exchanges, like a single engine.  Same answer as the oracle, fewer sweeps
+    than the same partition with ping-pong passes, every rank with the same sweep counts."""
+    build_mock()
+    monkeypatch.setenv('CWR_NO_SMALL', '1')
+    monkeypatch.setenv('CWR_TEST_BIG', '1')
+    monkeypatch.setenv('CWR_TCL_GRID', str(grid))
+    monkeypatch.setenv('CWR_TILE_ORDER', 'lanes')
+    chained = run_ranks(world, _rank_main, (K, 'jacobi', depth))
+    assert all(r[14] for r in chained), 'no schedule was built on some rank'
+    assert all(r[6] == chained[0][6] for r in chained)
+    monkeypatch.setenv('CWR_NO_CHAINS', '1')
+    plain = run_ranks(world, _rank_main, (K, 'jacobi', depth))
+    assert not any(r[14] for r in plain)
+    mesh, inputs3 = make_case(K)
+    n = mesh['nreal'] + 1
+    oracle.derive_coefficients(mesh)
+    ref = oracle.OracleModel(mesh, {f'c{k}': inputs3[:, :, k].copy() for k in range(K)})
+    for _ in range(3):
+        ref.update()
+    want = np.stack([ref.constituent_dict[f'c{k}'].state[3, :n] for k in range(K)], axis=1)
+    for results in (chained, plain):
+        state = np.full((n, K), np.nan)
+        for r in results:
+            state[r[1]] = r[3]
+        assert rel_err(state, want) <= 1e-9
+    sw_c = [s_ for s_, _ in chained[0][6]]
+    sw_p = [s_ for s_, _ in plain[0][6]]
+    assert sum(sw_c[1:]) < sum(sw_p[1:]), (sw_c, sw_p)
