@@ -226,10 +226,10 @@ int32_t cwr_synchronize(cwr_engine* e);
 int32_t cwr_apply_bytes(const cwr_engine* e, int64_t* bytes_read, int64_t* bytes_written);
 
 /* ---- tiling and the chained passes (diagnostics / tuning; no reference counterpart: spsolve is direct, transport.py:249) ----
- * The dominant sweep kernel walks tiles of cwr_tile_rows(K) rows with a persistent grid.  On one GPU the engine links the
- * tiles into chains along the flow of the level being solved and relaxes IN PLACE along them (block Gauss-Seidel along the
- * flow without any block waiting for another; rebuilt every CWR_CHAIN_REFRESH = 64 levels; CWR_NO_CHAINS=1: the
- * deterministic ping-pong passes).
+ * The dominant sweep kernel walks tiles of cwr_tile_rows(K) rows with a persistent grid.  From three tiles per block up the
+ * engine links the tiles into chains along the flow of the level being solved and relaxes IN PLACE along them (block
+ * Gauss-Seidel along the flow without any block waiting for another; what consecutive tiles of a block's list share is
+ * carried over in LDS; re-derived every CWR_CHAIN_REFRESH = 64 levels; CWR_NO_CHAINS=1: the deterministic ping-pong passes).
  * cwr_tiling_info: out = {tiled pass available, tiles, blocks of its grid, rows per tile}.
  * cwr_set_tile_schedule: install a caller's schedule instead: sched[it * n_lists + b] = it-th tile of block b, -1 = end of
  *   the list; n_lists must equal the grid, every tile must appear exactly once (checked).  depth = 0: back to the engine's own.
