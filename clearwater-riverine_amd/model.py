@@ -187,6 +187,27 @@ def input_array_from_csv(mesh: Mesh, initial_conditions_csv: str, boundary_condi
     return arr
 
 
+_LIVE_MODELS = None
+
+
+def _track(model):
+    """Facades alive at interpreter exit release their page locks and rings while the HIP runtime is still up."""
+    global _LIVE_MODELS
+    if _LIVE_MODELS is None:
+        import atexit
+        import weakref
+        _LIVE_MODELS = weakref.WeakSet()
+
+        def _close_all():
+            for mdl in list(_LIVE_MODELS):
+                try:
+                    mdl.close_output()
+                except Exception:
+                    pass
+        atexit.register(_close_all)
+    _LIVE_MODELS.add(model)
+
+
 class ClearwaterRiverine:
     """Drop-in for the transport path of the reference class of the same name
     (transport.py:68-276).  Construct either from arrays (``mesh=`` + ``input_arrays=``) or, when h5py
@@ -322,6 +343,7 @@ class ClearwaterRiverine:
         self._mass_start = None
         self._stream = None
         self._ring = None                                        # pinned one-slot ring of update()'s own read-out (opened lazily)
+        _track(self)
         if output_store is not None:
             self._stream = StreamedOutput(self.engine, output_store, self.constituents, T, with_flux=output_flux,
                                           attrs={'diffusion_coefficient': m.attrs['diffusion_coefficient']})
@@ -470,7 +492,11 @@ class ClearwaterRiverine:
 
     def __del__(self):
         # the page locks must go BEFORE the blocks' pages are unmapped: a stale registration of a recycled address range makes
-        # later copies fail (or land in the wrong pages)
+        # later copies fail (or land in the wrong pages).  At interpreter shutdown the atexit hook below has already done it
+        # (and the HIP runtime may be gone): nothing to do then.
+        import sys
+        if sys.is_finalizing():
+            return
         try:
             self.close_output()
         except Exception:
