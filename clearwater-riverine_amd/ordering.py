@@ -114,21 +114,6 @@ def flow_axis(mesh: dict, n_real: int, max_levels: int = 8):
     return (float(v[0, 1]), float(v[1, 1])), float(w[1] / max(w[0], 1e-300 * w[1]))
 
 
-def flow_aligned_order(mesh: dict, n_real: int, aspect: float = 2.0, min_ratio: float = 1.5) -> np.ndarray:
-    """Hilbert order in coordinates stretched by `aspect` ALONG the principal flow axis and squeezed by it across: the curve's
-    compact 64-cell tiles become ~ 8 / aspect cells long and 8 * aspect wide.  The chained passes (engine: tile chains along the
-    flow, relaxed in place) move information through a whole tile per visit only when two tile-local J^2 applications cross it,
-    i.e. when it is about four cells long: 47 -> 43 sweep equivalents per step on the 1 M-cell bench mesh at aspect 2
-    (profiles/r03_c_chained_passes.txt).  Only for engines that run chained passes: the ping-pong passes lose from it.
-    A field without a preferred axis (eigenvalue ratio < min_ratio) keeps the isotropic curve."""
-    (ax, ay), ratio = flow_axis(mesh, n_real)
-    x = np.asarray(mesh['face_x'], dtype=np.float64)
-    y = np.asarray(mesh['face_y'], dtype=np.float64)
-    if aspect == 1.0 or ratio < min_ratio:
-        return hilbert_order(x, y, n_real)
-    return hilbert_order((x * ax + y * ay) * aspect, (-x * ay + y * ax) / aspect, n_real)
-
-
 def lane_order(mesh: dict, n_real: int, tile_rows: int = 64, tile_len: int = 4, min_ratio: float = 1.5) -> np.ndarray:
     """Lane-major order for engines that run chained passes: the cells are cut into LANES -- strips along the principal flow
     axis, tile_rows / tile_len cells wide -- and numbered lane by lane, along the flow inside a lane.  A tile of the engine

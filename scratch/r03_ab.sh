@@ -1,5 +1,7 @@
 #!/bin/bash
-# A/B of chained passes and tile aspect on the bench line (same box), with live PMC traffic
+# A/B of chained passes and tile aspect on the bench line (same box), with live PMC traffic.
+# (The 'hilbert aspect' lines need ordering.flow_aligned_order / CWR_TILE_ASPECT of commit 7b1c... -- the stretched Hilbert curve was
+# measured (profiles/r03_c, section A) and removed when the lane-major order replaced it.)
 set -o pipefail
 export TMPDIR=/tmp
 out=gpurun_out/r03g_ab.txt; : > $out
