@@ -309,7 +309,7 @@ def main():
         b_r, b_w = eng.apply_bytes()
         kernel_name = {4: 'k_apply<VW,4>: fused Jacobi sweep of the face-flux operator',
                        5: 'k_apply<VW,5>: J^2 pass (two Jacobi iterations per launch)',
-                       6: 'k_sq_tiled<VW>: J^2 pass with the x tile staged in LDS, software-pipelined (two Jacobi iterations per launch)',
+                       6: 'k_sq_tiled<VW>: J^2 pass with the x tile staged in LDS, software-pipelined (two Jacobi iterations = two operator applies per launch)',
                        7: 'k_small_jacobi: one-launch LDS-resident solve'}.get(r.sweep_kernel, 'k_apply<VW,1>: BiCGSTAB product')
         back_to_back_us = eng.time_apply(args.warmup, reps=50) if world == 1 else None
         traffic = traffic_rw = None
@@ -367,6 +367,7 @@ def main():
                'host_cores': os.cpu_count()}
 
     if rank == 0:
+        chained = eng.get_tile_schedule()[0] is not None
         value = n * K * args.steps / elapsed / 1e6
         line = {
             'metric': 'Mcell-updates/s', 'value': round(value, 2), 'unit': 'Mcell-updates/s',
@@ -382,7 +383,11 @@ def main():
                        'cells': n, 'faces': int(len(mesh['edges_face1'])), 'constituents': K,
                        'numbering': args.renumber, 'partition': f'contiguous cell ranges x{world}' + (f', halo depth {pt.local.depth}' if world > 1 else ''),
                        'tol': args.tol},
-            'solver': {'method': 'block-asynchronous J^2 passes of fused Jacobi sweeps (BiCGSTAB fallback); K systems batched', 'iterations_per_step': iters,
+            'solver': {'method': ('J^2 passes of fused Jacobi sweeps, tiles chained along the flow and relaxed in place (block Gauss-Seidel '
+                                  'along the flow, no inter-block waiting)' if chained else
+                                  'block-asynchronous (ping-pong) J^2 passes of fused Jacobi sweeps') + '; exact closing sweep; BiCGSTAB '
+                                 'fallback; K systems batched',
+                       'chained_passes': chained, 'tile_local_applications': r.local_reps, 'iterations_per_step': iters,
                        'max_rel_residual': max_resid},
             'roofline': roofline, 'cpu_baseline': cpu,
         }

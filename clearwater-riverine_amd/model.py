@@ -11,6 +11,7 @@ Out of scope here: plotting, zarr/netCDF output, unit conv
 """
 from __future__ import annotations
 
+import sys
 from typing import Any, Dict, Optional
 
 import numpy as np
@@ -494,10 +495,9 @@ class ClearwaterRiverine:
         # the page locks must go BEFORE the blocks' pages are unmapped: a stale registration of a recycled address range makes
         # later copies fail (or land in the wrong pages).  At interpreter shutdown the atexit hook below has already done it
         # (and the HIP runtime may be gone): nothing to do then.
-        import sys
-        if sys.is_finalizing():
-            return
         try:
+            if sys is None or sys.is_finalizing():
+                return
             self.close_output()
         except Exception:
             pass
