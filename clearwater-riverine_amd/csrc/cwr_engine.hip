@@ -206,7 +206,7 @@ struct cwr_engine {
   bool chain_reuse = true;                 // CWR_CHAIN_REUSE=0: fetch every column, two interleaved streams per block (A/B)
   int chain_min_tiles = 3;                 // tiles per block of the persistent grid from which schedules are built
   int32_t* d_scols = nullptr;
-  std::vector<int32_t> h_tcl_ptr, h_tcl_cols, h_trow;     // host copies of the tiling (column lists, rows of every tile)
+  std::vector<int32_t> h_tcl_ptr, h_tcl_cols;             // host copies of the tiles' column lists
   std::vector<int32_t> sched_nxt;          // chain successor of every tile in the installed schedule (unchanged -> no rebuild)
   int own_cap = 0;                         // rows of the LDS staging area for a tile's results (tile rows when reuse is on)
   bool use_chains = true;
@@ -835,10 +835,13 @@ int ensure_sq_pattern(cwr_engine* e) {
       cap2 = std::max(cap2, ptr2[c1] - ptr2[c0]);
     }
     cap2 += cap2 & 1;                                            // even: the 16-bit index array keeps what follows 4-byte aligned
-    // (one GPU with chained passes: + a staging area for a tile's results, which the next tile of the block's list carries over)
-    const int own_cap = (e->use_chains && e->chain_reuse && !split) ? tr : 0;
-    const size_t lds = ((size_t)(max_cols + nvmax + own_cap) * e->K * sizeof(double) + (size_t)cap2 * (sizeof(double) + sizeof(uint16_t)) +
-                        (size_t)(tr + 1 + nvmax) * sizeof(int32_t) + 15) & ~(size_t)15;
+    // (chained passes: + a staging area for a tile's results, which the next tile of the block's list carries over -- only where
+    // the lists will be long enough to chain, so that engines below that size keep their LDS footprint and resident blocks)
+    auto lds_for = [&](int own) {
+      return ((size_t)(max_cols + nvmax + own) * e->K * sizeof(double) + (size_t)cap2 * (sizeof(double) + sizeof(uint16_t)) +
+              (size_t)(tr + 1 + nvmax) * sizeof(int32_t) + 15) & ~(size_t)15; };
+    int own_cap = 0;
+    size_t lds = lds_for(0);
     // the kernel's compile-time prefetch depths bound what a tile may hold; otherwise the plain J^2 pass stays
     e->tcl_cfg = -1;
     int q0 = 0;
@@ -855,16 +858,22 @@ int ensure_sq_pattern(cwr_engine* e) {
     }
     if (lds <= 64 * 1024 && e->tcl_cfg >= 0 && tr <= BLOCK && (int64_t)max_cols * e->K <= 65535) {
       const void* fn6 = tcl_kernel(e->tcl_vw, e->tcl_cfg);
-      int pc = std::min(resident_blocks(fn6, lds), 8);
-      if (const char* v = getenv("CWR_TCL_BLOCKS_PER_CU")) pc = std::max(1, std::min(pc, atoi(v)));
+      auto grid_for = [&](size_t l) {
+        int pcq = std::min(resident_blocks(fn6, l), 8);
+        if (const char* v = getenv("CWR_TCL_BLOCKS_PER_CU")) pcq = std::max(1, std::min(pcq, atoi(v)));
+        int g = std::max(N_XCD, std::min(cdiv(nt, N_XCD) * N_XCD, (n_cu * pcq / N_XCD) * N_XCD));
+        if (const char* v = getenv("CWR_TCL_GRID")) g = std::max(N_XCD, std::min(g, atoi(v) / N_XCD * N_XCD));
+        return g; };
+      if (e->use_chains && e->chain_reuse && !split && lds_for(tr) <= 64 * 1024 && nt >= e->chain_min_tiles * grid_for(lds_for(tr))) {
+        own_cap = tr; lds = lds_for(tr);
+      }
       e->n_tcl = n_t;
       e->tcl_seg = seg; e->tcl_nvmax = nvmax;
       e->tcl_TR = tr; e->tcl_ntiles = nt; e->tcl_max_cols = max_cols; e->tcl_stage_cap = cap2; e->tcl_lds = lds;
       e->tcl_total_cols = tcols.size();
       e->own_cap = own_cap;
-      if (own_cap > 0) { e->h_tcl_ptr = tptr; e->h_tcl_cols = tcols; e->h_trow = trow; }
-      e->tcl_grid = std::max(N_XCD, std::min(cdiv(nt, N_XCD) * N_XCD, (n_cu * pc / N_XCD) * N_XCD));
-      if (const char* v = getenv("CWR_TCL_GRID")) e->tcl_grid = std::max(N_XCD, std::min(e->tcl_grid, atoi(v) / N_XCD * N_XCD));
+      if (own_cap > 0) { e->h_tcl_ptr = tptr; e->h_tcl_cols = tcols; }
+      e->tcl_grid = grid_for(lds);
       TRY(dev_alloc(e, &e->d_tcl_ptr, (size_t)nt + 1));
       TRY(dev_alloc(e, &e->d_trow, (size_t)nt + 1));
       TRY(dev_alloc(e, &e->d_vptr, (size_t)nt + 1));
@@ -1007,6 +1016,8 @@ int install_schedule(cwr_engine* e, const std::vector<int32_t>& sched, int depth
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     for (auto& kv : e->batch_exec) if (kv.second) hipGraphExecDestroy(kv.second);
     e->batch_exec.clear(); e->batch_last = -1;
+    for (auto& kv : e->stretch_exec) if (kv.second) hipGraphExecDestroy(kv.second);
+    e->stretch_exec.clear();
   }
   if ((int)cnt > e->sched_cap) {
     hipFree(e->d_sched); e->d_sched = nullptr; e->sched_cap = 0;
@@ -1019,6 +1030,7 @@ int install_schedule(cwr_engine* e, const std::vector<int32_t>& sched, int depth
 }
 
 int build_chain_schedule(cwr_engine* e, int t) {
+  const auto w0 = std::chrono::steady_clock::now();
   TRY(build_tile_links(e));
   if (e->n_links == 0) { e->sched_level = t; return CWR_OK; }                // a single tile, or variable tiles: nothing to chain
   const int nt = e->tcl_ntiles, L = e->n_links;
@@ -1040,7 +1052,11 @@ int build_chain_schedule(cwr_engine* e, int t) {
   for (int a = 0; a < nt; ++a) { const int b = best_dn[(size_t)a]; if (b >= 0 && best_up[(size_t)b] == a) nxt[(size_t)a] = b; }
   e->sched_level = t;
   ++e->n_sched_builds;
-  if (e->sched_depth > 0 && !e->sched_user && nxt == e->sched_nxt) return CWR_OK;       // the same chains: the lists stand
+  if (e->sched_depth > 0 && !e->sched_user && nxt == e->sched_nxt) {                     // the same chains: the lists stand
+    if (getenv("CWR_VERBOSE")) fprintf(stderr, "[cwr] chained passes: level %d keeps the chains of the installed schedule (%.2f ms)\n", t,
+                                       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count());
+    return CWR_OK;
+  }
   const bool reuse = e->own_cap > 0 && !e->h_tcl_ptr.empty();
   std::vector<int32_t> sched; int depth = 0;
   chains_to_schedule(nt, e->tcl_grid, reuse ? 1 : 2, nxt, sched, depth);
@@ -1073,7 +1089,8 @@ int build_chain_schedule(cwr_engine* e, int t) {
   e->sched_nxt = nxt;
   if (getenv("CWR_VERBOSE")) {
     int linked = 0; for (int a = 0; a < nt; ++a) linked += nxt[(size_t)a] >= 0;
-    fprintf(stderr, "[cwr] chained passes: schedule for level %d: %d of %d tiles have a chain successor, %d lists x %d slots\n", t, linked, nt, e->tcl_grid, depth);
+    fprintf(stderr, "[cwr] chained passes: schedule for level %d: %d of %d tiles have a chain successor, %d lists x %d slots (%.2f ms)\n", t, linked, nt, e->tcl_grid, depth,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count());
   }
   return CWR_OK;
 }
