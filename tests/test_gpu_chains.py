@@ -211,3 +211,45 @@ def test_flow_that_reverses_mid_run_and_dry_cells(gpu_lib, monkeypatch):
         sweeps[refresh] = [r.sweeps for r in rs]
         pt.engine.close()
     assert sum(sweeps['1'][3:]) <= sum(sweeps['64'][3:]), sweeps      # lists that follow the reversed flow are never worse
+
+
+@pytest.mark.parametrize('seed', range(8))
+def test_random_meshes_flows_and_constituent_counts_through_the_chained_passes(gpu_lib, monkeypatch, seed):
+    """Seeded sweep over what the chained, column-reusing passes can meet: mesh aspect (the lane order turns with the flow axis),
+    share of 6- and 8-sided cells, dry cells, time step from CFL ~1 to ~60 (2 to 8 tile-local applications), steady / unsteady /
+    reversed fields, K in {1, 2, 5, 8, 16, 20}, grid caps that give lists of 3 to 20 tiles.  Every cell against spsolve."""
+    import warnings
+    import clearwater_riverine_amd as cw
+    from clearwater_riverine_amd.distributed import PartitionedTransport
+    rng = np.random.default_rng(1000 + seed)
+    Kc = int(rng.choice([1, 2, 5, 8, 16, 20]))
+    nx, ny = [(260, 150), (150, 260), (200, 200), (320, 120)][seed % 4]
+    dt = float(rng.choice([15.0, 40.0, 200.0, 900.0]))
+    steps = 2
+    mesh = cw.synthetic.make_mesh(nx, ny, steps, seed=50 + seed, n_merge=int(rng.integers(0, nx * ny // 8)),
+                                  n_merge4=int(rng.integers(0, 200)), n_dry=int(rng.integers(0, 3)), dt=dt,
+                                  diffusion_coefficient=float(rng.choice([0.05, 0.5, 2.0])), breathing=0.0 if dt > 100 else 0.02,
+                                  eddy=float(rng.choice([0.0, 0.3, 0.8])), steady=bool(rng.integers(0, 2)))
+    if seed % 3 == 2:                                           # the water runs the other way
+        for key in ('face_flow', 'edge_velocity'):
+            mesh[key] = -mesh[key]
+        if not np.allclose(mesh['volume'][0], mesh['volume'][-1]):
+            pytest.skip('a reversed unsteady field breaks continuity (volumes were integrated for the forward field)')
+    inputs3 = cw.synthetic.distinct_input_array(mesh, Kc, seed=seed)
+    inputs3[:, mesh['outlet_ghost_cells'], :] = 1.5
+    oracle.derive_coefficients(mesh)
+    ref = oracle_run(mesh, inputs3, steps)
+    n = mesh['nreal'] + 1
+    want = np.stack([ref.constituent_dict[f'c{k}'].state[steps, :n] for k in range(Kc)], axis=1)
+    monkeypatch.setenv('CWR_TCL_GRID', str(int(rng.choice([8, 16, 32]))))
+    monkeypatch.delenv('CWR_NO_CHAINS', raising=False)
+    pt = PartitionedTransport(mesh, inputs3, 0, 1)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore', RuntimeWarning)         # (dry cells / CFL 60: the clamp flag, tested elsewhere)
+        rs = [pt.step(t, tol=1e-12, max_iter=100000) for t in range(steps)]
+    assert all(r.sweep_kernel == 6 for r in rs)
+    if pt.engine.get_tile_schedule()[0] is None:
+        pytest.skip('lists too short to chain at this K / grid')
+    clamped = any(r.flags & cw.engine.INFO_ELEMENTWISE_CLAMPED for r in rs)
+    assert rel_err(pt.gather_state(), want, **({'ew_rtol': 1e-4, 'ew_atol': 1e-9} if clamped else {})) <= (1e-6 if clamped else 1e-9)
+    pt.engine.close()
