@@ -287,7 +287,8 @@ def main():
         t0 = time.perf_counter()
         for t in range(args.warmup, args.warmup + args.steps):
             r = pt.step(t, tol=args.tol, mass_flux=True, solver=args.solver)
-            iters.append({'sweeps': r.sweeps, 'bicgstab': r.iterations})
+            iters.append({'sweeps': r.sweeps, 'bicgstab': r.iterations} if world == 1 else
+                         {'sweeps': r.sweeps, 'bicgstab': r.iterations, 'exchanges': r.exchanges, 'overlapped': r.overlapped, 'checks': r.checks})
         barrier()
         el = time.perf_counter() - t0
         if world > 1:
