@@ -8,6 +8,10 @@
 //   k_vec_s/k_vec_x  the BiCGSTAB recurrences standing in for transport.py:249 (spsolve)
 //   k_ghost_writeback transport.py:258-264, constituents.py:39-48
 //   k_mass_flux      transport.py:406-429
+//   k_sq_tiled       two fused Jacobi sweeps per tile-local application, x tile in LDS: the dominant kernel; walks the default
+//                    tile order (ping-pong passes) or a per-block list of tiles chained along the flow, in place, carrying the
+//                    columns consecutive tiles share over in LDS (round 3)
+//   k_jnorm, k_link_flux   ||J||_inf of every level (scale of the element-wise stopping rule); flow between tiles (chains)
 //
 // Data layout (all device resident):
 //   x[cell*K + k]  float64, constituents inner.  A thread owns VW (1 or 2) consecutive constituents
