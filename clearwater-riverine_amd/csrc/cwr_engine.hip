@@ -247,6 +247,8 @@ struct cwr_engine {
   double* rho(int slot) const { return d_scal + (size_t)3 * ACC_N * K + (size_t)slot * K; }
   double* bb() const { return d_scal + (size_t)3 * ACC_N * K + (size_t)3 * K; }
   size_t scal_count() const { return (size_t)3 * ACC_N * K + 3 * K + K; }
+  double* bad_flag() const { return d_scal + scal_count() + 4; }   // 1.0 when k_rhs met the zero-coefficient precondition (behind the 8 counters)
+  bool ghost_bad_any = false;    // partitioned engines: some rank met it (all-reduced with the check scalars)
 };
 
 namespace {
@@ -443,13 +445,18 @@ int gather_check(cwr_engine* e, double* h) {
   const size_t K = (size_t)e->K;
   ++e->step_checks;
   if (!e->comm || (e->world == 1 && !e->force_coll)) return download(e, h, e->d_chk, 4 * K);
-  const size_t W = (size_t)e->world, n = 2 * K + W * 2 * K;
+  // (+ one word: the zero-coefficient precondition flag of k_rhs, so that every rank learns of a violation on ANY rank with the
+  // check it downloads anyway -- the step used to end with a second, blocking download of the rank's own counters, which also
+  // waited for the speculative tail behind the check)
+  const size_t W = (size_t)e->world, n = 2 * K + W * 2 * K + 1;
   HIP_TRY(e, hipMemsetAsync(e->d_chkx, 0, n * sizeof(double), e->stream));
   HIP_TRY(e, hipMemcpyAsync(e->d_chkx, e->d_chk, 2 * K * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
   HIP_TRY(e, hipMemcpyAsync(e->d_chkx + 2 * K + (size_t)e->rank * 2 * K, e->d_chk + 2 * K, 2 * K * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(e->d_chkx + n - 1, e->bad_flag(), sizeof(double), hipMemcpyDeviceToDevice, e->stream));
   TRY(allreduce(e, e->d_chkx, n));
   std::vector<double> all(n);
   TRY(download(e, all.data(), e->d_chkx, n));
+  e->ghost_bad_any = all[n - 1] > 0.0;
   for (size_t k = 0; k < 2 * K; ++k) h[k] = all[k];
   for (size_t k = 0; k < 2 * K; ++k) {
     double m = -INFINITY;
@@ -483,7 +490,7 @@ int launch_rhs(cwr_engine* e, int t, const double* x, double* b, bool scale, dou
   const int used = (e->D != 0.0) ? 1 : 0;
 #define CWR_RHS(VWv, SC) k_rhs<VWv, SC><<<grid, BLOCK, 0, e->stream>>>(e->n_owned, e->K, e->G, e->d_ptr, e->d_ent_edge, \
     e->d_ent_nb, vol_t, e->dt[t], vel_n, adv_n, dif_n, used, bc_n, x, e->d_diag, e->d_row_ghost, b, e->d_counters, keep, e->n_owned, e->n_cells - e->n_owned, \
-    e->d_chk + 4 * (size_t)e->K, e->ew_rel)
+    e->d_chk + 4 * (size_t)e->K, e->ew_rel, e->bad_flag())
   if (e->VW == 2) { if (scale) CWR_RHS(2, true); else CWR_RHS(2, false); }
   else            { if (scale) CWR_RHS(1, true); else CWR_RHS(1, false); }
 #undef CWR_RHS
@@ -1461,6 +1468,8 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
     // whose exchange is a collective -- is entered and, if the check fails, repeated by all ranks alike)
     if (e->spec_t >= 0) { TRY(step_tail(e, e->spec_t, e->spec_flags)); speculated = true; }
     TRY(gather_check(e, h.data()));
+    // (a rank met the zero-coefficient precondition: its right-hand side is NaN-poisoned, every rank leaves here with the same code)
+    if (e->comm && e->ghost_bad_any) { st.status = CWR_ERR_GHOST_COEFF; return CWR_ERR_GHOST_COEFF; }
     bool ok = true;
     double worst = 0.0;                                                   // max over columns of rr / (tol^2 bb)
     st.max_rel = 0.0;
@@ -1829,7 +1838,7 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   CREATE_TRY(dev_alloc(eng, &eng->d_t, nK));
   CREATE_TRY(dev_alloc(eng, &eng->d_b, nK));
   // (the 8 step counters live behind the solver scalars: one memset clears both at the start of a step)
-  CREATE_TRY(dev_alloc(eng, &eng->d_scal, eng->scal_count() + 4));
+  CREATE_TRY(dev_alloc(eng, &eng->d_scal, eng->scal_count() + 5));      // (+ 8 int32 counters + the precondition flag as a double)
   eng->d_counters = reinterpret_cast<int32_t*>(eng->d_scal + eng->scal_count());
   CREATE_TRY(dev_alloc(eng, &eng->d_partial, (size_t)std::max(eng->apply_grid, 256 * 8) * 4 * K));
   if (getenv("CWR_VERBOSE")) fprintf(stderr, "[cwr] K=%d VW=%d G=%d U=%d tiles=%d stage_cap=%d lds=%zu grid=%d\n", K, eng->VW, eng->G, eng->U, eng->ntiles, eng->stage_cap, eng->apply_lds, eng->apply_grid);
@@ -1853,7 +1862,7 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   CREATE_HIP(hipMemsetAsync(eng->d_c, 0, (size_t)n_cells * K * sizeof(double), eng->stream));
   for (double* v : {eng->d_r, eng->d_r0, eng->d_p, eng->d_v, eng->d_s, eng->d_t, eng->d_b})
     CREATE_HIP(hipMemsetAsync(v, 0, nK * sizeof(double), eng->stream));
-  CREATE_HIP(hipMemsetAsync(eng->d_scal, 0, (eng->scal_count() + 4) * sizeof(double), eng->stream));
+  CREATE_HIP(hipMemsetAsync(eng->d_scal, 0, (eng->scal_count() + 5) * sizeof(double), eng->stream));
   CREATE_HIP(hipStreamSynchronize(eng->stream));
 #undef CREATE_TRY
 #undef CREATE_HIP
@@ -2130,7 +2139,7 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
     return fail(e, CWR_ERR_GHOST_COEFF, "active ghost face with a zero advection/diffusion coefficient at level t+1 "
                 "(the reference raises a shape-mismatch ValueError, linalg.py:349-351)");
   TRY(prep_step(e, t));
-  HIP_TRY(e, hipMemsetAsync(e->d_scal, 0, (e->scal_count() + 4) * sizeof(double), e->stream));   // (+ the counters behind them)
+  HIP_TRY(e, hipMemsetAsync(e->d_scal, 0, (e->scal_count() + 5) * sizeof(double), e->stream));   // (+ the counters and the precondition flag behind them)
   // the inner halo layers need x_t for their right-hand sides; the exchange that closed the previous step (for its face
   // fluxes) already delivered it unless the state was touched in between.  Every rank makes the same calls, so every
   // rank takes the same branch.
@@ -2164,11 +2173,14 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
   const int status = st.status;
   const int total_it = st.iterations + st.sweeps;
   const double max_rel = st.max_rel;
-  if (e->comm) {                                                           // (one GPU: checked before the step began)
+  if (e->comm && (st.status != CWR_OK || st.iterations > 0 || force_bicg)) {
+    // (one GPU: checked before the step began.  Partitioned: the sweeps learn of it with their check, on every rank; this
+    // download of the rank's own counters is left for the paths without that check -- BiCGSTAB, failed steps)
     int32_t h_cnt[8];
     TRY(download(e, h_cnt, e->d_counters, (size_t)8));
-    if (h_cnt[2]) st.status = CWR_ERR_GHOST_COEFF;                         // takes precedence over the NaN it caused
+    if (h_cnt[2] || e->ghost_bad_any) st.status = CWR_ERR_GHOST_COEFF;     // takes precedence over the NaN it caused
   }
+  e->ghost_bad_any = false;
   if (e->profiling) { hipStreamSynchronize(e->stream); collect_profile(e); }
   e->profiling = false;
   local.iterations = st.iterations; local.sweeps = st.sweeps; local.restarts = st.restarts; local.operator_launches = st.launches;
@@ -2644,7 +2656,7 @@ int32_t cwr_attach_comm(cwr_engine* e, int32_t rank, int32_t world, const uint8_
   TRY(dev_alloc(e, &e->d_recvbuf, (size_t)n_recv * e->K));
   TRY(upload(e, e->d_send_cells, send_cells, (size_t)n_send));
   TRY(upload(e, e->d_recv_cells, recv_cells, (size_t)n_recv));
-  TRY(dev_alloc(e, &e->d_chkx, (size_t)(2 + 2 * world) * e->K));
+  TRY(dev_alloc(e, &e->d_chkx, (size_t)(2 + 2 * world) * e->K + 1));
   if (const char* v = getenv("CWR_NO_OVERLAP")) e->overlap = atoi(v) == 0;
   if (const char* v = getenv("CWR_TEST_POISON_HALO")) e->test_poison_halo = atoi(v) != 0;
   if (const char* v = getenv("CWR_OVERLAP_RESERVE")) e->overlap_reserve = std::max(0, atoi(v)) / N_XCD * N_XCD;

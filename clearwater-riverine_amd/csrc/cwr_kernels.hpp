@@ -429,7 +429,8 @@ __global__ void __launch_bounds__(BLOCK) k_rhs(
     const float* __restrict__ vel_n, const float* __restrict__ adv_n, const double* __restrict__ dif_n,
     int use_diffusion, const double* __restrict__ bc_n, const double* __restrict__ x,
     const double* __restrict__ diag, const uint8_t* __restrict__ row_ghost, double* __restrict__ b,
-    int32_t* __restrict__ counters, double* __restrict__ x_keep, int keep_from, int keep_rows, double* __restrict__ ew_out, double ew_val) {
+    int32_t* __restrict__ counters, double* __restrict__ x_keep, int keep_from, int keep_rows, double* __restrict__ ew_out, double ew_val,
+    double* __restrict__ bad_flag) {
   const int R = BLOCK / G;
   const int r = threadIdx.x / G, g = threadIdx.x - r * G;
   // this step's relative element-wise tolerance, for every MODE 4 sweep that follows (k_apply reads it from memory)
@@ -459,11 +460,11 @@ __global__ void __launch_bounds__(BLOCK) k_rhs(
     double cg[VW];
     ldv<VW>(bc_n + (size_t)(-1 - nb) * K + col, cg);
     if (v1 < 0.0f) {
-      if (a == 0.0 || (use_diffusion && d == 0.0)) { counters[2] = 1; bad = true; }
+      if (a == 0.0 || (use_diffusion && d == 0.0)) { counters[2] = 1; bad_flag[0] = 1.0; bad = true; }
 #pragma unroll
       for (int w = 0; w < VW; ++w) gin[w] = (a + d) * cg[w];
     } else {
-      if (use_diffusion && d == 0.0) { counters[2] = 1; bad = true; }
+      if (use_diffusion && d == 0.0) { counters[2] = 1; bad_flag[0] = 1.0; bad = true; }
 #pragma unroll
       for (int w = 0; w < VW; ++w) gout[w] = d * cg[w];
     }

@@ -403,3 +403,52 @@ def test_partitioned_engines_chain_their_tiles_too(gpu_lib, world, K, depth, gri
     sw_c = [s_ for s_, _ in chained[0][6]]
     sw_p = [s_ for s_, _ in plain[0][6]]
     assert sum(sw_c[1:]) < sum(sw_p[1:]), (sw_c, sw_p)
+
+
+def _rank_ghost(rank, world, K, uid_pipe, out_queue):
+    """A partitioned run whose flow field violates the reference's zero-coefficient precondition (linalg.py:349-351) at level 2,
+    on faces that only ONE rank owns."""
+    try:
+        os.environ['CWR_RCCL_LIB'] = MOCK_LIB
+        import clearwater_riverine_amd as cw
+        from clearwater_riverine_amd.distributed import PartitionedTransport
+        mesh, inputs3 = make_case(K)
+        f2 = np.asarray(mesh['edges_face2'])
+        inlet_faces = np.nonzero(np.isin(f2, mesh['inlet_ghost_cells']))[0]
+        mesh['face_flow'] = mesh['face_flow'].copy()
+        mesh['face_flow'][2, inlet_faces[:2]] = 0.0            # advection_coeff becomes 0 while the velocity stays < 0
+        if rank == 0:
+            uid = cw.TransportEngine.comm_unique_id()
+            for _ in range(world - 1):
+                uid_pipe.put(uid)
+        else:
+            uid = uid_pipe.get(timeout=120)
+        pt = PartitionedTransport(mesh, inputs3, rank, world, device=0, unique_id=uid, halo_depth=4, renumber='hilbert')
+        pt.step(0, tol=1e-12, mass_flux=True)
+        before = pt.owned_state().copy()
+        what = 'no error'
+        try:
+            pt.step(1, tol=1e-12, mass_flux=True)              # its right-hand side needs level 2
+        except ValueError as exc:
+            what = 'ValueError: ' + str(exc)
+        except Exception as exc:                              # noqa: BLE001
+            what = type(exc).__name__ + ': ' + str(exc)
+        same = bool(np.array_equal(pt.owned_state(), before))
+        owns = bool(np.isin(np.asarray(mesh['edges_face1'])[inlet_faces[:2]], pt.owned_reference_ids()).any())
+        out_queue.put((rank, what, same, owns, None, None, None, None))
+        pt.engine.close()
+    except Exception as exc:
+        out_queue.put((rank, None, None, None, None, None, None, repr(exc)))
+
+
+def test_zero_coefficient_precondition_in_a_partitioned_run_is_raised_by_every_rank(gpu_lib, monkeypatch):
+    """The violating rank NaN-poisons its right-hand side so that nobody is left in a collective; round 3: the flag travels with
+    the all-reduced check, so EVERY rank raises the reference's ValueError (not just a NaN failure) and restores its state --
+    without the second blocking download per step that used to fetch each rank's own counters."""
+    build_mock()
+    monkeypatch.setenv('CWR_NO_SMALL', '1')
+    results = run_ranks(3, _rank_ghost, (2,))
+    assert sum(r[3] for r in results) >= 1 and not all(r[3] for r in results)      # some ranks own the faces, some do not
+    for r in results:
+        assert r[1].startswith('ValueError') and 'ghost face' in r[1], r
+        assert r[2], 'the failed step did not restore the state'
