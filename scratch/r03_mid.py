@@ -8,7 +8,7 @@ from clearwater_riverine_amd.distributed import PartitionedTransport
 nx, K = int(sys.argv[1]), int(sys.argv[2])
 caps = [int(v) for v in sys.argv[3:]] or [0]
 steps, warm = 12, 3
-mesh = cw.synthetic.make_mesh(nx, nx, warm + steps + 1, seed=4, dt=40.0, diffusion_coefficient=0.5, n_merge=int(0.05 * nx * nx))
+mesh = cw.synthetic.make_mesh(nx, nx, warm + steps + 1, seed=4, dt=float(os.environ.get("MID_DT", "40")), diffusion_coefficient=0.5, n_merge=int(0.05 * nx * nx))
 inputs3 = cw.synthetic.distinct_input_array(mesh, K, seed=4)
 for cap in caps:
     for chains in (False, True):
