@@ -382,7 +382,7 @@ def main():
                                    f'{"distinct " if args.inputs == "distinct" and K > 1 else ""}constituents, implicit upwind '
                                    f'advection-diffusion step, dt={args.dt} s, D={args.diffusion}',
                        'cells': n, 'faces': int(len(mesh['edges_face1'])), 'constituents': K,
-                       'numbering': args.renumber, 'partition': f'contiguous cell ranges x{world}' + (f', halo depth {pt.local.depth}' if world > 1 else ''),
+                       'numbering': pt.numbering + (' + tile-balanced windows' if pt.numbering != 'reference' else ''), 'partition': f'contiguous cell ranges x{world}' + (f', halo depth {pt.local.depth}' if world > 1 else ''),
                        'tol': args.tol},
             'solver': {'method': ('J^2 passes of fused Jacobi sweeps, tiles chained along the flow and relaxed in place (block Gauss-Seidel '
                                   'along the flow, no inter-block waiting)' if chained else

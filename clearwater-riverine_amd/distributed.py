@@ -86,6 +86,14 @@ def shared_hilbert_order(mesh: dict, n: int, rank: int, world: int, K: int = 16)
     return t.cpu().numpy()
 
 
+def curve_kind(n: int, K: int, world: int = 1) -> str:
+    """'lanes' or 'hilbert': which numbering _curve_order builds for n real cells, K constituents and `world` ranks."""
+    want = os.environ.get('CWR_TILE_ORDER', 'auto')
+    lanes = want == 'lanes' or (want == 'auto' and not os.environ.get('CWR_NO_CHAINS') and
+                                (world == 1 or n // world >= 3 * 1024 * tile_rows(K)))
+    return 'lanes' if lanes else 'hilbert'
+
+
 def _curve_order(mesh: dict, n: int, K: int, world: int = 1) -> np.ndarray:
     """Lane-major or Hilbert order (see below), the cells of every tile-sized window sorted by their J^2 row length
     (ordering.balance_windows; the tile size of the engine's sweep kernel depends on K: cwr_tile_rows).  CWR_NO_BALANCE=1: the
@@ -95,9 +103,7 @@ def _curve_order(mesh: dict, n: int, K: int, world: int = 1) -> np.ndarray:
     # tiles (3.62 -> 4.07 ms per step on the bench mesh) and keep the isotropic Hilbert curve, which also gives compact rank
     # ranges (fewer halo rows).  CWR_TILE_ORDER=lanes|hilbert overrides.
     tr = tile_rows(K)
-    want = os.environ.get('CWR_TILE_ORDER', 'auto')
-    lanes = want == 'lanes' or (want == 'auto' and not os.environ.get('CWR_NO_CHAINS') and
-                                (world == 1 or n // world >= 3 * 1024 * tr))
+    lanes = curve_kind(n, K, world) == 'lanes'
     order = lane_order(mesh, n, tile_rows=tr) if lanes else hilbert_order(mesh['face_x'], mesh['face_y'], n)
     if os.environ.get('CWR_NO_BALANCE'):
         return order
@@ -132,6 +138,7 @@ class PartitionedTransport:
             raise ValueError(f'unknown renumbering {renumber!r}')
         self.n_global = n
         self.K = int(inputs3.shape[2])
+        self.numbering = 'reference' if renumber is None else curve_kind(n, self.K, world)
         # (rank ranges start at multiples of the tile size when the numbering was arranged in tile-sized windows)
         align = tile_rows(self.K) if (renumber == 'hilbert' and not os.environ.get('CWR_NO_BALANCE')) else 1
         self.local: LocalMesh = partition_mesh(f1, f2, n, world, rank, depth=halo_depth, align=max(1, align))
