@@ -206,10 +206,17 @@ struct cwr_engine {
   bool chain_reuse = true;                 // CWR_CHAIN_REUSE=0: fetch every column, two interleaved streams per block (A/B)
   int chain_min_tiles = 3;                 // tiles per block of the persistent grid from which schedules are built
   int32_t* d_scols = nullptr;
+  // partitioned engines: the interior and the cut tiles chained SEPARATELY, so that an exchange runs beside the interior lists
+  // (one list position per tile in either: one shared copy of the column lists serves both)
+  struct SubSched { int32_t* d = nullptr; int depth = 0, cap = 0, grid = 0; };
+  SubSched sched_in, sched_out;
+  int32_t* d_scols_io = nullptr;
+  std::vector<int32_t> h_tile_inner, h_tile_outer;
   std::vector<int32_t> h_tcl_ptr, h_tcl_cols;             // host copies of the tiles' column lists
   std::vector<int32_t> sched_nxt;          // chain successor of every tile in the installed schedule (unchanged -> no rebuild)
   int own_cap = 0;                         // rows of the LDS staging area for a tile's results (tile rows when reuse is on)
   bool use_chains = true;
+  bool shape_agreed = false, any_tiled = false;   // partitioned engines: see agree_on_pass_shape
   bool sched_user = false;                 // installed by cwr_set_tile_schedule: never rebuilt by the engine
   int sched_level = -1, sched_refresh = 64; // level the schedule was built for; rebuilt when the step is this many levels away
   int cur_t = 0;                           // level of the step in progress
@@ -912,6 +919,7 @@ int ensure_sq_pattern(cwr_engine* e) {
           (in ? inner : outer).push_back(t);
         }
         e->n_tile_inner = (int)inner.size(); e->n_tile_outer = (int)outer.size();
+        e->h_tile_inner = inner; e->h_tile_outer = outer;
         TRY(dev_alloc(e, &e->d_tile_inner, inner.size()));
         TRY(dev_alloc(e, &e->d_tile_outer, outer.size()));
         TRY(upload(e, e->d_tile_inner, inner.data(), inner.size()));
@@ -978,18 +986,26 @@ int build_tile_links(cwr_engine* e) {
 }
 
 // chains -> schedule [depth][grid], -1 padded (see schedule.py: the same construction)
-void chains_to_schedule(int nt, int grid, int SPB, const std::vector<int32_t>& nxt, std::vector<int32_t>& sched, int& depth) {
-  std::vector<char> has_prev((size_t)nt, 0), seen((size_t)nt, 0);
-  for (int t = 0; t < nt; ++t) if (nxt[(size_t)t] >= 0) has_prev[(size_t)nxt[(size_t)t]] = 1;
+// subset (optional): schedule only these tiles -- a chain ends where its successor is not one of them
+void chains_to_schedule(int nt_all, int grid, int SPB, const std::vector<int32_t>& nxt, std::vector<int32_t>& sched, int& depth,
+                        const std::vector<int32_t>* subset = nullptr) {
+  std::vector<char> has_prev((size_t)nt_all, 0), seen((size_t)nt_all, subset ? 1 : 0);
+  if (subset) for (int32_t t : *subset) seen[(size_t)t] = 0;                // (tiles outside the subset count as visited)
+  const int nt = subset ? (int)subset->size() : nt_all;
+  if (nt == 0 || grid <= 0) { sched.clear(); depth = 0; return; }
+  std::vector<char> member(seen.size());
+  for (size_t t = 0; t < seen.size(); ++t) member[t] = !seen[t];
+  auto next = [&](int t) { const int u = nxt[(size_t)t]; return (u >= 0 && member[(size_t)u]) ? u : -1; };
+  for (int t = 0; t < nt_all; ++t) if (member[(size_t)t] && next(t) >= 0) has_prev[(size_t)next(t)] = 1;
   std::vector<std::vector<int32_t>> chains;
   auto walk = [&](int start) {
     if (seen[(size_t)start]) return;
     std::vector<int32_t> ch;
-    for (int c = start; c >= 0 && !seen[(size_t)c]; c = nxt[(size_t)c]) { seen[(size_t)c] = 1; ch.push_back(c); }
+    for (int c = start; c >= 0 && !seen[(size_t)c]; c = next(c)) { seen[(size_t)c] = 1; ch.push_back(c); }
     chains.push_back(std::move(ch));
   };
-  for (int t = 0; t < nt; ++t) if (!has_prev[(size_t)t]) walk(t);           // heads first,
-  for (int t = 0; t < nt; ++t) walk(t);                                      // then whatever sits on a cycle
+  for (int t = 0; t < nt_all; ++t) if (!has_prev[(size_t)t]) walk(t);       // heads first,
+  for (int t = 0; t < nt_all; ++t) walk(t);                                  // then whatever sits on a cycle
   std::stable_sort(chains.begin(), chains.end(), [](const std::vector<int32_t>& a, const std::vector<int32_t>& b) { return a[0] < b[0]; });
   std::vector<int32_t> seq; seq.reserve((size_t)nt);
   for (const auto& ch : chains) seq.insert(seq.end(), ch.begin(), ch.end());
@@ -1036,6 +1052,41 @@ int install_schedule(cwr_engine* e, const std::vector<int32_t>& sched, int depth
   return CWR_OK;
 }
 
+// Per-schedule column lists: a column the PREVIOUS tile of the same list holds in LDS is coded -2 - (its position there).
+// scols starts as a copy of the tiles' column lists; only the tiles of `sched` are rewritten.
+void reuse_codes(const cwr_engine* e, const std::vector<int32_t>& sched, int grid, int depth, std::vector<int32_t>& scols) {
+  const std::vector<int32_t>& tp = e->h_tcl_ptr; const std::vector<int32_t>& tc = e->h_tcl_cols;
+  std::vector<int32_t> owner((size_t)e->n_real, -1), pos((size_t)e->n_real, 0);
+  for (int b = 0; b < grid; ++b) {
+    int prev = -1;
+    for (int it = 0; it < depth; ++it) {
+      const int tl = sched[(size_t)it * grid + b];
+      if (tl < 0) break;
+      if (prev >= 0) {
+        for (int q = tp[(size_t)prev]; q < tp[(size_t)prev + 1]; ++q) { owner[(size_t)tc[(size_t)q]] = prev; pos[(size_t)tc[(size_t)q]] = q - tp[(size_t)prev]; }
+        for (int q = tp[(size_t)tl]; q < tp[(size_t)tl + 1]; ++q) {
+          const int g = tc[(size_t)q];
+          if (owner[(size_t)g] == prev) scols[(size_t)q] = -2 - pos[(size_t)g];
+        }
+      }
+      prev = tl;
+    }
+  }
+}
+
+int install_sub_schedule(cwr_engine* e, cwr_engine::SubSched& ss, const std::vector<int32_t>& sched, int depth, int grid) {
+  const size_t cnt = sched.size();
+  if ((int)cnt > ss.cap) {
+    if (ss.d) hipFree(ss.d);
+    ss.d = nullptr; ss.cap = 0;
+    TRY(dev_alloc(e, &ss.d, cnt + 1024));
+    ss.cap = (int)(cnt + 1024);
+  }
+  if (cnt > 0) TRY(upload(e, ss.d, sched.data(), cnt));
+  ss.depth = depth; ss.grid = grid;
+  return CWR_OK;
+}
+
 int build_chain_schedule(cwr_engine* e, int t) {
   const auto w0 = std::chrono::steady_clock::now();
   TRY(build_tile_links(e));
@@ -1068,37 +1119,62 @@ int build_chain_schedule(cwr_engine* e, int t) {
   std::vector<int32_t> sched; int depth = 0;
   chains_to_schedule(nt, e->tcl_grid, reuse ? 1 : 2, nxt, sched, depth);
   if (reuse) {
-    // per-schedule column lists: a column the PREVIOUS tile of the same list holds in LDS is coded -2 - (its position there)
-    const std::vector<int32_t>& tp = e->h_tcl_ptr; const std::vector<int32_t>& tc = e->h_tcl_cols;
-    std::vector<int32_t> scols(tc);
-    std::vector<int32_t> owner((size_t)e->n_real, -1), pos((size_t)e->n_real, 0);
-    const int grid = e->tcl_grid;
-    for (int b = 0; b < grid; ++b) {
-      int prev = -1;
-      for (int it = 0; it < depth; ++it) {
-        const int tl = sched[(size_t)it * grid + b];
-        if (tl < 0) break;
-        if (prev >= 0) {
-          for (int q = tp[(size_t)prev]; q < tp[(size_t)prev + 1]; ++q) { owner[(size_t)tc[(size_t)q]] = prev; pos[(size_t)tc[(size_t)q]] = q - tp[(size_t)prev]; }
-          for (int q = tp[(size_t)tl]; q < tp[(size_t)tl + 1]; ++q) {
-            const int g = tc[(size_t)q];
-            if (owner[(size_t)g] == prev) scols[(size_t)q] = -2 - pos[(size_t)g];
-          }
-        }
-        prev = tl;
-      }
-    }
+    std::vector<int32_t> scols(e->h_tcl_cols);
+    reuse_codes(e, sched, e->tcl_grid, depth, scols);
     if (!e->d_scols) TRY(dev_alloc(e, &e->d_scols, scols.size()));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     TRY(upload(e, e->d_scols, scols.data(), scols.size()));
   }
   TRY(install_schedule(e, sched, depth));
+  if (e->comm && e->overlap && e->comm_stream && !e->h_tile_inner.empty() && reuse) {
+    // the same chains cut at the boundary between interior and cut tiles: two schedules for the pass an exchange runs beside
+    // (the interior lists leave a few block slots to RCCL's copy kernels, like the interior launch of the ping-pong passes)
+    int gi = e->tcl_grid;
+    if (gi > 4 * e->overlap_reserve) gi = std::max(N_XCD, (gi - e->overlap_reserve) / N_XCD * N_XCD);
+    gi = std::max(N_XCD, std::min(gi, cdiv((int)e->h_tile_inner.size(), N_XCD) * N_XCD));
+    const int go = std::max(N_XCD, std::min(e->tcl_grid, cdiv((int)e->h_tile_outer.size(), N_XCD) * N_XCD));
+    std::vector<int32_t> s_in, s_out; int d_in = 0, d_out = 0;
+    chains_to_schedule(nt, gi, 1, nxt, s_in, d_in, &e->h_tile_inner);
+    chains_to_schedule(nt, go, 1, nxt, s_out, d_out, &e->h_tile_outer);
+    std::vector<int32_t> scols(e->h_tcl_cols);
+    reuse_codes(e, s_in, gi, d_in, scols);
+    reuse_codes(e, s_out, go, d_out, scols);
+    if (!e->d_scols_io) TRY(dev_alloc(e, &e->d_scols_io, scols.size()));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (e->comm_stream) HIP_TRY(e, hipStreamSynchronize(e->comm_stream));
+    TRY(upload(e, e->d_scols_io, scols.data(), scols.size()));
+    TRY(install_sub_schedule(e, e->sched_in, s_in, d_in, gi));
+    TRY(install_sub_schedule(e, e->sched_out, s_out, d_out, go));
+  }
   e->sched_nxt = nxt;
   if (getenv("CWR_VERBOSE")) {
     int linked = 0; for (int a = 0; a < nt; ++a) linked += nxt[(size_t)a] >= 0;
     fprintf(stderr, "[cwr] chained passes: schedule for level %d: %d of %d tiles have a chain successor, %d lists x %d slots (%.2f ms)\n", t, linked, nt, e->tcl_grid, depth,
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count());
   }
+  return CWR_OK;
+}
+
+// Partitioned engines, once, at the first Jacobi solve (collective): the exchanges of a batch must be the same on every rank, and
+// they follow from the batch shape -- chained ranks always close with one plain sweep, ping-pong ranks choose by the sweep count;
+// tiled ranks refresh their halos before the closing sweep.  So: every rank chains or none does (ranks of very different size,
+// or a middle rank whose two halos lift it over the three-tiles-per-block threshold, would otherwise differ), and the closing
+// exchange is forced everywhere as soon as one rank runs tiled passes.
+int agree_on_pass_shape(cwr_engine* e, bool tiled) {
+  const bool can_chain = tiled && e->use_chains && !e->two_closing &&
+                         (e->sched_user ? e->sched_depth > 0 : e->tcl_ntiles >= e->chain_min_tiles * e->tcl_grid);
+  double h[2] = {can_chain ? 0.0 : 1.0, tiled ? 1.0 : 0.0};
+  DevTmp<double> buf;
+  TRY(dev_alloc(e, &buf.p, 2));
+  TRY(upload(e, buf.p, h, 2));
+  TRY(allreduce(e, buf.p, 2));
+  TRY(download(e, h, buf.p, 2));
+  if (h[0] > 0.0 && e->use_chains) {
+    e->use_chains = false;
+    if (getenv("CWR_VERBOSE")) fprintf(stderr, "[cwr] rank %d: %d rank(s) cannot chain their tiles: ping-pong passes on all ranks\n", e->rank, (int)h[0]);
+  }
+  e->any_tiled = h[1] > 0.0;
+  e->shape_agreed = true;
   return CWR_OK;
 }
 
@@ -1128,9 +1204,14 @@ int prepare_sq(cwr_engine* e, bool& active) {
 // tile_list (device, optional): the launch covers only these `n_list` tiles (interior / cut tiles of a partitioned engine)
 // chained = true: every block walks its own list of the schedule e->d_sched (all tiles; single GPU); xin == yout then makes
 // the pass an in-place (block Gauss-Seidel along the chains) relaxation
+// sub (optional, with chained): walk this schedule (the interior or the cut tiles of a partitioned engine) instead of the full one
 int launch_sq_tiled(cwr_engine* e, const double* xin, double* yout, const int32_t* tile_list = nullptr, int n_list = 0, bool tail = true,
-                    bool chained = false) {
+                    bool chained = false, const cwr_engine::SubSched* sub = nullptr) {
   const int ntiles = tile_list ? n_list : e->tcl_ntiles;
+  if (sub && sub->depth <= 0) {                        // (no such tiles on this rank)
+    if (tail && e->n_sq > e->n_tcl) TRY(launch_apply<5>(e, xin, yout, nullptr, e->d_t, nullptr, nullptr, e->n_sq, e->n_tcl));
+    return CWR_OK;
+  }
   if (ntiles <= 0) return CWR_OK;
   int grid = std::max(N_XCD, std::min(e->tcl_grid, cdiv(ntiles, N_XCD) * N_XCD));
   // an interior launch that runs beside an exchange leaves a few block slots free: the grid is persistent (every resident
@@ -1139,6 +1220,7 @@ int launch_sq_tiled(cwr_engine* e, const double* xin, double* yout, const int32_
   int depth = 0;
   const int32_t* scols = nullptr;
   if (chained) { tile_list = e->d_sched; depth = e->sched_depth; grid = e->tcl_grid; scols = e->d_scols; }
+  if (chained && sub) { tile_list = sub->d; depth = sub->depth; grid = sub->grid; scols = e->d_scols_io; }
   const int inplace = (xin == yout) ? 1 : 0;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (e->profiling && e->dominant_mode == 6 && e->ev_used + 2 <= e->ev.size()) {
@@ -1226,6 +1308,7 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
   bool sq = false;
   TRY(prepare_sq(e, sq));
   const bool tiled = sq && e->tcl_ready;
+  if (e->comm && !e->shape_agreed) TRY(agree_on_pass_shape(e, tiled));
   if (tiled && e->use_chains && !e->two_closing && !e->sched_user && e->tcl_ntiles >= e->chain_min_tiles * e->tcl_grid &&
       (e->sched_level < 0 || std::abs(e->cur_t - e->sched_level) >= e->sched_refresh))
     // (worth it from a few tiles per block up: CWR_CHAIN_MIN_TILES, default 3)
@@ -1258,9 +1341,9 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
       // the partner -- and the closing sweep carries the result into the state vector: any number of passes, one closing sweep.
       // (A later batch of the same step goes on in the partner; the closing sweep's own progress is not used.)
       // Partitioned engines (round 3): the same, between the halo exchanges -- which then run on the engine's stream in front of
-      // the pass that needs them instead of beside its interior tiles (a chained pass walks ALL tiles of a rank in one launch;
-      // chaining the interior and the cut tiles separately is the next step).  A rank chains when ITS lists are long enough, so
-      // ranks may differ: the exchanges, the batch shape and the checks do not depend on it.
+      // the pass that needs them, or -- where a rank has interior tiles -- beside the lists of its interior tiles, which are
+      // chained separately from the cut tiles for that pass (build_chain_schedule).  Every rank chains or none does
+      // (agree_on_pass_shape): the batch shape, and with it the exchanges of a batch, must be the same on all ranks.
       const bool chained = tiled && e->use_chains && e->sched_depth > 0 && !e->two_closing;
       const bool first_batch = st.sweeps == 0;
       if (e->reps_auto) {
@@ -1347,7 +1430,8 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
         while (exec && doubles >= cwr_engine::GRAPH_SWEEPS) { HIP_TRY(e, hipGraphLaunch(exec, e->stream)); doubles -= cwr_engine::GRAPH_SWEEPS; }
       }
       // a J^2 pass uses up two halo layers of validity, a plain sweep one
-      const bool can_overlap = e->comm && tiled && !chained && e->overlap && e->comm_stream && e->n_tile_inner > 0 && !e->peers.empty();
+      const bool can_overlap = e->comm && tiled && e->overlap && e->comm_stream && e->n_tile_inner > 0 && !e->peers.empty() &&
+                               (!chained || (e->sched_in.depth > 0 && e->d_scols_io && !e->sched_user));
       for (int i = 0; i < doubles;) {
         double* src = srcb(i);
         double* dst = dstb(i);
@@ -1370,6 +1454,15 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
               HIP_TRY(e, hipMemsetAsync(dst + off, 0xFF, cnt, e->stream));
             }
             TRY(exchange_begin(e, src));
+            if (chained) {
+              // in place along the interior lists (they read and write core rows only; the rows just packed may be among them:
+              // the pack precedes this launch on the stream), then along the lists of the cut tiles behind the unpack
+              TRY(launch_sq_tiled(e, src, dst, nullptr, 0, false, true, &e->sched_in));
+              TRY(exchange_finish(e, src, dst != src ? dst : nullptr));
+              TRY(launch_sq_tiled(e, src, dst, nullptr, 0, true, true, &e->sched_out));
+              since_exchange = 2; ++i;
+              continue;
+            }
             TRY(launch_sq_tiled(e, src, dst, e->d_tile_inner, e->n_tile_inner, false));
             TRY(exchange_finish(e, src, dst));
             TRY(launch_sq_tiled(e, src, dst, e->d_tile_outer, e->n_tile_outer, true));
@@ -1416,13 +1509,13 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
       // them so that the two plain sweeps below are exact on the core and the check is the true residual
       if (one_closing) {
         if (e->comm) {
-          if (tiled && e->local_reps > 1 && passes > 0) since_exchange = e->exch_every;
+          if (e->any_tiled && e->local_reps > 1 && passes > 0) since_exchange = e->exch_every;
           if (since_exchange + 1 > e->exch_every) { TRY(exchange_halo(e, srcb(passes))); since_exchange = 0; }
           ++since_exchange;
         }
         TRY(launch_apply<4>(e, srcb(passes), dstb(passes), nullptr, e->d_b, nullptr, nullptr));
       } else {
-      if (e->comm && tiled && e->local_reps > 1 && passes > 0) since_exchange = e->exch_every;
+      if (e->comm && e->any_tiled && e->local_reps > 1 && passes > 0) since_exchange = e->exch_every;
       if (since_exchange + 1 > e->exch_every) { TRY(exchange_halo(e, e->d_c)); since_exchange = 0; }
       TRY(launch_apply<4>(e, e->d_c, e->d_p, nullptr, e->d_b, nullptr, nullptr));
       ++since_exchange;
@@ -1891,7 +1984,7 @@ void cwr_destroy(cwr_engine* e) {
   for (hipEvent_t ev : e->ev) hipEventDestroy(ev);
   void* ptrs[] = {e->d_f1, e->d_f2, e->d_ptr, e->d_ent_edge, e->d_ent_nb, e->d_adv, e->d_vel, e->d_vol, e->d_dif,
                   e->d_bc, e->d_rec, e->d_diag, e->d_c, e->d_r, e->d_r0, e->d_p, e->d_v, e->d_s, e->d_t, e->d_b,
-                  e->d_scal, e->d_partial, e->d_fadv, e->d_fdif, e->d_ftot, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf, e->d_ptr2, e->d_col2, e->d_row2, e->d_rec2, e->d_w, e->d_react, e->d_info, e->d_tcl_ptr, e->d_tcl_cols, e->d_loc2, e->d_w2, e->d_pair_ptr, e->d_slots, e->d_line_ptr, e->d_line_faces, e->d_ledger, e->d_mass_out, e->d_chk, e->d_face_orig, e->d_row_ghost, e->d_keep, e->d_in_rows, e->d_in_vals, e->d_face_pos, e->d_trow, e->d_vptr, e->d_meta, e->d_tile_inner, e->d_tile_outer, e->d_chkx, e->d_sq_fast, e->d_sched, e->d_link_ptr, e->d_link_ent, e->d_link_flux, e->d_scols};
+                  e->d_scal, e->d_partial, e->d_fadv, e->d_fdif, e->d_ftot, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf, e->d_ptr2, e->d_col2, e->d_row2, e->d_rec2, e->d_w, e->d_react, e->d_info, e->d_tcl_ptr, e->d_tcl_cols, e->d_loc2, e->d_w2, e->d_pair_ptr, e->d_slots, e->d_line_ptr, e->d_line_faces, e->d_ledger, e->d_mass_out, e->d_chk, e->d_face_orig, e->d_row_ghost, e->d_keep, e->d_in_rows, e->d_in_vals, e->d_face_pos, e->d_trow, e->d_vptr, e->d_meta, e->d_tile_inner, e->d_tile_outer, e->d_chkx, e->d_sq_fast, e->d_sched, e->d_link_ptr, e->d_link_ent, e->d_link_flux, e->d_scols, e->d_scols_io, e->sched_in.d, e->sched_out.d};
   for (void* p : ptrs) if (p) hipFree(p);
   if (e->stream) hipStreamDestroy(e->stream);
   delete e;

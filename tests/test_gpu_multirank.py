@@ -403,6 +403,68 @@ def test_partitioned_engines_chain_their_tiles_too(gpu_lib, world, K, depth, gri
     sw_c = [s_ for s_, _ in chained[0][6]]
     sw_p = [s_ for s_, _ in plain[0][6]]
     assert sum(sw_c[1:]) < sum(sw_p[1:]), (sw_c, sw_p)
+    # the in-loop exchanges of the chained ranks run beside their interior lists (separate schedules for interior and cut tiles;
+    # the end ranks have interior tiles at this size, a middle rank of three may have none and then exchanges on its own stream)
+    for r in (chained[0], chained[-1]):
+        assert sum(o for _, o, _ in r[13]) > 0, r[13]
+
+
+def test_ranks_that_cannot_all_chain_keep_the_ping_pong_passes_together(gpu_lib, monkeypatch):
+    """Three ranks x 4 constituents (128-row tiles), grid capped at 16 blocks: the middle rank, with two halos, has 50 tiles and
+    could chain (>= 3 per block), the end ranks with 45 cannot.  A chained rank always closes a batch with one plain sweep, a
+    ping-pong rank chooses by the sweep count -- different exchanges per batch, i.e. a deadlock (seen with this very case).
+    The ranks agree at their first solve: all chain or none."""
+    build_mock()
+    monkeypatch.setenv('CWR_NO_SMALL', '1')
+    monkeypatch.setenv('CWR_TEST_BIG', '1')
+    monkeypatch.setenv('CWR_TCL_GRID', '16')
+    monkeypatch.setenv('CWR_TILE_ORDER', 'lanes')
+    K = 4
+    results = run_ranks(3, _rank_main, (K, 'jacobi', 6))
+    assert not any(r[14] for r in results), 'a rank chained although not every rank can'
+    assert all(r[6] == results[0][6] for r in results)
+    mesh, inputs3 = make_case(K)
+    n = mesh['nreal'] + 1
+    oracle.derive_coefficients(mesh)
+    ref = oracle.OracleModel(mesh, {f'c{k}': inputs3[:, :, k].copy() for k in range(K)})
+    for _ in range(3):
+        ref.update()
+    want = np.stack([ref.constituent_dict[f'c{k}'].state[3, :n] for k in range(K)], axis=1)
+    state = np.full((n, K), np.nan)
+    for r in results:
+        state[r[1]] = r[3]
+    assert rel_err(state, want) <= 1e-9
+
+
+@pytest.mark.parametrize('world,K,depth,grid', [(2, 16, 8, 32), (3, 16, 6, 16)])
+def test_chained_ranks_overlap_their_exchanges_and_survive_poisoned_halo_rows(gpu_lib, world, K, depth, grid, monkeypatch):
+    """The poison test of the ping-pong passes for the chained ones: before every overlapped exchange all halo rows are NaN; the
+    interior lists (in place, beside the exchange) must not read one, the lists of the cut tiles must wait for the unpacked rows.
+    Chained passes are not bitwise reproducible, so the answer is checked against the oracle."""
+    build_mock()
+    monkeypatch.setenv('CWR_NO_SMALL', '1')
+    monkeypatch.setenv('CWR_TEST_BIG', '1')
+    monkeypatch.setenv('CWR_TCL_GRID', str(grid))
+    monkeypatch.setenv('CWR_TILE_ORDER', 'lanes')
+    monkeypatch.setenv('CWR_MOCK_ASYNC', '2')
+    monkeypatch.setenv('CWR_TEST_POISON_HALO', '1')
+    results = run_ranks(world, _rank_main, (K, 'jacobi', depth))
+    assert all(r[14] for r in results), 'no schedule was built on some rank'
+    assert all(r[12] == 1 for r in results), 'the stand-in fell back to its host-synchronous mode'
+    for r in (results[0], results[-1]):
+        assert sum(o for _, o, _ in r[13]) > 0, r[13]
+    mesh, inputs3 = make_case(K)
+    n = mesh['nreal'] + 1
+    oracle.derive_coefficients(mesh)
+    ref = oracle.OracleModel(mesh, {f'c{k}': inputs3[:, :, k].copy() for k in range(K)})
+    for _ in range(3):
+        ref.update()
+    want = np.stack([ref.constituent_dict[f'c{k}'].state[3, :n] for k in range(K)], axis=1)
+    state = np.full((n, K), np.nan)
+    for r in results:
+        state[r[1]] = r[3]
+    assert not np.isnan(state).any()
+    assert rel_err(state, want) <= 1e-9
 
 
 def _rank_ghost(rank, world, K, uid_pipe, out_queue):
