@@ -214,3 +214,24 @@ def test_synthetic_meshes_with_eight_sided_cells():
     b = cw.synthetic.make_mesh(24, 10, 3, seed=9, n_merge=12, n_dry=1, n_merge4=0)
     assert all(np.array_equal(a[k], b[k], equal_nan=True) for k in a if isinstance(a[k], np.ndarray))
     assert int(np.asarray(a['edges_face1']).sum()) == 57280      # pinned: the generator's stream for existing seeds
+
+
+def test_curve_kind_follows_the_size_of_a_rank_and_the_environment(monkeypatch):
+    """distributed.curve_kind: lanes along the flow for engines that will chain their tiles (one GPU; ranks of at least three
+    tiles per resident block), the isotropic Hilbert curve below that and whenever the chains are switched off."""
+    from clearwater_riverine_amd.distributed import curve_kind
+    from clearwater_riverine_amd.engine import tile_rows
+    for v in ('CWR_TILE_ORDER', 'CWR_NO_CHAINS'):
+        monkeypatch.delenv(v, raising=False)
+    tr = tile_rows(16)
+    assert curve_kind(1_000_000, 16, 1) == 'lanes'
+    assert curve_kind(1_000_000, 16, 2) == 'lanes' and curve_kind(1_000_000, 16, 4) == 'lanes'
+    assert curve_kind(1_000_000, 16, 8) == 'hilbert'               # 125 k cells per rank < 3 x 1024 x 64
+    assert curve_kind(3 * 1024 * tr * 2, 16, 2) == 'lanes' and curve_kind(3 * 1024 * tr * 2 - 2, 16, 2) == 'hilbert'
+    monkeypatch.setenv('CWR_NO_CHAINS', '1')
+    assert curve_kind(1_000_000, 16, 1) == 'hilbert'
+    monkeypatch.setenv('CWR_TILE_ORDER', 'lanes')
+    assert curve_kind(1_000_000, 16, 8) == 'lanes'
+    monkeypatch.setenv('CWR_TILE_ORDER', 'hilbert')
+    monkeypatch.delenv('CWR_NO_CHAINS')
+    assert curve_kind(1_000_000, 16, 1) == 'hilbert'
