@@ -8,7 +8,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, 'csrc', 'cwr_engine.hip')
 DEPS = [SRC, os.path.join(HERE, 'csrc', 'cwr_kernels.hpp'),
-        os.path.join(os.path.dirname(HERE), 'include', 'cwr_transport.h')]
+        os.path.join(HERE, "csrc", "cwr_host_builders.hpp"),
+        os.path.join(os.path.dirname(HERE), "include", "cwr_transport.h")]
 OUT = os.path.join(HERE, 'libcwr_transport.so')
 
 FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-munsafe-fp-atomics', '-fPIC', '-shared',

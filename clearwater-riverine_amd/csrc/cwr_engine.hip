@@ -3,6 +3,7 @@
 // Built for gfx950 only:  hipcc -O3 --offload-arch=gfx950 -munsafe-fp-atomics -shared -fPIC
 #include "../../include/cwr_transport.h"
 #include "cwr_kernels.hpp"
+#include "cwr_host_builders.hpp"
 
 #include <dlfcn.h>
 #include <atomic>
@@ -57,6 +58,19 @@ struct Rccl {
   }
 };
 Rccl g_rccl;
+
+// ---- process exit ----
+// The HIP runtime tears itself down from exit handlers of its own.  A host that still calls into this library after that -- the
+// finalizer of a garbage-collected wrapper object, a static destructor of the embedding program -- would reach hip* on a dead
+// runtime.  The first successful cwr_create registers ONE exit handler; exit handlers run in reverse order of registration and
+// the runtime registered its own during the hip calls before that point, so this one runs BEFORE the runtime goes down.  It only
+// raises a flag: from then on the three releasing entry points (cwr_destroy, cwr_output_close, cwr_host_unregister) return
+// without touching HIP -- the process is about to give everything back anyway.  Nothing is destroyed here: a stream that waits
+// for a dead peer must not keep the process from exiting.
+std::atomic<bool> g_down{false};
+std::atomic<bool> g_exit_hooked{false};
+void on_process_exit() { g_down.store(true); }
+
 constexpr int NCCL_FLOAT64 = 8;   // ncclDataType_t::ncclFloat64
 constexpr int NCCL_SUM = 0;       // ncclRedOp_t::ncclSum
 
@@ -686,64 +700,19 @@ const void* tcl_kernel(int vw, int cfg) {
 // the device (k_sq_numeric; k_build_sq for very long rows), then c2 = bhat + J bhat with one plain sweep of bhat.
 int ensure_sq_pattern(cwr_engine* e) {
   if (e->sq_pattern || e->sq_failed) return CWR_OK;
-  // rows with a J^2 row: the longest prefix of computed rows all of whose real neighbours have rows of their own
-  // (single GPU: every row; partitioned with halo depth s: the core and layers 1..s-2)
-  int n = e->n_owned;
-  for (int c = 0; c < e->n_owned && n == e->n_owned; ++c)
-    for (int j = e->h_ptr[c]; j < e->h_ptr[c + 1]; ++j)
-      if (e->h_nb[j] >= e->n_owned) { n = c; break; }
-  if (n < e->n_core) { e->sq_failed = true; return CWR_OK; }   // halo too shallow: plain sweeps only
+  // symbolic J^2 on the host (cwr_host_builders.hpp: also what the CPU sanitizer build exercises)
+  host::SqPattern sqp;
+  if (!host::symbolic_sq(e->n_owned, e->n_core, e->max_degree, e->h_ptr, e->h_nb, sqp)) { e->sq_failed = true; return CWR_OK; }   // halo too shallow: plain sweeps only
+  const int n = sqp.n_sq;
   e->n_sq = n;
-  std::vector<int32_t> ptr2((size_t)n + 1, 0), col2, pair_ptr((size_t)n + 1, 0);
-  std::vector<uint8_t> slots;
-  col2.reserve((size_t)e->nnz * 3 + 16);
-  slots.reserve((size_t)e->nnz * 4 + 16);
-  bool rowwise = true;
-  std::vector<int32_t> tmp;
-  const int TR = e->R * e->U;
-  for (int c = 0; c < n; ++c) {
-    tmp.clear();
-    for (int j = e->h_ptr[c]; j < e->h_ptr[c + 1]; ++j) {
-      const int m = e->h_nb[j];
-      if (m < 0) continue;
-      for (int i = e->h_ptr[m]; i < e->h_ptr[m + 1]; ++i) {
-        const int k = e->h_nb[i];
-        // columns in order of first discovery (faces ascending, then the neighbour's faces ascending): that order does
-        // not depend on the local numbering, so a partitioned run sums every row exactly like the single-GPU run
-        if (k < 0) continue;
-        auto it = std::find(tmp.begin(), tmp.end(), k);
-        if (it == tmp.end()) { tmp.push_back(k); it = tmp.end() - 1; }
-        slots.push_back((uint8_t)std::min<size_t>(255, (size_t)(it - tmp.begin())));   // slot of every product, in order
-      }
-    }
-    if ((int)tmp.size() > SQN_MAXC) rowwise = false;             // such a row needs the per-entry kernel
-    e->sq_max_row = std::max(e->sq_max_row, (int)tmp.size());
-    col2.insert(col2.end(), tmp.begin(), tmp.end());
-    ptr2[c + 1] = (int32_t)col2.size();
-    pair_ptr[c + 1] = (int32_t)slots.size();
-  }
+  const std::vector<int32_t>& ptr2 = sqp.ptr2; const std::vector<int32_t>& col2 = sqp.col2; const std::vector<int32_t>& pair_ptr = sqp.pair_ptr;
+  const std::vector<uint8_t>& slots = sqp.slots;
+  bool rowwise = sqp.rowwise;
+  e->sq_max_row = std::max(e->sq_max_row, sqp.max_row);
   e->nnz2 = (int)col2.size();
-  {
-    // rows k_sq_numeric may take through its branch-free path (see there): a property of the topology
-    const int DEGsel = e->max_degree <= 4 ? 4 : (e->max_degree <= 6 ? 6 : 8);
-    std::vector<uint8_t> ghosty((size_t)e->n_owned, 0), fastv((size_t)n, 0);
-    for (int c = 0; c < e->n_owned; ++c)
-      for (int j = e->h_ptr[c]; j < e->h_ptr[c + 1]; ++j) if (e->h_nb[j] < 0) ghosty[(size_t)c] = 1;
-    for (int c = 0; c < n; ++c) {
-      const int deg = e->h_ptr[c + 1] - e->h_ptr[c];
-      bool ok = deg > 0 && deg <= DEGsel && ptr2[c + 1] > ptr2[c];
-      bool any = false;
-      for (int j = e->h_ptr[c]; j < e->h_ptr[c + 1] && ok; ++j) {
-        const int m = e->h_nb[j];
-        if (m < 0) continue;
-        any = true;
-        ok = (e->h_ptr[m + 1] - e->h_ptr[m] <= DEGsel) && !ghosty[(size_t)m];
-      }
-      fastv[(size_t)c] = (ok && any) ? 1 : 0;
-    }
-    TRY(dev_alloc(e, &e->d_sq_fast, (size_t)n));
-    TRY(upload(e, e->d_sq_fast, fastv.data(), (size_t)n));
-  }
+  const int TR = e->R * e->U;
+  TRY(dev_alloc(e, &e->d_sq_fast, (size_t)n));
+  TRY(upload(e, e->d_sq_fast, sqp.fast.data(), (size_t)n));
   int cap = 1;
   for (int b = 0; b * TR < n; ++b) cap = std::max(cap, ptr2[std::min((b + 1) * TR, n)] - ptr2[b * TR]);
   if (cap > 8192) { e->sq_failed = true; return CWR_OK; }      // would not fit LDS staging: stay with plain sweeps
@@ -811,44 +780,11 @@ int ensure_sq_pattern(cwr_engine* e) {
     split = split && CWR_WORK_ITEMS && e->VW == 1 && !want4;     // (only the one-constituent-per-lane kernels carry the item logic)
     const int seg = split ? TCL_SEG : (1 << 20);
     const int nvmax = split ? TCL_NVMAX : 0;
-    std::vector<int32_t> trow(1, 0), vptr(1, 0);
-    std::vector<uint16_t> vtab;
-    bool tile_ok = true;
-    for (int c = 0; c < n_t && tile_ok;) {
-      int rows = 0, virt = 0;
-      while (c + rows < n_t && rows < 256) {
-        const int len = ptr2[c + rows + 1] - ptr2[c + rows];
-        const int extra = (len > seg) ? (len - 1) / seg : 0;
-        if (rows + 1 + virt + extra > tr || virt + extra > nvmax || extra > 255) break;
-        for (int ch = 1; ch <= extra; ++ch) vtab.push_back((uint16_t)(rows | (ch << 8)));
-        ++rows; virt += extra;
-      }
-      if (rows == 0) { tile_ok = false; break; }                 // a single row needs more slots than a tile has
-      c += rows;
-      trow.push_back(c); vptr.push_back((int32_t)vtab.size());
-    }
-    if (!tile_ok) continue;
-    const int nt = (int)trow.size() - 1;
-    std::vector<int32_t> tptr((size_t)nt + 1, 0), tcols;
-    std::vector<uint16_t> loc2((size_t)e->nnz2, 0);
-    tcols.reserve((size_t)n_t * 3);
-    std::vector<int32_t> stamp((size_t)e->n_real, -1), pos((size_t)e->n_real, 0), others;
-    int max_cols = 0, cap2 = 1;
-    for (int t = 0; t < nt; ++t) {
-      const int c0 = trow[t], c1 = trow[t + 1];
-      const int base = (int)tcols.size();
-      for (int c = c0; c < c1; ++c) { stamp[c] = t; pos[c] = c - c0; tcols.push_back(c); }
-      others.clear();
-      for (int q = ptr2[c0]; q < ptr2[c1]; ++q) { const int k = col2[q]; if (stamp[k] != t) { stamp[k] = t; others.push_back(k); } }
-      std::sort(others.begin(), others.end());
-      for (size_t u = 0; u < others.size(); ++u) { pos[others[u]] = (c1 - c0) + (int)u; tcols.push_back(others[u]); }
-      // (stored pre-multiplied by K: the entry's double index into the tile's x image, so the kernel's inner loop has no multiply)
-      for (int q = ptr2[c0]; q < ptr2[c1]; ++q) loc2[q] = (uint16_t)(pos[col2[q]] * e->K);
-      tptr[t + 1] = (int32_t)tcols.size();
-      max_cols = std::max(max_cols, (int)tcols.size() - base);
-      cap2 = std::max(cap2, ptr2[c1] - ptr2[c0]);
-    }
-    cap2 += cap2 & 1;                                            // even: the 16-bit index array keeps what follows 4-byte aligned
+    host::Tiling tl;
+    if (!host::build_tiling(n_t, tr, seg, nvmax, e->K, e->n_real, ptr2, col2, tl)) continue;
+    const std::vector<int32_t>&trow = tl.trow, &vptr = tl.vptr, &tptr = tl.tptr, &tcols = tl.tcols;
+    const std::vector<uint16_t>&vtab = tl.vtab, &loc2 = tl.loc2;
+    const int nt = tl.ntiles(), max_cols = tl.max_cols, cap2 = tl.cap2;
     // (chained passes: + a staging area for a tile's results, which the next tile of the block's list carries over -- only where
     // the lists will be long enough to chain, so that engines below that size keep their LDS footprint and resident blocks)
     auto lds_for = [&](int own) {
@@ -892,13 +828,7 @@ int ensure_sq_pattern(cwr_engine* e) {
       TRY(dev_alloc(e, &e->d_trow, (size_t)nt + 1));
       TRY(dev_alloc(e, &e->d_vptr, (size_t)nt + 1));
       {
-        // per tile: the ptr2 entries of its rows, then the codes of its virtual items (one prefetch stream in the kernel)
-        std::vector<int32_t> meta((size_t)n_t + vtab.size());
-        for (int t = 0; t < nt; ++t) {
-          int32_t* m = meta.data() + trow[t] + vptr[t];
-          for (int c = trow[t]; c < trow[t + 1]; ++c) *m++ = ptr2[c];
-          for (int v = vptr[t]; v < vptr[t + 1]; ++v) *m++ = (int32_t)vtab[(size_t)v];
-        }
+        const std::vector<int32_t> meta = host::tile_meta(n_t, ptr2, tl);
         TRY(dev_alloc(e, &e->d_meta, meta.size()));
         TRY(upload(e, e->d_meta, meta.data(), meta.size()));
       }
@@ -913,11 +843,7 @@ int ensure_sq_pattern(cwr_engine* e) {
       if (e->comm) {
         // interior tiles: every row they hold and every x row they read is a core row -- no exchange touches them
         std::vector<int32_t> inner, outer;
-        for (int t = 0; t < nt; ++t) {
-          bool in = trow[t + 1] <= e->n_core;
-          for (int q = tptr[t]; q < tptr[t + 1] && in; ++q) in = tcols[(size_t)q] < e->n_core;
-          (in ? inner : outer).push_back(t);
-        }
+        host::split_interior(e->n_core, tl, inner, outer);
         e->n_tile_inner = (int)inner.size(); e->n_tile_outer = (int)outer.size();
         e->h_tile_inner = inner; e->h_tile_outer = outer;
         TRY(dev_alloc(e, &e->d_tile_inner, inner.size()));
@@ -954,27 +880,10 @@ int ensure_sq_pattern(cwr_engine* e) {
 // tile-local applications (profiles/r03_c_chained_passes.txt).
 int build_tile_links(cwr_engine* e) {
   if (e->n_links > 0 || !e->tcl_ready || e->tcl_seg < (1 << 20)) return CWR_OK;     // (fixed-size tiles only: tile = row / TR)
-  const int TR = e->tcl_TR, n = e->n_tcl;
-  struct Ent { int64_t key; int32_t code; };
-  std::vector<Ent> ents;
-  const int nt = e->tcl_ntiles;
-  for (int c = 0; c < n; ++c)
-    for (int j = e->h_ptr[c]; j < e->h_ptr[c + 1]; ++j) {
-      const int m = e->h_nb[j];
-      if (m < 0 || m >= n || m / TR == c / TR) continue;
-      ents.push_back({(int64_t)(c / TR) * nt + (m / TR), e->h_edge[(size_t)j]});       // flow leaving c's side of the face
-    }
-  std::stable_sort(ents.begin(), ents.end(), [](const Ent& a, const Ent& b) { return a.key < b.key; });
-  std::vector<int32_t> lptr(1, 0), lent(ents.size());
-  e->link_src.clear(); e->link_dst.clear();
-  for (size_t i = 0; i < ents.size(); ++i) {
-    if (i == 0 || ents[i].key != ents[i - 1].key) {
-      if (i > 0) lptr.push_back((int32_t)i);
-      e->link_src.push_back((int32_t)(ents[i].key / nt)); e->link_dst.push_back((int32_t)(ents[i].key % nt));
-    }
-    lent[i] = ents[i].code;
-  }
-  lptr.push_back((int32_t)ents.size());
+  host::TileLinks lk;
+  host::build_links(e->n_tcl, e->tcl_TR, e->tcl_ntiles, e->h_ptr, e->h_nb, e->h_edge, lk);
+  e->link_src = lk.src; e->link_dst = lk.dst;
+  const std::vector<int32_t>&lptr = lk.lptr, &lent = lk.lent;
   e->n_links = (int)e->link_src.size();
   if (e->n_links == 0) return CWR_OK;
   TRY(dev_alloc(e, &e->d_link_ptr, lptr.size()));
@@ -985,52 +894,7 @@ int build_tile_links(cwr_engine* e) {
   return CWR_OK;
 }
 
-// chains -> schedule [depth][grid], -1 padded (see schedule.py: the same construction)
-// subset (optional): schedule only these tiles -- a chain ends where its successor is not one of them
-void chains_to_schedule(int nt_all, int grid, int SPB, const std::vector<int32_t>& nxt, std::vector<int32_t>& sched, int& depth,
-                        const std::vector<int32_t>* subset = nullptr) {
-  std::vector<char> has_prev((size_t)nt_all, 0), seen((size_t)nt_all, subset ? 1 : 0);
-  if (subset) for (int32_t t : *subset) seen[(size_t)t] = 0;                // (tiles outside the subset count as visited)
-  const int nt = subset ? (int)subset->size() : nt_all;
-  if (nt == 0 || grid <= 0) { sched.clear(); depth = 0; return; }
-  std::vector<char> member(seen.size());
-  for (size_t t = 0; t < seen.size(); ++t) member[t] = !seen[t];
-  auto next = [&](int t) { const int u = nxt[(size_t)t]; return (u >= 0 && member[(size_t)u]) ? u : -1; };
-  for (int t = 0; t < nt_all; ++t) if (member[(size_t)t] && next(t) >= 0) has_prev[(size_t)next(t)] = 1;
-  std::vector<std::vector<int32_t>> chains;
-  auto walk = [&](int start) {
-    if (seen[(size_t)start]) return;
-    std::vector<int32_t> ch;
-    for (int c = start; c >= 0 && !seen[(size_t)c]; c = next(c)) { seen[(size_t)c] = 1; ch.push_back(c); }
-    chains.push_back(std::move(ch));
-  };
-  for (int t = 0; t < nt_all; ++t) if (!has_prev[(size_t)t]) walk(t);       // heads first,
-  for (int t = 0; t < nt_all; ++t) walk(t);                                  // then whatever sits on a cycle
-  std::stable_sort(chains.begin(), chains.end(), [](const std::vector<int32_t>& a, const std::vector<int32_t>& b) { return a[0] < b[0]; });
-  std::vector<int32_t> seq; seq.reserve((size_t)nt);
-  for (const auto& ch : chains) seq.insert(seq.end(), ch.begin(), ch.end());
-  // the chains, in the order of their first tile (along the cell curve: an XCD keeps a compact region), are cut into SPB * grid
-  // consecutive STREAMS of equal length (+-1); block b = lidx * 8 + xcd walks streams SPB (xcd * grid / 8 + lidx) ...
-  // SPB = 1 (column reuse on): a tile's successor takes the rows they share from LDS, so it simply comes next.
-  // SPB = 2 (reuse off): the kernel prefetches a tile's x rows from memory one tile ahead, so a chain successor has to come
-  // two slots later to read its predecessor's results: two streams INTERLEAVED (A1 B1 A2 B2 ...)
-  const int ns = grid * SPB, bpx = grid / N_XCD;
-  auto bound = [&](int s_) { return (int)(((int64_t)s_ * nt) / ns); };
-  int longest = 0;
-  for (int s_ = 0; s_ < ns; ++s_) longest = std::max(longest, bound(s_ + 1) - bound(s_));
-  depth = longest * SPB;
-  sched.assign((size_t)depth * grid, -1);
-  for (int b = 0; b < grid; ++b) {
-    const int xcd = b % N_XCD, lidx = b / N_XCD;
-    const int s0 = (xcd * bpx + lidx) * SPB;
-    int it = 0;
-    for (int i = 0; i < longest; ++i)
-      for (int q = 0; q < SPB; ++q) {
-        const int lo = bound(s0 + q), hi = bound(s0 + q + 1);
-        if (lo + i < hi) sched[(size_t)(it++) * grid + b] = seq[(size_t)(lo + i)];
-      }
-  }
-}
+using host::chains_to_schedule;          // chains -> schedule [depth][grid], -1 padded (cwr_host_builders.hpp; schedule.py: the same construction)
 
 int install_schedule(cwr_engine* e, const std::vector<int32_t>& sched, int depth) {
   const size_t cnt = sched.size();
@@ -1052,26 +916,10 @@ int install_schedule(cwr_engine* e, const std::vector<int32_t>& sched, int depth
   return CWR_OK;
 }
 
-// Per-schedule column lists: a column the PREVIOUS tile of the same list holds in LDS is coded -2 - (its position there).
-// scols starts as a copy of the tiles' column lists; only the tiles of `sched` are rewritten.
+// Per-schedule column lists: a column the PREVIOUS tile of the same list holds in LDS is coded -2 - (its position there)
+// (cwr_host_builders.hpp).  scols starts as a copy of the tiles' column lists; only the tiles of `sched` are rewritten.
 void reuse_codes(const cwr_engine* e, const std::vector<int32_t>& sched, int grid, int depth, std::vector<int32_t>& scols) {
-  const std::vector<int32_t>& tp = e->h_tcl_ptr; const std::vector<int32_t>& tc = e->h_tcl_cols;
-  std::vector<int32_t> owner((size_t)e->n_real, -1), pos((size_t)e->n_real, 0);
-  for (int b = 0; b < grid; ++b) {
-    int prev = -1;
-    for (int it = 0; it < depth; ++it) {
-      const int tl = sched[(size_t)it * grid + b];
-      if (tl < 0) break;
-      if (prev >= 0) {
-        for (int q = tp[(size_t)prev]; q < tp[(size_t)prev + 1]; ++q) { owner[(size_t)tc[(size_t)q]] = prev; pos[(size_t)tc[(size_t)q]] = q - tp[(size_t)prev]; }
-        for (int q = tp[(size_t)tl]; q < tp[(size_t)tl + 1]; ++q) {
-          const int g = tc[(size_t)q];
-          if (owner[(size_t)g] == prev) scols[(size_t)q] = -2 - pos[(size_t)g];
-        }
-      }
-      prev = tl;
-    }
-  }
+  host::reuse_codes(e->n_real, e->h_tcl_ptr, e->h_tcl_cols, sched, grid, depth, scols);
 }
 
 int install_sub_schedule(cwr_engine* e, cwr_engine::SubSched& ss, const std::vector<int32_t>& sched, int depth, int grid) {
@@ -1096,18 +944,13 @@ int build_chain_schedule(cwr_engine* e, int t) {
   HIP_TRY(e, hipGetLastError());
   std::vector<float> flux((size_t)L);
   TRY(download(e, flux.data(), e->d_link_flux, (size_t)L));
-  // tile t -> best_dn[t]: the destination of its largest outflow; best_up[u]: the source of u's largest inflow; ties go to the
-  // smaller tile id (links are sorted by (src, dst))
-  std::vector<int32_t> best_dn((size_t)nt, -1), best_up((size_t)nt, -1), nxt((size_t)nt, -1);
-  std::vector<float> w_dn((size_t)nt, 0.f), w_up((size_t)nt, 0.f);
-  for (int l = 0; l < L; ++l) {
-    const float w = flux[(size_t)l];
-    if (!(w > 0.f)) continue;
-    const int a = e->link_src[(size_t)l], b = e->link_dst[(size_t)l];
-    if (w > w_dn[(size_t)a]) { w_dn[(size_t)a] = w; best_dn[(size_t)a] = b; }
-    if (w > w_up[(size_t)b] || (w == w_up[(size_t)b] && a < best_up[(size_t)b])) { w_up[(size_t)b] = w; best_up[(size_t)b] = a; }
+  // tile t -> nxt[t]: the destination of its largest outflow, kept when that tile's largest inflow comes from t
+  std::vector<int32_t> nxt;
+  {
+    host::TileLinks lk;                                                      // (only src / dst are read)
+    lk.src = e->link_src; lk.dst = e->link_dst;
+    host::chains_from_flux(nt, lk, flux, nxt);
   }
-  for (int a = 0; a < nt; ++a) { const int b = best_dn[(size_t)a]; if (b >= 0 && best_up[(size_t)b] == a) nxt[(size_t)a] = b; }
   e->sched_level = t;
   ++e->n_sched_builds;
   if (e->sched_depth > 0 && !e->sched_user && nxt == e->sched_nxt) {                     // the same chains: the lists stand
@@ -1959,12 +1802,13 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   CREATE_HIP(hipStreamSynchronize(eng->stream));
 #undef CREATE_TRY
 #undef CREATE_HIP
+  if (!g_exit_hooked.exchange(true)) std::atexit(on_process_exit);
   *out = eng;
   return CWR_OK;
 }
 
 void cwr_destroy(cwr_engine* e) {
-  if (!e) return;
+  if (!e || g_down.load()) return;                   // (after the library's exit handler: see g_down)
   hipSetDevice(e->dev);
   if (e->stream) hipStreamSynchronize(e->stream);
   cwr_output_close(e);
@@ -2374,18 +2218,8 @@ int32_t cwr_set_tile_schedule(cwr_engine* e, int32_t n_lists, int32_t depth, con
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   if (depth <= 0) { e->sched_depth = 0; e->sched_user = false; e->sched_level = -1; return CWR_OK; }
   if (!sched || !e->tcl_ready || n_lists != e->tcl_grid) return fail(e, CWR_ERR_BAD_ARG, "cwr_set_tile_schedule: n_lists must equal the grid of the tiled pass (cwr_tiling_info)");
-  std::vector<char> seen((size_t)e->tcl_ntiles, 0);
-  int count = 0;
-  for (int b = 0; b < n_lists; ++b) {
-    bool ended = false;
-    for (int it = 0; it < depth; ++it) {
-      const int t = sched[(size_t)it * n_lists + b];
-      if (t < 0) { ended = true; continue; }
-      if (ended || t >= e->tcl_ntiles || seen[(size_t)t]) return fail(e, CWR_ERR_BAD_ARG, "cwr_set_tile_schedule: a tile out of range, listed twice, or behind the end of a list");
-      seen[(size_t)t] = 1; ++count;
-    }
-  }
-  if (count != e->tcl_ntiles) return fail(e, CWR_ERR_BAD_ARG, "cwr_set_tile_schedule: every tile must appear exactly once");
+  if (const char* why = host::validate_schedule(e->tcl_ntiles, n_lists, depth, sched))
+    return fail(e, CWR_ERR_BAD_ARG, std::string("cwr_set_tile_schedule: ") + why);
   TRY(install_schedule(e, std::vector<int32_t>(sched, sched + (size_t)n_lists * depth), depth));
   e->sched_user = true;
   // (the column lists of the engine's own schedule do not fit another one: plain lists, every column fetched)
@@ -2536,7 +2370,7 @@ int32_t cwr_domain_mass(cwr_engine* e, int32_t t_level, double* out) {
 
 int32_t cwr_output_close(cwr_engine* e) {
   if (!e) return CWR_ERR_BAD_ARG;
-  if (!e->out_stream) return CWR_OK;
+  if (!e->out_stream || g_down.load()) return CWR_OK;
   hipSetDevice(e->dev);
   hipStreamSynchronize(e->out_stream);
   for (auto& sl : e->out_slots) { if (sl.h) hipHostFree(sl.h); if (sl.done) hipEventDestroy(sl.done); }
@@ -2647,6 +2481,7 @@ int32_t cwr_host_register(void* ptr, int64_t bytes) {
 }
 int32_t cwr_host_unregister(void* ptr) {
   if (!ptr) return CWR_ERR_BAD_ARG;
+  if (g_down.load()) return CWR_OK;
   if (hipHostUnregister(ptr) != hipSuccess) { (void)hipGetLastError(); return CWR_ERR_HIP; }
   return CWR_OK;
 }

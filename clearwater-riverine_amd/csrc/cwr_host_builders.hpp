@@ -1,0 +1,312 @@
+// cwr_host_builders.hpp -- the HOST-side index builders of the transport engine, free of any HIP dependency.
+//
+// Everything the kernels of cwr_kernels.hpp index with is built here, once per engine or once per tile schedule, as plain
+// std::vector data: the symbolic J^2 (rows reachable in two face steps), the tiling of the tiled J^2 pass (per tile the distinct
+// x rows it touches and the 16-bit in-tile position of every entry), the directed links between tiles, the chains along the
+// flow, the per-block tile lists of a chained pass and the carry-over codes of the columns consecutive tiles share.  A bug
+// here becomes an out-of-range LDS or global access in k_sq_tiled / k_sq_numeric, i.e. a GPU fault -- so this header is also
+// compiled on the CPU with -fsanitize=address,undefined and -D_GLIBCXX_ASSERTIONS (bounds-checked operator[]) by
+// tests/test_host_builders.py, which drives tests/host_builders/builders_main.cpp over random meshes and compares the
+// results with numpy statements of the same constructions (schedule.py, tests/test_host_builders.py).
+// (Round 3's one process fault was exactly such a bug, in an experimental build: profiles/r04_b_exit_fault_forensics.txt.)
+//
+// cwr_engine.hip includes this file and uploads the vectors; nothing here allocates device memory or launches anything.
+#pragma once
+#include <stdint.h>
+
+#include <algorithm>
+#include <cstddef>
+#include <vector>
+
+namespace cwr {
+namespace host {
+
+constexpr int HB_N_XCD = 8;            // = cwr::N_XCD (kept separate: this header must not pull in the HIP kernels)
+constexpr int HB_SQN_MAXC = 255;       // = cwr::SQN_MAXC: longest J^2 row the row-wise numeric kernel takes (8-bit slots)
+
+// ---- symbolic J^2 -----------------------------------------------------------------------------------------------------------
+// Adjacency in CSR form over the computed rows: ptr[c] .. ptr[c+1] are the (cell, face) entries of row c, nb[j] >= 0 the local
+// id of the real neighbour (owned or halo), nb[j] < 0 a ghost (boundary) cell.
+struct SqPattern {
+  int n_sq = 0;                         // rows with a J^2 row (a prefix of the computed rows)
+  int max_row = 0;                      // longest J^2 row
+  bool rowwise = true;                  // every row short enough for the row-wise numeric kernel
+  std::vector<int32_t> ptr2, col2;      // CSR of J^2: columns of row c in order of first discovery
+  std::vector<int32_t> pair_ptr;        // first product of row c in `slots`
+  std::vector<uint8_t> slots;           // per product J[c,m] J[m,k] (faces of c ascending, then faces of m ascending): slot of k in row c
+  std::vector<uint8_t> fast;            // 1: k_sq_numeric may take the row through its branch-free path
+};
+
+// Rows with a J^2 row: the longest prefix of computed rows all of whose real neighbours have rows of their own (single GPU: every
+// row; partitioned with halo depth s: the core and layers 1..s-2).  Returns false when that prefix does not cover the core.
+inline bool symbolic_sq(int n_owned, int n_core, int max_degree, const std::vector<int32_t>& ptr, const std::vector<int32_t>& nb,
+                        SqPattern& out) {
+  int n = n_owned;
+  for (int c = 0; c < n_owned && n == n_owned; ++c)
+    for (int j = ptr[(size_t)c]; j < ptr[(size_t)c + 1]; ++j)
+      if (nb[(size_t)j] >= n_owned) { n = c; break; }
+  if (n < n_core) return false;
+  out = SqPattern();
+  out.n_sq = n;
+  out.ptr2.assign((size_t)n + 1, 0);
+  out.pair_ptr.assign((size_t)n + 1, 0);
+  const size_t nnz = (size_t)ptr[(size_t)n_owned];
+  out.col2.reserve(nnz * 3 + 16);
+  out.slots.reserve(nnz * 4 + 16);
+  std::vector<int32_t> tmp;
+  for (int c = 0; c < n; ++c) {
+    tmp.clear();
+    for (int j = ptr[(size_t)c]; j < ptr[(size_t)c + 1]; ++j) {
+      const int m = nb[(size_t)j];
+      if (m < 0) continue;
+      for (int i = ptr[(size_t)m]; i < ptr[(size_t)m + 1]; ++i) {
+        const int k = nb[(size_t)i];
+        // columns in order of first discovery (faces ascending, then the neighbour's faces ascending): that order does
+        // not depend on the local numbering, so a partitioned run sums every row exactly like the single-GPU run
+        if (k < 0) continue;
+        auto it = std::find(tmp.begin(), tmp.end(), k);
+        if (it == tmp.end()) { tmp.push_back(k); it = tmp.end() - 1; }
+        out.slots.push_back((uint8_t)std::min<size_t>(255, (size_t)(it - tmp.begin())));   // slot of every product, in order
+      }
+    }
+    if ((int)tmp.size() > HB_SQN_MAXC) out.rowwise = false;        // such a row needs the per-entry kernel
+    out.max_row = std::max(out.max_row, (int)tmp.size());
+    out.col2.insert(out.col2.end(), tmp.begin(), tmp.end());
+    out.ptr2[(size_t)c + 1] = (int32_t)out.col2.size();
+    out.pair_ptr[(size_t)c + 1] = (int32_t)out.slots.size();
+  }
+  // rows k_sq_numeric may take through its branch-free path: 0 < deg <= DEG, a J^2 row of its own, at least one real neighbour,
+  // and every real neighbour's row has <= DEG entries and no ghost face (so that its r-th entry is its r-th product)
+  const int DEGsel = max_degree <= 4 ? 4 : (max_degree <= 6 ? 6 : 8);
+  std::vector<uint8_t> ghosty((size_t)n_owned, 0);
+  out.fast.assign((size_t)n, 0);
+  for (int c = 0; c < n_owned; ++c)
+    for (int j = ptr[(size_t)c]; j < ptr[(size_t)c + 1]; ++j) if (nb[(size_t)j] < 0) ghosty[(size_t)c] = 1;
+  for (int c = 0; c < n; ++c) {
+    const int deg = ptr[(size_t)c + 1] - ptr[(size_t)c];
+    bool ok = deg > 0 && deg <= DEGsel && out.ptr2[(size_t)c + 1] > out.ptr2[(size_t)c];
+    bool any = false;
+    for (int j = ptr[(size_t)c]; j < ptr[(size_t)c + 1] && ok; ++j) {
+      const int m = nb[(size_t)j];
+      if (m < 0) continue;
+      any = true;
+      ok = (ptr[(size_t)m + 1] - ptr[(size_t)m] <= DEGsel) && !ghosty[(size_t)m];
+    }
+    out.fast[(size_t)c] = (ok && any) ? 1 : 0;
+  }
+  return true;
+}
+
+// ---- tiling of the tiled J^2 pass ---------------------------------------------------------------------------------------------
+struct Tiling {
+  std::vector<int32_t> trow, vptr;      // rows [trow[t], trow[t+1]) and virtual items [vptr[t], vptr[t+1]) of tile t
+  std::vector<uint16_t> vtab;           // virtual items (chunks 1.. of long rows): row in tile | chunk << 8
+  std::vector<int32_t> tptr, tcols;     // per tile the DISTINCT x rows its J^2 rows touch: own rows first, then the others ascending
+  std::vector<uint16_t> loc2;           // per J^2 entry: position of its column in the tile's list, pre-multiplied by K
+  int max_cols = 0;                     // most distinct x rows of a tile
+  int cap2 = 0;                         // most J^2 entries of a tile, rounded up to even
+  int ntiles() const { return (int)trow.size() - 1; }
+};
+
+// Tiles of up to `tr` lane-group slots over rows [0, n_t): a row of more than `seg` entries occupies one slot per chunk (work
+// items; seg = 1 << 20, nvmax = 0: plain fixed-size tiles).  Returns false when a single row needs more slots than a tile has or
+// a tile's positions do not fit 16 bits.  n_cols = rows a column id may name (the real rows of the engine).
+inline bool build_tiling(int n_t, int tr, int seg, int nvmax, int K, int n_cols, const std::vector<int32_t>& ptr2,
+                         const std::vector<int32_t>& col2, Tiling& out) {
+  out = Tiling();
+  out.trow.assign(1, 0); out.vptr.assign(1, 0);
+  for (int c = 0; c < n_t;) {
+    int rows = 0, virt = 0;
+    while (c + rows < n_t && rows < 256) {
+      const int len = ptr2[(size_t)(c + rows) + 1] - ptr2[(size_t)(c + rows)];
+      const int extra = (len > seg) ? (len - 1) / seg : 0;
+      if (rows + 1 + virt + extra > tr || virt + extra > nvmax || extra > 255) break;
+      for (int ch = 1; ch <= extra; ++ch) out.vtab.push_back((uint16_t)(rows | (ch << 8)));
+      ++rows; virt += extra;
+    }
+    if (rows == 0) return false;                                   // a single row needs more slots than a tile has
+    c += rows;
+    out.trow.push_back(c); out.vptr.push_back((int32_t)out.vtab.size());
+  }
+  const int nt = out.ntiles();
+  out.tptr.assign((size_t)nt + 1, 0);
+  out.loc2.assign((size_t)ptr2.back(), 0);               // (one slot per J^2 entry of the engine, also of rows behind n_t)
+  out.tcols.reserve((size_t)n_t * 3);
+  std::vector<int32_t> stamp((size_t)n_cols, -1), pos((size_t)n_cols, 0), others;
+  int cap2 = 1;
+  for (int t = 0; t < nt; ++t) {
+    const int c0 = out.trow[(size_t)t], c1 = out.trow[(size_t)t + 1];
+    const int base = (int)out.tcols.size();
+    for (int c = c0; c < c1; ++c) { stamp[(size_t)c] = t; pos[(size_t)c] = c - c0; out.tcols.push_back(c); }
+    others.clear();
+    for (int q = ptr2[(size_t)c0]; q < ptr2[(size_t)c1]; ++q) { const int k = col2[(size_t)q]; if (stamp[(size_t)k] != t) { stamp[(size_t)k] = t; others.push_back(k); } }
+    std::sort(others.begin(), others.end());
+    for (size_t u = 0; u < others.size(); ++u) { pos[(size_t)others[u]] = (c1 - c0) + (int)u; out.tcols.push_back(others[u]); }
+    const int ncol = (int)out.tcols.size() - base;
+    if ((int64_t)ncol * K > 65535) return false;                   // positions travel pre-multiplied by K in 16 bits
+    // (stored pre-multiplied by K: the entry's double index into the tile's x image, so the kernel's inner loop has no multiply)
+    for (int q = ptr2[(size_t)c0]; q < ptr2[(size_t)c1]; ++q) out.loc2[(size_t)q] = (uint16_t)(pos[(size_t)col2[(size_t)q]] * K);
+    out.tptr[(size_t)t + 1] = (int32_t)out.tcols.size();
+    out.max_cols = std::max(out.max_cols, ncol);
+    cap2 = std::max(cap2, ptr2[(size_t)c1] - ptr2[(size_t)c0]);
+  }
+  out.cap2 = cap2 + (cap2 & 1);                                    // even: the 16-bit index array keeps what follows 4-byte aligned
+  return true;
+}
+
+// per tile: the ptr2 entries of its rows, then the codes of its virtual items (one prefetch stream in the kernel)
+inline std::vector<int32_t> tile_meta(int n_t, const std::vector<int32_t>& ptr2, const Tiling& tl) {
+  std::vector<int32_t> meta((size_t)n_t + tl.vtab.size());
+  for (int t = 0; t < tl.ntiles(); ++t) {
+    size_t m = (size_t)tl.trow[(size_t)t] + (size_t)tl.vptr[(size_t)t];
+    for (int c = tl.trow[(size_t)t]; c < tl.trow[(size_t)t + 1]; ++c) meta[m++] = ptr2[(size_t)c];
+    for (int v = tl.vptr[(size_t)t]; v < tl.vptr[(size_t)t + 1]; ++v) meta[m++] = (int32_t)tl.vtab[(size_t)v];
+  }
+  return meta;
+}
+
+// interior tiles of a partitioned engine: every row they hold and every x row they read is a core row (no exchange touches them)
+inline void split_interior(int n_core, const Tiling& tl, std::vector<int32_t>& inner, std::vector<int32_t>& outer) {
+  inner.clear(); outer.clear();
+  for (int t = 0; t < tl.ntiles(); ++t) {
+    bool in = tl.trow[(size_t)t + 1] <= n_core;
+    for (int q = tl.tptr[(size_t)t]; q < tl.tptr[(size_t)t + 1] && in; ++q) in = tl.tcols[(size_t)q] < n_core;
+    (in ? inner : outer).push_back(t);
+  }
+}
+
+// ---- chained passes: links, chains, schedule, carry-over codes ----------------------------------------------------------------
+// Directed tile links over FIXED-size tiles (tile = row / TR): for every ordered pair of distinct tiles that share a face, the
+// adjacency entries (edge code = face index << 1 | side, as in ent_edge) through which a cell of src meets a cell of dst, sorted by
+// (src, dst), entries of a link in their adjacency order.
+struct TileLinks {
+  std::vector<int32_t> src, dst, lptr, lent;
+  int n() const { return (int)src.size(); }
+};
+inline void build_links(int n, int TR, int nt, const std::vector<int32_t>& ptr, const std::vector<int32_t>& nb,
+                        const std::vector<int32_t>& edge, TileLinks& out) {
+  struct Ent { int64_t key; int32_t code; };
+  std::vector<Ent> ents;
+  for (int c = 0; c < n; ++c)
+    for (int j = ptr[(size_t)c]; j < ptr[(size_t)c + 1]; ++j) {
+      const int m = nb[(size_t)j];
+      if (m < 0 || m >= n || m / TR == c / TR) continue;
+      ents.push_back({(int64_t)(c / TR) * nt + (m / TR), edge[(size_t)j]});         // flow leaving c's side of the face
+    }
+  std::stable_sort(ents.begin(), ents.end(), [](const Ent& a, const Ent& b) { return a.key < b.key; });
+  out = TileLinks();
+  out.lptr.assign(1, 0);
+  out.lent.resize(ents.size());
+  for (size_t i = 0; i < ents.size(); ++i) {
+    if (i == 0 || ents[i].key != ents[i - 1].key) {
+      if (i > 0) out.lptr.push_back((int32_t)i);
+      out.src.push_back((int32_t)(ents[i].key / nt)); out.dst.push_back((int32_t)(ents[i].key % nt));
+    }
+    out.lent[i] = ents[i].code;
+  }
+  out.lptr.push_back((int32_t)ents.size());
+}
+
+// tile t -> nxt[t]: the destination of its largest outflow, kept when that tile's largest inflow comes from t; ties go to the
+// smaller tile id (links are sorted by (src, dst)).  flux[l] = flow leaving link l's source side (k_link_flux).
+inline void chains_from_flux(int nt, const TileLinks& lk, const std::vector<float>& flux, std::vector<int32_t>& nxt) {
+  std::vector<int32_t> best_dn((size_t)nt, -1), best_up((size_t)nt, -1);
+  std::vector<float> w_dn((size_t)nt, 0.f), w_up((size_t)nt, 0.f);
+  nxt.assign((size_t)nt, -1);
+  for (int l = 0; l < lk.n(); ++l) {
+    const float w = flux[(size_t)l];
+    if (!(w > 0.f)) continue;
+    const int a = lk.src[(size_t)l], b = lk.dst[(size_t)l];
+    if (w > w_dn[(size_t)a]) { w_dn[(size_t)a] = w; best_dn[(size_t)a] = b; }
+    if (w > w_up[(size_t)b] || (w == w_up[(size_t)b] && a < best_up[(size_t)b])) { w_up[(size_t)b] = w; best_up[(size_t)b] = a; }
+  }
+  for (int a = 0; a < nt; ++a) { const int b = best_dn[(size_t)a]; if (b >= 0 && best_up[(size_t)b] == a) nxt[(size_t)a] = b; }
+}
+
+// chains -> schedule [depth][grid], -1 padded (schedule.py: the same construction)
+// subset (optional): schedule only these tiles -- a chain ends where its successor is not one of them
+inline void chains_to_schedule(int nt_all, int grid, int SPB, const std::vector<int32_t>& nxt, std::vector<int32_t>& sched, int& depth,
+                               const std::vector<int32_t>* subset = nullptr) {
+  std::vector<char> has_prev((size_t)nt_all, 0), seen((size_t)nt_all, subset ? 1 : 0);
+  if (subset) for (int32_t t : *subset) seen[(size_t)t] = 0;                // (tiles outside the subset count as visited)
+  const int nt = subset ? (int)subset->size() : nt_all;
+  if (nt == 0 || grid <= 0) { sched.clear(); depth = 0; return; }
+  std::vector<char> member(seen.size());
+  for (size_t t = 0; t < seen.size(); ++t) member[t] = !seen[t];
+  auto next = [&](int t) { const int u = nxt[(size_t)t]; return (u >= 0 && member[(size_t)u]) ? u : -1; };
+  for (int t = 0; t < nt_all; ++t) if (member[(size_t)t] && next(t) >= 0) has_prev[(size_t)next(t)] = 1;
+  std::vector<std::vector<int32_t>> chains;
+  auto walk = [&](int start) {
+    if (seen[(size_t)start]) return;
+    std::vector<int32_t> ch;
+    for (int c = start; c >= 0 && !seen[(size_t)c]; c = next(c)) { seen[(size_t)c] = 1; ch.push_back(c); }
+    chains.push_back(std::move(ch));
+  };
+  for (int t = 0; t < nt_all; ++t) if (!has_prev[(size_t)t]) walk(t);       // heads first,
+  for (int t = 0; t < nt_all; ++t) walk(t);                                  // then whatever sits on a cycle
+  std::stable_sort(chains.begin(), chains.end(), [](const std::vector<int32_t>& a, const std::vector<int32_t>& b) { return a[0] < b[0]; });
+  std::vector<int32_t> seq; seq.reserve((size_t)nt);
+  for (const auto& ch : chains) seq.insert(seq.end(), ch.begin(), ch.end());
+  // the chains, in the order of their first tile (along the cell curve: an XCD keeps a compact region), are cut into SPB * grid
+  // consecutive STREAMS of equal length (+-1); block b = lidx * 8 + xcd walks streams SPB (xcd * grid / 8 + lidx) ...
+  // SPB = 1 (column reuse on): a tile's successor takes the rows they share from LDS, so it simply comes next.
+  // SPB = 2 (reuse off): the kernel prefetches a tile's x rows from memory one tile ahead, so a chain successor has to come
+  // two slots later to read its predecessor's results: two streams INTERLEAVED (A1 B1 A2 B2 ...)
+  const int ns = grid * SPB, bpx = grid / HB_N_XCD;
+  auto bound = [&](int s_) { return (int)(((int64_t)s_ * nt) / ns); };
+  int longest = 0;
+  for (int s_ = 0; s_ < ns; ++s_) longest = std::max(longest, bound(s_ + 1) - bound(s_));
+  depth = longest * SPB;
+  sched.assign((size_t)depth * grid, -1);
+  for (int b = 0; b < grid; ++b) {
+    const int xcd = b % HB_N_XCD, lidx = b / HB_N_XCD;
+    const int s0 = (xcd * bpx + lidx) * SPB;
+    int it = 0;
+    for (int i = 0; i < longest; ++i)
+      for (int q = 0; q < SPB; ++q) {
+        const int lo = bound(s0 + q), hi = bound(s0 + q + 1);
+        if (lo + i < hi) sched[(size_t)(it++) * grid + b] = seq[(size_t)(lo + i)];
+      }
+  }
+}
+
+// Per-schedule column lists: a column the PREVIOUS tile of the same list holds in LDS is coded -2 - (its position there).
+// scols starts as a copy of the tiles' column lists; only the tiles of `sched` are rewritten.  n_cols = rows a column may name.
+inline void reuse_codes(int n_cols, const std::vector<int32_t>& tptr, const std::vector<int32_t>& tcols, const std::vector<int32_t>& sched,
+                        int grid, int depth, std::vector<int32_t>& scols) {
+  std::vector<int32_t> owner((size_t)n_cols, -1), pos((size_t)n_cols, 0);
+  for (int b = 0; b < grid; ++b) {
+    int prev = -1;
+    for (int it = 0; it < depth; ++it) {
+      const int tl = sched[(size_t)it * grid + b];
+      if (tl < 0) break;
+      if (prev >= 0) {
+        for (int q = tptr[(size_t)prev]; q < tptr[(size_t)prev + 1]; ++q) { owner[(size_t)tcols[(size_t)q]] = prev; pos[(size_t)tcols[(size_t)q]] = q - tptr[(size_t)prev]; }
+        for (int q = tptr[(size_t)tl]; q < tptr[(size_t)tl + 1]; ++q) {
+          const int g = tcols[(size_t)q];
+          if (owner[(size_t)g] == prev) scols[(size_t)q] = -2 - pos[(size_t)g];
+        }
+      }
+      prev = tl;
+    }
+  }
+}
+
+// A caller's schedule (cwr_set_tile_schedule): every tile exactly once, lists dense from the top.  Returns nullptr when valid.
+inline const char* validate_schedule(int ntiles, int n_lists, int depth, const int32_t* sched) {
+  std::vector<char> seen((size_t)ntiles, 0);
+  int count = 0;
+  for (int b = 0; b < n_lists; ++b) {
+    bool ended = false;
+    for (int it = 0; it < depth; ++it) {
+      const int t = sched[(size_t)it * n_lists + b];
+      if (t < 0) { ended = true; continue; }
+      if (ended || t >= ntiles || seen[(size_t)t]) return "a tile out of range, listed twice, or behind the end of a list";
+      seen[(size_t)t] = 1; ++count;
+    }
+  }
+  return count == ntiles ? nullptr : "every tile must appear exactly once";
+}
+
+}  // namespace host
+}  // namespace cwr

@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from dataclasses import dataclass
 
 import numpy as np
@@ -274,11 +275,13 @@ class TransportEngine:
     def load_boundary(self, ghost_conc):
         g = _arr(ghost_conc, np.float64)
         T = g.shape[0]
-        g = _arr(g.reshape(T, self.n_ghost, -1), np.float64, (T, self.n_ghost, self.K), 'ghost_conc')
+        # (a rank of a partitioned run may hold no boundary cell at all -- seen first at 8 ranks: numpy cannot infer -1 of an empty array)
+        g = _arr(g.reshape(T, self.n_ghost, self.K if g.size == 0 else -1), np.float64, (T, self.n_ghost, self.K), 'ghost_conc')
         self._check(self._lib.cwr_load_boundary(self._h, T, _ptr(g)))
 
     def set_boundary_level(self, t: int, ghost_conc_level):
-        g = _arr(ghost_conc_level, np.float64).reshape(self.n_ghost, -1)
+        g = _arr(ghost_conc_level, np.float64)
+        g = g.reshape(self.n_ghost, self.K if g.size == 0 else -1)
         g = _arr(g, np.float64, (self.n_ghost, self.K), 'ghost_conc_level')
         self._check(self._lib.cwr_set_boundary_level(self._h, int(t), _ptr(g)))
 
@@ -567,7 +570,12 @@ class TransportEngine:
             self._h = C.c_void_p()
 
     def __del__(self):
+        # At interpreter shutdown nothing is released: module globals (ctypes, the library handle) may already be gone, and the
+        # process is about to give everything back anyway.  The library itself ignores calls that arrive after its own exit
+        # handler has run (cwr_engine.hip, g_down), so a finalizer that does slip through is harmless.
         try:
+            if sys is None or sys.is_finalizing():
+                return
             self.close()
         except Exception:
             pass

@@ -191,21 +191,23 @@ def input_array_from_csv(mesh: Mesh, initial_conditions_csv: str, boundary_condi
 _LIVE_MODELS = None
 
 
+def _close_all_models():
+    """atexit hook (registered by _track): every facade still alive releases its page locks and rings while the HIP runtime is
+    up and -- the point -- while the pages of its history blocks are still mapped ("process exit")."""
+    for mdl in list(_LIVE_MODELS or ()):
+        try:
+            mdl.close_output()
+        except Exception:
+            pass
+
+
 def _track(model):
-    """Facades alive at interpreter exit release their page locks and rings while the HIP runtime is still up."""
     global _LIVE_MODELS
     if _LIVE_MODELS is None:
         import atexit
         import weakref
         _LIVE_MODELS = weakref.WeakSet()
-
-        def _close_all():
-            for mdl in list(_LIVE_MODELS):
-                try:
-                    mdl.close_output()
-                except Exception:
-                    pass
-        atexit.register(_close_all)
+        atexit.register(_close_all_models)
     _LIVE_MODELS.add(model)
 
 

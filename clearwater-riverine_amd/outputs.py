@@ -15,6 +15,7 @@ from __future__ import annotations
 import json
 import os
 import queue
+import sys
 import threading
 
 import numpy as np
@@ -88,6 +89,7 @@ class StreamedOutput:
         self._q: queue.Queue = queue.Queue()
         self._err: list = []
         self.levels_written = 0
+        self._closed = False
         self._thread = threading.Thread(target=self._drain, name='cwr-output-writer', daemon=True)
         self._thread.start()
 
@@ -120,6 +122,12 @@ class StreamedOutput:
                     self._err.append(exc)
 
     def close(self):
+        """Drain the ring, join the writer, close the engine's ring.  Idempotent.  During interpreter finalisation (a facade
+        collected after the atexit hook of model.py has run, or a caller's own late finalizer) nothing is done: the daemon
+        writer thread no longer runs then -- a join would never return -- and the engine ignores late calls by itself."""
+        if self._closed or sys.is_finalizing():
+            return
+        self._closed = True
         self._q.put(None)
         self._thread.join()
         self.engine.output_close()

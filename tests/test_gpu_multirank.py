@@ -58,46 +58,97 @@ def case_lines(mesh):
     return [gf[0::3], gf[1::3], gf[2::3]]
 
 
+def _rank_body(rank, world, K, solver, depth, uid):
+    """Three steps of one rank of a partitioned run; returns the tuple the tests read (see run_ranks)."""
+    import clearwater_riverine_amd as cw
+    from clearwater_riverine_amd.distributed import PartitionedTransport
+    mesh, inputs3 = make_case(K)
+    pt = PartitionedTransport(mesh, inputs3, rank, world, device=0, unique_id=uid, halo_depth=depth,
+                              renumber='hilbert' if depth >= 4 else None)
+    infos, comm_counts = [], []
+    pt.set_boundary_lines(case_lines(mesh))
+    mass0 = pt.engine.domain_mass(0)
+    for t in range(3):
+        r = pt.step(t, tol=1e-12, mass_flux=True, solver=solver, mass_balance=True)
+        infos.append((r.sweeps, r.iterations))
+        comm_counts.append((r.exchanges, r.overlapped, r.checks))
+    adv, dif, tot = pt.engine.get_mass_flux()
+    owned_faces = pt.local.face1 < pt.local.n_core
+    overlapped = pt.engine.comm_selftest(257)             # self send/recv through the stand-in + the overlap counter
+    import ctypes
+    is_async = ctypes.CDLL(MOCK_LIB).mockRcclLastCommAsync()      # 1: the stand-in only enqueued on the engine's streams
+    out = (rank, pt.owned_reference_ids(), pt.local.hi, pt.owned_state(), pt.local.edge_global[owned_faces],
+           tot[owned_faces], infos, None, pt.engine.get_mass_balance(), mass0, pt.engine.domain_mass(3), overlapped,
+           is_async, comm_counts, pt.engine.get_tile_schedule()[0] is not None)
+    return pt, out
+
+
 def _rank_main(rank, world, K, solver, depth, uid_pipe, out_queue):
     try:
         os.environ['CWR_RCCL_LIB'] = MOCK_LIB
         import clearwater_riverine_amd as cw
-        from clearwater_riverine_amd.distributed import PartitionedTransport
-        mesh, inputs3 = make_case(K)
         if rank == 0:
             uid = cw.TransportEngine.comm_unique_id()
             for _ in range(world - 1):
                 uid_pipe.put(uid)
         else:
             uid = uid_pipe.get(timeout=120)
-        pt = PartitionedTransport(mesh, inputs3, rank, world, device=0, unique_id=uid, halo_depth=depth,
-                                  renumber='hilbert' if depth >= 4 else None)
-        infos, comm_counts = [], []
-        pt.set_boundary_lines(case_lines(mesh))
-        mass0 = pt.engine.domain_mass(0)
-        for t in range(3):
-            r = pt.step(t, tol=1e-12, mass_flux=True, solver=solver, mass_balance=True)
-            infos.append((r.sweeps, r.iterations))
-            comm_counts.append((r.exchanges, r.overlapped, r.checks))
-        adv, dif, tot = pt.engine.get_mass_flux()
-        owned_faces = pt.local.face1 < pt.local.n_core
-        overlapped = pt.engine.comm_selftest(257)             # self send/recv through the stand-in + the overlap counter
-        import ctypes
-        is_async = ctypes.CDLL(MOCK_LIB).mockRcclLastCommAsync()      # 1: the stand-in only enqueued on the engine's streams
-        out_queue.put((rank, pt.owned_reference_ids(), pt.local.hi, pt.owned_state(), pt.local.edge_global[owned_faces],
-                       tot[owned_faces], infos, None, pt.engine.get_mass_balance(), mass0, pt.engine.domain_mass(3), overlapped,
-                       is_async, comm_counts, pt.engine.get_tile_schedule()[0] is not None))
+        pt, out = _rank_body(rank, world, K, solver, depth, uid)
+        out_queue.put(out)
         pt.engine.close()
     except Exception as exc:                                  # surface the failure in the parent
         out_queue.put((rank, 0, 0, None, None, None, None, repr(exc), None, None, None, 0, -1, None, False))
 
 
-def run_ranks(world, target, args):
+def _host_main(host, world, per_host, K, solver, depth, uid_pipe, out_queue):
+    """One PROCESS hosting `per_host` consecutive ranks as threads (ranks host * per_host ...): how 8 ranks run on the one-GPU
+    box, which allows at most 6 processes on its card.  Every rank is a complete engine with its own streams and communicator;
+    the C-ABI calls release the GIL, so the ranks of a process block in their collectives independently."""
+    import threading
+    ranks = list(range(host * per_host, min(world, (host + 1) * per_host)))
+    try:
+        os.environ['CWR_RCCL_LIB'] = MOCK_LIB
+        import clearwater_riverine_amd as cw
+        uid = cw.TransportEngine.comm_unique_id()             # (every host calls it once: loads the stand-in before threads start)
+        n_hosts = -(-world // per_host)
+        if host == 0:
+            for _ in range(n_hosts - 1):
+                uid_pipe.put(uid)
+        else:
+            uid = uid_pipe.get(timeout=120)
+    except Exception as exc:
+        for r in ranks:
+            out_queue.put((r, 0, 0, None, None, None, None, repr(exc), None, None, None, 0, -1, None, False))
+        return
+    engines, lock = [], threading.Lock()
+
+    def body(rank):
+        try:
+            pt, out = _rank_body(rank, world, K, solver, depth, uid)
+            with lock:
+                engines.append(pt)
+            out_queue.put(out)
+        except Exception as exc:
+            out_queue.put((rank, 0, 0, None, None, None, None, repr(exc), None, None, None, 0, -1, None, False))
+    threads = [threading.Thread(target=body, args=(r,)) for r in ranks]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    for pt in engines:                                        # (every rank of this host is done stepping: the communicators go together)
+        pt.engine.close()
+
+
+def run_ranks(world, target, args, per_host=1):
     """Spawn `world` rank processes, collect one result per rank, and ALWAYS reap the children: a rank that dies without
-    posting a result (segfault, mock-RCCL timeout) must not leave its peers alive on the GPU box."""
+    posting a result (segfault, mock-RCCL timeout) must not leave its peers alive on the GPU box.
+    per_host > 1: ceil(world / per_host) processes, each hosting per_host ranks as threads (target = _host_main)."""
     ctx = mp.get_context('spawn')
     uid_pipe, out_queue = ctx.Queue(), ctx.Queue()
-    procs = [ctx.Process(target=target, args=(r, world) + tuple(args) + (uid_pipe, out_queue)) for r in range(world)]
+    if per_host > 1:
+        procs = [ctx.Process(target=target, args=(h, world, per_host) + tuple(args) + (uid_pipe, out_queue)) for h in range(-(-world // per_host))]
+    else:
+        procs = [ctx.Process(target=target, args=(r, world) + tuple(args) + (uid_pipe, out_queue)) for r in range(world)]
     results = []
     try:
         for p in procs:
@@ -181,6 +232,58 @@ def test_partitioned_step_matches_single_rank_and_oracle(gpu_lib, world, K, solv
         tot[r[4]] = r[5]
     want_flux = np.stack([ref.constituent_dict[f'c{k}'].total_mass_flux[2] for k in range(K)], axis=1)
     assert flux_err(tot, want_flux) <= 1e-8
+
+
+@pytest.mark.parametrize('K,depth', [(16, 8), (1, 6)])
+def test_eight_ranks_through_the_asynchronous_stand_in(gpu_lib, K, depth, monkeypatch):
+    """the target machine is one 8-GPU node, and 8 ranks had never executed by any route.  The one-GPU box
+    allows 6 processes on its card, so the 8 ranks are 4 processes x 2 rank threads (_host_main): eight complete engines, eight
+    communicators of the stream-asynchronous stand-in (CWR_MOCK_ASYNC=2: asynchronous or fail), the real partition of 8 with its
+    middle ranks (two cut sides, few or no interior tiles) and end ranks.  Oracle parity, every rank the same solver decisions and
+    the same exchange / overlap / check counts per step."""
+    build_mock()
+    world = 8
+    monkeypatch.setenv('CWR_NO_SMALL', '1')
+    monkeypatch.setenv('CWR_TEST_BIG', '1')
+    monkeypatch.setenv('CWR_MOCK_ASYNC', '2')
+    monkeypatch.setenv('CWR_MOCK_TIMEOUT_S', '45')
+    monkeypatch.setenv('GPU_MAX_HW_QUEUES', '16')        # (two ranks' streams in one process must not share a hardware queue: a stream
+                                                         #  waiting for a peer's flag would block the stream that publishes it)
+    results = run_ranks(world, _host_main, (K, 'jacobi', depth), per_host=2)
+    assert [r[0] for r in results] == list(range(world))
+    assert all(r[12] == 1 for r in results), 'the stand-in fell back to its host-synchronous mode'
+    mesh, inputs3 = make_case(K)
+    n = mesh['nreal'] + 1
+    state = np.full((n, K), np.nan)
+    tot = np.full((len(mesh['edges_face1']), K), np.nan)
+    for r in results:
+        state[r[1]] = r[3]
+        tot[r[4]] = r[5]
+    assert not np.isnan(state).any() and sum(len(r[1]) for r in results) == n
+    assert all(r[6] == results[0][6] for r in results), [r[6] for r in results]        # sweeps / iterations per step
+    assert all(r[13] == results[0][13] for r in results), [r[13] for r in results]     # exchanges / overlapped / checks per step
+    for (sweeps, its), (exch, over, checks) in list(zip(results[0][6], results[0][13]))[1:]:
+        passes = (sweeps - 1) // 2
+        assert its == 0 and sweeps >= 20, (sweeps, its)                                # the case really iterates, on the sweep path
+        assert 0 < exch <= -(-passes // max(1, depth // 2)) + 4, (sweeps, exch, depth)
+        assert 0 <= over <= exch and 1 <= checks <= 2, (over, exch, checks)
+    # some rank of the eight has interior tiles and ran its in-loop exchanges beside them
+    assert any(r[11] > 0 for r in results), [r[11] for r in results]
+    oracle.derive_coefficients(mesh)
+    ref = oracle.OracleModel(mesh, {f'c{k}': inputs3[:, :, k].copy() for k in range(K)})
+    for _ in range(3):
+        ref.update()
+    want = np.stack([ref.constituent_dict[f'c{k}'].state[3, :n] for k in range(K)], axis=1)
+    assert rel_err(state, want) <= 1e-9
+    want_flux = np.stack([ref.constituent_dict[f'c{k}'].total_mass_flux[2] for k in range(K)], axis=1)
+    assert flux_err(tot, want_flux) <= 1e-8
+    # the single-rank engine on the same mesh: the same answer to solver tolerance, and a comparable number of sweeps
+    from clearwater_riverine_amd.distributed import PartitionedTransport
+    single = PartitionedTransport(mesh, inputs3, 0, 1)
+    single_sweeps = [single.step(t, tol=1e-12, mass_flux=True, solver='jacobi').sweeps for t in range(3)]
+    assert rel_err(state, single.gather_state()) <= 1e-10
+    got = [s_ for s_, _ in results[0][6]]
+    assert all(g <= 1.5 * s_ + 4 for g, s_ in zip(got[1:], single_sweeps[1:])), (got, single_sweeps)
 
 
 @pytest.mark.parametrize('world,K,depth', [(2, 4, 8), (4, 16, 8), (3, 1, 6), (2, 16, 14), (4, 4, 16)])

@@ -1,0 +1,277 @@
+"""The engine's host-side index builders (csrc/cwr_host_builders.hpp) on the CPU, under AddressSanitizer + UBSan with
+bounds-checked std::vector access.
+
+A wrong index here is an out-of-range LDS / global access in k_sq_tiled or k_sq_numeric on the GPU; the one process fault of
+round 3 was an out-of-bounds read of an (empty) host vector in exactly this code (profiles/r04_b_exit_fault_forensics.txt).  The
+driver tests/host_builders/builders_main.cpp is compiled here with g++ -fsanitize=address,undefined -D_GLIBCXX_ASSERTIONS, fed
+random meshes (merged 5-8-sided cells, dry cells, shuffled numberings, single engines and ranks of a partition with deep halos)
+and its results are compared with numpy statements of the same constructions: the two-hop pattern in discovery order, the
+per-tile column lists and 16-bit positions, the tile links, the chains and per-block lists (schedule.py) and the carry-over
+codes of consecutive tiles."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import clearwater_riverine_amd as cw
+from clearwater_riverine_amd import schedule as sch
+from clearwater_riverine_amd.ordering import hilbert_order, lane_order, renumber_mesh
+from clearwater_riverine_amd.partition import partition_mesh
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, 'host_builders', 'builders_main.cpp')
+HDR = os.path.join(os.path.dirname(HERE), 'clearwater-riverine_amd', 'csrc', 'cwr_host_builders.hpp')
+
+
+@pytest.fixture(scope='module')
+def driver(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp('hb') / 'builders_main')
+    subprocess.run(['g++', '-O1', '-g', '-std=c++17', '-fsanitize=address,undefined', '-fno-sanitize-recover=all',
+                    '-D_GLIBCXX_ASSERTIONS', '-Wall', '-Werror', SRC, '-o', exe], check=True)
+    return exe
+
+
+def write_bag(path, bag):
+    with open(path, 'wb') as fh:
+        fh.write(struct.pack('<i', len(bag)))
+        for name, arr in bag.items():
+            a = np.ascontiguousarray(arr)
+            if a.dtype == np.float32:
+                a = a.view(np.int32)
+            a = a.astype('<i4')
+            fh.write(struct.pack('<i', len(name))); fh.write(name.encode()); fh.write(struct.pack('<i', a.size)); fh.write(a.tobytes())
+
+
+def read_bag(path):
+    raw = open(path, 'rb').read()
+    off, bag = 4, {}
+    for _ in range(struct.unpack_from('<i', raw, 0)[0]):
+        ln = struct.unpack_from('<i', raw, off)[0]; off += 4
+        name = raw[off:off + ln].decode(); off += ln
+        cnt = struct.unpack_from('<i', raw, off)[0]; off += 4
+        bag[name] = np.frombuffer(raw, dtype='<i4', count=cnt, offset=off).copy(); off += 4 * cnt
+    return bag
+
+
+def adjacency(f1, f2, n_owned, n_real):
+    """CSR adjacency as cwr_create builds it: per computed row its (cell, face) entries in ascending face id; neighbour id, or
+    -1 - ghost; edge code = face << 1 | side (identity face order here)."""
+    f1 = np.asarray(f1, dtype=np.int64); f2 = np.asarray(f2, dtype=np.int64)
+    e = np.arange(len(f1), dtype=np.int64)
+    cell = np.concatenate([f1, f2])
+    code = np.concatenate([e << 1, (e << 1) | 1])
+    nb = np.concatenate([np.where(f2 < n_real, f2, -1 - (f2 - n_real)), f1])
+    keep = cell < n_owned
+    cell, code, nb = cell[keep], code[keep], nb[keep]
+    o = np.lexsort((code, cell))
+    ptr = np.zeros(n_owned + 1, dtype=np.int64)
+    np.add.at(ptr, cell + 1, 1)
+    return np.cumsum(ptr).astype(np.int32), nb[o].astype(np.int32), code[o].astype(np.int32)
+
+
+def run(driver, tmp_path, ptr, nb, edge, adv, n_owned, n_core, n_real, K, tr, grid, seg=1 << 20, nvmax=0):
+    fin, fout = str(tmp_path / 'in.bin'), str(tmp_path / 'out.bin')
+    write_bag(fin, {'params': np.array([n_owned, n_core, n_real, K, tr, grid, seg, nvmax]), 'ptr': ptr, 'nb': nb, 'edge': edge,
+                    'adv': np.asarray(adv, dtype=np.float32)})
+    env = dict(os.environ, ASAN_OPTIONS='detect_leaks=1:abort_on_error=1', UBSAN_OPTIONS='print_stacktrace=1')
+    res = subprocess.run([driver, fin, fout], capture_output=True, text=True, env=env, timeout=600)
+    assert res.returncode == 0 and res.stderr == '', (res.returncode, res.stderr[-3000:])
+    return read_bag(fout)
+
+
+def check_pattern(out, ptr, nb, n_owned, n_core):
+    n = int(out['n_sq'][0])
+    # rows with a J^2 row: the longest prefix whose real neighbours all have rows of their own
+    want_n = n_owned
+    for c in range(n_owned):
+        if (nb[ptr[c]:ptr[c + 1]] >= n_owned).any():
+            want_n = c
+            break
+    assert n == want_n >= n_core
+    ptr2, col2, pair_ptr, slots = out['ptr2'], out['col2'], out['pair_ptr'], out['slots']
+    longest = 0
+    for c in range(n):
+        cols, sl = [], []
+        for j in range(ptr[c], ptr[c + 1]):
+            m = nb[j]
+            if m < 0:
+                continue
+            for i in range(ptr[m], ptr[m + 1]):
+                k = nb[i]
+                if k < 0:
+                    continue
+                if k not in cols:
+                    cols.append(k)
+                sl.append(cols.index(k))
+        assert list(col2[ptr2[c]:ptr2[c + 1]]) == cols, c
+        assert list(slots[pair_ptr[c]:pair_ptr[c + 1]]) == sl, c
+        longest = max(longest, len(cols))
+    assert int(out['n_sq'][1]) == longest and len(col2) == ptr2[n] and len(slots) == pair_ptr[n]
+    # the branch-free path of k_sq_numeric reads neighbour rows as if their r-th entry were their r-th product
+    deg = np.diff(ptr)
+    DEG = 4 if deg.max() <= 4 else (6 if deg.max() <= 6 else 8)
+    ghosty = np.array([(nb[ptr[c]:ptr[c + 1]] < 0).any() for c in range(n_owned)])
+    for c in np.nonzero(out['fast'])[0]:
+        ms = [m for m in nb[ptr[c]:ptr[c + 1]] if m >= 0]
+        assert 0 < deg[c] <= DEG and ms and all(deg[m] <= DEG and not ghosty[m] for m in ms)
+    return n
+
+
+def check_tiling(out, n, K, tr, n_real):
+    ptr2, col2 = out['ptr2'], out['col2']
+    trow, tptr, tcols, loc2 = out['trow'], out['tptr'], out['tcols'], out['loc2']
+    nt = len(trow) - 1
+    assert list(trow) == list(range(0, n, tr)) + [n]                      # fixed-size tiles
+    max_cols = cap = 0
+    for t in range(nt):
+        c0, c1 = trow[t], trow[t + 1]
+        ent = col2[ptr2[c0]:ptr2[c1]]
+        others = np.setdiff1d(np.unique(ent), np.arange(c0, c1))
+        want = np.concatenate([np.arange(c0, c1), others])
+        got = tcols[tptr[t]:tptr[t + 1]]
+        assert np.array_equal(got, want), t
+        assert got.min() >= 0 and got.max() < n_real
+        pos = {int(g): i for i, g in enumerate(want)}
+        assert np.array_equal(loc2[ptr2[c0]:ptr2[c1]], [pos[int(k)] * K for k in ent]), t
+        max_cols, cap = max(max_cols, len(want)), max(cap, len(ent))
+    assert list(out['tile_dims']) == [max_cols, cap + (cap & 1), nt] and max_cols * K <= 65535
+    assert len(loc2) == len(col2)
+    # meta: per tile its rows' ptr2 entries (fixed tiles have no virtual items)
+    assert np.array_equal(out['meta'], ptr2[:n]) and len(out['vtab']) == 0
+    return nt
+
+
+def check_chains(out, f1, f2, adv, n, tr, nt, grid, n_real, n_core):
+    # links: every ordered pair of distinct tiles that share a face between rows with a J^2 row, sorted by (src, dst)
+    f1 = np.asarray(f1, dtype=np.int64); f2 = np.asarray(f2, dtype=np.int64)
+    ok = (f1 < n) & (f2 < n) & (f1 // tr != f2 // tr)
+    a, b = f1[ok] // tr, f2[ok] // tr
+    keys = np.unique(np.concatenate([a * nt + b, b * nt + a]))
+    assert np.array_equal(out['link_src'].astype(np.int64) * nt + out['link_dst'], keys)
+    flux = out['link_flux'].view(np.float32).astype(np.float64)
+    us, ud, w = sch.tile_links(f1, f2, adv, n, tr, nt)                     # the numpy statement (links with flow only)
+    live = flux > 0
+    assert np.array_equal(out['link_src'][live].astype(np.int64) * nt + out['link_dst'][live], us * nt + ud)
+    assert np.allclose(flux[live], w, rtol=1e-6)
+    # chains from the driver's own float sums (so that ties fall the same way), then lists: schedule.py is the specification
+    chains = sch.chains(out['link_src'][live].astype(np.int64), out['link_dst'][live].astype(np.int64), flux[live], nt)
+    nxt = np.full(nt, -1, dtype=np.int64)
+    for ch in chains:
+        nxt[ch[:-1]] = ch[1:]
+    assert np.array_equal(out['nxt'], nxt)
+    for spb in (1, 2):
+        depth = int(out[f'depth{spb}'][0])
+        got = out[f'sched{spb}'].reshape(depth, grid)
+        assert np.array_equal(got, sch.schedule(chains, nt, grid, streams_per_block=spb))
+    # carry-over codes along every list: -2 - (position in the previous tile's column list) exactly for the shared columns
+    tptr, tcols = out['tptr'], out['tcols']
+    sched = out['sched1'].reshape(int(out['depth1'][0]), grid)
+    check_codes(out['scols'], [sched], tptr, tcols)
+    if 'sched_in' in out:
+        gi, d_in, go, d_out = (int(v) for v in out['sub_dims'])
+        s_in, s_out = out['sched_in'].reshape(d_in, gi), out['sched_out'].reshape(d_out, go)
+        inner, outer = set(out['inner'].tolist()), set(out['outer'].tolist())
+        assert inner | outer == set(range(nt)) and not (inner & outer)
+        assert sorted(s_in[s_in >= 0].tolist()) == sorted(inner) and sorted(s_out[s_out >= 0].tolist()) == sorted(outer)
+        for t in inner:                                                     # an interior tile touches core rows only
+            assert out['trow'][t + 1] <= n_core and (tcols[tptr[t]:tptr[t + 1]] < n_core).all()
+        for s, members in ((s_in, inner), (s_out, outer)):                  # a chain link inside one of the two sets stays a list neighbour
+            follows = {int(p): int(q) for bcol in s.T for p, q in zip(bcol[bcol >= 0][:-1], bcol[bcol >= 0][1:])}
+            firsts = {int(bcol[0]) for bcol in s.T if bcol[0] >= 0}
+            for p in members:
+                if nxt[p] >= 0 and int(nxt[p]) in members:
+                    assert follows.get(int(p)) == int(nxt[p]) or int(nxt[p]) in firsts, (p, nxt[p])   # (or the list was cut there)
+        check_codes(out['scols_io'], [s_in, s_out], tptr, tcols)
+
+
+def check_codes(scols, scheds, tptr, tcols):
+    want = tcols.copy()
+    for sched in scheds:
+        for bcol in sched.T:
+            lst = bcol[bcol >= 0]
+            assert (bcol[:len(lst)] >= 0).all()                             # dense from the top
+            for prev, cur in zip(lst[:-1], lst[1:]):
+                pcols = tcols[tptr[prev]:tptr[prev + 1]]
+                where = {int(g): i for i, g in enumerate(pcols)}
+                for q in range(tptr[cur], tptr[cur + 1]):
+                    if int(tcols[q]) in where:
+                        want[q] = -2 - where[int(tcols[q])]
+    assert np.array_equal(scols, want)
+    assert (scols <= -2).any() or all(len(bcol[bcol >= 0]) < 2 for sched in scheds for bcol in sched.T)      # (the case really carries columns over)
+    # what the kernel relies on: a coded position fits 16 bits below the 0xFFFF marker
+    coded = scols[scols <= -2]
+    assert len(coded) == 0 or (-2 - coded).max() < 0xFFFF
+
+
+CASES = [  # nx, ny, seed, merges, dry, K (-> tile rows), grid, order
+    (40, 24, 1, 40, 0, 16, 8, 'lanes'),
+    (57, 31, 2, 120, 3, 1, 8, 'hilbert'),
+    (64, 20, 3, 0, 0, 12, 16, 'lanes'),
+    (33, 33, 4, 150, 5, 4, 8, 'shuffled'),
+    (90, 12, 5, 60, 1, 8, 24, 'lanes'),
+]
+
+
+@pytest.mark.parametrize('nx,ny,seed,n_merge,n_dry,K,grid,order', CASES)
+def test_single_engine_builders_against_numpy_statements(driver, tmp_path, nx, ny, seed, n_merge, n_dry, K, grid, order):
+    mesh = cw.synthetic.make_mesh(nx, ny, 3, seed=seed, n_merge=n_merge, n_dry=n_dry, shuffle_window=16 if order == 'shuffled' else 0,
+                                  dt=40.0, diffusion_coefficient=0.5)
+    n = mesh['nreal'] + 1
+    tr = {16: 64, 12: 85, 8: 128, 4: 128, 1: 256}[K]
+    if order == 'lanes':
+        mesh = renumber_mesh(mesh, lane_order(mesh, n, tile_rows=tr))
+    elif order == 'hilbert':
+        mesh = renumber_mesh(mesh, hilbert_order(mesh['face_x'], mesh['face_y'], n))
+    f1, f2 = np.asarray(mesh['edges_face1']), np.asarray(mesh['edges_face2'])
+    adv = np.asarray(mesh['face_flow'][1], dtype=np.float32)
+    ptr, nb, edge = adjacency(f1, f2, n, n)
+    out = run(driver, tmp_path, ptr, nb, edge, adv, n, n, n, K, tr, grid)
+    assert out['sq_ok'][0] == 1 and out['tiled'][0] == 1
+    assert check_pattern(out, ptr, nb, n, n) == n
+    nt = check_tiling(out, n, K, tr, n)
+    check_chains(out, f1, f2, adv, n, tr, nt, grid, n, n)
+
+
+@pytest.mark.parametrize('world,rank,depth,K', [(3, 1, 6, 16), (8, 3, 8, 16), (8, 0, 4, 1), (2, 1, 1, 4)])
+def test_builders_on_a_rank_of_a_partition(driver, tmp_path, world, rank, depth, K):
+    """Halo rows: the J^2 rows stop at the first row with a neighbour outside the computed rows (depth 1: no J^2 at all), column
+    lists reach into the halo, and the interior / cut tiles get schedules of their own over one shared copy of the codes."""
+    mesh = cw.synthetic.make_mesh(120, 64, 3, seed=7, n_merge=300, dt=40.0, diffusion_coefficient=0.5)
+    n = mesh['nreal'] + 1
+    tr = {16: 64, 4: 128, 1: 256}[K]
+    mesh = renumber_mesh(mesh, lane_order(mesh, n, tile_rows=tr))
+    lm = partition_mesh(mesh['edges_face1'], mesh['edges_face2'], n, world, rank, depth=depth, align=tr)
+    n_owned, n_real = lm.n_rows, lm.n_rows + lm.n_halo
+    ptr, nb, edge = adjacency(lm.face1, lm.face2, n_owned, n_real)
+    adv = np.asarray(mesh['face_flow'][1], dtype=np.float32)[lm.edge_global]
+    out = run(driver, tmp_path, ptr, nb, edge, adv, n_owned, lm.n_core, n_real, K, tr, 8)
+    if depth < 2:
+        assert out['sq_ok'][0] == 0                                         # halo too shallow for two sweeps per launch
+        return
+    assert out['sq_ok'][0] == 1 and out['tiled'][0] == 1
+    n_sq = check_pattern(out, ptr, nb, n_owned, lm.n_core)
+    assert lm.n_core <= n_sq <= n_owned
+    nt = check_tiling(out, n_sq, K, tr, n_real)
+    check_chains(out, lm.face1, lm.face2, adv, n_sq, tr, nt, 8, n_real, lm.n_core)
+
+
+def test_work_item_tiles_cover_every_row_once(driver, tmp_path):
+    """seg = 12 (the work-item build): long rows occupy one lane-group slot per chunk, tiles hold a variable number of rows."""
+    mesh = cw.synthetic.make_mesh(48, 40, 3, seed=11, n_merge=400)
+    n = mesh['nreal'] + 1
+    f1, f2 = np.asarray(mesh['edges_face1']), np.asarray(mesh['edges_face2'])
+    ptr, nb, edge = adjacency(f1, f2, n, n)
+    out = run(driver, tmp_path, ptr, nb, edge, np.zeros(len(f1), np.float32), n, n, n, 1, 256, 8, seg=12, nvmax=48)
+    assert out['tiled'][0] == 1
+    trow, vptr, vtab, ptr2 = out['trow'], out['vptr'], out['vtab'], out['ptr2']
+    assert trow[0] == 0 and trow[-1] == n and (np.diff(trow) > 0).all()
+    for t in range(len(trow) - 1):
+        rows = trow[t + 1] - trow[t]
+        lens = np.diff(ptr2[trow[t]:trow[t + 1] + 1])
+        extra = np.maximum(0, (lens - 1) // 12)
+        assert rows + extra.sum() <= 256 and extra.sum() <= 48 and vptr[t + 1] - vptr[t] == extra.sum()
+        codes = vtab[vptr[t]:vptr[t + 1]]
+        want = [r | (ch << 8) for r in range(rows) for ch in range(1, extra[r] + 1)]
+        assert list(codes) == want
