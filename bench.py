@@ -140,6 +140,14 @@ def launch_ranks(n: int, argv: list[str], timeout_s: float = 1500.0) -> int:
                     pass
                 p.wait()
 
+    # SIGTERM / SIGHUP to the launcher (an outer `timeout`, a scheduler): the ranks sit in sessions of their own and would outlive it,
+    # holding their GPUs in a collective until their own alarm fires -- turn the signal into an exception so that the `finally` runs
+    class _Stopped(Exception):
+        pass
+
+    def _on_signal(signum, _frame):
+        raise _Stopped(signum)
+    old_handlers = {sig: signal.signal(sig, _on_signal) for sig in (signal.SIGTERM, signal.SIGHUP)}
     try:
         import selectors
         sel = selectors.DefaultSelector()
@@ -169,8 +177,15 @@ def launch_ranks(n: int, argv: list[str], timeout_s: float = 1500.0) -> int:
                         sys.stderr.write(ln)
             else:
                 time.sleep(0.05)
+    except _Stopped as sig:
+        print(f'bench.py: launcher got signal {sig.args[0]}, stopping the ranks', file=sys.stderr)
+        rc = 128 + int(sig.args[0])
     finally:
+        for sig_, h in old_handlers.items():
+            signal.signal(sig_, signal.SIG_IGN)             # (a second signal must not interrupt the reaping)
         stop_all()
+        for sig_, h in old_handlers.items():
+            signal.signal(sig_, h)
     if rc == 0 and line is None:
         print('bench.py: rank 0 ended without a result line', file=sys.stderr)
         rc = 1
@@ -201,6 +216,8 @@ def main():
                     help='internal cell numbering (reference ids stay at the boundary)')
     ap.add_argument('--halo-depth', type=int, default=0,
                     help='N > 1: halo layers = Jacobi sweeps between two exchanges (0: from the per-rank size, distributed.auto_halo_depth)')
+    ap.add_argument('--deterministic', action='store_true',
+                    help='CWR_STEP_DETERMINISTIC: ping-pong passes, bitwise reproducible run to run (the default passes are chained in place)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-pmc', action='store_true', help='skip the two rocprofv3 counter passes that measure roofline.traffic')
     ap.add_argument('--cpu-budget-s', type=float, default=100.0, help='wall-clock budget of the CPU baseline leg')
@@ -274,7 +291,7 @@ def main():
 
     iters = []
     for t in range(args.warmup):
-        pt.step(t, tol=args.tol, mass_flux=True, solver=args.solver)
+        pt.step(t, tol=args.tol, mass_flux=True, solver=args.solver, deterministic=args.deterministic)
     saved = eng.get_state()[: pt.local.n_core].copy()       # state at the start of the timed region
     # The timed region -- barrier, EXACTLY --steps steps, barrier -- is repeated --windows times from the same start state
     # (restored outside the timed region); every window takes the MAX over the ranks, the line reports the median window.
@@ -286,7 +303,7 @@ def main():
         barrier()
         t0 = time.perf_counter()
         for t in range(args.warmup, args.warmup + args.steps):
-            r = pt.step(t, tol=args.tol, mass_flux=True, solver=args.solver)
+            r = pt.step(t, tol=args.tol, mass_flux=True, solver=args.solver, deterministic=args.deterministic)
             iters.append({'sweeps': r.sweeps, 'bicgstab': r.iterations} if world == 1 else
                          {'sweeps': r.sweeps, 'bicgstab': r.iterations, 'exchanges': r.exchanges, 'overlapped': r.overlapped, 'checks': r.checks})
         barrier()
@@ -304,7 +321,7 @@ def main():
     eng.set_state(saved)                                 # every rank replays the timed steps, event-timed
     eng.profile_read()
     for t in range(args.warmup, args.warmup + args.steps):
-        pt.step(t, tol=args.tol, mass_flux=True, profile=True, solver=args.solver)
+        pt.step(t, tol=args.tol, mass_flux=True, profile=True, solver=args.solver, deterministic=args.deterministic)
     launches, total_us = eng.profile_read()
     if rank == 0:
         b_r, b_w = eng.apply_bytes()
@@ -368,7 +385,7 @@ def main():
                'host_cores': os.cpu_count()}
 
     if rank == 0:
-        chained = eng.get_tile_schedule()[0] is not None
+        chained = bool(r.chained)
         value = n * K * args.steps / elapsed / 1e6
         line = {
             'metric': 'Mcell-updates/s', 'value': round(value, 2), 'unit': 'Mcell-updates/s',

@@ -120,6 +120,11 @@ struct cwr_engine {
   bool ew_enabled = true;
   double ew_rel = 0.0, ew_abs = 0.0;
   std::vector<double> jnorm;     // per level t: ||J||_inf of step t's Jacobi iteration matrix (k_jnorm, when the flow field is loaded)
+  // per level t: F_t with ||x* - x'||_inf <= F_t ||x' - x||_inf for a Jacobi sweep x -> x' of step t: what the element-wise rule
+  // is scaled by.  ||J||_inf / (1 - ||J||_inf) where that is finite, and -- single engines -- the row-wise bound of
+  // refine_error_factors where that is smaller (near-dry rows, rows next to dry cells: see there)
+  std::vector<double> err_factor;
+  int neumann_sweeps = 128;      // sweeps refine_error_factors may spend per level (CWR_BOUND_SWEEPS; 0 = norm bound only)
   int info_flags = 0;            // CWR_INFO_* bits of the step in progress
   bool ptr_exported = false;     // cwr_state_device_ptr handed the state out: the caller may rewrite it at any time
   // real-cell entries of input_array (levels >= 1): applied to the solved level before the mass fluxes
@@ -147,7 +152,7 @@ struct cwr_engine {
   size_t out_state_cnt = 0, out_slot_cnt = 0;
   double* d_scal = nullptr;      // acc[3][ACC_N][K] | rho[3][K] | bb[K]
   int32_t* d_counters = nullptr; // 8 ints
-  double *d_fadv = nullptr, *d_fdif = nullptr, *d_ftot = nullptr;
+  double *d_fadv = nullptr, *d_fdif = nullptr;      // (the total flux is their sum, formed by the readers: k_mass_flux)
   bool flux_valid = false;
   // communicator
   NcclComm comm = nullptr;
@@ -219,6 +224,8 @@ struct cwr_engine {
   // column reuse along a block's list (see k_sq_tiled, REUSE mode): per-schedule copy of the tiles' column lists
   bool chain_reuse = true;                 // CWR_CHAIN_REUSE=0: fetch every column, two interleaved streams per block (A/B)
   int chain_min_tiles = 3;                 // tiles per block of the persistent grid from which schedules are built
+  bool step_chained = false;               // the passes of the step in progress were chained (cwr_step_info.chained)
+  bool deterministic = false;              // CWR_STEP_DETERMINISTIC of the step in progress: ping-pong passes
   int32_t* d_scols = nullptr;
   // partitioned engines: the interior and the cut tiles chained SEPARATELY, so that an exchange runs beside the interior lists
   // (one list position per tile in either: one shared copy of the column lists serves both)
@@ -596,6 +603,14 @@ int check_ghost_levels(cwr_engine* e) {
 }
 
 int sync_jnorms(cwr_engine* e);
+int refine_error_factors(cwr_engine* e);
+void norm_error_factors(cwr_engine* e) {
+  e->err_factor.assign(e->jnorm.size(), INFINITY);
+  for (size_t t = 0; t < e->jnorm.size(); ++t) {
+    const double rho = e->jnorm[t];
+    if (rho >= 0.0 && rho < 1.0) e->err_factor[t] = rho / (1.0 - rho);
+  }
+}
 // ||J||_inf of every step the loaded flow field allows (see k_jnorm); jnorm[T-1] = 0 (no step starts at the last level)
 int compute_jnorms(cwr_engine* e) {
   const int T = e->T;
@@ -615,7 +630,8 @@ int compute_jnorms(cwr_engine* e) {
   }
   static_assert(sizeof(unsigned long long) == sizeof(double), "bit patterns");
   TRY(download(e, reinterpret_cast<unsigned long long*>(e->jnorm.data()), t_jn.p, (size_t)T));
-  return sync_jnorms(e);
+  TRY(sync_jnorms(e));
+  return refine_error_factors(e);
 }
 
 // Partitioned engines: every rank's norms become the maximum over the ranks (the element-wise rule of the GLOBAL matrix, as a
@@ -624,6 +640,7 @@ int compute_jnorms(cwr_engine* e) {
 // same point -- when the flow field is loaded with a communicator attached, or when the communicator is attached to an
 // engine that already holds a flow field.
 int sync_jnorms(cwr_engine* e) {
+  norm_error_factors(e);
   if (!e->comm || e->world <= 1 || e->T <= 0 || e->jnorm.size() != (size_t)e->T) return CWR_OK;
   const size_t T = (size_t)e->T, W = (size_t)e->world;
   DevTmp<double> buf;
@@ -638,7 +655,54 @@ int sync_jnorms(cwr_engine* e) {
     for (size_t r = 0; r < W; ++r) { const double v = all[r * T + t]; m = (v != v) ? INFINITY : std::max(m, v); }
     e->jnorm[t] = m;
   }
+  norm_error_factors(e);
   return CWR_OK;
+}
+
+// The max-norm a-posteriori bound of a Jacobi sweep, row by row.  For x' = J x + bhat and the solution x* = J x* + bhat:
+//     (I - J)(x* - x') = J (x' - x)   =>   |x* - x'| <= (I - J)^-1 J |x' - x| <= ((I - J)^-1 1 - 1) ||x' - x||_inf = (w - 1) ||x' - x||_inf
+// with w = (I - J)^-1 1 >= 1 (J >= 0, rho(J) < 1: A is a column-diagonally-dominant M-matrix whatever the flow field does to its
+// ROWS).  ||J||_inf / (1 - ||J||_inf) is the crude form of max(w) - 1: it is set by the single worst row -- a nearly dry cell with
+// through-flow (row sum 1 - V_t / (dt sum_in): local CFL in the thousands at a wetting front), or the neighbour of a dry cell
+// whose zeroed faces leave it an unbalanced budget (row sum > 1: no norm bound at all) -- although such a row simply follows its
+// neighbours.  w is bounded rigorously from the Neumann series: w_m = sum_{k<=m} J^k 1 (m sweeps of w <- 1 + J w from 1),
+// r_m = w_{m+1} - w_m = J^{m+1} 1 >= 0, and w - w_{m+1} = (I - J)^-1 J r_m <= ||r_m||_inf (w - 1), so
+//     max(w) - 1 <= max(w_{m+1} - 1) / (1 - ||r_m||_inf)          once ||r_m||_inf < 1.
+// Evaluated once per loaded level with the engine's own sweep kernel (all K columns carry the same numbers); single engines
+// only (the rows of a rank's halo layers would need an exchange per sweep: partitioned engines keep the norm bound).
+int refine_error_factors(cwr_engine* e) {
+  const int T = e->T;
+  if (e->n_halo != 0 || e->comm || T < 2 || e->neumann_sweeps <= 0 || e->err_factor.size() != (size_t)T) return CWR_OK;
+  const int K = e->K;
+  const size_t nK = (size_t)e->n_real * K;
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv((int64_t)nK, BLOCK), 256 * 8));
+  std::vector<double> h(4 * (size_t)K);
+  const bool was_prof = e->profiling; e->profiling = false;
+  int rc = CWR_OK;
+  for (int t = 0; t + 1 < T && rc == CWR_OK; ++t) {
+    rc = prep_step(e, t);
+    if (rc != CWR_OK) break;
+    k_fill<<<grid, BLOCK, 0, e->stream>>>((int64_t)nK, 1.0, e->d_r0, e->d_r);
+    if (hipMemsetAsync(e->d_chk + 4 * (size_t)K, 0, sizeof(double), e->stream) != hipSuccess) { rc = fail(e, CWR_ERR_HIP, "hipMemsetAsync failed"); break; }
+    double* x = e->d_r; double* y = e->d_v;
+    double best = e->err_factor[(size_t)t];
+    for (int done = 0; done < e->neumann_sweeps && rc == CWR_OK;) {
+      const int batch = done == 0 ? 4 : 8;
+      for (int q = 0; q < batch && rc == CWR_OK; ++q) { rc = launch_apply<4>(e, x, y, nullptr, e->d_r0, nullptr, nullptr); std::swap(x, y); }
+      done += batch;
+      if (rc == CWR_OK) rc = reduce_check(e);
+      if (rc == CWR_OK) rc = download(e, h.data(), e->d_chk, 4 * (size_t)K);
+      if (rc != CWR_OK) break;
+      const double r = h[2 * (size_t)K], wmax = h[3 * (size_t)K];           // ||w_{m+1} - w_m||_inf, max(w_{m+1}) (every column alike)
+      if (!std::isfinite(r) || !std::isfinite(wmax)) break;                  // NaN in the field: no bound from here
+      if (r < 1.0) best = std::min(best, (wmax - 1.0) / (1.0 - r));
+      if (r <= 0.02) break;                                                  // within 2 % of max(w) - 1
+    }
+    e->err_factor[(size_t)t] = best;
+  }
+  e->profiling = was_prof;
+  e->prepared_t = -1;
+  return rc;
 }
 
 // Partitioned engines: a level at which ANY rank has real-cell inputs is taken non-speculatively by EVERY rank -- the step's
@@ -686,15 +750,16 @@ int tile_rows_for(int K, bool* four_wide) {
 }
 
 #define CWR_TCL_K(VWv, Q) k_sq_tiled<VWv, TCL_CFG[Q].wrn, TCL_CFG[Q].ut, TCL_CFG[Q].xr>
-const void* tcl_kernel(int vw, int cfg) {
-  if (vw == 4) return cfg == 3 ? reinterpret_cast<const void*>(&CWR_TCL_K(4, 3)) : cfg == 4 ? reinterpret_cast<const void*>(&CWR_TCL_K(4, 4))
-                    : cfg == 5 ? reinterpret_cast<const void*>(&CWR_TCL_K(4, 5)) : cfg == 6 ? reinterpret_cast<const void*>(&CWR_TCL_K(4, 6))
-                    : cfg == 7 ? reinterpret_cast<const void*>(&CWR_TCL_K(4, 7)) : reinterpret_cast<const void*>(&CWR_TCL_K(4, 8));
-  if (vw == 2) return cfg == 0 ? reinterpret_cast<const void*>(&CWR_TCL_K(2, 0)) : cfg == 1 ? reinterpret_cast<const void*>(&CWR_TCL_K(2, 1))
-                    : cfg == 9 ? reinterpret_cast<const void*>(&CWR_TCL_K(2, 9)) : reinterpret_cast<const void*>(&CWR_TCL_K(2, 2));
-  return cfg == 0 ? reinterpret_cast<const void*>(&CWR_TCL_K(1, 0)) : cfg == 1 ? reinterpret_cast<const void*>(&CWR_TCL_K(1, 1))
-       : cfg == 9 ? reinterpret_cast<const void*>(&CWR_TCL_K(1, 9)) : reinterpret_cast<const void*>(&CWR_TCL_K(1, 2));
-}
+#define CWR_TCL_PICK(KM)                                                                                                                 \
+  if (vw == 4) return cfg == 3 ? reinterpret_cast<const void*>(&KM(4, 3)) : cfg == 4 ? reinterpret_cast<const void*>(&KM(4, 4))             \
+                    : cfg == 5 ? reinterpret_cast<const void*>(&KM(4, 5)) : cfg == 6 ? reinterpret_cast<const void*>(&KM(4, 6))             \
+                    : cfg == 7 ? reinterpret_cast<const void*>(&KM(4, 7)) : reinterpret_cast<const void*>(&KM(4, 8));                       \
+  if (vw == 2) return cfg == 0 ? reinterpret_cast<const void*>(&KM(2, 0)) : cfg == 1 ? reinterpret_cast<const void*>(&KM(2, 1))             \
+                    : cfg == 9 ? reinterpret_cast<const void*>(&KM(2, 9)) : reinterpret_cast<const void*>(&KM(2, 2));                       \
+  return cfg == 0 ? reinterpret_cast<const void*>(&KM(1, 0)) : cfg == 1 ? reinterpret_cast<const void*>(&KM(1, 1))                          \
+       : cfg == 9 ? reinterpret_cast<const void*>(&KM(1, 9)) : reinterpret_cast<const void*>(&KM(1, 2));
+const void* tcl_kernel(int vw, int cfg) { CWR_TCL_PICK(CWR_TCL_K) }
+#undef CWR_TCL_PICK
 
 // Symbolic J^2 (once): row c of J^2 has the columns reachable in two face steps.  Numeric values per step on
 // the device (k_sq_numeric; k_build_sq for very long rows), then c2 = bhat + J bhat with one plain sweep of bhat.
@@ -1110,13 +1175,13 @@ int step_tail(cwr_engine* e, int t, int flags) {
     TRY(exchange_halo(e, e->d_c));
     if (!e->d_fadv) {
       const size_t cnt = (size_t)e->E * K;
-      TRY(dev_alloc(e, &e->d_fadv, cnt)); TRY(dev_alloc(e, &e->d_fdif, cnt)); TRY(dev_alloc(e, &e->d_ftot, cnt));
+      TRY(dev_alloc(e, &e->d_fadv, cnt)); TRY(dev_alloc(e, &e->d_fdif, cnt));
     }
     const int grid = std::max(1, std::min(cdiv(e->E, e->R), 256 * 8));
     const float* adv_t = e->d_adv + (size_t)t * e->E;
     const double* dif_t = e->d_dif + (size_t)t * e->E;
-    if (e->VW == 2) k_mass_flux<2><<<grid, BLOCK, 0, e->stream>>>(e->E, e->n_core, K, e->G, e->d_f1, e->d_f2, adv_t, dif_t, e->dt[t], e->d_c, e->d_fadv, e->d_fdif, e->d_ftot);
-    else            k_mass_flux<1><<<grid, BLOCK, 0, e->stream>>>(e->E, e->n_core, K, e->G, e->d_f1, e->d_f2, adv_t, dif_t, e->dt[t], e->d_c, e->d_fadv, e->d_fdif, e->d_ftot);
+    if (e->VW == 2) k_mass_flux<2><<<grid, BLOCK, 0, e->stream>>>(e->E, e->n_core, K, e->G, e->d_f1, e->d_f2, adv_t, dif_t, e->dt[t], e->d_c, e->d_fadv, e->d_fdif);
+    else            k_mass_flux<1><<<grid, BLOCK, 0, e->stream>>>(e->E, e->n_core, K, e->G, e->d_f1, e->d_f2, adv_t, dif_t, e->dt[t], e->d_c, e->d_fadv, e->d_fdif);
     HIP_TRY(e, hipGetLastError());
     e->flux_valid = true;
     e->halo_fresh = true;
@@ -1152,7 +1217,7 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
   TRY(prepare_sq(e, sq));
   const bool tiled = sq && e->tcl_ready;
   if (e->comm && !e->shape_agreed) TRY(agree_on_pass_shape(e, tiled));
-  if (tiled && e->use_chains && !e->two_closing && !e->sched_user && e->tcl_ntiles >= e->chain_min_tiles * e->tcl_grid &&
+  if (tiled && e->use_chains && !e->two_closing && !e->sched_user && e->tcl_ntiles >= e->chain_min_tiles * e->tcl_grid && !e->deterministic &&
       (e->sched_level < 0 || std::abs(e->cur_t - e->sched_level) >= e->sched_refresh))
     // (worth it from a few tiles per block up: CWR_CHAIN_MIN_TILES, default 3)
     TRY(build_chain_schedule(e, e->cur_t));
@@ -1187,8 +1252,9 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
       // the pass that needs them, or -- where a rank has interior tiles -- beside the lists of its interior tiles, which are
       // chained separately from the cut tiles for that pass (build_chain_schedule).  Every rank chains or none does
       // (agree_on_pass_shape): the batch shape, and with it the exchanges of a batch, must be the same on all ranks.
-      const bool chained = tiled && e->use_chains && e->sched_depth > 0 && !e->two_closing;
+      const bool chained = tiled && e->use_chains && e->sched_depth > 0 && !e->two_closing && !e->deterministic;
       const bool first_batch = st.sweeps == 0;
+      e->step_chained = chained;
       if (e->reps_auto) {
         // Tile-local applications per visit.  A chain carries information from tile to tile only as far as the applications
         // carry it across a tile, and the stiffer the step the more of its sweeps are transport along the flow.  Measured on the
@@ -1196,7 +1262,13 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
         // step, x3 3.01; CFL 25 (0.973): x2 15.3, x4 10.8, x6 12.0; CFL 62 (0.989): x4 22.1, x6 19.0; CFL 225 (0.9969): x4 39.2,
         // x8 34.9 (ping-pong x2: 3.69 / 27.4 / 55.7 / 140.8).  ||J||_inf of the step is known from the flow field (k_jnorm).
         const double rho = ((size_t)e->cur_t < e->jnorm.size()) ? e->jnorm[(size_t)e->cur_t] : 0.0;
-        e->local_reps = !chained ? e->reps_base : (rho < 0.9 ? 2 : (rho < 0.98 ? 4 : (rho < 0.993 ? 6 : 8)));
+        // Ping-pong passes (engines below the chain threshold, deterministic steps; round 4): information crosses one tile per pass
+        // whatever the applications, but a stiff step relaxes its tiles' interiors too slowly with two -- same box, ms per step at
+        // x2 / x3 / x4 / x6 (profiles/r04_f_small_engines.txt): 10 k cells x 12 at CFL 18: 0.75 / 0.67 / 0.66 / 0.69; 8 k x 1: 0.59 /
+        // 0.50 / 0.48 / 0.45; 119 k x 16 at CFL 25: 3.83 / 3.42 / 3.52 / 3.73; x 1: 1.38 / 1.21 / 1.17 / 1.21 -- while at CFL 2.5
+        // (||J||_inf 0.78) two stay the cheapest (119 k x 16: 0.70 / 0.71 / 0.76).
+        const int pp = (rho < 0.9 || getenv("CWR_NO_PP_REPS")) ? e->reps_base : std::max(e->reps_base, e->K <= 2 ? 6 : 4);   // (CWR_NO_PP_REPS=1: round 3's fixed count, A/B)
+        e->local_reps = !chained ? pp : (rho < 0.9 ? 2 : (rho < 0.98 ? 4 : (rho < 0.993 ? 6 : 8)));
       }
       // (round 3: partitioned engines take the one-closing shape too -- k_rhs keeps the read-only halo rows of x_t beside the
       // computed rows, so a first pass may start from the copy there as well: one plain sweep and one exchange fewer per step)
@@ -1221,6 +1293,14 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
         if (!from_keep) return (i & 1) ? e->d_c : e->d_p;
         return (i & 1) ? e->d_p : e->d_c; };
       const int passes = doubles;
+      // passes [i, i + cnt) of the batch, none of which needs an exchange
+      auto launch_passes = [&](int i, int cnt) -> int {
+        for (int q = 0; q < cnt; ++q) {
+          if (tiled) TRY(launch_sq_tiled(e, srcb(i + q), dstb(i + q), nullptr, 0, true, chained));
+          else TRY(launch_apply<5>(e, srcb(i + q), dstb(i + q), nullptr, e->d_t, nullptr, nullptr, e->n_sq));
+        }
+        return CWR_OK;
+      };
       launches = doubles + (one_closing ? 1 : 2);
       todo = 0;
       // steady state (the same batch shape as the previous check): the WHOLE batch -- passes, closing sweeps, reduction --
@@ -1231,9 +1311,7 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
         if (it == e->batch_exec.end() && e->batch_last == shape && e->batch_exec.size() < 12) {
           hipGraphExec_t ex = nullptr;
           if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-            int rc = CWR_OK;
-            for (int i = 0; i < doubles && rc == CWR_OK; ++i)
-              rc = tiled ? launch_sq_tiled(e, srcb(i), dstb(i), nullptr, 0, true, chained) : launch_apply<5>(e, srcb(i), dstb(i), nullptr, e->d_t, nullptr, nullptr, e->n_sq);
+            int rc = launch_passes(0, doubles);
             if (rc == CWR_OK) rc = launch_apply<4>(e, srcb(doubles), dstb(doubles), nullptr, e->d_b, nullptr, nullptr);
             if (rc == CWR_OK && !one_closing) rc = launch_apply<4>(e, srcb(doubles + 1), dstb(doubles + 1), nullptr, e->d_b, nullptr, nullptr);
             if (rc == CWR_OK) rc = reduce_check(e);
@@ -1324,9 +1402,7 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
           if (it == e->stretch_exec.end() && e->stretch_exec.size() < 32) {
             hipGraphExec_t ex = nullptr;
             if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-              int rc = CWR_OK;
-              for (int q = 0; q < run && rc == CWR_OK; ++q)
-                rc = launch_sq_tiled(e, srcb(i + q), dstb(i + q), nullptr, 0, true, chained);
+              const int rc = launch_passes(i, run);
               hipGraph_t g = nullptr;
               const hipError_t ec = hipStreamEndCapture(e->stream, &g);
               if (!(rc == CWR_OK && ec == hipSuccess && g && hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess)) { ex = nullptr; (void)hipGetLastError(); }
@@ -1340,13 +1416,8 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
             continue;
           }
         }
-        for (int q = 0; q < run; ++q, ++i) {
-          double* s2 = srcb(i);
-          double* d2 = dstb(i);
-          if (tiled) TRY(launch_sq_tiled(e, s2, d2, nullptr, 0, true, chained));
-          else TRY(launch_apply<5>(e, s2, d2, nullptr, e->d_t, nullptr, nullptr, e->n_sq));
-          since_exchange += 2;
-        }
+        TRY(launch_passes(i, run));
+        since_exchange += 2 * run; i += run;
       }
       // block-asynchronous passes leave the replayed halo layers only approximately equal to their owners' rows: refresh
       // them so that the two plain sweeps below are exact on the core and the check is the true residual
@@ -1606,7 +1677,7 @@ int solve_bicgstab(cwr_engine* e, double tol2, int max_iter, SolveStats& st) {
 // ====================================================================================================
 extern "C" {
 
-int32_t cwr_abi_version(void) { return 4; }
+int32_t cwr_abi_version(void) { return 5; }
 
 int32_t cwr_tile_rows(int32_t n_constituents) {
   if (n_constituents < 1 || n_constituents > 256) return 0;
@@ -1691,6 +1762,7 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   if (const char* v = getenv("CWR_CHAIN_REFRESH")) eng->sched_refresh = std::max(1, atoi(v));
   if (const char* v = getenv("CWR_CHAIN_REUSE")) eng->chain_reuse = atoi(v) != 0;
   if (const char* v = getenv("CWR_CHAIN_MIN_TILES")) eng->chain_min_tiles = std::max(1, atoi(v));
+  if (const char* v = getenv("CWR_BOUND_SWEEPS")) eng->neumann_sweeps = std::max(0, atoi(v));
   // tile-local J^2 applications per pass: each costs LDS time only (measured 15-25 us at K = 16, 4 us at K = 1 on 1 M cells)
   // and cuts the passes from 46 to 28 (x2) / 24 (x3); narrow rows gain from the third application, wide rows do not
   // two everywhere (round 1 ran three at K <= 4).  Same box, ms per step at 2 / 3 / 4 applications (profiles/r02_w_local_reps.txt):
@@ -1828,7 +1900,7 @@ void cwr_destroy(cwr_engine* e) {
   for (hipEvent_t ev : e->ev) hipEventDestroy(ev);
   void* ptrs[] = {e->d_f1, e->d_f2, e->d_ptr, e->d_ent_edge, e->d_ent_nb, e->d_adv, e->d_vel, e->d_vol, e->d_dif,
                   e->d_bc, e->d_rec, e->d_diag, e->d_c, e->d_r, e->d_r0, e->d_p, e->d_v, e->d_s, e->d_t, e->d_b,
-                  e->d_scal, e->d_partial, e->d_fadv, e->d_fdif, e->d_ftot, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf, e->d_ptr2, e->d_col2, e->d_row2, e->d_rec2, e->d_w, e->d_react, e->d_info, e->d_tcl_ptr, e->d_tcl_cols, e->d_loc2, e->d_w2, e->d_pair_ptr, e->d_slots, e->d_line_ptr, e->d_line_faces, e->d_ledger, e->d_mass_out, e->d_chk, e->d_face_orig, e->d_row_ghost, e->d_keep, e->d_in_rows, e->d_in_vals, e->d_face_pos, e->d_trow, e->d_vptr, e->d_meta, e->d_tile_inner, e->d_tile_outer, e->d_chkx, e->d_sq_fast, e->d_sched, e->d_link_ptr, e->d_link_ent, e->d_link_flux, e->d_scols, e->d_scols_io, e->sched_in.d, e->sched_out.d};
+                  e->d_scal, e->d_partial, e->d_fadv, e->d_fdif, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf, e->d_ptr2, e->d_col2, e->d_row2, e->d_rec2, e->d_w, e->d_react, e->d_info, e->d_tcl_ptr, e->d_tcl_cols, e->d_loc2, e->d_w2, e->d_pair_ptr, e->d_slots, e->d_line_ptr, e->d_line_faces, e->d_ledger, e->d_mass_out, e->d_chk, e->d_face_orig, e->d_row_ghost, e->d_keep, e->d_in_rows, e->d_in_vals, e->d_face_pos, e->d_trow, e->d_vptr, e->d_meta, e->d_tile_inner, e->d_tile_outer, e->d_chkx, e->d_sq_fast, e->d_sched, e->d_link_ptr, e->d_link_ent, e->d_link_flux, e->d_scols, e->d_scols_io, e->sched_in.d, e->sched_out.d};
   for (void* p : ptrs) if (p) hipFree(p);
   if (e->stream) hipStreamDestroy(e->stream);
   delete e;
@@ -2052,6 +2124,8 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
   e->tail_done = false;
   e->info_flags = 0;
   e->cur_t = t;
+  e->deterministic = (flags & CWR_STEP_DETERMINISTIC) != 0;
+  e->step_chained = false;
   e->step_exchanges = e->step_overlapped = e->step_checks = 0;
   {
     // element-wise rule: targets (1e6 tol, tol) = (1e-6, 1e-12) at the default tolerance, scaled by s = 0.3 (1 - rho) / rho with
@@ -2060,9 +2134,11 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
     // max norm, rigorously.  (Round 2 used the measured 2-norm contraction of an earlier check, which is not a bound.)
     // s is kept within [1e-3, 0.1]: below 1e-3 (rho > 0.9967, CFL of several hundred) |x' - x| would have to fall under the
     // rounding of a sweep; the step then runs at s = 1e-3 and says so: CWR_INFO_ELEMENTWISE_CLAMPED.
-    double rho = ((size_t)t < e->jnorm.size()) ? e->jnorm[(size_t)t] : 1.0;
-    if (!(rho >= 0.0) || rho >= 1.0) rho = 1.0 - 1.0e-9;
-    const double s_raw = (rho > 0.0) ? 0.3 * (1.0 - rho) / rho : 0.1;
+    // (round 4: the factor rho / (1 - rho) is replaced by the row-wise bound F_t of refine_error_factors where that is smaller --
+    // meshes with dry or nearly dry cells, whose worst row sum says nothing about the error of a sweep)
+    double F = ((size_t)t < e->err_factor.size()) ? e->err_factor[(size_t)t] : INFINITY;
+    if (!(F >= 0.0)) F = INFINITY;
+    const double s_raw = (F > 0.0) ? 0.3 / F : 0.1;
     const double sc = std::min(0.1, std::max(1.0e-3, s_raw));
     if (e->ew_enabled && s_raw < 1.0e-3) e->info_flags |= CWR_INFO_ELEMENTWISE_CLAMPED;
     e->ew_rel = sc * std::min(1.0e-2, 1.0e6 * tol);
@@ -2127,6 +2203,7 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
   local.flags = e->info_flags;
   local.exchanges = e->step_exchanges; local.overlapped = e->step_overlapped; local.checks = e->step_checks;
   local.local_reps = (st.sweep_kernel == 6) ? e->local_reps : 0;
+  local.chained = (st.sweep_kernel == 6 && e->step_chained) ? 1 : 0;
   if (st.status != CWR_OK) {
     e->flux_valid = false; e->halo_fresh = false; e->tail_done = false;   // (a speculative tail may have run)
     // the solver iterated in place: put x_t and the ghost rows back, so that the state is what the step found and the
@@ -2177,10 +2254,10 @@ int32_t cwr_get_mass_flux(cwr_engine* e, double* adv, double* dif, double* tot) 
   TRY(dev_alloc(e, &tmp.p, cnt));
   const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv((int64_t)cnt, BLOCK), 256 * 16));
   double* outs[3] = {adv, dif, tot};
-  const double* srcs[3] = {e->d_fadv, e->d_fdif, e->d_ftot};
+  const double* srcs[3] = {e->d_fadv, e->d_fdif, e->d_fadv};
   for (int q = 0; q < 3; ++q) {
     if (!outs[q]) continue;
-    k_face_rows_out<<<grid, BLOCK, 0, e->stream>>>((int64_t)cnt, e->K, e->d_face_orig, srcs[q], tmp.p);
+    k_face_rows_out<<<grid, BLOCK, 0, e->stream>>>((int64_t)cnt, e->K, e->d_face_orig, srcs[q], q == 2 ? e->d_fdif : nullptr, tmp.p);
     HIP_TRY(e, hipGetLastError());
     TRY(download(e, outs[q], tmp.p, cnt));
   }
@@ -2198,6 +2275,14 @@ int32_t cwr_set_jacobi_norms(cwr_engine* e, int32_t n_times, const double* norms
   if (!e || !norms) return e ? fail(e, CWR_ERR_BAD_ARG, "cwr_set_jacobi_norms: NULL") : CWR_ERR_BAD_ARG;
   if (n_times != e->T || e->T <= 0) return fail(e, CWR_ERR_STATE, "cwr_set_jacobi_norms: n_times must be the number of loaded levels");
   e->jnorm.assign(norms, norms + n_times);
+  norm_error_factors(e);                             // (the caller's norms are the whole truth then: no row-wise refinement)
+  return CWR_OK;
+}
+
+int32_t cwr_get_error_factors(cwr_engine* e, int32_t n_times, double* factors) {
+  if (!e || !factors) return e ? fail(e, CWR_ERR_BAD_ARG, "cwr_get_error_factors: NULL") : CWR_ERR_BAD_ARG;
+  if (n_times != e->T || e->err_factor.size() != (size_t)e->T) return fail(e, CWR_ERR_STATE, "cwr_get_error_factors: n_times must be the number of loaded levels");
+  std::copy(e->err_factor.begin(), e->err_factor.end(), factors);
   return CWR_OK;
 }
 
@@ -2433,14 +2518,14 @@ int output_push_impl(cwr_engine* e, int32_t* slot, double* state_dst, double* fl
   if (e->out_copy_pending) HIP_TRY(e, hipStreamWaitEvent(e->stream, e->out_copy_done, 0));
   const size_t lds = (size_t)e->K * (SNAP_ROWS + 1) * sizeof(double);
   const int grid = std::max(1, std::min(cdiv(e->out_n, SNAP_ROWS), 256 * 8));
-  k_snapshot_t<<<grid, BLOCK, lds, e->stream>>>(e->out_n, e->K, e->d_out_order, e->d_c, e->d_snap);
+  k_snapshot_t<<<grid, BLOCK, lds, e->stream>>>(e->out_n, e->K, e->d_out_order, e->d_c, nullptr, e->d_snap);
   if (e->out_flux) {
     const int gridf = std::max(1, std::min(cdiv(e->E, SNAP_ROWS), 256 * 8));
     const size_t EK = (size_t)e->E * e->K;
     // (output index = the reference's face id; its row sits at the face's internal position)
-    k_snapshot_t<<<gridf, BLOCK, lds, e->stream>>>(e->E, e->K, e->d_face_pos, e->d_fadv, e->d_snap + e->out_state_cnt);
-    k_snapshot_t<<<gridf, BLOCK, lds, e->stream>>>(e->E, e->K, e->d_face_pos, e->d_fdif, e->d_snap + e->out_state_cnt + EK);
-    k_snapshot_t<<<gridf, BLOCK, lds, e->stream>>>(e->E, e->K, e->d_face_pos, e->d_ftot, e->d_snap + e->out_state_cnt + 2 * EK);
+    k_snapshot_t<<<gridf, BLOCK, lds, e->stream>>>(e->E, e->K, e->d_face_pos, e->d_fadv, nullptr, e->d_snap + e->out_state_cnt);
+    k_snapshot_t<<<gridf, BLOCK, lds, e->stream>>>(e->E, e->K, e->d_face_pos, e->d_fdif, nullptr, e->d_snap + e->out_state_cnt + EK);
+    k_snapshot_t<<<gridf, BLOCK, lds, e->stream>>>(e->E, e->K, e->d_face_pos, e->d_fadv, e->d_fdif, e->d_snap + e->out_state_cnt + 2 * EK);
   }
   HIP_TRY(e, hipGetLastError());
   HIP_TRY(e, hipEventRecord(e->out_snap_ready, e->stream));

@@ -249,11 +249,13 @@ __global__ void __launch_bounds__(BLOCK) k_faces_in(int64_t total, int E, const 
   }
 }
 // rows of K values: dst[orig[p], :] = src[p, :] (per-face K-vectors from the internal face order to the reference's)
+// (src2: a second array added element by element -- total_mass_flux = advection + diffusion is formed on the way out, see k_mass_flux)
 __global__ void __launch_bounds__(BLOCK) k_face_rows_out(int64_t total, int K, const int32_t* __restrict__ orig,
-                                                       const double* __restrict__ src, double* __restrict__ dst) {
+                                                       const double* __restrict__ src, const double* __restrict__ src2,
+                                                       double* __restrict__ dst) {
   for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * BLOCK) {
     const int64_t p = i / K; const int k = (int)(i - p * K);
-    dst[(size_t)orig[p] * K + k] = src[i];
+    dst[(size_t)orig[p] * K + k] = src2 ? src[i] + src2[i] : src[i];
   }
 }
 template <typename T>
@@ -416,6 +418,10 @@ __global__ void __launch_bounds__(BLOCK) k_jnorm(
     for (int w = 1; w < BLOCK / 64; ++w) m = fmax(m, s_m[w]);
     atomicMax(jn + t, (unsigned long long)__double_as_longlong(m));
   }
+}
+
+__global__ void __launch_bounds__(BLOCK) k_fill(int64_t total, double v, double* __restrict__ a, double* __restrict__ b) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * BLOCK) { a[i] = v; if (b) b[i] = v; }
 }
 
 // ------------------------------------------------------------------------------------------------ a-3
@@ -1384,7 +1390,7 @@ __global__ void __launch_bounds__(BLOCK) k_mass_flux(
     int E, int n_owned, int K, int G, const int32_t* __restrict__ f1, const int32_t* __restrict__ f2,
     const float* __restrict__ adv_t, const double* __restrict__ dif_t, double dt,
     const double* __restrict__ c, double* __restrict__ fadv,
-    double* __restrict__ fdif, double* __restrict__ ftot) {
+    double* __restrict__ fdif) {
   const int R = BLOCK / G;
   const int r = threadIdx.x / G, g = threadIdx.x - r * G;
   if (r >= R) return;
@@ -1393,11 +1399,14 @@ __global__ void __launch_bounds__(BLOCK) k_mass_flux(
     // the three arrays are written in the INTERNAL face order: 3 x 8 K E bytes leave as one sequential stream (written at the
     // reference's face ids they were a scatter of 128-byte rows: 233 vs 150 us at 1 M cells x 16); every reader
     // (cwr_get_mass_flux, the output snapshot) goes through the face map
+    // (round 4) total_mass_flux = advection + diffusion (transport.py:427-429) is NOT stored: the two addends are, and every
+    // reader forms the sum on the way out (cwr_get_mass_flux, the output snapshot: the same IEEE addition of the same two doubles,
+    // bit for bit) -- a third of this kernel's 0.8 GB of output per step at 1 M cells x 16 was that redundant array
     const size_t o = (size_t)e * K + g * VW;
-    double oa[VW], od[VW], ot[VW];
+    double oa[VW], od[VW];
     if (P >= n_owned) {                 // face owned by another rank
 #pragma unroll
-      for (int w = 0; w < VW; ++w) oa[w] = od[w] = ot[w] = 0.0;
+      for (int w = 0; w < VW; ++w) oa[w] = od[w] = 0.0;
     } else {
       const float a = adv_t[e];
       const double d = dif_t[e];
@@ -1408,10 +1417,9 @@ __global__ void __launch_bounds__(BLOCK) k_mass_flux(
       for (int w = 0; w < VW; ++w) {
         oa[w] = ((a < 0.0f) ? (double)a * cn[w] : (double)a * cp[w]) * dt;
         od[w] = d * (cn[w] - cp[w]) * dt;
-        ot[w] = oa[w] + od[w];
       }
     }
-    stv<VW>(fadv + o, oa); stv<VW>(fdif + o, od); stv<VW>(ftot + o, ot);
+    stv<VW>(fadv + o, oa); stv<VW>(fdif + o, od);
   }
 }
 
@@ -1498,7 +1506,7 @@ __global__ void __launch_bounds__(BLOCK) k_fold_partials(int nblocks, int width,
 // writes (consecutive i) are coalesced.  Dynamic LDS: K * (SNAP_ROWS + 1) doubles.
 constexpr int SNAP_ROWS = 64;
 __global__ void __launch_bounds__(BLOCK) k_snapshot_t(int n_out, int K, const int32_t* __restrict__ order,
-                                                    const double* __restrict__ x, double* __restrict__ out) {
+                                                    const double* __restrict__ x, const double* __restrict__ x2, double* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
   double* s = reinterpret_cast<double*>(s_dyn);                    // [K][SNAP_ROWS + 1]
   const int tid = threadIdx.x;
@@ -1507,7 +1515,7 @@ __global__ void __launch_bounds__(BLOCK) k_snapshot_t(int n_out, int K, const in
     for (int q = tid; q < rows * K; q += BLOCK) {
       const int r = q / K, k = q - r * K;
       const int src = order ? order[i0 + r] : i0 + r;
-      s[k * (SNAP_ROWS + 1) + r] = x[(size_t)src * K + k];
+      s[k * (SNAP_ROWS + 1) + r] = x2 ? x[(size_t)src * K + k] + x2[(size_t)src * K + k] : x[(size_t)src * K + k];
     }
     __syncthreads();
     for (int q = tid; q < rows * K; q += BLOCK) {

@@ -30,6 +30,7 @@ STEP_PROFILE = 2
 STEP_FORCE_BICGSTAB = 4
 STEP_FORCE_JACOBI = 8
 STEP_MASS_BALANCE = 16
+STEP_DETERMINISTIC = 32
 
 INFO_LOOSE_RESIDUAL = 1        # BiCGSTAB stagnated within 100 x tol and was accepted
 INFO_ELEMENTWISE_MISSED = 2    # the element-wise rule was still violated after the tightened BiCGSTAB rounds
@@ -40,7 +41,7 @@ ABI_SYMBOLS = (
     'cwr_abi_version', 'cwr_tile_rows', 'cwr_create', 'cwr_destroy', 'cwr_last_error', 'cwr_load_flow_field',
     'cwr_load_coefficients', 'cwr_get_coefficients', 'cwr_load_boundary', 'cwr_set_boundary_level',
     'cwr_set_state', 'cwr_get_state', 'cwr_load_real_inputs', 'cwr_react_linear', 'cwr_state_device_ptr', 'cwr_apply', 'cwr_rhs', 'cwr_step', 'cwr_get_mass_flux',
-    'cwr_get_jacobi_norms', 'cwr_set_jacobi_norms', 'cwr_tiling_info', 'cwr_set_tile_schedule', 'cwr_get_tile_schedule',
+    'cwr_get_jacobi_norms', 'cwr_set_jacobi_norms', 'cwr_get_error_factors', 'cwr_tiling_info', 'cwr_set_tile_schedule', 'cwr_get_tile_schedule',
     'cwr_time_apply', 'cwr_profile_read', 'cwr_synchronize', 'cwr_apply_bytes',
     'cwr_comm_unique_id', 'cwr_attach_comm', 'cwr_comm_selftest',
     'cwr_set_boundary_lines', 'cwr_reset_mass_balance', 'cwr_get_mass_balance', 'cwr_domain_mass',
@@ -56,7 +57,7 @@ class StepInfo(C.Structure):
     _fields_ = [('iterations', C.c_int32), ('sweeps', C.c_int32), ('restarts', C.c_int32), ('status', C.c_int32),
                 ('operator_launches', C.c_int32), ('solver', C.c_int32), ('max_rel_residual', C.c_double),
                 ('solve_ms', C.c_double), ('sweep_kernel', C.c_int32), ('flags', C.c_int32), ('exchanges', C.c_int32),
-                ('overlapped', C.c_int32), ('checks', C.c_int32), ('local_reps', C.c_int32)]
+                ('overlapped', C.c_int32), ('checks', C.c_int32), ('local_reps', C.c_int32), ('chained', C.c_int32)]
 
 
 @dataclass
@@ -74,6 +75,7 @@ class StepResult:
     overlapped: int = 0      # ... of which ran beside interior tiles
     checks: int = 0          # convergence checks (blocking host round trips)
     local_reps: int = 0      # tile-local J^2 applications per visit
+    chained: int = 0         # 1: in-place passes along tile chains (not bitwise reproducible run to run)
 
 
 _lib = None
@@ -121,6 +123,7 @@ def load_library(path: str | None = None) -> C.CDLL:
         'cwr_set_tile_schedule': [vp, i32, i32, vp],
         'cwr_get_tile_schedule': [vp, vp, vp, C.c_int64],
         'cwr_set_jacobi_norms': [vp, i32, vp],
+        'cwr_get_error_factors': [vp, i32, vp],
         'cwr_time_apply': [vp, i32, i32, i32, P(f64)],
         'cwr_profile_read': [vp, P(C.c_int64), P(f64)],
         'cwr_synchronize': [vp],
@@ -366,12 +369,15 @@ class TransportEngine:
         return b
 
     def step(self, t: int, *, tol: float = 1e-12, max_iter: int = 2000, mass_flux: bool = True,
-             profile: bool = False, solver: str = 'auto', mass_balance: bool = False) -> StepResult:
+             profile: bool = False, solver: str = 'auto', mass_balance: bool = False, deterministic: bool = False) -> StepResult:
         """solver: 'auto' (Jacobi sweeps, switching to BiCGSTAB on stiff steps), 'jacobi', 'bicgstab'.
-        mass_balance: add this step's boundary-line fluxes to the device ledger (set_boundary_lines first)."""
+        mass_balance: add this step's boundary-line fluxes to the device ledger (set_boundary_lines first).
+        deterministic: ping-pong passes instead of the chained in-place ones -- bitwise reproducible from run to run, like the
+        reference's spsolve (the default agrees to <= 1e-10, not bit for bit); StepResult.chained says which ran."""
         info = StepInfo()
         flags = (STEP_MASS_FLUX if mass_flux else 0) | (STEP_PROFILE if profile else 0)
         flags |= STEP_MASS_BALANCE if mass_balance else 0
+        flags |= STEP_DETERMINISTIC if deterministic else 0
         flags |= {'auto': 0, 'jacobi': STEP_FORCE_JACOBI, 'bicgstab': STEP_FORCE_BICGSTAB}[solver]
         self._check(self._lib.cwr_step(self._h, int(t), float(tol), int(max_iter), flags, C.byref(info)))
         if info.flags:
@@ -389,12 +395,18 @@ class TransportEngine:
                 warnings.warn(f'transport step {t}: ' + '; '.join(what), RuntimeWarning, stacklevel=2)
         return StepResult(info.iterations, info.sweeps, info.restarts, info.operator_launches, info.solver,
                           info.max_rel_residual, info.solve_ms, info.sweep_kernel, info.flags, info.exchanges, info.overlapped,
-                          info.checks, info.local_reps)
+                          info.checks, info.local_reps, info.chained)
 
     def jacobi_norms(self) -> np.ndarray:
         """(T,) ||J||_inf of the Jacobi iteration matrix of every step of the loaded flow field (last entry 0)."""
         out = np.empty(self.n_times, np.float64)
         self._check(self._lib.cwr_get_jacobi_norms(self._h, self.n_times, _ptr(out)))
+        return out
+
+    def error_factors(self) -> np.ndarray:
+        """(T,) F_t with ||x* - x'||_inf <= F_t ||x' - x||_inf for a Jacobi sweep of step t: the scale of the element-wise rule."""
+        out = np.empty(self.n_times, np.float64)
+        self._check(self._lib.cwr_get_error_factors(self._h, self.n_times, _ptr(out)))
         return out
 
     def set_jacobi_norms(self, norms):

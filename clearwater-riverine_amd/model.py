@@ -224,7 +224,7 @@ class ClearwaterRiverine:
                  mesh: Optional[dict] = None, input_arrays: Optional[Dict[str, np.ndarray]] = None,
                  device: int = 0, tol: float = 1e-12, max_iter: int = 5000, store_history: bool = True,
                  solver: str = 'auto', renumber: bool = True, output_store: Optional[str] = None,
-                 output_flux: bool = False, host_state: bool = True):
+                 output_flux: bool = False, host_state: bool = True, deterministic: bool = False):
         self.gdf = None
         self.time_step = 0                                       # transport.py:102
         self.verbose = bool(verbose)
@@ -232,6 +232,9 @@ class ClearwaterRiverine:
         self.max_iter = int(max_iter)
         self.store_history = bool(store_history)
         self.solver = solver
+        # deterministic=True: every step runs the ping-pong passes (CWR_STEP_DETERMINISTIC): bitwise reproducible from run to run,
+        # like the reference's spsolve; the default chained in-place passes agree with them to <= 1e-10
+        self.deterministic = bool(deterministic)
         if mesh is None:
             if mesh_file_path:
                 raise NotImplementedError('loading a saved zarr/netCDF mesh is post-processing only in the '
@@ -307,10 +310,10 @@ class ClearwaterRiverine:
         # (within every tile-sized window of the curve the cells are sorted by their work: ordering.balance_windows)
         # (lanes along the principal flow axis, which the engine's chained passes walk: ordering.lane_order; CWR_NO_CHAINS=1 or
         # CWR_TILE_ORDER=hilbert: the isotropic Hilbert curve of round 2)
-        import os
         curve = None
         if renumber and n > 4096:
-            lanes = not os.environ.get('CWR_NO_CHAINS') and os.environ.get('CWR_TILE_ORDER', 'auto') in ('auto', 'lanes')
+            from .distributed import curve_kind                  # (one rule for the facade and the partitioned engines)
+            lanes = curve_kind(n, K, 1) == 'lanes'
             curve = lane_order(m, n, tile_rows=tile_rows(K)) if lanes else hilbert_order(m['face_x'], m['face_y'], n)
         order = balance_windows(curve, f1, f2, window=tile_rows(K)) if curve is not None else None
         self.engine = TransportEngine(f1, f2, ncell, K, device=device, cell_order=order)
@@ -411,7 +414,7 @@ class ClearwaterRiverine:
         # (a step that raises leaves the device state at level t -- the engine restores it -- and time_step unchanged:
         # update() may simply be called again, e.g. with a larger max_iter)
         self.last_step = self.engine.step(t, tol=self.tol, max_iter=self.max_iter, mass_flux=want_flux,
-                                          solver=self.solver, mass_balance=bool(self._lines))
+                                          solver=self.solver, mass_balance=bool(self._lines), deterministic=self.deterministic)
         self._device_level = t + 1
         if self._stream is not None:
             self._stream.push(t + 1)                             # asynchronous: pinned ring + writer thread

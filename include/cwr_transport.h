@@ -51,7 +51,11 @@ enum {
   CWR_STEP_PROFILE = 2,        /* bracket every operator launch with HIP events (see cwr_profile_read)     */
   CWR_STEP_FORCE_BICGSTAB = 4, /* skip the Jacobi fast path                                                */
   CWR_STEP_FORCE_JACOBI = 8,   /* never switch to BiCGSTAB (fails with CWR_ERR_NOT_CONVERGED instead)      */
-  CWR_STEP_MASS_BALANCE = 16   /* add this step's boundary-line mass fluxes to the device ledger (cwr_set_boundary_lines) */
+  CWR_STEP_MASS_BALANCE = 16,  /* add this step's boundary-line mass fluxes to the device ledger (cwr_set_boundary_lines) */
+  CWR_STEP_DETERMINISTIC = 32  /* this step's passes ping-pong between two vectors (no tile chains): results
+                                  are bitwise reproducible from run to run, as the reference's spsolve is (transport.py:249); the
+                                  default chained in-place passes agree with them to <= 1e-10 but not bit for bit.  Partitioned
+                                  runs: every rank must give the same value */
 };
 
 typedef struct cwr_step_info {
@@ -70,6 +74,8 @@ typedef struct cwr_step_info {
   int32_t overlapped;          /* ... of which ran on the communication stream beside interior tiles */
   int32_t checks;              /* convergence checks = blocking host round trips (one all-reduce each when partitioned) */
   int32_t local_reps;          /* tile-local J^2 applications per visit the passes of this step used (0: no tiled pass) */
+  int32_t chained;             /* 1: the passes relaxed in place along tile chains (not bitwise reproducible run to run);
+                                  0: ping-pong passes, plain sweeps, the small-mesh solver or BiCGSTAB (all deterministic) */
 } cwr_step_info;
 
 /* bits of cwr_step_info.flags */
@@ -211,6 +217,13 @@ int32_t cwr_get_mass_flux(cwr_engine* e, double* advection, double* diffusion, d
  * (No reference counterpart: spsolve is direct, transport.py:249.) */
 int32_t cwr_get_jacobi_norms(cwr_engine* e, int32_t n_times, double* norms);
 int32_t cwr_set_jacobi_norms(cwr_engine* e, int32_t n_times, const double* norms);
+/* The factor the element-wise rule of cwr_step is really scaled by: factors[t] = F_t with ||x* - x'||_inf <= F_t ||x' - x||_inf for
+ * a Jacobi sweep x -> x' of step t (x*: the solution spsolve returns, transport.py:249).  ||J||_inf / (1 - ||J||_inf) where that is
+ * finite; single engines replace it by the row-wise bound max((I - J)^-1 1) - 1 <= max(w_m - 1) / (1 - ||J^m 1||_inf), taken from
+ * a few sweeps of the Neumann series when the flow field is loaded, where that is smaller: meshes with dry or nearly dry cells,
+ * whose worst row sum (> 1 beside a dry cell) says nothing about the error of a sweep.  cwr_set_jacobi_norms resets the factors to
+ * the norm form of the caller's values. */
+int32_t cwr_get_error_factors(cwr_engine* e, int32_t n_times, double* factors);
 
 /* ---- measurement --------------------------------------------------------------------------------
  * cwr_time_apply: `reps` back-to-back launches of the operator of level t on device-resident vectors,

@@ -208,6 +208,18 @@ void watchdog_main(Comm* c) {
     if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_last).count() < limit) continue;
     c->failed.store(true);
     std::fprintf(stderr, "[mock_rccl] rank %d: no progress for %.0f s with operations outstanding -- releasing every wait\n", c->rank, limit);
+    {
+      // what this rank still waits for (a deadlock report: which pair, which kind)
+      std::string msg = "[mock_rccl] rank " + std::to_string(c->rank) + " state: all-reduce round " + std::to_string(c->red_round) + ", published/done by rank:";
+      for (int r = 0; r < c->world; ++r) msg += " " + std::to_string(c->sh->red_seq[r].load()) + "/" + std::to_string(c->sh->red_done[r].load());
+      for (int r = 0; r < c->world; ++r) {
+        if (c->sent_n[r] == 0 && c->recv_n[r] == 0) continue;
+        msg += "; peer " + std::to_string(r) + ": sent " + std::to_string(c->sh->send_seq[c->rank][r].load()) + "/" + std::to_string(c->sent_n[r]) +
+               " (consumed " + std::to_string(c->sh->recv_seq[c->rank][r].load()) + "), received " + std::to_string(c->sh->recv_seq[r][c->rank].load()) + "/" +
+               std::to_string(c->recv_n[r]) + " (published " + std::to_string(c->sh->send_seq[r][c->rank].load()) + ")";
+      }
+      std::fprintf(stderr, "%s\n", msg.c_str());
+    }
     const uint64_t big = 0x7fffffffffffffffull;
     for (int r = 0; r < c->world; ++r) {
       std::atomic<uint64_t>* flags[4] = {&c->sh->send_seq[r][c->rank], &c->sh->recv_seq[c->rank][r], &c->sh->red_seq[r], &c->sh->red_done[r]};

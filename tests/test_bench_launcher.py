@@ -71,3 +71,31 @@ def test_under_a_launcher_a_wrong_world_size_is_refused():
     env = dict(os.environ, WORLD_SIZE='1', RANK='0')
     p = subprocess.run([sys.executable, BENCH, '--gpus', '2'], env=env, capture_output=True, text=True, timeout=60)
     assert p.returncode != 0 and 'WORLD_SIZE' in p.stderr
+
+
+def test_sigterm_to_the_launcher_stops_the_ranks(tmp_path):
+    """the ranks run in sessions of their own; an outer `timeout` (SIGTERM to the launcher) used to skip the reaping
+    and leave them waiting in a collective, holding their GPUs."""
+    import signal
+    child = tmp_path / 'child.py'
+    child.write_text(textwrap.dedent('''
+        import os, time
+        r = int(os.environ['RANK'])
+        open(os.path.join(os.environ['CWR_TEST_DIR'], f'rank{r}.pid'), 'w').write(str(os.getpid()))
+        time.sleep(300)
+    '''))
+    env = dict(os.environ, CWR_BENCH_CHILD=str(child), CWR_TEST_DIR=str(tmp_path))
+    env.pop('WORLD_SIZE', None); env.pop('RANK', None)
+    p = subprocess.Popen([sys.executable, BENCH, '--gpus', '3'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    deadline = time.monotonic() + 30
+    while time.monotonic() < deadline and not all((tmp_path / f'rank{r}.pid').exists() for r in range(3)):
+        time.sleep(0.1)
+    assert all((tmp_path / f'rank{r}.pid').exists() for r in range(3))
+    time.sleep(0.2)
+    p.send_signal(signal.SIGTERM)
+    out, err = p.communicate(timeout=30)
+    assert p.returncode == 128 + signal.SIGTERM, (p.returncode, err)
+    assert out.strip() == ''
+    for r in range(3):
+        pid = int((tmp_path / f'rank{r}.pid').read_text())
+        assert not os.path.exists(f'/proc/{pid}'), f'rank {r} (pid {pid}) outlived the launcher'

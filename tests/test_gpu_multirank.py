@@ -235,23 +235,27 @@ def test_partitioned_step_matches_single_rank_and_oracle(gpu_lib, world, K, solv
 
 
 @pytest.mark.parametrize('K,depth', [(16, 8), (1, 6)])
-def test_eight_ranks_through_the_asynchronous_stand_in(gpu_lib, K, depth, monkeypatch):
+def test_eight_ranks_through_the_stand_in(gpu_lib, K, depth, monkeypatch):
     """the target machine is one 8-GPU node, and 8 ranks had never executed by any route.  The one-GPU box
     allows 6 processes on its card, so the 8 ranks are 4 processes x 2 rank threads (_host_main): eight complete engines, eight
-    communicators of the stream-asynchronous stand-in (CWR_MOCK_ASYNC=2: asynchronous or fail), the real partition of 8 with its
-    middle ranks (two cut sides, few or no interior tiles) and end ranks.  Oracle parity, every rank the same solver decisions and
-    the same exchange / overlap / check counts per step."""
+    communicators, the real partition of 8 with its middle ranks (up to six peers, two cut sides, few or no interior tiles) and its
+    end ranks.  Oracle parity, every rank the same solver decisions and the same exchange / overlap / check counts per step.
+    Two ranks in ONE process is an arrangement of this test only (the product runs one engine per process), and the HIP runtime
+    limits it twice: (i) while one rank thread captures a hipGraph the other thread's copies are refused ("operation not permitted
+    when stream is capturing") -> CWR_NO_GRAPHS=1; (ii) stream wait-values of two ranks of one process block each other (the
+    second rank of every process never got past its first exchange: gpurun_out/r04g_eight.log) -> the stand-in runs in its
+    HOST-synchronous mode here.  Up to 4 ranks (one process each) the stream-asynchronous mode is what every other test of this
+    file uses, the poison tests included."""
     build_mock()
     world = 8
     monkeypatch.setenv('CWR_NO_SMALL', '1')
     monkeypatch.setenv('CWR_TEST_BIG', '1')
-    monkeypatch.setenv('CWR_MOCK_ASYNC', '2')
+    monkeypatch.setenv('CWR_NO_GRAPHS', '1')
+    monkeypatch.setenv('CWR_MOCK_ASYNC', '0')
     monkeypatch.setenv('CWR_MOCK_TIMEOUT_S', '45')
-    monkeypatch.setenv('GPU_MAX_HW_QUEUES', '16')        # (two ranks' streams in one process must not share a hardware queue: a stream
-                                                         #  waiting for a peer's flag would block the stream that publishes it)
     results = run_ranks(world, _host_main, (K, 'jacobi', depth), per_host=2)
     assert [r[0] for r in results] == list(range(world))
-    assert all(r[12] == 1 for r in results), 'the stand-in fell back to its host-synchronous mode'
+    assert all(r[12] == 0 for r in results)
     mesh, inputs3 = make_case(K)
     n = mesh['nreal'] + 1
     state = np.full((n, K), np.nan)
@@ -261,12 +265,15 @@ def test_eight_ranks_through_the_asynchronous_stand_in(gpu_lib, K, depth, monkey
         tot[r[4]] = r[5]
     assert not np.isnan(state).any() and sum(len(r[1]) for r in results) == n
     assert all(r[6] == results[0][6] for r in results), [r[6] for r in results]        # sweeps / iterations per step
-    assert all(r[13] == results[0][13] for r in results), [r[13] for r in results]     # exchanges / overlapped / checks per step
-    for (sweeps, its), (exch, over, checks) in list(zip(results[0][6], results[0][13]))[1:]:
-        passes = (sweeps - 1) // 2
-        assert its == 0 and sweeps >= 20, (sweeps, its)                                # the case really iterates, on the sweep path
-        assert 0 < exch <= -(-passes // max(1, depth // 2)) + 4, (sweeps, exch, depth)
-        assert 0 <= over <= exch and 1 <= checks <= 2, (over, exch, checks)
+    # exchanges and checks per step are the same calls on every rank; how many exchanges ran BESIDE interior tiles is each rank's own
+    # (a middle rank of eight may have no interior tile at all)
+    assert all([(e_, c_) for e_, _, c_ in r[13]] == [(e_, c_) for e_, _, c_ in results[0][13]] for r in results), [r[13] for r in results]
+    for r in results:
+        for (sweeps, its), (exch, over, checks) in list(zip(r[6], r[13]))[1:]:
+            passes = (sweeps - 1) // 2
+            assert its == 0 and sweeps >= 20, (sweeps, its)                            # the case really iterates, on the sweep path
+            assert 0 < exch <= -(-passes // max(1, depth // 2)) + 4, (sweeps, exch, depth)
+            assert 0 <= over <= exch and 1 <= checks <= 2, (over, exch, checks)
     # some rank of the eight has interior tiles and ran its in-loop exchanges beside them
     assert any(r[11] > 0 for r in results), [r[11] for r in results]
     oracle.derive_coefficients(mesh)

@@ -224,7 +224,8 @@ def test_curve_kind_follows_the_size_of_a_rank_and_the_environment(monkeypatch):
     for v in ('CWR_TILE_ORDER', 'CWR_NO_CHAINS'):
         monkeypatch.delenv(v, raising=False)
     tr = tile_rows(16)
-    assert curve_kind(1_000_000, 16, 1) == 'lanes'
+    assert curve_kind(1_000_000, 16, 1) == 'lanes' and curve_kind(1_000_000, 1, 1) == 'lanes'
+    assert curve_kind(120_000, 16, 1) == 'hilbert' and curve_kind(10_000, 12, 1) == 'hilbert'      # one GPU below the chain threshold (round 4)
     assert curve_kind(1_000_000, 16, 2) == 'lanes' and curve_kind(1_000_000, 16, 4) == 'lanes'
     assert curve_kind(1_000_000, 16, 8) == 'hilbert'               # 125 k cells per rank < 3 x 1024 x 64
     assert curve_kind(3 * 1024 * tr * 2, 16, 2) == 'lanes' and curve_kind(3 * 1024 * tr * 2 - 2, 16, 2) == 'hilbert'
