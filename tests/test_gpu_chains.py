@@ -159,6 +159,35 @@ def test_without_chains_runs_are_bitwise_reproducible_and_with_them_within_the_t
     assert rel_err(runs[True][0], runs[True][1]) <= 1e-10
 
 
+def test_the_deterministic_step_flag_selects_ping_pong_passes_per_step(gpu_lib, monkeypatch):
+    """regression-stable output without an environment variable.  On ONE engine that chains by default, steps taken with
+    deterministic=True (CWR_STEP_DETERMINISTIC) run the ping-pong passes -- cwr_step_info.chained says which ran -- and two engines
+    driven that way agree bit for bit, while the default steps of the same engines agree to the solver tolerance only.  The facade
+    forwards its constructor keyword."""
+    import clearwater_riverine_amd as cw
+    mesh, inputs3 = case(3)
+    outs = {True: [], False: []}
+    for det in (True, False):
+        for _ in range(2):
+            pt = transport(mesh, inputs3, monkeypatch, CWR_TILE_ORDER='lanes')
+            rs = [pt.step(t, tol=1e-12, deterministic=det) for t in range(3)]
+            assert all(r.sweep_kernel == 6 and r.chained == (0 if det else 1) for r in rs), [(r.sweep_kernel, r.chained) for r in rs]
+            outs[det].append(pt.gather_state())
+            # the flag is per step: the other kind of pass on the same engine, same answer to the tolerance
+            pt.engine.set_state(inputs3[0, :mesh['nreal'] + 1, :])
+            r = pt.step(0, tol=1e-12, deterministic=not det)
+            assert r.chained == (1 if det else 0)
+            pt.engine.close()
+    assert np.array_equal(outs[True][0], outs[True][1])
+    assert rel_err(outs[False][0], outs[False][1]) <= 1e-10 and rel_err(outs[False][0], outs[True][0]) <= 1e-10
+    names = [f'c{k}' for k in range(K)]
+    model = cw.ClearwaterRiverine(mesh=dict(mesh), input_arrays={nm: inputs3[:, :, k].copy() for k, nm in enumerate(names)},
+                                  deterministic=True)
+    model.update()
+    assert model.last_step.chained == 0 and model.last_step.sweep_kernel == 6
+    model.engine.close()
+
+
 @pytest.mark.parametrize('Kc,grid', [(1, 32), (3, 32), (12, 32)])
 def test_chained_passes_at_other_constituent_counts_match_the_oracle(gpu_lib, monkeypatch, Kc, grid):
     """The lane mappings of the tiled pass other than K = 16 (one constituent per lane with 256-row tiles, odd K, the four-wide
