@@ -535,7 +535,10 @@ __global__ void __launch_bounds__(BLOCK, CWR_APPLY_MIN_WAVES) k_apply(
     int row0, int n_owned, int n_dot, int K, int G, int U, int ntiles, int stage_cap, int nt, const int32_t* __restrict__ ptr,
     const FaceRec* __restrict__ rec, const double* __restrict__ diag, const double* __restrict__ xin,
     double* __restrict__ yout, const double* __restrict__ r0, const double* __restrict__ bhat,
-    double* __restrict__ r0_out, double* __restrict__ p_out, double* __restrict__ partial, const double* __restrict__ ew_p, int seg) {
+    double* __restrict__ r0_out, double* __restrict__ p_out, double* __restrict__ partial, const double* __restrict__ ew_p, int seg,
+    const int32_t* __restrict__ tile_list, int slot0) {
+  // tile_list (optional): the launch covers these `ntiles` row tiles only (the closing sweep of a partitioned engine in two parts:
+  // core tiles beside the halo exchange, cut tiles behind it); slot0: first slot of this launch in the partials buffer
   extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
   // ew_rel lives in device memory (written by k_rhs at the start of every step): these launches are captured into hipGraphs
   // that later steps replay, and a by-value argument would freeze the value of the step that captured them
@@ -561,8 +564,9 @@ __global__ void __launch_bounds__(BLOCK, CWR_APPLY_MIN_WAVES) k_apply(
   const int xcd = blockIdx.x % N_XCD, lidx = blockIdx.x / N_XCD, bpx = gridDim.x / N_XCD;
   const int tpx = (ntiles + N_XCD - 1) / N_XCD;
   for (int i = lidx; i < tpx; i += bpx) {
-    const int tile = xcd * tpx + i;
-    if (tile >= ntiles) break;                      // uniform per block
+    const int tslot = xcd * tpx + i;
+    if (tslot >= ntiles) break;                     // uniform per block
+    const int tile = tile_list ? tile_list[tslot] : tslot;
     const int c0 = row0 + tile * TR;                // rows [row0, n_owned) are this launch's
     const int c1 = min(c0 + TR, n_owned);
     __syncthreads();                                // previous tile's readers are done with the LDS images
@@ -683,7 +687,7 @@ __global__ void __launch_bounds__(BLOCK, CWR_APPLY_MIN_WAVES) k_apply(
   }
   if constexpr (ND > 0) {
     __syncthreads();
-    block_reduce_cols<NP, VW, MAXFROM>(part, G, K, partial + (size_t)blockIdx.x * ND * K, s_red);
+    block_reduce_cols<NP, VW, MAXFROM>(part, G, K, partial + (size_t)(slot0 + blockIdx.x) * ND * K, s_red);
   }
 }
 
@@ -1390,11 +1394,15 @@ __global__ void __launch_bounds__(BLOCK) k_mass_flux(
     int E, int n_owned, int K, int G, const int32_t* __restrict__ f1, const int32_t* __restrict__ f2,
     const float* __restrict__ adv_t, const double* __restrict__ dif_t, double dt,
     const double* __restrict__ c, double* __restrict__ fadv,
-    double* __restrict__ fdif) {
+    double* __restrict__ fdif, const int32_t* __restrict__ face_list, int n_list) {
+  // face_list (optional): only these faces (a partitioned engine takes the faces between core cells beside the exchange that
+  // refreshes its halo rows, the others behind it)
   const int R = BLOCK / G;
   const int r = threadIdx.x / G, g = threadIdx.x - r * G;
   if (r >= R) return;
-  for (int e = blockIdx.x * R + r; e < E; e += gridDim.x * R) {   // e: internal face index (faces sorted along the cell order)
+  const int n_it = face_list ? n_list : E;
+  for (int it = blockIdx.x * R + r; it < n_it; it += gridDim.x * R) {
+    const int e = face_list ? face_list[it] : it;                 // e: internal face index (faces sorted along the cell order)
     const int P = f1[e], N = f2[e];
     // the three arrays are written in the INTERNAL face order: 3 x 8 K E bytes leave as one sequential stream (written at the
     // reference's face ids they were a scatter of 128-byte rows: 233 vs 150 us at 1 M cells x 16); every reader

@@ -463,6 +463,50 @@ def test_overlapped_exchange_with_poisoned_halo_rows_under_the_asynchronous_stan
     assert np.array_equal(state, single.gather_state())
 
 
+@pytest.mark.parametrize('world,K,depth', [(2, 16, 8), (4, 4, 6)])
+def test_closing_sweep_runs_its_core_tiles_beside_the_exchange_with_poisoned_halo_rows(gpu_lib, world, K, depth, monkeypatch):
+    """Round 4: the exchange in front of the closing sweep of a partitioned step no longer runs alone on the
+    engine's stream -- the sweep's core row tiles run beside it, its cut tiles and the replayed layers behind the unpack.  Default
+    batch shape (one closing sweep), ping-pong passes, every halo row NaN before every overlapped exchange, asynchronous stand-in: the
+    answer is the oracle's only if the core tiles read no halo row and the cut tiles wait for the unpacked values; the step counts
+    one more overlapped exchange than with CWR_NO_CLOSING_OVERLAP=1, and the same exchanges and sweeps."""
+    build_mock()
+    monkeypatch.setenv('CWR_NO_SMALL', '1')
+    monkeypatch.setenv('CWR_TEST_BIG', '1')
+    monkeypatch.setenv('CWR_MOCK_ASYNC', '2')
+    monkeypatch.setenv('CWR_TEST_POISON_HALO', '1')
+    split = run_ranks(world, _rank_main, (K, 'jacobi', depth))
+    monkeypatch.setenv('CWR_NO_CLOSING_OVERLAP', '1')
+    serial = run_ranks(world, _rank_main, (K, 'jacobi', depth))
+    assert all(r[12] == 1 for r in split + serial), 'the stand-in fell back to its host-synchronous mode'
+    mesh, inputs3 = make_case(K)
+    n = mesh['nreal'] + 1
+    oracle.derive_coefficients(mesh)
+    ref = oracle.OracleModel(mesh, {f'c{k}': inputs3[:, :, k].copy() for k in range(K)})
+    for _ in range(3):
+        ref.update()
+    want = np.stack([ref.constituent_dict[f'c{k}'].state[3, :n] for k in range(K)], axis=1)
+    want_flux = np.stack([ref.constituent_dict[f'c{k}'].total_mass_flux[2] for k in range(K)], axis=1)
+    states = []
+    for results in (split, serial):
+        state = np.full((n, K), np.nan)
+        tot = np.full((len(mesh['edges_face1']), K), np.nan)
+        for r in results:
+            state[r[1]] = r[3]
+            tot[r[4]] = r[5]
+        assert not np.isnan(state).any()
+        assert rel_err(state, want) <= 1e-9
+        # the exchange that closes a step runs beside the fluxes of the faces between core cells (poisoned halo rows there too):
+        # the fluxes of the cut faces must have waited for the unpacked rows
+        assert flux_err(tot, want_flux) <= 1e-8
+        states.append(state)
+    assert np.array_equal(states[0], states[1])                  # the same arithmetic either way (ping-pong passes are deterministic)
+    for a, b in zip(split, serial):
+        assert a[6] == b[6]                                      # same sweeps
+        for (ea, oa, ca), (eb, ob, cb) in zip(a[13], b[13]):
+            assert ea == eb and ca == cb and oa - ob == ca, (a[13], b[13])   # one closing sweep per batch (= per check): that many more overlapped exchanges
+
+
 def test_the_synchronous_mode_of_the_stand_in_still_works(gpu_lib, monkeypatch):
     build_mock()
     monkeypatch.setenv('CWR_NO_SMALL', '1')
