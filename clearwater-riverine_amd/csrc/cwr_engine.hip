@@ -165,7 +165,8 @@ struct cwr_engine {
   // overlap of a halo exchange with the interior tiles of the pass that needs it: the exchange runs on its own
   // stream between two events; `inner` tiles read core rows only, `outer` tiles read (or are) rows an exchange refreshes
   hipStream_t comm_stream = nullptr;
-  hipEvent_t ev_packed = nullptr, ev_halo = nullptr;
+  hipEvent_t ev_packed = nullptr, ev_halo = nullptr, ev_red_in = nullptr, ev_red_out = nullptr;
+  bool one_comm_stream = true;                  // every RCCL call on comm_stream (see exchange_halo)
   bool overlap = true;
   bool test_poison_halo = false;                // CWR_TEST_POISON_HALO=1 (tests): NaN every halo row of both vectors in front of an overlapped exchange
   int overlap_reserve = 8 * N_XCD;              // block slots an overlapped interior launch leaves to the communication kernels
@@ -405,8 +406,16 @@ int vec_grid(const cwr_engine* e) {
 
 // vec2 (optional): a second vector whose halo rows receive the same values -- the ping-pong partner of a J^2 pass, whose
 // outermost (never computed) layers would otherwise keep the values of an exchange several passes back
+int exchange_begin(cwr_engine* e, const double* vec);
+int exchange_finish(cwr_engine* e, double* vec, double* vec2, bool beside = true);
 int exchange_halo(cwr_engine* e, double* vec, double* vec2 = nullptr) {
   if (!e->comm || e->peers.empty()) return CWR_OK;
+  // (round 4) ONE stream per communicator: every RCCL call of an engine -- the exchanges that run beside compute, the plain ones,
+  // the all-reduces -- is issued on the communication stream, ordered against the engine's stream by events.  Round 3 issued the
+  // plain exchanges and the all-reduces on the engine's stream and the overlapped ones on the communication stream: serialised by
+  // the same events, but a communicator fed from two streams is exactly what RCCL documents as "serialise it yourself", and the
+  // one-GPU box cannot show that the events are enough for the real library.  CWR_COMM_TWO_STREAMS=1: round 3's form.
+  if (e->one_comm_stream && e->comm_stream) { const int rc = exchange_begin(e, vec); return rc != CWR_OK ? rc : exchange_finish(e, vec, vec2, false); }
   ++e->step_exchanges;
   const int64_t total = (int64_t)e->n_send * e->K;
   if (total > 0) {
@@ -441,7 +450,7 @@ int exchange_begin(cwr_engine* e, const double* vec) {
   HIP_TRY(e, hipEventRecord(e->ev_packed, e->stream));
   return CWR_OK;
 }
-int exchange_finish(cwr_engine* e, double* vec, double* vec2) {
+int exchange_finish(cwr_engine* e, double* vec, double* vec2, bool beside) {
   HIP_TRY(e, hipStreamWaitEvent(e->comm_stream, e->ev_packed, 0));
   NCCL_TRY(e, g_rccl.GroupStart());
   for (size_t i = 0; i < e->peers.size(); ++i) {
@@ -458,12 +467,21 @@ int exchange_finish(cwr_engine* e, double* vec, double* vec2) {
   }
   HIP_TRY(e, hipEventRecord(e->ev_halo, e->comm_stream));
   HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_halo, 0));
-  ++e->n_overlapped; ++e->step_exchanges; ++e->step_overlapped;
+  ++e->step_exchanges;
+  if (beside) { ++e->n_overlapped; ++e->step_overlapped; }        // (the caller put work on the engine's stream between the two halves)
   return CWR_OK;
 }
 
 int allreduce(cwr_engine* e, double* p, size_t count) {
   if (!e->comm || (e->world == 1 && !e->force_coll)) return CWR_OK;
+  if (e->one_comm_stream && e->comm_stream && e->ev_red_in) {      // on the communication stream, behind the producer, in front of the consumer
+    HIP_TRY(e, hipEventRecord(e->ev_red_in, e->stream));
+    HIP_TRY(e, hipStreamWaitEvent(e->comm_stream, e->ev_red_in, 0));
+    NCCL_TRY(e, g_rccl.AllReduce(p, p, count, NCCL_FLOAT64, NCCL_SUM, e->comm, e->comm_stream));
+    HIP_TRY(e, hipEventRecord(e->ev_red_out, e->comm_stream));
+    HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_red_out, 0));
+    return CWR_OK;
+  }
   NCCL_TRY(e, g_rccl.AllReduce(p, p, count, NCCL_FLOAT64, NCCL_SUM, e->comm, e->stream));
   return CWR_OK;
 }
@@ -1940,6 +1958,8 @@ void cwr_destroy(cwr_engine* e) {
   for (auto& kv : e->stretch_exec) if (kv.second) hipGraphExecDestroy(kv.second);
   if (e->ev_packed) hipEventDestroy(e->ev_packed);
   if (e->ev_halo) hipEventDestroy(e->ev_halo);
+  if (e->ev_red_in) hipEventDestroy(e->ev_red_in);
+  if (e->ev_red_out) hipEventDestroy(e->ev_red_out);
   if (e->comm_stream) hipStreamDestroy(e->comm_stream);
   if (e->sweep_exec) hipGraphExecDestroy(e->sweep_exec);
   if (e->sweep_graph) hipGraphDestroy(e->sweep_graph);
@@ -2756,6 +2776,9 @@ int32_t cwr_attach_comm(cwr_engine* e, int32_t rank, int32_t world, const uint8_
   HIP_TRY(e, hipStreamCreateWithFlags(&e->comm_stream, hipStreamNonBlocking));
   HIP_TRY(e, hipEventCreateWithFlags(&e->ev_packed, hipEventDisableTiming));
   HIP_TRY(e, hipEventCreateWithFlags(&e->ev_halo, hipEventDisableTiming));
+  HIP_TRY(e, hipEventCreateWithFlags(&e->ev_red_in, hipEventDisableTiming));
+  HIP_TRY(e, hipEventCreateWithFlags(&e->ev_red_out, hipEventDisableTiming));
+  if (const char* v = getenv("CWR_COMM_TWO_STREAMS")) e->one_comm_stream = atoi(v) == 0;
   TRY(sync_jnorms(e));
   return sync_input_levels(e);
 }
