@@ -293,6 +293,196 @@ def test_eight_ranks_through_the_stand_in(gpu_lib, K, depth, monkeypatch):
     assert all(g <= 1.5 * s_ + 4 for g, s_ in zip(got[1:], single_sweeps[1:])), (got, single_sweeps)
 
 
+def _rank_config4(rank, world, uid):
+    """One rank of BASELINE config 4 as it is specified: the 1 M-cell floodplain mesh, ONE tracer, contiguous id ranges with
+    the automatic halo depth."""
+    import clearwater_riverine_amd as cw
+    from clearwater_riverine_amd.distributed import PartitionedTransport
+    exp = np.load(os.path.join(HERE, 'golden', 'config4_1m_expected.npz'))
+    steps = int(exp['steps'])
+    mesh = cw.synthetic.bench_mesh(steps + 1)
+    inputs3 = np.ascontiguousarray(cw.synthetic.distinct_input_array(mesh, int(exp['K']), seed=cw.synthetic.BENCH_SEED)[:, :, :1])
+    pt = PartitionedTransport(mesh, inputs3, rank, world, device=0, unique_id=uid, halo_depth=0, renumber='hilbert')
+    owned_faces = pt.local.face1 < pt.local.n_core
+    states, fluxes, infos = [], [], []
+    for t in range(steps):
+        r = pt.step(t, tol=1e-12, mass_flux=True)
+        infos.append((r.sweeps, r.iterations, r.exchanges, r.overlapped, r.checks, r.flags, r.sweep_kernel))
+        states.append(pt.owned_state()[:, 0].copy())
+        fluxes.append(pt.engine.get_mass_flux()[2][owned_faces, 0].copy())
+    out = (rank, pt.owned_reference_ids(), pt.local.depth, states, pt.local.edge_global[owned_faces], fluxes, infos, None,
+           pt.local.n_core, pt.local.n_rows, len(pt.local.peers))
+    return pt, out
+
+
+def _rank_config5(rank, world, uid):
+    """One rank of BASELINE config 5: the 4 M-cell mesh, 16 constituents, a K x K reaction applied on the device to the rank's own
+    rows before the second step (test_gpu_fullsize.py: the same two levels the committed fixture holds)."""
+    import importlib.util
+    import clearwater_riverine_amd as cw
+    from clearwater_riverine_amd.distributed import PartitionedTransport
+    spec = importlib.util.spec_from_file_location('make_expected_large', os.path.join(HERE, 'golden', 'make_expected_large.py'))
+    large = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(large)
+    exp = np.load(os.path.join(HERE, 'golden', 'config5_4m_expected.npz'))
+    K, dt, steps = int(exp['K']), float(exp['dt']), int(exp['steps'])
+    mesh = cw.synthetic.bench_mesh(steps, scale=2)
+    inputs3 = cw.synthetic.distinct_input_array(mesh, K, seed=cw.synthetic.BENCH_SEED + 1)
+    M = large.reaction_matrix(K, dt)
+    cols = [int(k) for k in exp['cols']]
+    pt = PartitionedTransport(mesh, inputs3, rank, world, device=0, unique_id=uid, halo_depth=0, renumber='hilbert')
+    infos, states = [], []
+    r = pt.step(0, tol=1e-12, mass_flux=True)
+    infos.append((r.sweeps, r.iterations, r.exchanges, r.overlapped, r.checks, r.flags, r.sweep_kernel, r.chained))
+    states.append(pt.owned_state()[:, cols].copy())
+    pt.engine.react_linear(M)                                    # the device reaction hook, on this rank's own rows
+    r = pt.step(1, tol=1e-12, mass_flux=True)
+    infos.append((r.sweeps, r.iterations, r.exchanges, r.overlapped, r.checks, r.flags, r.sweep_kernel, r.chained))
+    states.append(pt.owned_state()[:, cols].copy())
+    out = (rank, pt.owned_reference_ids(), pt.local.depth, states, None, None, infos, None, pt.local.n_core, pt.local.n_rows, len(pt.local.peers),
+           pt.numbering, np.diag(M)[cols])
+    return pt, out
+
+
+def _host_config4(host, world, per_host, uid_pipe, out_queue, which=4):
+    import threading
+    ranks = list(range(host * per_host, min(world, (host + 1) * per_host)))
+    try:
+        os.environ['CWR_RCCL_LIB'] = MOCK_LIB
+        import clearwater_riverine_amd as cw
+        uid = cw.TransportEngine.comm_unique_id()
+        if host == 0:
+            for _ in range(-(-world // per_host) - 1):
+                uid_pipe.put(uid)
+        else:
+            uid = uid_pipe.get(timeout=240)
+    except Exception as exc:
+        for r in ranks:
+            out_queue.put((r, None, 0, None, None, None, None, repr(exc)))
+        return
+    engines, lock = [], threading.Lock()
+
+    def body(rank):
+        try:
+            pt, out = (_rank_config4 if which == 4 else _rank_config5)(rank, world, uid)
+            with lock:
+                engines.append(pt)
+            out_queue.put(out)
+        except Exception as exc:
+            out_queue.put((rank, None, 0, None, None, None, None, repr(exc)))
+    threads = [threading.Thread(target=body, args=(r,)) for r in ranks]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    for pt in engines:
+        pt.engine.close()
+
+
+def test_config4_as_specified_one_tracer_on_the_1m_cell_mesh_across_eight_ranks(gpu_lib, monkeypatch):
+    """BASELINE config 4 literally: "synthetic 1 M-cell unstructured floodplain mesh, 1 tracer, domain-decomposed across 8 x MI355X
+    with ghost-halo RCCL" -- the decomposition, the halo exchanges and the solver loop of eight ranks on the FULL mesh (124 992-125 056
+    cells per rank, halo depth 14, ping-pong passes with overlapped exchanges), element-wise against the committed SuperLU output of
+    the full mesh (tests/golden/config4_1m_expected.npz: 65 536 sampled cells over the plume's decades, every ghost cell, whole-column
+    norms, 16 384 sampled face fluxes).  Eight engines on ONE GPU through the stand-in (4 processes x 2 rank threads, see
+    test_eight_ranks_through_the_stand_in): functional, not a measurement -- the one thing of config 4 that needs eight GPUs is its speed."""
+    build_mock()
+    world = 8
+    monkeypatch.setenv('CWR_NO_GRAPHS', '1')
+    monkeypatch.setenv('CWR_MOCK_ASYNC', '0')
+    monkeypatch.setenv('CWR_MOCK_TIMEOUT_S', '90')
+    results = _run_hosts(_host_config4, (4,), world, 2, 420)
+    import clearwater_riverine_amd as cw
+    exp = np.load(os.path.join(HERE, 'golden', 'config4_1m_expected.npz'))
+    steps = int(exp['steps'])
+    n, E = 1_000_000, None
+    assert sum(len(r[1]) for r in results) == n and all(r[2] == 14 for r in results)       # every cell owned once; the automatic halo depth
+    assert all(124_000 <= r[8] <= 126_000 for r in results) and all(r[10] >= 2 for r in results)
+    assert all([i[:2] for i in r[6]] == [i[:2] for i in results[0][6]] for r in results)     # the same sweeps on every rank
+    for r in results:
+        for sweeps, its, exch, over, checks, flags, kern in r[6]:
+            assert its == 0 and flags == 0 and kern == 6 and sweeps >= 20 and 0 < over <= exch and 1 <= checks <= 3, r[6]
+    mesh_faces = 2_054_728
+    for s_ in range(steps):
+        col = np.full(n, np.nan)
+        tot = np.full(mesh_faces, np.nan)
+        seen = np.zeros(mesh_faces, bool)
+        for r in results:
+            col[r[1]] = r[3][s_]
+            tot[r[4]] = r[5][s_]
+            seen[r[4]] = True
+        assert not np.isnan(col).any() and seen.all()            # (a boundary face without a boundary value has a NaN flux, as in the reference)
+        assert rel_err(col[exp['cells']], exp['state'][s_, 0]) <= 1e-9                       # element-wise 1e-6 |b| + 1e-12 peak inside
+        got = np.array([np.linalg.norm(col), np.sum(col), np.max(np.abs(col))])
+        assert np.allclose(got, exp['norms'][s_, 0], rtol=1e-9, atol=0.0)                    # the WHOLE column
+        assert flux_err(tot[exp['flux_faces']], exp['total_flux'][s_, 0]) <= 1e-8
+
+
+def _run_hosts(target, args, world, per_host, timeout_s):
+    ctx = mp.get_context('spawn')
+    uid_pipe, out_queue = ctx.Queue(), ctx.Queue()
+    procs = [ctx.Process(target=target, args=(h, world, per_host, uid_pipe, out_queue) + tuple(args)) for h in range(-(-world // per_host))]
+    results = []
+    try:
+        for p in procs:
+            p.start()
+        import time
+        deadline = time.monotonic() + timeout_s
+        while len(results) < world and time.monotonic() < deadline:
+            try:
+                results.append(out_queue.get(timeout=1))
+            except queue.Empty:
+                if any(p.exitcode not in (None, 0) for p in procs):
+                    break
+    finally:
+        for p in procs:
+            p.join(5 if len(results) < world else 180)
+            if p.is_alive():
+                p.terminate(); p.join(10)
+            if p.is_alive():
+                p.kill(); p.join(10)
+    assert len(results) == world, f'{world - len(results)} rank(s) posted no result; exit codes {[p.exitcode for p in procs]}'
+    errs = [r[7] for r in results if r[7]]
+    assert not errs, errs
+    results.sort(key=lambda r: r[0])
+    return results
+
+
+def test_config5_as_specified_4m_cells_16_constituents_device_reaction_across_eight_ranks(gpu_lib, monkeypatch):
+    """BASELINE config 5: "synthetic 4 M-cell mesh, 16 constituents + per-step TSM / NSM reaction callback, 8 x MI355X" -- eight ranks of
+    500 k cells each: large enough to CHAIN their tiles (lane-major numbering, interior and cut tiles chained separately, exchanges
+    beside the interior lists), the reaction on the device between the steps (every rank on its own rows; the start-of-step exchange
+    then carries the reacted halo rows).  Both levels of the committed SuperLU fixture (config5_4m_expected.npz: plain step, step
+    behind the reaction; pulse and plume columns; 32 768 sampled cells element-wise + whole-column norms).  Functional: eight
+    engines share one GPU through the stand-in (4 processes x 2 rank threads)."""
+    build_mock()
+    world = 8
+    monkeypatch.setenv('CWR_NO_GRAPHS', '1')
+    monkeypatch.setenv('CWR_MOCK_ASYNC', '0')
+    monkeypatch.setenv('CWR_MOCK_TIMEOUT_S', '180')
+    results = _run_hosts(_host_config4, (5,), world, 2, 900)
+    exp = np.load(os.path.join(HERE, 'golden', 'config5_4m_expected.npz'))
+    n = 4_000_000
+    assert sum(len(r[1]) for r in results) == n and all(r[2] == 16 for r in results)
+    assert all(r[11].startswith('lanes') for r in results), [r[11] for r in results]
+    assert all([i[:2] for i in r[6]] == [i[:2] for i in results[0][6]] for r in results)
+    for r in results:
+        for sweeps, its, exch, over, checks, flags, kern, chained in r[6]:
+            assert its == 0 and flags == 0 and kern == 6 and chained == 1 and 0 < over <= exch and 1 <= checks <= 3, r[6]
+    diagM = results[0][12]
+    for level in range(2):
+        for ci in range(len(exp['cols'])):
+            col = np.full(n, np.nan)
+            for r in results:
+                col[r[1]] = r[3][level][:, ci]
+            assert not np.isnan(col).any()
+            if level == 0:                                       # (the fixture's level 1 holds the override M[k, k] x the solved level: test_gpu_fullsize.py)
+                col = col * diagM[ci]
+            assert rel_err(col[exp['cells']], exp['state'][level, ci]) <= 1e-9          # element-wise 1e-6 |b| + 1e-12 peak inside
+            got = np.array([np.linalg.norm(col), np.sum(col), np.max(np.abs(col))])
+            assert np.allclose(got, exp['norms'][level, ci], rtol=1e-9, atol=0.0)
+
+
 @pytest.mark.parametrize('world,K,depth', [(2, 4, 8), (4, 16, 8), (3, 1, 6), (2, 16, 14), (4, 4, 16)])
 def test_partitioned_block_asynchronous_passes_keep_the_single_rank_sweep_count(gpu_lib, world, K, depth, monkeypatch):
     """Deep halos + tile-local re-application: the replayed layers (tiled like the core) and the never-computed outer
