@@ -123,6 +123,9 @@ def lane_order(mesh: dict, n_real: int, tile_rows: int = 64, tile_len: int = 4, 
     applications carry information across the whole tile.  Against the Hilbert curve (compact tiles, chains of ~6 tiles whose
     concurrently active tiles are scattered over the XCD's region) -- measured in profiles/r03_c_chained_passes.txt.
     A field without a preferred axis keeps the Hilbert curve."""
+    import os
+    if os.environ.get('CWR_LANE_LEN'):                       # (A/B knob: tile length along the flow in cells; lanes are tile_rows / it wide)
+        tile_len = max(1, int(os.environ['CWR_LANE_LEN']))
     (ax, ay), ratio = flow_axis(mesh, n_real)
     x = np.asarray(mesh['face_x'], dtype=np.float64)[:n_real]
     y = np.asarray(mesh['face_y'], dtype=np.float64)[:n_real]
