@@ -217,7 +217,7 @@ def main():
     ap.add_argument('--halo-depth', type=int, default=0,
                     help='N > 1: halo layers = Jacobi sweeps between two exchanges (0: from the per-rank size, distributed.auto_halo_depth)')
     ap.add_argument('--deterministic', action='store_true',
-                    help='CWR_STEP_DETERMINISTIC: ping-pong passes, bitwise reproducible run to run (the default passes are chained in place)')
+                    help='CWR_STEP_DETERMINISTIC: passes between two vectors, bitwise reproducible run to run (the default passes are chained in place)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-pmc', action='store_true', help='skip the two rocprofv3 counter passes that measure roofline.traffic')
     ap.add_argument('--cpu-budget-s', type=float, default=100.0, help='wall-clock budget of the CPU baseline leg')
@@ -385,7 +385,8 @@ def main():
                'host_cores': os.cpu_count()}
 
     if rank == 0:
-        chained = bool(r.chained)
+        chained = r.chained == 1
+        walked = r.chained == 2
         value = n * K * args.steps / elapsed / 1e6
         line = {
             'metric': 'Mcell-updates/s', 'value': round(value, 2), 'unit': 'Mcell-updates/s',
@@ -403,9 +404,11 @@ def main():
                        'tol': args.tol},
             'solver': {'method': ('J^2 passes of fused Jacobi sweeps, tiles chained along the flow and relaxed in place (block Gauss-Seidel '
                                   'along the flow, no inter-block waiting)' if chained else
+                                  'J^2 passes of fused Jacobi sweeps between two vectors, tiles chained along the flow (a tile takes its '
+                                  'predecessor\'s rows from LDS): deterministic' if walked else
                                   'block-asynchronous (ping-pong) J^2 passes of fused Jacobi sweeps') + '; exact closing sweep; BiCGSTAB '
                                  'fallback; K systems batched',
-                       'chained_passes': chained, 'tile_local_applications': r.local_reps, 'iterations_per_step': iters,
+                       'chained_passes': chained, 'deterministic_chained_passes': walked, 'tile_local_applications': r.local_reps, 'iterations_per_step': iters,
                        'max_rel_residual': max_resid},
             'roofline': roofline, 'cpu_baseline': cpu,
         }

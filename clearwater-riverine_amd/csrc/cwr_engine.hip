@@ -234,7 +234,8 @@ struct cwr_engine {
   // column reuse along a block's list (see k_sq_tiled, REUSE mode): per-schedule copy of the tiles' column lists
   bool chain_reuse = true;                 // CWR_CHAIN_REUSE=0: fetch every column, two interleaved streams per block (A/B)
   int chain_min_tiles = 3;                 // tiles per block of the persistent grid from which schedules are built
-  bool step_chained = false;               // the passes of the step in progress were chained (cwr_step_info.chained)
+  bool det_walk = true;                    // deterministic steps walk the chain lists too (ping-pong between the vectors); CWR_DET_WALK=0: tile order
+  int step_chained = 0;                    // the passes of the step in progress: 1 chained in place, 2 chained between two vectors (cwr_step_info.chained)
   bool deterministic = false;              // CWR_STEP_DETERMINISTIC of the step in progress: ping-pong passes
   int32_t* d_scols = nullptr;
   // partitioned engines: the interior and the cut tiles chained SEPARATELY, so that an exchange runs beside the interior lists
@@ -1270,7 +1271,7 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
   TRY(prepare_sq(e, sq));
   const bool tiled = sq && e->tcl_ready;
   if (e->comm && !e->shape_agreed) TRY(agree_on_pass_shape(e, tiled));
-  if (tiled && e->use_chains && !e->two_closing && !e->sched_user && e->tcl_ntiles >= e->chain_min_tiles * e->tcl_grid && !e->deterministic &&
+  if (tiled && e->use_chains && !e->two_closing && !e->sched_user && e->tcl_ntiles >= e->chain_min_tiles * e->tcl_grid && (!e->deterministic || e->det_walk) &&
       (e->sched_level < 0 || std::abs(e->cur_t - e->sched_level) >= e->sched_refresh))
     // (worth it from a few tiles per block up: CWR_CHAIN_MIN_TILES, default 3)
     TRY(build_chain_schedule(e, e->cur_t));
@@ -1306,8 +1307,12 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
       // chained separately from the cut tiles for that pass (build_chain_schedule).  Every rank chains or none does
       // (agree_on_pass_shape): the batch shape, and with it the exchanges of a batch, must be the same on all ranks.
       const bool chained = tiled && e->use_chains && e->sched_depth > 0 && !e->two_closing && !e->deterministic;
+      // Deterministic steps of a single engine WALK the same lists, ping-ponging between the two vectors: a tile takes its
+      // predecessor's rows from LDS (fresh: block Gauss-Seidel along a list, which is where the flow carries the information) and
+      // every other row from the pass's input vector, which no block writes -- nothing depends on timing.
+      const bool walk = chained || (tiled && e->use_chains && e->sched_depth > 0 && !e->two_closing && e->deterministic && e->det_walk && !e->comm && e->d_scols);
       const bool first_batch = st.sweeps == 0;
-      e->step_chained = chained;
+      e->step_chained = chained ? 1 : (walk ? 2 : 0);
       if (e->reps_auto) {
         // Tile-local applications per visit.  A chain carries information from tile to tile only as far as the applications
         // carry it across a tile, and the stiffer the step the more of its sweeps are transport along the flow.  Measured on the
@@ -1321,7 +1326,7 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
         // 0.50 / 0.48 / 0.45; 119 k x 16 at CFL 25: 3.83 / 3.42 / 3.52 / 3.73; x 1: 1.38 / 1.21 / 1.17 / 1.21 -- while at CFL 2.5
         // (||J||_inf 0.78) two stay the cheapest (119 k x 16: 0.70 / 0.71 / 0.76).
         const int pp = (rho < 0.9 || getenv("CWR_NO_PP_REPS")) ? e->reps_base : std::max(e->reps_base, e->K <= 2 ? 6 : 4);   // (CWR_NO_PP_REPS=1: round 3's fixed count, A/B)
-        e->local_reps = !chained ? pp : (rho < 0.9 ? 2 : (rho < 0.98 ? 4 : (rho < 0.993 ? 6 : 8)));
+        e->local_reps = !walk ? pp : (rho < 0.9 ? 2 : (rho < 0.98 ? 4 : (rho < 0.993 ? 6 : 8)));
       }
       // (round 3: partitioned engines take the one-closing shape too -- k_rhs keeps the read-only halo rows of x_t beside the
       // computed rows, so a first pass may start from the copy there as well: one plain sweep and one exchange fewer per step)
@@ -1349,7 +1354,7 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
       // passes [i, i + cnt) of the batch, none of which needs an exchange
       auto launch_passes = [&](int i, int cnt) -> int {
         for (int q = 0; q < cnt; ++q) {
-          if (tiled) TRY(launch_sq_tiled(e, srcb(i + q), dstb(i + q), nullptr, 0, true, chained));
+          if (tiled) TRY(launch_sq_tiled(e, srcb(i + q), dstb(i + q), nullptr, 0, true, walk));
           else TRY(launch_apply<5>(e, srcb(i + q), dstb(i + q), nullptr, e->d_t, nullptr, nullptr, e->n_sq));
         }
         return CWR_OK;
@@ -1359,7 +1364,7 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
       // steady state (the same batch shape as the previous check): the WHOLE batch -- passes, closing sweeps, reduction --
       // is one hipGraph, captured the second time a shape is seen (the kernel arguments of a batch never change)
       if (!e->comm && !e->profiling && e->use_graphs) {
-        const int shape = 2 * doubles + (one_closing ? 1 : 0) + (chained ? (first_batch ? (1 << 20) : (1 << 21)) : 0) + (e->local_reps << 24);
+        const int shape = 2 * doubles + (one_closing ? 1 : 0) + (chained ? (first_batch ? (1 << 20) : (1 << 21)) : 0) + (walk && !chained ? (1 << 22) : 0) + (e->local_reps << 24);
         auto it = e->batch_exec.find(shape);
         if (it == e->batch_exec.end() && e->batch_last == shape && e->batch_exec.size() < 12) {
           hipGraphExec_t ex = nullptr;
@@ -1382,7 +1387,7 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
         }
       }
       if (!batch_graph) {
-      if (!e->comm && !e->profiling && e->use_graphs && !from_keep && !chained) {
+      if (!e->comm && !e->profiling && e->use_graphs && !from_keep && !walk) {
         hipGraphExec_t& exec = tiled ? e->tcl_exec : e->sq_exec;
         hipGraph_t& graph = tiled ? e->tcl_graph : e->sq_graph;
         bool& tried = tiled ? e->tcl_graph_tried : e->sq_graph_tried;
@@ -1830,6 +1835,7 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   if (const char* v = getenv("CWR_SWEEP_MARGIN")) eng->sweep_margin = std::max(0, atoi(v));
   if (const char* v = getenv("CWR_NO_TCL")) eng->use_tcl = atoi(v) == 0;
   if (const char* v = getenv("CWR_NO_CHAINS")) eng->use_chains = atoi(v) == 0;
+  if (const char* v = getenv("CWR_DET_WALK")) eng->det_walk = atoi(v) != 0;
   if (const char* v = getenv("CWR_CHAIN_REFRESH")) eng->sched_refresh = std::max(1, atoi(v));
   if (const char* v = getenv("CWR_CHAIN_REUSE")) eng->chain_reuse = atoi(v) != 0;
   if (const char* v = getenv("CWR_CHAIN_MIN_TILES")) eng->chain_min_tiles = std::max(1, atoi(v));
@@ -2199,7 +2205,7 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
   e->info_flags = 0;
   e->cur_t = t;
   e->deterministic = (flags & CWR_STEP_DETERMINISTIC) != 0;
-  e->step_chained = false;
+  e->step_chained = 0;
   e->step_exchanges = e->step_overlapped = e->step_checks = 0;
   {
     // element-wise rule: targets (1e6 tol, tol) = (1e-6, 1e-12) at the default tolerance, scaled by s = 0.3 (1 - rho) / rho with
@@ -2277,7 +2283,7 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
   local.flags = e->info_flags;
   local.exchanges = e->step_exchanges; local.overlapped = e->step_overlapped; local.checks = e->step_checks;
   local.local_reps = (st.sweep_kernel == 6) ? e->local_reps : 0;
-  local.chained = (st.sweep_kernel == 6 && e->step_chained) ? 1 : 0;
+  local.chained = (st.sweep_kernel == 6) ? e->step_chained : 0;
   if (st.status != CWR_OK) {
     e->flux_valid = false; e->halo_fresh = false; e->tail_done = false;   // (a speculative tail may have run)
     // the solver iterated in place: put x_t and the ghost rows back, so that the state is what the step found and the

@@ -75,7 +75,7 @@ class StepResult:
     overlapped: int = 0      # ... of which ran beside interior tiles
     checks: int = 0          # convergence checks (blocking host round trips)
     local_reps: int = 0      # tile-local J^2 applications per visit
-    chained: int = 0         # 1: in-place passes along tile chains (not bitwise reproducible run to run)
+    chained: int = 0         # 1: in-place passes along tile chains (not bitwise reproducible run to run); 2: the chains walked between two vectors (deterministic)
 
 
 _lib = None
@@ -372,7 +372,7 @@ class TransportEngine:
              profile: bool = False, solver: str = 'auto', mass_balance: bool = False, deterministic: bool = False) -> StepResult:
         """solver: 'auto' (Jacobi sweeps, switching to BiCGSTAB on stiff steps), 'jacobi', 'bicgstab'.
         mass_balance: add this step's boundary-line fluxes to the device ledger (set_boundary_lines first).
-        deterministic: ping-pong passes instead of the chained in-place ones -- bitwise reproducible from run to run, like the
+        deterministic: passes between two vectors instead of the chained in-place ones -- bitwise reproducible from run to run, like the
         reference's spsolve (the default agrees to <= 1e-10, not bit for bit); StepResult.chained says which ran."""
         info = StepInfo()
         flags = (STEP_MASS_FLUX if mass_flux else 0) | (STEP_PROFILE if profile else 0)

@@ -52,9 +52,10 @@ enum {
   CWR_STEP_FORCE_BICGSTAB = 4, /* skip the Jacobi fast path                                                */
   CWR_STEP_FORCE_JACOBI = 8,   /* never switch to BiCGSTAB (fails with CWR_ERR_NOT_CONVERGED instead)      */
   CWR_STEP_MASS_BALANCE = 16,  /* add this step's boundary-line mass fluxes to the device ledger (cwr_set_boundary_lines) */
-  CWR_STEP_DETERMINISTIC = 32  /* this step's passes ping-pong between two vectors (no tile chains): results
+  CWR_STEP_DETERMINISTIC = 32  /* this step's passes ping-pong between two vectors (nothing is relaxed in place): results
                                   are bitwise reproducible from run to run, as the reference's spsolve is (transport.py:249); the
-                                  default chained in-place passes agree with them to <= 1e-10 but not bit for bit.  Partitioned
+                                  default chained in-place passes agree with them to <= 1e-10 but not bit for bit.  A single engine
+                                  still walks its tile chains (a tile takes its predecessor's rows from LDS).  Partitioned
                                   runs: every rank must give the same value */
 };
 
@@ -75,7 +76,8 @@ typedef struct cwr_step_info {
   int32_t checks;              /* convergence checks = blocking host round trips (one all-reduce each when partitioned) */
   int32_t local_reps;          /* tile-local J^2 applications per visit the passes of this step used (0: no tiled pass) */
   int32_t chained;             /* 1: the passes relaxed in place along tile chains (not bitwise reproducible run to run);
-                                  0: ping-pong passes, plain sweeps, the small-mesh solver or BiCGSTAB (all deterministic) */
+                                  2: the passes walked the tile chains between two vectors (CWR_STEP_DETERMINISTIC, single engine);
+                                  0: ping-pong passes in tile order, plain sweeps, the small-mesh solver or BiCGSTAB (0, 2: deterministic) */
 } cwr_step_info;
 
 /* bits of cwr_step_info.flags */

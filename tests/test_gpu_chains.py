@@ -171,20 +171,33 @@ def test_the_deterministic_step_flag_selects_ping_pong_passes_per_step(gpu_lib, 
         for _ in range(2):
             pt = transport(mesh, inputs3, monkeypatch, CWR_TILE_ORDER='lanes')
             rs = [pt.step(t, tol=1e-12, deterministic=det) for t in range(3)]
-            assert all(r.sweep_kernel == 6 and r.chained == (0 if det else 1) for r in rs), [(r.sweep_kernel, r.chained) for r in rs]
+            assert all(r.sweep_kernel == 6 and r.chained == (2 if det else 1) for r in rs), [(r.sweep_kernel, r.chained) for r in rs]
             outs[det].append(pt.gather_state())
             # the flag is per step: the other kind of pass on the same engine, same answer to the tolerance
             pt.engine.set_state(inputs3[0, :mesh['nreal'] + 1, :])
             r = pt.step(0, tol=1e-12, deterministic=not det)
-            assert r.chained == (1 if det else 0)
+            assert r.chained == (1 if det else 2)
             pt.engine.close()
     assert np.array_equal(outs[True][0], outs[True][1])
     assert rel_err(outs[False][0], outs[False][1]) <= 1e-10 and rel_err(outs[False][0], outs[True][0]) <= 1e-10
+    # round 4: the deterministic passes of a single engine walk the same lists along the flow (a tile takes its predecessor's rows
+    # fresh from LDS, everything else from the pass's read-only input): fewer sweeps than in tile order (CWR_DET_WALK=0), same answer
+    sweeps = {}
+    for walk in ('0', '1'):                                      # (ends with the default for the facade below)
+        pt = transport(mesh, inputs3, monkeypatch, CWR_TILE_ORDER='lanes', CWR_DET_WALK=walk)
+        rs = [pt.step(t, tol=1e-12, deterministic=True) for t in range(3)]
+        assert all(r.chained == (2 if walk == '1' else 0) for r in rs)
+        sweeps[walk] = sum(r.sweeps for r in rs)
+        assert rel_err(pt.gather_state(), outs[True][0]) <= 1e-10
+        if walk == '1':
+            assert np.array_equal(pt.gather_state(), outs[True][0])
+        pt.engine.close()
+    assert sweeps['1'] < sweeps['0'], sweeps
     names = [f'c{k}' for k in range(K)]
     model = cw.ClearwaterRiverine(mesh=dict(mesh), input_arrays={nm: inputs3[:, :, k].copy() for k, nm in enumerate(names)},
                                   deterministic=True)
     model.update()
-    assert model.last_step.chained == 0 and model.last_step.sweep_kernel == 6
+    assert model.last_step.chained == 2 and model.last_step.sweep_kernel == 6
     model.engine.close()
 
 
