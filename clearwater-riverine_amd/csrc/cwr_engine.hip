@@ -234,6 +234,8 @@ struct cwr_engine {
   // column reuse along a block's list (see k_sq_tiled, REUSE mode): per-schedule copy of the tiles' column lists
   bool chain_reuse = true;                 // CWR_CHAIN_REUSE=0: fetch every column, two interleaved streams per block (A/B)
   int chain_min_tiles = 3;                 // tiles per block of the persistent grid from which schedules are built
+  int det_default_k = 8;                   // single engines with up to this many constituents take the deterministic passes by default: they cost 1-3.5 % there
+                                           // (K = 12: 19 %, K = 16: 14 %; profiles/r04_t_*); CWR_DET_DEFAULT_K=0: in place at every K
   bool det_walk = true;                    // deterministic steps walk the chain lists too (ping-pong between the vectors); CWR_DET_WALK=0: tile order
   int step_chained = 0;                    // the passes of the step in progress: 1 chained in place, 2 chained between two vectors (cwr_step_info.chained)
   bool deterministic = false;              // CWR_STEP_DETERMINISTIC of the step in progress: ping-pong passes
@@ -1836,6 +1838,7 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   if (const char* v = getenv("CWR_NO_TCL")) eng->use_tcl = atoi(v) == 0;
   if (const char* v = getenv("CWR_NO_CHAINS")) eng->use_chains = atoi(v) == 0;
   if (const char* v = getenv("CWR_DET_WALK")) eng->det_walk = atoi(v) != 0;
+  if (const char* v = getenv("CWR_DET_DEFAULT_K")) eng->det_default_k = std::max(0, atoi(v));
   if (const char* v = getenv("CWR_CHAIN_REFRESH")) eng->sched_refresh = std::max(1, atoi(v));
   if (const char* v = getenv("CWR_CHAIN_REUSE")) eng->chain_reuse = atoi(v) != 0;
   if (const char* v = getenv("CWR_CHAIN_MIN_TILES")) eng->chain_min_tiles = std::max(1, atoi(v));
@@ -2204,7 +2207,7 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
   e->tail_done = false;
   e->info_flags = 0;
   e->cur_t = t;
-  e->deterministic = (flags & CWR_STEP_DETERMINISTIC) != 0;
+  e->deterministic = (flags & CWR_STEP_DETERMINISTIC) != 0 || (!e->comm && e->det_walk && e->K <= e->det_default_k);
   e->step_chained = 0;
   e->step_exchanges = e->step_overlapped = e->step_checks = 0;
   {

@@ -216,12 +216,19 @@ def test_chained_passes_at_other_constituent_counts_match_the_oracle(gpu_lib, mo
     want = np.stack([ref.constituent_dict[f'c{k}'].state[steps, :n] for k in range(Kc)], axis=1)
     monkeypatch.setenv('CWR_TCL_GRID', str(grid))
     monkeypatch.delenv('CWR_NO_CHAINS', raising=False)
-    pt = PartitionedTransport(mesh, inputs3, 0, 1)
-    rs = [pt.step(t, tol=1e-12) for t in range(steps)]
-    sched, _, _ = pt.engine.get_tile_schedule()
-    assert sched is not None and all(r.sweep_kernel == 6 and r.flags == 0 for r in rs)
-    assert rel_err(pt.gather_state(), want) <= 1e-9
-    pt.engine.close()
+    # a single engine with up to 8 constituents takes the deterministic chained passes by default (they cost 1-3.5 % there);
+    # CWR_DET_DEFAULT_K=0 gives the in-place passes at every K: both kinds through every lane mapping
+    for det_k, kind in (('0', 1), (None, 2 if Kc <= 8 else 1)):
+        if det_k is None:
+            monkeypatch.delenv('CWR_DET_DEFAULT_K', raising=False)
+        else:
+            monkeypatch.setenv('CWR_DET_DEFAULT_K', det_k)
+        pt = PartitionedTransport(mesh, inputs3, 0, 1)
+        rs = [pt.step(t, tol=1e-12) for t in range(steps)]
+        sched, _, _ = pt.engine.get_tile_schedule()
+        assert sched is not None and all(r.sweep_kernel == 6 and r.flags == 0 and r.chained == kind for r in rs), [(r.sweep_kernel, r.chained) for r in rs]
+        assert rel_err(pt.gather_state(), want) <= 1e-9
+        pt.engine.close()
 
 
 def test_flow_that_reverses_mid_run_and_dry_cells(gpu_lib, monkeypatch):
