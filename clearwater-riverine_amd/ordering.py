@@ -114,6 +114,111 @@ def flow_axis(mesh: dict, n_real: int, max_levels: int = 8):
     return (float(v[0, 1]), float(v[1, 1])), float(w[1] / max(w[0], 1e-300 * w[1]))
 
 
+def _sample_levels(T: int, max_levels: int = 8) -> np.ndarray:
+    return np.unique(np.linspace(0, T - 1, min(T, max_levels)).astype(np.int64))
+
+
+def channel_coordinates(mesh: dict, n_real: int, max_levels: int = 8, smooth: int = 64):
+    """Curvilinear coordinates of a channel that bends: q = distance from the longest bank, measured THROUGH the mesh (shortest
+    paths over the cell graph, edge = centre-to-centre distance, then smoothed), and sigma = arc length along that bank of the
+    point a cell reaches by walking down q -- cross-sections perpendicular to the banks, counted along the bank -- so that lanes
+    of constant q and their cells in order of sigma follow a meander where a straight axis cannot.  Open boundary = a perimeter face that carries flow at a sampled level (inflow:
+    net flow into the real cell); bank = real cells at perimeter faces that never do; the banks fall into connected pieces along
+    the perimeter, the one with the most cells is the reference bank.  Returns (sigma, q) or None (no inflow, no bank, or cells that
+    cannot be reached)."""
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.csgraph import connected_components, dijkstra
+    f1 = np.asarray(mesh['edges_face1'], dtype=np.int64)
+    f2 = np.asarray(mesh['edges_face2'], dtype=np.int64)
+    x = np.asarray(mesh['face_x'], dtype=np.float64)
+    y = np.asarray(mesh['face_y'], dtype=np.float64)
+    flow = np.asarray(mesh['face_flow'])
+    real = (f1 < n_real) & (f2 < n_real)
+    peri = ~real
+    if not real.any() or not peri.any():
+        return None
+    levels = _sample_levels(flow.shape[0], max_levels)
+    net = np.zeros(len(f1)); mag = np.zeros(len(f1))
+    for t in levels:
+        ft = np.asarray(flow[t], dtype=np.float64)
+        net += ft; mag = np.maximum(mag, np.abs(ft))
+    inner = np.where(f1 < n_real, f1, f2)                    # the real cell of a perimeter face (face1, in HEC-RAS output)
+    into = np.where(f1 < n_real, net < 0, net > 0)            # flow(face1 -> face2) < 0 enters face1
+    inflow = np.unique(inner[peri & (mag > 0) & into])
+    bank = np.unique(inner[peri & (mag == 0)])
+    if len(inflow) == 0 or len(bank) == 0:
+        return None
+    a, b = f1[real], f2[real]
+    w = np.maximum(np.hypot(x[a] - x[b], y[a] - y[b]), 1e-300)
+    g = csr_matrix((np.concatenate([w, w]), (np.concatenate([a, b]), np.concatenate([b, a]))), shape=(n_real, n_real))
+    s = dijkstra(g, directed=False, indices=inflow, min_only=True)
+    is_bank = np.zeros(n_real, dtype=bool); is_bank[bank] = True
+    keep = is_bank[a] & is_bank[b]
+    sub = csr_matrix((np.ones(int(keep.sum())), (a[keep], b[keep])), shape=(n_real, n_real))
+    _, lab = connected_components(sub, directed=False)
+    piece = np.bincount(lab[bank]).argmax()                   # (cells off the banks are singletons of their own)
+    q = dijkstra(g, directed=False, indices=bank[lab[bank] == piece], min_only=True)
+    if not (np.all(np.isfinite(s)) and np.all(np.isfinite(q))):
+        return None
+    # shortest paths zig-zag through a jittered mesh, so the contours of q are ragged at the scale of a cell -- and every step of a
+    # lane boundary is a face the main flow crosses.  A few sweeps of neighbour averaging (the reference bank held at 0) remove
+    # the cell-scale noise and leave the shape: the lanes' cross flow falls by 3-4 x, to that of straight lanes on a straight channel
+    adj = csr_matrix((np.ones(2 * len(a)), (np.concatenate([a, b]), np.concatenate([b, a]))), shape=(n_real, n_real))
+    deg = np.maximum(np.asarray(adj.sum(axis=1)).ravel(), 1.0)
+    ref = bank[lab[bank] == piece]
+    fixed = np.zeros(n_real, dtype=bool); fixed[ref] = True
+    for _ in range(smooth):
+        q = np.where(fixed, q, 0.5 * q + 0.5 * (adj @ q) / deg)
+    # The distance from the inflow boundary is no coordinate ALONG the lanes: shortest paths cut every bend on its inside, so its
+    # contours lean across the channel (by the channel's width per radian turned) and 64 consecutive cells of a lane would be a
+    # sheared stripe.  Cross-sections perpendicular to the banks instead: sigma = arc length along the reference bank, carried
+    # into the channel down the slope of q -- every cell takes the q-weighted mean of its neighbours nearer the bank, which in
+    # ascending order of q is one sparse triangular solve.  (A cell with no neighbour nearer the bank -- a dimple that the
+    # smoothing left -- keeps its distance from the inflow boundary.)
+    from scipy.sparse.linalg import spsolve_triangular
+    keep = fixed[a] & fixed[b]
+    gb = csr_matrix((np.concatenate([w[keep], w[keep]]), (np.concatenate([a[keep], b[keep]]), np.concatenate([b[keep], a[keep]]))),
+                    shape=(n_real, n_real))
+    start = ref[np.argmin(s[ref])]
+    sig_ref = dijkstra(gb, directed=False, indices=start)
+    if not np.all(np.isfinite(sig_ref[ref])):
+        return None
+    rank = np.empty(n_real, dtype=np.int64)
+    perm = np.lexsort((np.arange(n_real), q))                          # ascending q (ties: by id)
+    rank[perm] = np.arange(n_real)
+    aa = np.concatenate([a, b]); bb = np.concatenate([b, a])
+    down = rank[bb] < rank[aa]                                          # bb is nearer the bank than aa
+    wgt = np.maximum(q[aa[down]] - q[bb[down]], 1e-12 * max(float(q.max()), 1e-300))
+    rows, cols = rank[aa[down]], rank[bb[down]]
+    free = ~fixed[aa[down]]
+    tot = np.bincount(rows[free], weights=wgt[free], minlength=n_real)
+    orphan = (tot == 0) & ~fixed[perm]
+    rhs = np.zeros(n_real)
+    rhs[rank[ref]] = sig_ref[ref]
+    rhs[orphan] = s[perm][orphan]
+    m_low = csr_matrix((-wgt[free] / tot[rows[free]], (rows[free], cols[free])), shape=(n_real, n_real))
+    from scipy.sparse import identity
+    sig = spsolve_triangular((identity(n_real, format='csr') + m_low).tocsr(), rhs, lower=True)
+    sigma = np.empty(n_real); sigma[perm] = sig
+    return sigma, q
+
+
+def cross_lane_flow(lane: np.ndarray, mesh: dict, n_real: int, max_levels: int = 8) -> float:
+    """Share of the (sampled) flow between real cells that crosses from one lane into another: lanes are stream tubes when it is
+    small.  The measure by which lane_order chooses between straight and curvilinear lanes."""
+    f1 = np.asarray(mesh['edges_face1'], dtype=np.int64)
+    f2 = np.asarray(mesh['edges_face2'], dtype=np.int64)
+    real = (f1 < n_real) & (f2 < n_real)
+    flow = np.asarray(mesh['face_flow'])
+    mag = np.zeros(int(real.sum()))
+    for t in _sample_levels(flow.shape[0], max_levels):
+        mag += np.abs(np.asarray(flow[t], dtype=np.float64)[real])
+    tot = float(mag.sum())
+    if tot <= 0:
+        return 1.0
+    return float(mag[lane[f1[real]] != lane[f2[real]]].sum()) / tot
+
+
 def lane_order(mesh: dict, n_real: int, tile_rows: int = 64, tile_len: int = 4, min_ratio: float = 1.5) -> np.ndarray:
     """Lane-major order for engines that run chained passes: the cells are cut into LANES -- strips along the principal flow
     axis, tile_rows / tile_len cells wide -- and numbered lane by lane, along the flow inside a lane.  A tile of the engine
@@ -129,16 +234,41 @@ def lane_order(mesh: dict, n_real: int, tile_rows: int = 64, tile_len: int = 4, 
     (ax, ay), ratio = flow_axis(mesh, n_real)
     x = np.asarray(mesh['face_x'], dtype=np.float64)[:n_real]
     y = np.asarray(mesh['face_y'], dtype=np.float64)[:n_real]
-    if ratio < min_ratio or n_real < 4 * tile_rows:
+    if n_real < 4 * tile_rows:
         return hilbert_order(mesh['face_x'], mesh['face_y'], n_real)
-    s_along = x * ax + y * ay
-    q_across = -x * ay + y * ax
     f1 = np.asarray(mesh['edges_face1'], dtype=np.int64)
     f2 = np.asarray(mesh['edges_face2'], dtype=np.int64)
     real = f2 < n_real
     h = float(np.median(np.hypot(x[f1[real]] - x[f2[real]], y[f1[real]] - y[f2[real]]))) if real.any() else 1.0
     width = max(1, tile_rows // tile_len) * max(h, 1e-300)
-    lane = np.floor((q_across - q_across.min()) / width).astype(np.int64)
+    # candidate 1: straight lanes along the principal axis of the flow (a field with no preferred axis has none)
+    straight = None
+    if ratio >= min_ratio:
+        s_along = x * ax + y * ay
+        q_across = -x * ay + y * ax
+        straight = (s_along, np.floor((q_across - q_across.min()) / width).astype(np.int64))
+    # candidate 2 (round 4): lanes that follow the banks of a channel that bends -- s = distance from the inflow boundary, q =
+    # distance from the longest bank, both through the mesh.  Taken when its lanes are clearly better stream tubes than the
+    # straight ones (less of the flow crosses from lane to lane), or when there is no axis and they are good ones.
+    want = os.environ.get('CWR_LANE_KIND', 'auto')                    # auto | straight | channel (A/B knob)
+    curved = None
+    c_str = cross_lane_flow(straight[1], mesh, n_real) if straight is not None else 1.0
+    # (straight lanes that are already stream tubes -- under 1 % of the flow crosses them, 0.65 % on the bench mesh -- are kept
+    # without looking further: the two shortest-path passes cost ~2 s per million cells)
+    if want == 'channel' or (want == 'auto' and c_str >= 0.01):
+        sq = channel_coordinates(mesh, n_real)
+        if sq is not None:
+            curved = (sq[0], np.floor(sq[1] / width).astype(np.int64))
+    pick = straight
+    if curved is not None:
+        c_cur = cross_lane_flow(curved[1], mesh, n_real)
+        if straight is None:
+            pick = curved if (c_cur < 0.05 or want == 'channel') else None
+        elif want == 'channel' or c_cur < 0.7 * c_str:
+            pick = curved
+    if pick is None:
+        return hilbert_order(mesh['face_x'], mesh['face_y'], n_real)
+    s_along, lane = pick
     # snake: odd lanes run against the axis, so that the end of a lane and the start of the next are neighbours (the tile that
     # straddles two lanes stays compact); the engine's chains follow the flow whatever the numbering direction
     key = np.where(lane & 1, -s_along, s_along)

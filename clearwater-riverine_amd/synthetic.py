@@ -235,6 +235,37 @@ def make_mesh(nx: int, ny: int, n_steps: int, *, seed: int = 0, n_merge: int = 0
     }
 
 
+def bend_channel(mesh: dict, theta0: float = 1.0, wavelength: float | None = None) -> dict:
+    """The same mesh laid along a meander: the x axis of make_mesh becomes the arc length of a sine-generated centre line (direction
+    angle theta0 * sin(2 pi s / wavelength), the textbook river meander), y the offset along its normal.  Topology, flows and
+    volumes are untouched -- only the cell-centre coordinates move, and with them what depends on them: the internal numbering
+    (ordering.py) and the face-to-face distances of the diffusion term.  theta0 in radians (1.0: the channel swings +-57 degrees);
+    the wavelength defaults to the channel length and must keep the radius of curvature above half the channel width."""
+    x = np.asarray(mesh['face_x'], dtype=np.float64)
+    y = np.asarray(mesh['face_y'], dtype=np.float64)
+    L = float(x.max() - x.min())
+    lam = float(wavelength) if wavelength else L
+    half = 0.5 * float(y.max() - y.min())
+    if theta0 * 2 * np.pi / lam * half >= 0.9:
+        raise ValueError('bend_channel: the inner bank would fold (radius of curvature below half the channel width)')
+    sg = np.linspace(x.min(), x.max(), 20001)
+    th = theta0 * np.sin(2 * np.pi * (sg - sg[0]) / lam)
+    ds = sg[1] - sg[0]
+    cx = np.concatenate([[0.0], np.cumsum(0.5 * (np.cos(th[1:]) + np.cos(th[:-1])) * ds)])
+    cy = np.concatenate([[0.0], np.cumsum(0.5 * (np.sin(th[1:]) + np.sin(th[:-1])) * ds)])
+    # (ghost centres lie just outside [x.min, x.max]: clamp the arc length, extend along the end tangents)
+    sc = np.clip(x, sg[0], sg[-1])
+    t_ = np.interp(sc, sg, th)
+    px = np.interp(sc, sg, cx) + (x - sc) * np.cos(t_)
+    py = np.interp(sc, sg, cy) + (x - sc) * np.sin(t_)
+    off = y - 0.5 * (y.max() + y.min())
+    m = dict(mesh)
+    m['face_x'] = px - off * np.sin(t_)
+    m['face_y'] = py + off * np.cos(t_)
+    m.pop('face_to_face_dist', None)
+    return m
+
+
 BENCH_SEED = 4
 BENCH_GRID = (1026, 1026)
 BENCH_MERGES = 52676            # 5.0 % of the 1 052 676 base quads fused into 6-sided cells: exactly 10^6 real cells

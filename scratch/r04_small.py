@@ -1,6 +1,6 @@
 """Round 4: engines below the chain threshold (one rank of 8 of the 1 M-cell mesh = 125 k cells; 60 k; the Ohio-sized band).
 One engine per environment combination, same mesh and inputs; prints ms per step and sweeps.
-usage: r04_small.py <case: sq354|sq245|band200x50|...> <K> [label=ENV1=v,ENV2=v ...]"""
+usage: r04_small.py <case: sq354|sq245|band200x50|bend1026x256@1.0|...> <K> [label=ENV1=v,ENV2=v ...]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -10,7 +10,15 @@ from clearwater_riverine_amd.distributed import PartitionedTransport
 case, K = sys.argv[1], int(sys.argv[2])
 combos = sys.argv[3:] or ['default=']
 steps, warm = 16, 4
-if case.startswith('sq'):
+if case.startswith('bend'):
+    # bendNXxNY[@theta0]: the jittered, 5 %-merged channel of make_mesh laid along a meander (synthetic.bend_channel)
+    dims, _, th = case[4:].partition('@')
+    nx, ny = (int(v) for v in dims.split('x'))
+    mesh = cw.synthetic.make_mesh(nx, ny, warm + steps + 1, seed=4, dt=float(os.environ.get('MID_DT', '40')), diffusion_coefficient=0.5, n_merge=int(0.05 * nx * ny))
+    if th and float(th) > 0:
+        mesh = cw.synthetic.bend_channel(mesh, float(th), wavelength=float(os.environ.get('BEND_WAVELENGTH', '0')) or None)
+    inputs3 = cw.synthetic.distinct_input_array(mesh, K, seed=4)
+elif case.startswith('sq'):
     nx = int(case[2:])
     mesh = cw.synthetic.make_mesh(nx, nx, warm + steps + 1, seed=4, dt=float(os.environ.get('MID_DT', '40')), diffusion_coefficient=0.5, n_merge=int(0.05 * nx * nx))
     inputs3 = cw.synthetic.distinct_input_array(mesh, K, seed=4)

@@ -308,3 +308,28 @@ def test_random_meshes_flows_and_constituent_counts_through_the_chained_passes(g
     clamped = any(r.flags & cw.engine.INFO_ELEMENTWISE_CLAMPED for r in rs)
     assert rel_err(pt.gather_state(), want, **({'ew_rtol': 1e-4, 'ew_atol': 1e-9} if clamped else {})) <= (1e-6 if clamped else 1e-9)
     pt.engine.close()
+
+
+def test_chained_passes_on_a_meander_follow_the_channel(gpu_lib, monkeypatch):
+    """Round 4: a channel that bends (synthetic.bend_channel: the straight test mesh laid along a sine-generated centre line).  The
+    lanes of the internal numbering follow the banks (ordering.channel_coordinates), the engine's chains follow the lanes, and the
+    answer is the oracle's whichever numbering ran -- straight lanes, which cut across the bends, need more sweeps for it."""
+    import clearwater_riverine_amd as cw
+    steps = 3
+    mesh = cw.synthetic.make_mesh(400, 96, steps, seed=14, n_merge=1900, dt=40.0, diffusion_coefficient=0.5)
+    mesh = cw.synthetic.bend_channel(mesh, 1.0)
+    inputs3 = cw.synthetic.distinct_input_array(mesh, K, seed=5)
+    oracle.derive_coefficients(mesh)
+    ref = oracle_run(mesh, inputs3, steps)
+    n = mesh['nreal'] + 1
+    want = np.stack([ref.constituent_dict[f'c{k}'].state[steps, :n] for k in range(K)], axis=1)
+    sweeps = {}
+    for kind in ('straight', 'auto'):
+        pt = transport(mesh, inputs3, monkeypatch, CWR_TILE_ORDER='lanes', CWR_LANE_KIND=kind)
+        rs = [pt.step(t, tol=1e-12) for t in range(steps)]
+        assert all(r.sweep_kernel == 6 and r.chained == 1 and r.flags == 0 for r in rs)
+        assert pt.engine.get_tile_schedule()[0] is not None
+        assert rel_err(pt.gather_state(), want) <= 1e-9
+        sweeps[kind] = sum(r.sweeps for r in rs)
+        pt.engine.close()
+    assert sweeps['auto'] < sweeps['straight'], sweeps

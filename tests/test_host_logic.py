@@ -236,3 +236,62 @@ def test_curve_kind_follows_the_size_of_a_rank_and_the_environment(monkeypatch):
     monkeypatch.setenv('CWR_TILE_ORDER', 'hilbert')
     monkeypatch.delenv('CWR_NO_CHAINS')
     assert curve_kind(1_000_000, 16, 1) == 'hilbert'
+
+
+def _tile_extent(order, mesh, n, tile=64, dx=10.0):
+    """Median (along, across) extent in cells of the tiles of `order`, measured in the coordinates of the UNBENT mesh."""
+    x = np.asarray(mesh['face_x'])[:n][order] / dx
+    y = np.asarray(mesh['face_y'])[:n][order] / dx
+    nt = n // tile
+    xs = x[:nt * tile].reshape(nt, tile); ys = y[:nt * tile].reshape(nt, tile)
+    return float(np.median(xs.max(1) - xs.min(1))), float(np.median(ys.max(1) - ys.min(1)))
+
+
+def test_lanes_follow_a_channel_that_bends(monkeypatch):
+    """ordering.lane_order on a meander (synthetic.bend_channel: same cells, faces and flows, laid along a sine-generated centre
+    line).  Straight lanes along the principal axis cut across the bends; the curvilinear coordinates (distance from the longest
+    bank through the mesh, cross-sections perpendicular to the banks) give lanes that are stream tubes again and tiles as compact
+    as on the straight channel.  A straight channel keeps its straight lanes."""
+    import clearwater_riverine_amd as cw
+    from clearwater_riverine_amd import ordering as od
+    monkeypatch.delenv('CWR_LANE_KIND', raising=False)
+    monkeypatch.delenv('CWR_LANE_LEN', raising=False)
+    mesh = cw.synthetic.make_mesh(384, 96, 6, seed=4, dt=40.0, diffusion_coefficient=0.5, n_merge=1800)
+    n = mesh['nreal'] + 1
+    bent = cw.synthetic.bend_channel(mesh, 1.0)
+    # (what moved: coordinates only)
+    assert np.array_equal(bent['edges_face1'], mesh['edges_face1']) and bent['face_flow'] is mesh['face_flow']
+    assert not np.allclose(bent['face_y'][:n], mesh['face_y'][:n])
+    sig, q = od.channel_coordinates(bent, n)
+    assert np.all(np.isfinite(sig)) and np.all(np.isfinite(q)) and q.min() == 0.0
+    # q is the distance from one bank, sigma runs along the channel: in the unbent coordinates they are y and x again
+    y0 = np.asarray(mesh['face_y'])[:n]; x0 = np.asarray(mesh['face_x'])[:n]
+    cy = abs(np.corrcoef(q, y0)[0, 1]); cx = abs(np.corrcoef(sig, x0)[0, 1])
+    # (sigma counts along the reference BANK, which a bend makes shorter or longer than the centre line: monotone, not linear)
+    assert cy > 0.995 and cx > 0.98, (cy, cx)
+    width = 16 * 10.0
+    lanes_c = np.floor(q / width).astype(np.int64)
+    (ax, ay), ratio = od.flow_axis(bent, n)
+    qa = -np.asarray(bent['face_x'])[:n] * ay + np.asarray(bent['face_y'])[:n] * ax
+    lanes_s = np.floor((qa - qa.min()) / width).astype(np.int64)
+    c_cur, c_str = od.cross_lane_flow(lanes_c, bent, n), od.cross_lane_flow(lanes_s, bent, n)
+    assert c_cur < 0.012 and c_str > 2.5 * c_cur, (c_cur, c_str)
+    order = od.lane_order(bent, n)
+    assert np.array_equal(np.sort(order), np.arange(n))
+    monkeypatch.setenv('CWR_LANE_KIND', 'straight')
+    order_s = od.lane_order(bent, n)
+    monkeypatch.delenv('CWR_LANE_KIND')
+    assert not np.array_equal(order, order_s)                     # the curvilinear lanes were chosen ...
+    along, across = _tile_extent(order, mesh, n)
+    along_s, across_s = _tile_extent(order_s, mesh, n)
+    assert along <= 5.5 and across <= 16.5 and along_s >= 2 * along, (along, across, along_s, across_s)   # ... and their tiles are 4-5 x 16 cells
+    # the straight channel: its straight lanes are stream tubes already and stay (the bench mesh's numbering is what it was)
+    order0 = od.lane_order(mesh, n)
+    monkeypatch.setenv('CWR_LANE_KIND', 'straight')
+    assert np.array_equal(order0, od.lane_order(mesh, n))
+    monkeypatch.setenv('CWR_LANE_KIND', 'channel')
+    along_c, across_c = _tile_extent(od.lane_order(mesh, n), mesh, n)
+    assert along_c <= 5.5 and across_c <= 16.5
+    # no inflow boundary (every perimeter face closed) -> no channel coordinates; a field without an axis then keeps the Hilbert curve
+    closed = dict(mesh); closed['face_flow'] = np.zeros_like(mesh['face_flow'])
+    assert od.channel_coordinates(closed, n) is None
