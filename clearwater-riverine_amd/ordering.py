@@ -240,7 +240,7 @@ def lane_order(mesh: dict, n_real: int, tile_rows: int = 64, tile_len: int = 4, 
     f2 = np.asarray(mesh['edges_face2'], dtype=np.int64)
     real = f2 < n_real
     h = float(np.median(np.hypot(x[f1[real]] - x[f2[real]], y[f1[real]] - y[f2[real]]))) if real.any() else 1.0
-    width = max(1, tile_rows // tile_len) * max(h, 1e-300)
+    width = max(1, tile_rows // tile_len) * max(h, 1e-300) * float(os.environ.get('CWR_LANE_WIDTH_SCALE', '1.0'))   # (A/B knob)
     # candidate 1: straight lanes along the principal axis of the flow (a field with no preferred axis has none)
     straight = None
     if ratio >= min_ratio:
