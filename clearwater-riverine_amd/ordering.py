@@ -114,6 +114,13 @@ def flow_axis(mesh: dict, n_real: int, max_levels: int = 8):
     return (float(v[0, 1]), float(v[1, 1])), float(w[1] / max(w[0], 1e-300 * w[1]))
 
 
+def _cell_adjacency(a: np.ndarray, b: np.ndarray, n_real: int):
+    """0/1 adjacency of the real cells (one entry per face, both directions) and the cells' face counts, for neighbour averaging."""
+    from scipy.sparse import csr_matrix
+    adj = csr_matrix((np.ones(2 * len(a)), (np.concatenate([a, b]), np.concatenate([b, a]))), shape=(n_real, n_real))
+    return adj, np.maximum(np.asarray(adj.sum(axis=1)).ravel(), 1.0)
+
+
 def _sample_levels(T: int, max_levels: int = 8) -> np.ndarray:
     return np.unique(np.linspace(0, T - 1, min(T, max_levels)).astype(np.int64))
 
@@ -163,8 +170,7 @@ def channel_coordinates(mesh: dict, n_real: int, max_levels: int = 8, smooth: in
     # shortest paths zig-zag through a jittered mesh, so the contours of q are ragged at the scale of a cell -- and every step of a
     # lane boundary is a face the main flow crosses.  A few sweeps of neighbour averaging (the reference bank held at 0) remove
     # the cell-scale noise and leave the shape: the lanes' cross flow falls by 3-4 x, to that of straight lanes on a straight channel
-    adj = csr_matrix((np.ones(2 * len(a)), (np.concatenate([a, b]), np.concatenate([b, a]))), shape=(n_real, n_real))
-    deg = np.maximum(np.asarray(adj.sum(axis=1)).ravel(), 1.0)
+    adj, deg = _cell_adjacency(a, b, n_real)
     ref = bank[lab[bank] == piece]
     fixed = np.zeros(n_real, dtype=bool); fixed[ref] = True
     for _ in range(smooth):
@@ -246,6 +252,16 @@ def lane_order(mesh: dict, n_real: int, tile_rows: int = 64, tile_len: int = 4, 
     if ratio >= min_ratio:
         s_along = x * ax + y * ay
         q_across = -x * ay + y * ax
+        # The lane boundaries are cut in a SMOOTHED across-coordinate (neighbour averaging over the cell graph): where a boundary
+        # runs within a cell's jitter of a row of cell centres, the raw coordinate deals that row's cells out between two lanes,
+        # and every such step is a face through which the main flow crosses from one list to another.  Measured on the bench
+        # workload, same box (profiles/r04_w): 0 / 4 / 12 / 32 / 64 / 128 sweeps: 2.54 / 2.49 / 2.46 / 2.39-2.46 / 2.45 / 2.47 ms per
+        # step (35-37 -> 33-35 sweeps of the solver); the across-coordinate of channel_coordinates is smoothed for the same reason.
+        smooth = int(os.environ.get('CWR_LANE_SMOOTH', '32'))
+        if smooth > 0:
+            adj, deg = _cell_adjacency(f1[real], f2[real], n_real)
+            for _ in range(smooth):
+                q_across = 0.5 * q_across + 0.5 * (adj @ q_across) / deg
         straight = (s_along, np.floor((q_across - q_across.min()) / width).astype(np.int64))
     # candidate 2 (round 4): lanes that follow the banks of a channel that bends -- s = distance from the inflow boundary, q =
     # distance from the longest bank, both through the mesh.  Taken when its lanes are clearly better stream tubes than the
