@@ -288,4 +288,6 @@ def lane_order(mesh: dict, n_real: int, tile_rows: int = 64, tile_len: int = 4, 
     # snake: odd lanes run against the axis, so that the end of a lane and the start of the next are neighbours (the tile that
     # straddles two lanes stays compact); the engine's chains follow the flow whatever the numbering direction
     key = np.where(lane & 1, -s_along, s_along)
+    # (measured and dropped: taking the cells of a lane cross-section by cross-section -- floor(key / h), then across the lane --
+    # instead of by their raw along-coordinate: 2.449-2.459 vs 2.439-2.460 ms per step on the bench workload, profiles/r04_w)
     return np.lexsort((key, lane)).astype(np.int64)
