@@ -56,8 +56,8 @@ enum {
                                   are bitwise reproducible from run to run, as the reference's spsolve is (transport.py:249); the
                                   default chained in-place passes agree with them to <= 1e-10 but not bit for bit.  A single engine
                                   still walks its tile chains (a tile takes its predecessor's rows from LDS), and with up to 8
-                                  constituents it takes these passes whether the flag is given or not (1-3.5 % slower than in place
-                                  there; 14 % at 16 constituents, where the flag decides).  Partitioned runs: every rank must give
+                                  constituents it takes these passes whether the flag is given or not (1-4 % slower than in place
+                                  there, as at 12-16 constituents, where the flag decides; more on very stiff steps).  Partitioned runs: every rank must give
                                   the same value */
 };
 
