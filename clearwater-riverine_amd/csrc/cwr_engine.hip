@@ -233,7 +233,10 @@ struct cwr_engine {
   int sched_depth = 0, sched_cap = 0;
   // column reuse along a block's list (see k_sq_tiled, REUSE mode): per-schedule copy of the tiles' column lists
   bool chain_reuse = true;                 // CWR_CHAIN_REUSE=0: fetch every column, two interleaved streams per block (A/B)
-  int chain_min_tiles = 3;                 // tiles per block of the persistent grid from which schedules are built
+  double chain_min_tiles = 1.75;           // tiles per block of the persistent grid from which schedules are built.  3 until the lane boundaries of
+                                           // the numbering were smoothed (ordering.lane_order); since, lanes + chains over lists of two tiles beat the Hilbert curve +
+                                           // ping-pong passes from ~1.5 tiles per block: 1.1-1.3: 0.60-0.62 vs 0.55-0.56 ms per step, 1.5: 0.57 vs 0.59, 1.8: 0.575 vs
+                                           // 0.689 (119 k cells x 16: one rank of 8 of the 1 M-cell mesh; CFL 25: 2.49 vs 3.51), 2.3: 0.68 vs 0.81 (profiles/r04_x)
   int det_default_k = 8;                   // single engines with up to this many constituents take the deterministic passes by default: they cost 1-3.5 % there
                                            // (K = 12: 19 %, K = 16: 14 %; profiles/r04_t_*); CWR_DET_DEFAULT_K=0: in place at every K
   bool det_walk = true;                    // deterministic steps walk the chain lists too (ping-pong between the vectors); CWR_DET_WALK=0: tile order
@@ -1841,7 +1844,7 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   if (const char* v = getenv("CWR_DET_DEFAULT_K")) eng->det_default_k = std::max(0, atoi(v));
   if (const char* v = getenv("CWR_CHAIN_REFRESH")) eng->sched_refresh = std::max(1, atoi(v));
   if (const char* v = getenv("CWR_CHAIN_REUSE")) eng->chain_reuse = atoi(v) != 0;
-  if (const char* v = getenv("CWR_CHAIN_MIN_TILES")) eng->chain_min_tiles = std::max(1, atoi(v));
+  if (const char* v = getenv("CWR_CHAIN_MIN_TILES")) eng->chain_min_tiles = std::max(1.0, atof(v));
   if (const char* v = getenv("CWR_BOUND_SWEEPS")) eng->neumann_sweeps = std::max(0, atoi(v));
   // tile-local J^2 applications per pass: each costs LDS time only (measured 15-25 us at K = 16, 4 us at K = 1 on 1 M cells)
   // and cuts the passes from 46 to 28 (x2) / 24 (x3); narrow rows gain from the third application, wide rows do not

@@ -86,15 +86,19 @@ def shared_hilbert_order(mesh: dict, n: int, rank: int, world: int, K: int = 16)
     return t.cpu().numpy()
 
 
+CHAIN_MIN_TILES = 1.75      # = cwr_engine.hip chain_min_tiles (CWR_CHAIN_MIN_TILES overrides the engine's; the numbering follows this constant)
+
+
 def curve_kind(n: int, K: int, world: int = 1) -> str:
     """'lanes' or 'hilbert': which numbering _curve_order (and the facade, model.py) builds for n real cells, K constituents and
-    `world` ranks.  Lanes along the flow are for engines that will CHAIN their tiles -- from three tiles per block of the persistent
-    grid up (1 024 blocks: about 200 k cells per engine at K = 16, 800 k at K = 1); below that the passes ping-pong between two
+    `world` ranks.  Lanes along the flow are for engines that will CHAIN their tiles -- from CHAIN_MIN_TILES = 1.75 tiles per block of the
+    persistent grid up (1 024 blocks: about 115 k cells per engine at K = 16, 460 k at K = 1; three tiles per block until the lane
+    boundaries were smoothed: profiles/r04_x); below that the passes ping-pong between two
     vectors, which lose on anisotropic tiles, and the isotropic Hilbert curve is kept -- on one GPU too since round 4 (ADVICE r03;
     same-box pairs in profiles/r04_f_small_engines.txt: 0.699 vs 0.754 ms per step at 119 k cells x 16, equal within 3 % at K = 1)."""
     want = os.environ.get('CWR_TILE_ORDER', 'auto')
     lanes = want == 'lanes' or (want == 'auto' and not os.environ.get('CWR_NO_CHAINS') and
-                                n // max(1, world) >= 3 * 1024 * tile_rows(K))
+                                n // max(1, world) >= CHAIN_MIN_TILES * 1024 * tile_rows(K))
     return 'lanes' if lanes else 'hilbert'
 
 

@@ -755,7 +755,7 @@ def test_partitioned_engines_chain_their_tiles_too(gpu_lib, world, K, depth, gri
 
 def test_ranks_that_cannot_all_chain_keep_the_ping_pong_passes_together(gpu_lib, monkeypatch):
     """Three ranks x 4 constituents (128-row tiles), grid capped at 16 blocks: the middle rank, with two halos, has 50 tiles and
-    could chain (>= 3 per block), the end ranks with 45 cannot.  A chained rank always closes a batch with one plain sweep, a
+    could chain (>= 3 per block: CWR_CHAIN_MIN_TILES=3 here), the end ranks with 45 cannot.  A chained rank always closes a batch with one plain sweep, a
     ping-pong rank chooses by the sweep count -- different exchanges per batch, i.e. a deadlock (seen with this very case).
     The ranks agree at their first solve: all chain or none."""
     build_mock()
@@ -763,6 +763,7 @@ def test_ranks_that_cannot_all_chain_keep_the_ping_pong_passes_together(gpu_lib,
     monkeypatch.setenv('CWR_TEST_BIG', '1')
     monkeypatch.setenv('CWR_TCL_GRID', '16')
     monkeypatch.setenv('CWR_TILE_ORDER', 'lanes')
+    monkeypatch.setenv('CWR_CHAIN_MIN_TILES', '3')            # (the threshold this case was built around; the default is 1.75 since round 4)
     K = 4
     results = run_ranks(3, _rank_main, (K, 'jacobi', 6))
     assert not any(r[14] for r in results), 'a rank chained although not every rank can'

@@ -217,7 +217,7 @@ def test_synthetic_meshes_with_eight_sided_cells():
 
 
 def test_curve_kind_follows_the_size_of_a_rank_and_the_environment(monkeypatch):
-    """distributed.curve_kind: lanes along the flow for engines that will chain their tiles (one GPU; ranks of at least three
+    """distributed.curve_kind: lanes along the flow for engines that will chain their tiles (one GPU; ranks of at least 1.75
     tiles per resident block), the isotropic Hilbert curve below that and whenever the chains are switched off."""
     from clearwater_riverine_amd.distributed import curve_kind
     from clearwater_riverine_amd.engine import tile_rows
@@ -225,10 +225,13 @@ def test_curve_kind_follows_the_size_of_a_rank_and_the_environment(monkeypatch):
         monkeypatch.delenv(v, raising=False)
     tr = tile_rows(16)
     assert curve_kind(1_000_000, 16, 1) == 'lanes' and curve_kind(1_000_000, 1, 1) == 'lanes'
-    assert curve_kind(120_000, 16, 1) == 'hilbert' and curve_kind(10_000, 12, 1) == 'hilbert'      # one GPU below the chain threshold (round 4)
+    assert curve_kind(100_000, 16, 1) == 'hilbert' and curve_kind(10_000, 12, 1) == 'hilbert'      # one GPU below the chain threshold (round 4)
     assert curve_kind(1_000_000, 16, 2) == 'lanes' and curve_kind(1_000_000, 16, 4) == 'lanes'
-    assert curve_kind(1_000_000, 16, 8) == 'hilbert'               # 125 k cells per rank < 3 x 1024 x 64
-    assert curve_kind(3 * 1024 * tr * 2, 16, 2) == 'lanes' and curve_kind(3 * 1024 * tr * 2 - 2, 16, 2) == 'hilbert'
+    # 125 k cells per rank: 1.9 tiles per block -- chained since the lane boundaries were smoothed (1.75 tiles per block; was 3)
+    assert curve_kind(1_000_000, 16, 8) == 'lanes' and curve_kind(120_000, 16, 1) == 'lanes'
+    assert curve_kind(1_000_000, 1, 2) == 'lanes' and curve_kind(1_000_000, 1, 4) == 'hilbert'       # (256-row tiles at K = 1)
+    lim = int(1.75 * 1024 * tr)
+    assert curve_kind(lim * 2, 16, 2) == 'lanes' and curve_kind(lim * 2 - 2, 16, 2) == 'hilbert'
     monkeypatch.setenv('CWR_NO_CHAINS', '1')
     assert curve_kind(1_000_000, 16, 1) == 'hilbert'
     monkeypatch.setenv('CWR_TILE_ORDER', 'lanes')
