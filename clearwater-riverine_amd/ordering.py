@@ -225,7 +225,7 @@ def cross_lane_flow(lane: np.ndarray, mesh: dict, n_real: int, max_levels: int =
     return float(mag[lane[f1[real]] != lane[f2[real]]].sum()) / tot
 
 
-def lane_order(mesh: dict, n_real: int, tile_rows: int = 64, tile_len: int = 4, min_ratio: float = 1.5) -> np.ndarray:
+def lane_order(mesh: dict, n_real: int, tile_rows: int = 64, tile_len: float = 3, min_ratio: float = 1.5) -> np.ndarray:
     """Lane-major order for engines that run chained passes: the cells are cut into LANES -- strips along the principal flow
     axis, tile_rows / tile_len cells wide -- and numbered lane by lane, along the flow inside a lane.  A tile of the engine
     (tile_rows consecutive cells) is then ~tile_len cells long and a lane wide, and CONSECUTIVE tiles follow each other along
@@ -233,10 +233,13 @@ def lane_order(mesh: dict, n_real: int, tile_rows: int = 64, tile_len: int = 4, 
     the upstream halo of every tile is what the same block has just written (hot in its XCD's L2) and two tile-local J^2
     applications carry information across the whole tile.  Against the Hilbert curve (compact tiles, chains of ~6 tiles whose
     concurrently active tiles are scattered over the XCD's region) -- measured in profiles/r03_c_chained_passes.txt.
-    A field without a preferred axis keeps the Hilbert curve."""
+    A field without a preferred axis keeps the Hilbert curve.
+    tile_len: 4 in round 3; 3 (lanes 21 cells wide at 64-row tiles) since the lane boundaries are smoothed -- same-box pairs on the bench
+    workload, ms per step at 4 / 3: K = 16: 2.43 / 2.34, 12: 2.16 / 2.08, 8: 1.77 / 1.66, 4: 1.19 / 1.15, 2: 0.97 / 0.94, 1: 0.81 / 0.79; 2 and 5
+    and 8 lose everywhere (profiles/r04_y)."""
     import os
     if os.environ.get('CWR_LANE_LEN'):                       # (A/B knob: tile length along the flow in cells; lanes are tile_rows / it wide)
-        tile_len = max(1, int(os.environ['CWR_LANE_LEN']))
+        tile_len = max(1.0, float(os.environ['CWR_LANE_LEN']))
     (ax, ay), ratio = flow_axis(mesh, n_real)
     x = np.asarray(mesh['face_x'], dtype=np.float64)[:n_real]
     y = np.asarray(mesh['face_y'], dtype=np.float64)[:n_real]
@@ -246,7 +249,7 @@ def lane_order(mesh: dict, n_real: int, tile_rows: int = 64, tile_len: int = 4, 
     f2 = np.asarray(mesh['edges_face2'], dtype=np.int64)
     real = f2 < n_real
     h = float(np.median(np.hypot(x[f1[real]] - x[f2[real]], y[f1[real]] - y[f2[real]]))) if real.any() else 1.0
-    width = max(1, tile_rows // tile_len) * max(h, 1e-300) * float(os.environ.get('CWR_LANE_WIDTH_SCALE', '1.0'))   # (A/B knob)
+    width = max(1, int(tile_rows / tile_len)) * max(h, 1e-300) * float(os.environ.get('CWR_LANE_WIDTH_SCALE', '1.0'))   # (A/B knob)
     # candidate 1: straight lanes along the principal axis of the flow (a field with no preferred axis has none)
     straight = None
     if ratio >= min_ratio:
@@ -274,7 +277,10 @@ def lane_order(mesh: dict, n_real: int, tile_rows: int = 64, tile_len: int = 4, 
     if want == 'channel' or (want == 'auto' and c_str >= 0.01):
         sq = channel_coordinates(mesh, n_real)
         if sq is not None:
-            curved = (sq[0], np.floor(sq[1] / width).astype(np.int64))
+            # (curvilinear lanes stay 4 cells long x tile_rows / 4 wide: sigma's cross-sections lean a little against the lanes, which
+            # a wider lane turns into longer tiles -- meander of 250 k cells x 16: 0.945 ms per step at 4, 1.114 at 3; profiles/r04_y)
+            width_c = max(1, int(tile_rows / max(tile_len, 4.0))) * max(h, 1e-300)
+            curved = (sq[0], np.floor(sq[1] / width_c).astype(np.int64))
     pick = straight
     if curved is not None:
         c_cur = cross_lane_flow(curved[1], mesh, n_real)

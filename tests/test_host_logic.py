@@ -272,8 +272,8 @@ def test_lanes_follow_a_channel_that_bends(monkeypatch):
     cy = abs(np.corrcoef(q, y0)[0, 1]); cx = abs(np.corrcoef(sig, x0)[0, 1])
     # (sigma counts along the reference BANK, which a bend makes shorter or longer than the centre line: monotone, not linear)
     assert cy > 0.995 and cx > 0.98, (cy, cx)
-    width = 16 * 10.0
-    lanes_c = np.floor(q / width).astype(np.int64)
+    width = 21 * 10.0                                            # straight lanes: 21 cells wide (tiles 3 long); curvilinear: 16 (4 long)
+    lanes_c = np.floor(q / (16 * 10.0)).astype(np.int64)
     (ax, ay), ratio = od.flow_axis(bent, n)
     qa = -np.asarray(bent['face_x'])[:n] * ay + np.asarray(bent['face_y'])[:n] * ax
     lanes_s = np.floor((qa - qa.min()) / width).astype(np.int64)

@@ -21,10 +21,10 @@ def test_flow_axis_and_lane_order_follow_the_flow():
     x, y = np.asarray(mesh['face_x'])[order], np.asarray(mesh['face_y'])[order]
     ext_x = np.array([np.ptp(x[i:i + 64]) for i in range(0, n - 63, 64)])
     ext_y = np.array([np.ptp(y[i:i + 64]) for i in range(0, n - 63, 64)])
-    # a tile (64 consecutive cells) is short along the flow and a lane wide: ~4 x 16 cells of 10 m (the few tiles that straddle
+    # a tile (64 consecutive cells) is short along the flow and a lane wide: ~3 x 21 cells of 10 m (the few tiles that straddle
     # two lanes excepted)
     assert np.median(ext_x) < 0.5 * np.median(ext_y)
-    assert 20.0 <= np.median(ext_x) <= 60.0 and 120.0 <= np.median(ext_y) <= 200.0
+    assert 20.0 <= np.median(ext_x) <= 50.0 and 160.0 <= np.median(ext_y) <= 250.0
     # consecutive tiles follow each other along the flow: neighbouring tile centres are about one tile length apart
     cx = np.array([x[i:i + 64].mean() for i in range(0, n - 63, 64)]); cy = np.array([y[i:i + 64].mean() for i in range(0, n - 63, 64)])
     step = np.hypot(np.diff(cx), np.diff(cy))
