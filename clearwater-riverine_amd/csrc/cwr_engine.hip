@@ -1331,7 +1331,10 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
         // 0.50 / 0.48 / 0.45; 119 k x 16 at CFL 25: 3.83 / 3.42 / 3.52 / 3.73; x 1: 1.38 / 1.21 / 1.17 / 1.21 -- while at CFL 2.5
         // (||J||_inf 0.78) two stay the cheapest (119 k x 16: 0.70 / 0.71 / 0.76).
         const int pp = (rho < 0.9 || getenv("CWR_NO_PP_REPS")) ? e->reps_base : std::max(e->reps_base, e->K <= 2 ? 6 : 4);   // (CWR_NO_PP_REPS=1: round 3's fixed count, A/B)
-        e->local_reps = !walk ? pp : (rho < 0.9 ? 2 : (rho < 0.98 ? 4 : (rho < 0.993 ? 6 : 8)));
+        // (round 4, after the numbering changed -- smoothed lane boundaries, 3-cell tiles -- the stiff steps want FEWER applications than
+        // round 3 measured: 1 M x 16, ms per step at x2 / x3 / x4 / x6 / x8 (profiles/r04_zb): CFL 12 (||J||_inf 0.95): 6.49 / 5.71 / 6.21; CFL 25
+        // (0.973): 10.66 / 8.67 / 9.19 / 11.73; CFL 62 (0.989): - / 15.43 / 15.08 / 18.84; CFL 225 (0.9969): - / - / 25.9 / 35.1 / 43.0)
+        e->local_reps = !walk ? pp : (rho < 0.9 ? 2 : (rho < 0.98 ? 3 : 4));
       }
       // (round 3: partitioned engines take the one-closing shape too -- k_rhs keeps the read-only halo rows of x_t beside the
       // computed rows, so a first pass may start from the copy there as well: one plain sweep and one exchange fewer per step)
