@@ -27,6 +27,7 @@ python tests/models/ohio_like.py > $O/ohio_like.txt 2>&1
 python scratch/r03_stiff.py 16 6 40 pingpong 2 chains auto 2>&1 | grep -v Warn >> $O/stiff.txt
 python scratch/r03_stiff.py 16 3 400 pingpong 2 chains auto 2>&1 | grep -v Warn >> $O/stiff.txt
 python scratch/r03_stiff.py 16 3 1000 pingpong 2 chains auto 2>&1 | grep -v Warn >> $O/stiff.txt
+python scratch/r03_stiff.py 16 2 3600 chains auto 2>&1 | grep -v Warn >> $O/stiff.txt
 python scratch/r03_stiff.py 1 8 40 pingpong auto chains auto 2>&1 | grep -v Warn >> $O/stiff.txt
 # engines below the chain threshold: round 3's choices (lanes, fixed applications) against round 4's (first combination = warm-up)
 : > $O/small_engines.txt
