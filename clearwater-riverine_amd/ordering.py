@@ -153,6 +153,10 @@ def channel_coordinates(mesh: dict, n_real: int, max_levels: int = 8, smooth: in
     into = np.where(f1 < n_real, net < 0, net > 0)            # flow(face1 -> face2) < 0 enters face1
     inflow = np.unique(inner[peri & (mag > 0) & into])
     bank = np.unique(inner[peri & (mag == 0)])
+    if len(inflow) == 0 and np.any(peri & (mag > 0)):
+        # a reversing (tidal) field whose sampled net flow cancels: either end will do -- the distance from it only says which end of
+        # the reference bank the arc length starts from; the engine's chains follow the flow of the level being solved
+        inflow = np.array([inner[np.argmax(np.where(peri, mag, -1.0))]])
     if len(inflow) == 0 or len(bank) == 0:
         return None
     a, b = f1[real], f2[real]

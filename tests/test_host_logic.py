@@ -298,3 +298,17 @@ def test_lanes_follow_a_channel_that_bends(monkeypatch):
     # no inflow boundary (every perimeter face closed) -> no channel coordinates; a field without an axis then keeps the Hilbert curve
     closed = dict(mesh); closed['face_flow'] = np.zeros_like(mesh['face_flow'])
     assert od.channel_coordinates(closed, n) is None
+    monkeypatch.delenv('CWR_LANE_KIND')
+    assert np.array_equal(od.lane_order(closed, n), od.hilbert_order(closed['face_x'], closed['face_y'], n))
+    # a NaN in the flow field (a face HEC-RAS left undefined) is neither an open boundary nor a bank: the order is still a permutation
+    holed = dict(bent); ff = np.array(bent['face_flow'], dtype=np.float32, copy=True); ff[:, ::97] = np.nan; holed['face_flow'] = ff
+    assert np.array_equal(np.sort(od.lane_order(holed, n)), np.arange(n))
+    # a reversing (tidal) field: the net flow through the open boundaries over the sampled levels decides which end is the inflow;
+    # when it cancels, the end with the largest flow serves (the arc length only needs AN end to start from): same lanes, same tiles
+    tidal = dict(bent); ft = np.array(bent['face_flow'], dtype=np.float32, copy=True); ft[1::2] *= -1.0
+    tidal['face_flow'] = ft[:6]                                    # (an even number of levels: sampled net flow exactly zero)
+    assert od.channel_coordinates(tidal, n) is not None
+    order_t = od.lane_order(tidal, n)
+    assert np.array_equal(np.sort(order_t), np.arange(n))
+    along_t, across_t = _tile_extent(order_t, mesh, n)
+    assert along_t <= 5.5 and across_t <= 16.5, (along_t, across_t)
