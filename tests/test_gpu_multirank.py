@@ -38,6 +38,14 @@ def build_mock():
 
 def make_case(K):
     import clearwater_riverine_amd as cw
+    if os.environ.get('CWR_TEST_SOAK_SEED'):     # the partitioned soak: a random mesh from the seed (every rank and the parent build the same one)
+        rng = np.random.default_rng(int(os.environ['CWR_TEST_SOAK_SEED']))
+        nx, ny = int(rng.integers(60, 200)), int(rng.integers(30, 110))
+        nb = nx * ny
+        mesh = cw.synthetic.make_mesh(nx, ny, 4, seed=int(rng.integers(1, 10**6)), n_merge=int(rng.choice([0, nb // 40, nb // 20])),
+                                      n_merge4=int(rng.choice([0, nb // 300])), n_dry=int(rng.choice([0, 2, nb // 100])), shuffle_window=int(rng.choice([16, 32])),
+                                      dt=float(rng.choice([10.0, 40.0, 40.0, 400.0])), diffusion_coefficient=float(rng.choice([0.1, 0.5, 2.0])))
+        return mesh, cw.synthetic.distinct_input_array(mesh, K, seed=int(rng.integers(1, 1000)))
     if os.environ.get('CWR_TEST_BIG'):           # several 64-row tiles per rank, stiff enough for ~50 sweeps
         mesh = cw.synthetic.make_mesh(160, 96, 4, seed=22, n_merge=200, shuffle_window=16, dt=40.0, diffusion_coefficient=0.5)
     else:
@@ -859,3 +867,50 @@ def test_zero_coefficient_precondition_in_a_partitioned_run_is_raised_by_every_r
     for r in results:
         assert r[1].startswith('ValueError') and 'ghost face' in r[1], r
         assert r[2], 'the failed step did not restore the state'
+
+
+@pytest.mark.parametrize('seed', [int(v) for v in os.environ.get('CWR_SOAK_SEEDS', '').split(',') if v] or list(range(101, 113)))   # (CWR_SOAK_SEEDS=a,b,...: a longer hunt)
+def test_partitioned_soak_random_meshes_worlds_and_depths(gpu_lib, seed, monkeypatch):
+    """A seeded soak of the partitioned step through the stand-in (round 4; cf. tests/test_gpu_soak.py for one engine): random mesh
+    (6- / 8-sided and dry cells, CFL 0.6 ... 25), 2-4 ranks, K, halo depth, numbering, grid caps that make the ranks chain or not, the
+    one-stream or two-stream exchange -- three steps, every rank the same solver decisions, state against the oracle (max-norm 1e-9 and
+    the element-wise bar), mass flux of the last step, the ledger against its own sum."""
+    build_mock()
+    rng = np.random.default_rng(seed)
+    world = int(rng.choice([2, 3, 4]))
+    K = int(rng.choice([1, 2, 4, 12, 16]))
+    depth = int(rng.choice([1, 2, 4, 6, 8, 12]))
+    monkeypatch.setenv('CWR_TEST_SOAK_SEED', str(seed))
+    monkeypatch.setenv('CWR_NO_SMALL', '1')
+    if rng.random() < 0.7:
+        monkeypatch.setenv('CWR_TCL_GRID', str(int(rng.choice([8, 16, 32]))))
+    if rng.random() < 0.6:
+        monkeypatch.setenv('CWR_TILE_ORDER', str(rng.choice(['lanes', 'hilbert'])))
+    if rng.random() < 0.3:
+        monkeypatch.setenv('CWR_CHAIN_MIN_TILES', '1')
+    if rng.random() < 0.25:
+        monkeypatch.setenv('CWR_COMM_TWO_STREAMS', '1')
+    if rng.random() < 0.25:
+        monkeypatch.setenv('CWR_NO_CLOSING_OVERLAP', '1')
+    results = run_ranks(world, _rank_main, (K, 'auto', depth))
+    mesh, inputs3 = make_case(K)
+    n = mesh['nreal'] + 1
+    state = np.full((n, K), np.nan)
+    for r in results:
+        state[r[1]] = r[3]
+    assert not np.isnan(state).any() and sum(len(r[1]) for r in results) == n
+    assert all(r[6] == results[0][6] for r in results), [r[6] for r in results]          # the same sweeps / iterations on every rank
+    oracle.derive_coefficients(mesh)
+    ref = oracle.OracleModel(mesh, {f'c{k}': inputs3[:, :, k].copy() for k in range(K)})
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for _ in range(3):
+            ref.update()
+    want = np.stack([ref.constituent_dict[f'c{k}'].state[3, :n] for k in range(K)], axis=1)
+    assert rel_err(state, want) <= 1e-9
+    tot = np.full((len(mesh['edges_face1']), K), np.nan)
+    for r in results:
+        tot[r[4]] = r[5]
+    want_flux = np.stack([ref.constituent_dict[f'c{k}'].total_mass_flux[2] for k in range(K)], axis=1)
+    assert flux_err(tot, want_flux) <= 1e-8
