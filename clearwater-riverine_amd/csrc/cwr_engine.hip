@@ -237,7 +237,7 @@ struct cwr_engine {
                                            // the numbering were smoothed (ordering.lane_order); since, lanes + chains over lists of two tiles beat the Hilbert curve +
                                            // ping-pong passes from ~1.5 tiles per block: 1.1-1.3: 0.60-0.62 vs 0.55-0.56 ms per step, 1.5: 0.57 vs 0.59, 1.8: 0.575 vs
                                            // 0.689 (119 k cells x 16: one rank of 8 of the 1 M-cell mesh; CFL 25: 2.49 vs 3.51), 2.3: 0.68 vs 0.81 (profiles/r04_x)
-  int det_default_k = 8;                   // single engines with up to this many constituents take the deterministic passes by default: they cost 1-3.5 % there
+  int det_default_k = 8;                   // engines with up to this many constituents take the deterministic passes by default: they cost 1-3.5 % there
                                            // (K = 12: 19 %, K = 16: 14 %; profiles/r04_t_*); CWR_DET_DEFAULT_K=0: in place at every K
   bool det_walk = true;                    // deterministic steps walk the chain lists too (ping-pong between the vectors); CWR_DET_WALK=0: tile order
   int step_chained = 0;                    // the passes of the step in progress: 1 chained in place, 2 chained between two vectors (cwr_step_info.chained)
@@ -1315,7 +1315,9 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
       // Deterministic steps of a single engine WALK the same lists, ping-ponging between the two vectors: a tile takes its
       // predecessor's rows from LDS (fresh: block Gauss-Seidel along a list, which is where the flow carries the information) and
       // every other row from the pass's input vector, which no block writes -- nothing depends on timing.
-      const bool walk = chained || (tiled && e->use_chains && e->sched_depth > 0 && !e->two_closing && e->deterministic && e->det_walk && !e->comm && e->d_scols);
+      // (partitioned engines too, when the ranks agreed to chain: the same lists, cut into interior and cut tiles for the passes with an exchange)
+      const bool walk = chained || (tiled && e->use_chains && e->sched_depth > 0 && !e->two_closing && e->deterministic && e->det_walk && e->d_scols &&
+                                    (!e->comm || !e->sched_user));
       const bool first_batch = st.sweeps == 0;
       e->step_chained = chained ? 1 : (walk ? 2 : 0);
       if (e->reps_auto) {
@@ -1418,13 +1420,13 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
       }
       // a J^2 pass uses up two halo layers of validity, a plain sweep one
       const bool can_overlap = e->comm && tiled && e->overlap && e->comm_stream && e->n_tile_inner > 0 && !e->peers.empty() &&
-                               (!chained || (e->sched_in.depth > 0 && e->d_scols_io && !e->sched_user));
+                               (!walk || (e->sched_in.depth > 0 && e->d_scols_io && !e->sched_user));
       for (int i = 0; i < doubles;) {
         double* src = srcb(i);
         double* dst = dstb(i);
         if (e->comm && from_keep && i == 0 && since_exchange + 2 <= e->exch_every) {
           // the pass that starts from the kept copy of x_t (it shifts the ping-pong parity): on its own, outside the stretch graphs
-          if (tiled) TRY(launch_sq_tiled(e, src, dst)); else TRY(launch_apply<5>(e, src, dst, nullptr, e->d_t, nullptr, nullptr, e->n_sq));
+          TRY(launch_passes(i, 1));
           since_exchange += 2; ++i;
           continue;
         }
@@ -1441,8 +1443,8 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
               HIP_TRY(e, hipMemsetAsync(dst + off, 0xFF, cnt, e->stream));
             }
             TRY(exchange_begin(e, src));
-            if (chained) {
-              // in place along the interior lists (they read and write core rows only; the rows just packed may be among them:
+            if (walk) {
+              // (in place, or from one vector into the other: deterministic steps) along the interior lists (they read and write core rows only; the rows just packed may be among them:
               // the pack precedes this launch on the stream), then along the lists of the cut tiles behind the unpack
               TRY(launch_sq_tiled(e, src, dst, nullptr, 0, false, true, &e->sched_in));
               TRY(exchange_finish(e, src, dst != src ? dst : nullptr));
@@ -1463,7 +1465,7 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
         int run = std::min(doubles - i, std::max(1, (e->exch_every - since_exchange) / 2));
         if (!e->comm) run = doubles - i;
         if (e->comm && tiled && run >= 3 && e->use_graphs && !e->profiling) {
-          const int key = (src == e->d_c ? 0 : 1) * 4096 + run + (chained ? (1 << 16) + (e->local_reps << 20) : 0);   // (which vector the stretch starts from)
+          const int key = (src == e->d_c ? 0 : (src == e->d_p ? 1 : 2)) * 4096 + run + (walk ? (chained ? (1 << 16) : (1 << 17)) + (e->local_reps << 20) : 0);   // (which vector the stretch starts from)
           auto it = e->stretch_exec.find(key);
           if (it == e->stretch_exec.end() && e->stretch_exec.size() < 32) {
             hipGraphExec_t ex = nullptr;
@@ -2213,7 +2215,7 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
   e->tail_done = false;
   e->info_flags = 0;
   e->cur_t = t;
-  e->deterministic = (flags & CWR_STEP_DETERMINISTIC) != 0 || (!e->comm && e->det_walk && e->K <= e->det_default_k);
+  e->deterministic = (flags & CWR_STEP_DETERMINISTIC) != 0 || (e->det_walk && e->K <= e->det_default_k);   // (the same on every rank: K and the environment are)
   e->step_chained = 0;
   e->step_exchanges = e->step_overlapped = e->step_checks = 0;
   {

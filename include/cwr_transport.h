@@ -54,11 +54,12 @@ enum {
   CWR_STEP_MASS_BALANCE = 16,  /* add this step's boundary-line mass fluxes to the device ledger (cwr_set_boundary_lines) */
   CWR_STEP_DETERMINISTIC = 32  /* this step's passes ping-pong between two vectors (nothing is relaxed in place): results
                                   are bitwise reproducible from run to run, as the reference's spsolve is (transport.py:249); the
-                                  default chained in-place passes agree with them to <= 1e-10 but not bit for bit.  A single engine
-                                  still walks its tile chains (a tile takes its predecessor's rows from LDS), and with up to 8
-                                  constituents it takes these passes whether the flag is given or not (1-4 % slower than in place
-                                  there, as at 12-16 constituents, where the flag decides; more on very stiff steps).  Partitioned runs: every rank must give
-                                  the same value */
+                                  default chained in-place passes agree with them to <= 1e-10 but not bit for bit.  The engine
+                                  still walks its tile chains (a tile takes its predecessor's rows from LDS; ranks of a partition
+                                  too), and with up to 8 constituents it takes these passes whether the flag is given or not
+                                  (1-4 % slower than in place there, as at 12-16 constituents, where the flag decides; more on
+                                  very stiff steps).  Partitioned runs: every rank must give the same value; bitwise
+                                  reproducible for the same partition (the tiling, hence the arithmetic, follows the ranks) */
 };
 
 typedef struct cwr_step_info {
@@ -78,7 +79,7 @@ typedef struct cwr_step_info {
   int32_t checks;              /* convergence checks = blocking host round trips (one all-reduce each when partitioned) */
   int32_t local_reps;          /* tile-local J^2 applications per visit the passes of this step used (0: no tiled pass) */
   int32_t chained;             /* 1: the passes relaxed in place along tile chains (not bitwise reproducible run to run);
-                                  2: the passes walked the tile chains between two vectors (CWR_STEP_DETERMINISTIC, single engine);
+                                  2: the passes walked the tile chains between two vectors (CWR_STEP_DETERMINISTIC, or <= 8 constituents);
                                   0: ping-pong passes in tile order, plain sweeps, the small-mesh solver or BiCGSTAB (0, 2: deterministic) */
 } cwr_step_info;
 

@@ -73,13 +73,15 @@ def _rank_body(rank, world, K, solver, depth, uid):
     mesh, inputs3 = make_case(K)
     pt = PartitionedTransport(mesh, inputs3, rank, world, device=0, unique_id=uid, halo_depth=depth,
                               renumber='hilbert' if depth >= 4 else None)
-    infos, comm_counts = [], []
+    infos, comm_counts, kinds = [], [], []
     pt.set_boundary_lines(case_lines(mesh))
     mass0 = pt.engine.domain_mass(0)
+    det = bool(os.environ.get('CWR_TEST_DETERMINISTIC'))      # CWR_STEP_DETERMINISTIC on every step of every rank
     for t in range(3):
-        r = pt.step(t, tol=1e-12, mass_flux=True, solver=solver, mass_balance=True)
+        r = pt.step(t, tol=1e-12, mass_flux=True, solver=solver, mass_balance=True, deterministic=det)
         infos.append((r.sweeps, r.iterations))
         comm_counts.append((r.exchanges, r.overlapped, r.checks))
+        kinds.append(r.chained)
     adv, dif, tot = pt.engine.get_mass_flux()
     owned_faces = pt.local.face1 < pt.local.n_core
     overlapped = pt.engine.comm_selftest(257)             # self send/recv through the stand-in + the overlap counter
@@ -87,7 +89,7 @@ def _rank_body(rank, world, K, solver, depth, uid):
     is_async = ctypes.CDLL(MOCK_LIB).mockRcclLastCommAsync()      # 1: the stand-in only enqueued on the engine's streams
     out = (rank, pt.owned_reference_ids(), pt.local.hi, pt.owned_state(), pt.local.edge_global[owned_faces],
            tot[owned_faces], infos, None, pt.engine.get_mass_balance(), mass0, pt.engine.domain_mass(3), overlapped,
-           is_async, comm_counts, pt.engine.get_tile_schedule()[0] is not None)
+           is_async, comm_counts, pt.engine.get_tile_schedule()[0] is not None, kinds)
     return pt, out
 
 
@@ -105,7 +107,7 @@ def _rank_main(rank, world, K, solver, depth, uid_pipe, out_queue):
         out_queue.put(out)
         pt.engine.close()
     except Exception as exc:                                  # surface the failure in the parent
-        out_queue.put((rank, 0, 0, None, None, None, None, repr(exc), None, None, None, 0, -1, None, False))
+        out_queue.put((rank, 0, 0, None, None, None, None, repr(exc), None, None, None, 0, -1, None, False, None))
 
 
 def _host_main(host, world, per_host, K, solver, depth, uid_pipe, out_queue):
@@ -126,7 +128,7 @@ def _host_main(host, world, per_host, K, solver, depth, uid_pipe, out_queue):
             uid = uid_pipe.get(timeout=120)
     except Exception as exc:
         for r in ranks:
-            out_queue.put((r, 0, 0, None, None, None, None, repr(exc), None, None, None, 0, -1, None, False))
+            out_queue.put((r, 0, 0, None, None, None, None, repr(exc), None, None, None, 0, -1, None, False, None))
         return
     engines, lock = [], threading.Lock()
 
@@ -137,7 +139,7 @@ def _host_main(host, world, per_host, K, solver, depth, uid_pipe, out_queue):
                 engines.append(pt)
             out_queue.put(out)
         except Exception as exc:
-            out_queue.put((rank, 0, 0, None, None, None, None, repr(exc), None, None, None, 0, -1, None, False))
+            out_queue.put((rank, 0, 0, None, None, None, None, repr(exc), None, None, None, 0, -1, None, False, None))
     threads = [threading.Thread(target=body, args=(r,)) for r in ranks]
     for th in threads:
         th.start()
@@ -914,3 +916,42 @@ def test_partitioned_soak_random_meshes_worlds_and_depths(gpu_lib, seed, monkeyp
         tot[r[4]] = r[5]
     want_flux = np.stack([ref.constituent_dict[f'c{k}'].total_mass_flux[2] for k in range(K)], axis=1)
     assert flux_err(tot, want_flux) <= 1e-8
+
+
+@pytest.mark.parametrize('world,K,depth,grid', [(2, 16, 8, 32), (3, 16, 6, 16), (3, 4, 8, 16)])
+def test_deterministic_steps_of_chained_ranks_walk_their_lists_and_repeat_bit_for_bit(gpu_lib, world, K, depth, grid, monkeypatch):
+    """Round 4: CWR_STEP_DETERMINISTIC on ranks that chain.  The passes go from one vector into the other -- along the same lists, cut
+    into interior and cut tiles for the passes with an exchange, a tile taking its predecessor's rows from LDS -- so nothing depends on
+    timing: two runs agree bit for bit (cwr_step_info.chained = 2 on every rank), the exchanges still run beside the interior lists
+    (poisoned halo rows), and the answer is the oracle's."""
+    build_mock()
+    monkeypatch.setenv('CWR_NO_SMALL', '1')
+    monkeypatch.setenv('CWR_TEST_BIG', '1')
+    monkeypatch.setenv('CWR_TCL_GRID', str(grid))
+    monkeypatch.setenv('CWR_TILE_ORDER', 'lanes')
+    monkeypatch.setenv('CWR_TEST_POISON_HALO', '1')
+    monkeypatch.setenv('CWR_TEST_DETERMINISTIC', '1')
+    runs = [run_ranks(world, _rank_main, (K, 'jacobi', depth)) for _ in range(2)]
+    for results in runs:
+        assert all(r[14] for r in results), 'no schedule was built on some rank'
+        assert all(k == 2 for r in results for k in r[15]), [r[15] for r in results]
+        assert all(r[6] == results[0][6] for r in results)
+        for r in (results[0], results[-1]):
+            assert sum(o for _, o, _ in r[13]) > 0, r[13]            # overlapped exchanges
+    for a, b in zip(*runs):
+        assert np.array_equal(a[3], b[3]) and a[6] == b[6]              # bit for bit, the same sweeps
+    mesh, inputs3 = make_case(K)
+    n = mesh['nreal'] + 1
+    oracle.derive_coefficients(mesh)
+    ref = oracle.OracleModel(mesh, {f'c{k}': inputs3[:, :, k].copy() for k in range(K)})
+    for _ in range(3):
+        ref.update()
+    want = np.stack([ref.constituent_dict[f'c{k}'].state[3, :n] for k in range(K)], axis=1)
+    state = np.full((n, K), np.nan)
+    for r in runs[0]:
+        state[r[1]] = r[3]
+    assert rel_err(state, want) <= 1e-9
+    # the same ranks without the flag: in place at more than 8 constituents (chained = 1); up to 8 the deterministic passes are the default
+    monkeypatch.delenv('CWR_TEST_DETERMINISTIC')
+    plain = run_ranks(world, _rank_main, (K, 'jacobi', depth))
+    assert all(k == (1 if K > 8 else 2) for r in plain for k in r[15]), [r[15] for r in plain]
