@@ -80,6 +80,7 @@ struct cwr_engine {
   int dev = 0;
   hipStream_t stream = nullptr;
   int n_owned = 0, n_halo = 0, n_real = 0, n_cells = 0, n_ghost = 0, E = 0, K = 0;
+  int Ku = 0;                   // the caller's constituents; K >= Ku is the engine's internal row width (pad_constituents: zero columns behind Ku)
   int n_core = 0;               // rows this rank owns (<= n_owned = rows it computes); inner products, results
   int exch_every = 1;           // Jacobi sweeps between two halo exchanges (= halo depth)
   int VW = 1, G = 1, R = 1;
@@ -111,6 +112,14 @@ struct cwr_engine {
          *d_t = nullptr, *d_b = nullptr;
   double* d_chk = nullptr;       // [4][K] convergence-check scalars of the Jacobi path: ||x'-x||^2, ||bhat||^2 (sums) and the
                                  // element-wise measures max(|x'-x| - ew_rel |x'|), max |x'| (k_apply MODE 4)
+  // (round 5) the check scalars of a single engine reach the host without a copy and without draining the stream: k_reduce_partials
+  // stores them into this page-locked buffer and publishes a sequence number behind them (ReduceNote); the host spins on it
+  double* h_note = nullptr;        // [4 K] doubles + the sequence word (hipHostMalloc, mapped)
+  unsigned long long* h_note_seq = nullptr;
+  unsigned long long* d_note_state = nullptr;   // device: [0] the sequence counter, [1] (as unsigned int) the arrival counter
+  unsigned long long note_expected = 0;         // notifications enqueued so far
+  bool use_note = true;            // CWR_NO_NOTE=1: the download of round 4 (A/B)
+  bool fused_begin = true;         // k_begin_step: operator set-up + right-hand side + kept rows + ghost write-back in one launch (CWR_NO_FUSED_BEGIN=1: round 4's three)
   double* d_chkx = nullptr;      // partitioned engines: [rr | bb | world x (m1 | m2)] -- the one all-reduce of a check (gather_check)
   double* d_keep = nullptr;      // x_t (computed rows, written by k_rhs) and the ghost rows as the step found them: a failed
                                  // step restores the state from here
@@ -121,7 +130,7 @@ struct cwr_engine {
   double ew_rel = 0.0, ew_abs = 0.0;
   std::vector<double> jnorm;     // per level t: ||J||_inf of step t's Jacobi iteration matrix (k_jnorm, when the flow field is loaded)
   // per level t: F_t with ||x* - x'||_inf <= F_t ||x' - x||_inf for a Jacobi sweep x -> x' of step t: what the element-wise rule
-  // is scaled by.  ||J||_inf / (1 - ||J||_inf) where that is finite, and -- single engines -- the row-wise bound of
+  // is scaled by.  ||J||_inf / (1 - ||J||_inf) where that is finite, and the row-wise bound of
   // refine_error_factors where that is smaller (near-dry rows, rows next to dry cells: see there)
   std::vector<double> err_factor;
   int neumann_sweeps = 128;      // sweeps refine_error_factors may spend per level (CWR_BOUND_SWEEPS; 0 = norm bound only)
@@ -291,11 +300,29 @@ struct cwr_engine {
   double* rho(int slot) const { return d_scal + (size_t)3 * ACC_N * K + (size_t)slot * K; }
   double* bb() const { return d_scal + (size_t)3 * ACC_N * K + (size_t)3 * K; }
   size_t scal_count() const { return (size_t)3 * ACC_N * K + 3 * K + K; }
+  // allocated / cleared size of d_scal (scalars + 8 counters + the precondition flag), a multiple of 256 bytes: ONE fill kernel per memset
+  size_t scal_alloc() const { return (scal_count() + 5 + 31) & ~(size_t)31; }
   double* bad_flag() const { return d_scal + scal_count() + 4; }   // 1.0 when k_rhs met the zero-coefficient precondition (behind the 8 counters)
   bool ghost_bad_any = false;    // partitioned engines: some rank met it (all-reduced with the check scalars)
 };
 
 namespace {
+
+// Every ABI entry that touches the device goes through here: the calling thread's stream-capture interaction mode becomes
+// ThreadLocal (once per thread), then the device is selected.  A thread's mode defaults to Global, in which the HIP runtime refuses
+// its "potentially unsafe" calls (allocations, synchronous copies, stream-memory operations) while ANY stream of the process is
+// being captured -- two engines driven by two threads of one process (SURVEY 8b allows "one process (or thread) per GPU") then fail
+// with "operation not permitted when stream is capturing" as soon as one of them captures a batch of passes into a hipGraph
+// (gpurun_out/r04f_eight.log).  In ThreadLocal mode only the thread's OWN captures count, and those never enclose such a call.
+hipError_t enter_device(int dev) {
+  static thread_local bool mode_set = false;
+  if (!mode_set) {
+    hipStreamCaptureMode m = hipStreamCaptureModeThreadLocal;
+    (void)hipThreadExchangeStreamCaptureMode(&m);
+    mode_set = true;
+  }
+  return hipSetDevice(dev);
+}
 
 int fail(cwr_engine* e, int code, const std::string& msg) {
   if (e) e->err = msg; else g_create_error = msg;
@@ -308,6 +335,8 @@ int fail(cwr_engine* e, int code, const std::string& msg) {
     if (_st != hipSuccess)                                                                     \
       return fail((e), CWR_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_st));       \
   } while (0)
+
+#define TRY_(call) do { int _rc = (call); if (_rc != CWR_OK) return _rc; } while (0)
 
 #define NCCL_TRY(e, call)                                                                      \
   do {                                                                                         \
@@ -343,6 +372,30 @@ template <typename T> int download(cwr_engine* e, T* dst, const T* src, size_t c
 
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// rows of the caller's Ku values <-> the engine's rows of K >= Ku values (zero columns behind Ku; see pad_constituents)
+int upload_cols(cwr_engine* e, double* dst, const double* src, size_t rows) {
+  if (e->K == e->Ku) return upload(e, dst, src, rows * (size_t)e->K);
+  if (rows == 0) return CWR_OK;
+  DevTmp<double> tmp;
+  TRY_(dev_alloc(e, &tmp.p, rows * (size_t)e->Ku));
+  TRY_(upload(e, tmp.p, src, rows * (size_t)e->Ku));
+  const int64_t total = (int64_t)rows * e->K;
+  k_pad_cols<<<(int)std::max<int64_t>(1, std::min<int64_t>(cdiv(total, BLOCK), 256 * 16)), BLOCK, 0, e->stream>>>(total, e->Ku, e->K, tmp.p, dst);
+  HIP_TRY(e, hipGetLastError());
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return CWR_OK;
+}
+int download_cols(cwr_engine* e, double* dst, const double* src, size_t rows) {
+  if (e->K == e->Ku) return download(e, dst, src, rows * (size_t)e->K);
+  if (rows == 0) return CWR_OK;
+  DevTmp<double> tmp;
+  TRY_(dev_alloc(e, &tmp.p, rows * (size_t)e->Ku));
+  const int64_t total = (int64_t)rows * e->Ku;
+  k_strip_cols<<<(int)std::max<int64_t>(1, std::min<int64_t>(cdiv(total, BLOCK), 256 * 16)), BLOCK, 0, e->stream>>>(total, e->Ku, e->K, src, tmp.p);
+  HIP_TRY(e, hipGetLastError());
+  return download(e, dst, tmp.p, rows * (size_t)e->Ku);
+}
+
 // Blocks of `fn` (BLOCK threads, `lds` bytes of dynamic LDS) that are resident on a CU at once -- the size of a PERSISTENT grid,
 // whose blocks walk a static share of the work: a block that is not resident from the start runs its share after the others
 // are done.  The occupancy query counts 5 blocks of 32 704 B (tiled pass, K = 1) into the 160 KB of LDS and the hardware
@@ -367,9 +420,12 @@ int prep_step(cwr_engine* e, int t) {
 }
 
 int reduce_partials(cwr_engine* e, int nslots, int ND, double* o0, double* o1 = nullptr, double* o2 = nullptr, double* o3 = nullptr,
-                    int max_from = 1 << 20) {
+                    int max_from = 1 << 20, bool notify = false) {
   ReduceOuts outs; outs.p[0] = o0; outs.p[1] = o1; outs.p[2] = o2; outs.p[3] = o3;
-  k_reduce_partials<<<ND, RBLOCK, 0, e->stream>>>(nslots, ND, e->K, e->d_partial, outs, max_from);
+  ReduceNote note{nullptr, nullptr, nullptr, nullptr};
+  if (notify && e->h_note && ND == 4 && o0 && o1 && o2 && o3)
+    note = ReduceNote{e->h_note, e->h_note_seq, reinterpret_cast<unsigned int*>(e->d_note_state + 1), e->d_note_state};
+  k_reduce_partials<<<ND, RBLOCK, 0, e->stream>>>(nslots, ND, e->K, e->d_partial, outs, max_from, note);
   HIP_TRY(e, hipGetLastError());
   return CWR_OK;
 }
@@ -495,18 +551,45 @@ int allreduce(cwr_engine* e, double* p, size_t count) {
 #define TRY(call) do { int _rc = (call); if (_rc != CWR_OK) return _rc; } while (0)
 
 // the closing check of a batch of sweeps: fold the per-block partials of the last MODE 4 launch into d_chk
-int reduce_check(cwr_engine* e) {
+int reduce_check(cwr_engine* e, bool notify = false) {
   const int K = e->K;
-  return reduce_partials(e, e->last_apply_grid, 4, e->d_chk, e->d_chk + K, e->d_chk + 2 * K, e->d_chk + 3 * K, 2);
+  return reduce_partials(e, e->last_apply_grid, 4, e->d_chk, e->d_chk + K, e->d_chk + 2 * K, e->d_chk + 3 * K, 2, notify);
+}
+
+// single engines (and a stand-alone rank): may this check be read from the notification buffer instead of a download?
+bool check_by_note(const cwr_engine* e) { return e->use_note && e->h_note && (!e->comm || (e->world == 1 && !e->force_coll)); }
+
+// Wait for the `note_expected`-th notification of k_reduce_partials and take the check scalars from the host buffer.  The host
+// spins on a word of page-locked memory: no copy is enqueued and the stream is not drained -- whatever was enqueued BEHIND the
+// reduction (the step's speculative tail) runs on while the host already decides and enqueues the next step.
+int wait_check_note(cwr_engine* e, double* h) {
+  const unsigned long long want = e->note_expected;
+  for (unsigned long long spin = 1;; ++spin) {
+    if (__atomic_load_n(e->h_note_seq, __ATOMIC_ACQUIRE) >= want) break;
+    __builtin_ia32_pause();
+    if ((spin & 0xFFFFu) == 0) {
+      // a fault on the stream would otherwise leave the host spinning: ask the runtime every 65 536 spins
+      const hipError_t st = hipStreamQuery(e->stream);
+      if (st != hipSuccess && st != hipErrorNotReady) return fail(e, CWR_ERR_HIP, std::string("convergence check: ") + hipGetErrorString(st));
+      if (st == hipSuccess && __atomic_load_n(e->h_note_seq, __ATOMIC_ACQUIRE) < want) {
+        // (the stream is idle and the word has not moved: settle once more, then give up loudly)
+        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        if (__atomic_load_n(e->h_note_seq, __ATOMIC_ACQUIRE) < want) return fail(e, CWR_ERR_HIP, "convergence check: the stream drained without the notification");
+      }
+    }
+  }
+  std::memcpy(h, e->h_note, 4 * (size_t)e->K * sizeof(double));
+  return CWR_OK;
 }
 
 // The check scalars of every rank, on the host: h = [rr | bb | m1 | m2] with the sums added and the maxima taken over the
 // ranks.  ONE all-reduce (sum) carries both: every rank adds its two maxima in its own slot of a (world x 2K) block that is
 // zero elsewhere, and the host takes the maximum over the slots -- a second (max) collective would cost another 20-40 us of
 // latency per check.  Single GPU: a plain download.
-int gather_check(cwr_engine* e, double* h) {
+int gather_check(cwr_engine* e, double* h, bool noted = false) {
   const size_t K = (size_t)e->K;
   ++e->step_checks;
+  if (noted) return wait_check_note(e, h);                      // (the reduction of this check was launched with a notification)
   if (!e->comm || (e->world == 1 && !e->force_coll)) return download(e, h, e->d_chk, 4 * K);
   // (+ one word: the zero-coefficient precondition flag of k_rhs, so that every rank learns of a violation on ANY rank with the
   // check it downloads anyway -- the step used to end with a second, blocking download of the rank's own counters, which also
@@ -558,6 +641,22 @@ int launch_rhs(cwr_engine* e, int t, const double* x, double* b, bool scale, dou
   else            { if (scale) CWR_RHS(1, true); else CWR_RHS(1, false); }
 #undef CWR_RHS
   HIP_TRY(e, hipGetLastError());
+  return CWR_OK;
+}
+
+// the opening of step t in one launch (k_begin_step): what prep_step + launch_rhs(scale, keep) + the ghost write-back of step_tail did
+int launch_begin_step(cwr_engine* e, int t) {
+  const size_t E = e->E;
+  const int used = (e->D != 0.0) ? 1 : 0;
+#define CWR_BEGIN(VWv) k_begin_step<VWv><<<cdiv(e->n_owned, BLOCK), BLOCK, 0, e->stream>>>(e->n_owned, e->n_real, e->n_cells, e->K, e->G, e->d_ptr, \
+    e->d_ent_edge, e->d_ent_nb, e->d_adv + (size_t)t * E, e->d_dif + (size_t)t * E, e->d_vol + (size_t)(t + 1) * e->n_cells, e->dt[t], e->d_rec, \
+    e->d_diag, e->d_w, e->d_vol + (size_t)t * e->n_cells, e->d_vel + (size_t)(t + 1) * E, e->d_adv + (size_t)(t + 1) * E, e->d_dif + (size_t)(t + 1) * E, \
+    used, e->d_bc + (size_t)(t + 1) * e->n_ghost * e->K, e->d_c, e->d_row_ghost, e->d_b, e->d_counters, e->d_keep, e->d_chk + 4 * (size_t)e->K, e->ew_rel, \
+    e->bad_flag())
+  if (e->VW == 2) CWR_BEGIN(2); else CWR_BEGIN(1);
+#undef CWR_BEGIN
+  HIP_TRY(e, hipGetLastError());
+  e->prepared_t = t;
   return CWR_OK;
 }
 
@@ -703,36 +802,79 @@ int sync_jnorms(cwr_engine* e) {
 // neighbours.  w is bounded rigorously from the Neumann series: w_m = sum_{k<=m} J^k 1 (m sweeps of w <- 1 + J w from 1),
 // r_m = w_{m+1} - w_m = J^{m+1} 1 >= 0, and w - w_{m+1} = (I - J)^-1 J r_m <= ||r_m||_inf (w - 1), so
 //     max(w) - 1 <= max(w_{m+1} - 1) / (1 - ||r_m||_inf)          once ||r_m||_inf < 1.
-// Evaluated once per loaded level with the engine's own sweep kernel (all K columns carry the same numbers); single engines
-// only (the rows of a rank's halo layers would need an exchange per sweep: partitioned engines keep the norm bound).
+// Evaluated once per loaded level with the engine's own sweep kernel (all K columns carry the same numbers).
+// Partitioned engines (round 5): the same sweeps over the rank's computed rows (core + replayed layers) with one halo exchange per
+// `exch_every` sweeps -- the deep halo serves the Neumann vector exactly as it serves the solver's sweeps -- and ONE all-reduce per
+// check that carries every rank's (||r_m||_inf, max w) in a slot of its own: every rank ends with the factor of the GLOBAL matrix, the
+// one a single engine would hold, and takes the same stop decisions.  COLLECTIVE then: called where the flow field is loaded with a
+// communicator attached, or where the communicator is attached to an engine that holds a flow field (cwr_attach_comm).
+int bound_check(cwr_engine* e, double* r, double* wmax) {
+  const size_t K = (size_t)e->K;
+  if (!e->comm || (e->world == 1 && !e->force_coll)) {
+    std::vector<double> h(4 * K);
+    TRY(download(e, h.data(), e->d_chk, 4 * K));
+    *r = h[2 * K]; *wmax = h[3 * K];
+    return CWR_OK;
+  }
+  const size_t W = (size_t)e->world, n = 2 * W;                 // (d_chkx holds (2 + 2 W) K + 1 doubles)
+  HIP_TRY(e, hipMemsetAsync(e->d_chkx, 0, n * sizeof(double), e->stream));
+  HIP_TRY(e, hipMemcpyAsync(e->d_chkx + 2 * (size_t)e->rank, e->d_chk + 2 * K, sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(e->d_chkx + 2 * (size_t)e->rank + 1, e->d_chk + 3 * K, sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+  TRY(allreduce(e, e->d_chkx, n));
+  std::vector<double> all(n);
+  TRY(download(e, all.data(), e->d_chkx, n));
+  double rr = 0.0, ww = 0.0;
+  for (size_t q = 0; q < W; ++q) {                              // (a NaN on any rank is everybody's NaN: no bound from there)
+    const double a = all[2 * q], b = all[2 * q + 1];
+    rr = (a != a || rr != rr) ? NAN : std::max(rr, a);
+    ww = (b != b || ww != ww) ? NAN : std::max(ww, b);
+  }
+  *r = rr; *wmax = ww;
+  return CWR_OK;
+}
+
 int refine_error_factors(cwr_engine* e) {
   const int T = e->T;
-  if (e->n_halo != 0 || e->comm || T < 2 || e->neumann_sweeps <= 0 || e->err_factor.size() != (size_t)T) return CWR_OK;
+  if (T < 2 || e->neumann_sweeps <= 0 || e->err_factor.size() != (size_t)T) return CWR_OK;
+  // an engine with halo rows and no communicator (yet): its halo rows would stay at w = 1 -- no bound of the global matrix;
+  // cwr_attach_comm calls again
+  if ((!e->comm || e->peers.empty()) && e->n_halo != 0) return CWR_OK;    // (a stand-alone rank likewise: its halo rows are frozen)
+  const bool part = e->comm && (e->world > 1 || e->force_coll);
   const int K = e->K;
   const size_t nK = (size_t)e->n_real * K;
   const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv((int64_t)nK, BLOCK), 256 * 8));
-  std::vector<double> h(4 * (size_t)K);
   const bool was_prof = e->profiling; e->profiling = false;
+  const int keep_mode = e->dominant_mode; e->dominant_mode = -1;
   int rc = CWR_OK;
   for (int t = 0; t + 1 < T && rc == CWR_OK; ++t) {
-    if (e->err_factor[(size_t)t] <= 3.0) continue;                           // (see below: nothing to gain)
+    // (the scale s = 0.3 / F of the element-wise rule is held within [1e-3, 0.1]: a factor below 3 changes nothing, so a level whose
+    // norm form is already there needs no sweeps, and the sweeps stop as soon as the bound is.  Partitioned: err_factor comes from the
+    // all-reduced norms, so every rank skips the same levels)
+    if (e->err_factor[(size_t)t] <= 3.0) continue;
     rc = prep_step(e, t);
     if (rc != CWR_OK) break;
     k_fill<<<grid, BLOCK, 0, e->stream>>>((int64_t)nK, 1.0, e->d_r0, e->d_r);
     if (hipMemsetAsync(e->d_chk + 4 * (size_t)K, 0, sizeof(double), e->stream) != hipSuccess) { rc = fail(e, CWR_ERR_HIP, "hipMemsetAsync failed"); break; }
     double* x = e->d_r; double* y = e->d_v;
     double best = e->err_factor[(size_t)t];
-    // (the scale s = 0.3 / F of the element-wise rule is held within [1e-3, 0.1]: a factor below 3 changes nothing, so a level whose
-    // norm form is already there needs no sweeps, and the sweeps stop as soon as the bound is)
-    if (best <= 3.0) continue;
+    int since_exchange = 0;                                                  // (w_0 = 1 on every row, halo rows included: exact everywhere)
+    if (part) {
+      k_fill<<<grid, BLOCK, 0, e->stream>>>((int64_t)nK, 1.0, e->d_v, nullptr);    // (the partner's read-only layer too)
+      if (hipGetLastError() != hipSuccess) { rc = fail(e, CWR_ERR_HIP, "k_fill failed"); break; }
+    }
     for (int done = 0; done < e->neumann_sweeps && rc == CWR_OK;) {
       const int batch = done == 0 ? 12 : 8;                                  // (one host round trip decides most levels: see the stop rules below)
-      for (int q = 0; q < batch && rc == CWR_OK; ++q) { rc = launch_apply<4>(e, x, y, nullptr, e->d_r0, nullptr, nullptr); std::swap(x, y); }
+      for (int q = 0; q < batch && rc == CWR_OK; ++q) {
+        if (part && since_exchange >= e->exch_every) { rc = exchange_halo(e, x, y); since_exchange = 0; if (rc != CWR_OK) break; }
+        rc = launch_apply<4>(e, x, y, nullptr, e->d_r0, nullptr, nullptr);
+        std::swap(x, y); ++since_exchange;
+      }
       done += batch;
       if (rc == CWR_OK) rc = reduce_check(e);
-      if (rc == CWR_OK) rc = download(e, h.data(), e->d_chk, 4 * (size_t)K);
+      double r = 0.0, wmax = 0.0;
+      if (rc == CWR_OK) rc = bound_check(e, &r, &wmax);
       if (rc != CWR_OK) break;
-      const double r = h[2 * (size_t)K], wmax = h[3 * (size_t)K];           // ||w_{m+1} - w_m||_inf, max(w_{m+1}) (every column alike)
+      // r = ||w_{m+1} - w_m||_inf, wmax = max(w_{m+1}) (every column alike; over the core rows of every rank)
       if (!std::isfinite(r) || !std::isfinite(wmax)) break;                  // NaN in the field: no bound from here
       if (r < 1.0) best = std::min(best, (wmax - 1.0) / (1.0 - r));
       if (r <= 0.1 || best <= 3.0) break;                                    // within 11 % of max(w) - 1, or below what matters
@@ -743,7 +885,9 @@ int refine_error_factors(cwr_engine* e) {
     e->err_factor[(size_t)t] = best;
   }
   e->profiling = was_prof;
+  e->dominant_mode = keep_mode;
   e->prepared_t = -1;
+  e->step_exchanges = e->step_overlapped = 0;
   return rc;
 }
 
@@ -765,6 +909,9 @@ int sync_input_levels(cwr_engine* e) {
   for (size_t t = 0; t < T; ++t) e->in_any[t] = flags[t] > 0.0 ? 1 : 0;
   return CWR_OK;
 }
+
+// Constituent columns the engine carries internally for a caller's K (see cwr_create: zero columns where that is faster)
+int pad_constituents(int K);
 
 // Rows (lane-group slots) of a tile of the tiled pass for K constituents -- also what cwr_tile_rows tells a host wrapper that
 // wants to arrange its cell numbering in tiles (ordering.balance_windows).
@@ -789,6 +936,18 @@ int tile_rows_for(int K, bool* four_wide) {
   }
   if (four_wide) *four_wide = want4;
   return std::max(1, std::min(tr, BLOCK));
+}
+
+// (round 5) Constituent counts off the kernels' wide mappings fall off a cliff: odd K runs one constituent per lane, K = 10 two per
+// lane on 5-lane groups -- 1 M cells, ms per step (profiles/r04_zc_per_K_final.txt): K = 3: 1.316 vs 4: 1.199; 5: 1.834 vs 6: 1.629 and
+// 8: 1.757; 10: 2.285 vs 12: 2.146.  The reference's cost is linear in K (transport.py:231), so the engine carries such a K as the next
+// count that runs well: zero columns behind the caller's (zero state, zero boundary values: they solve to zero, pass every check at
+// once and are stripped at every read-out).  Table measured once (profiles/r05_per_K.txt); CWR_K_PAD=0: the caller's K as it is.
+int pad_constituents(int K) {
+  if (const char* v = getenv("CWR_K_PAD")) if (atoi(v) == 0) return K;
+  if (K <= 2 || K > 252) return K;
+  if (K <= 8) return (K & 1) ? K + 1 : K;                       // 3 -> 4, 5 -> 6, 7 -> 8
+  return (K + 3) & ~3;                                           // 9, 10, 11 -> 12; 13, 14, 15 -> 16; ...
 }
 
 #define CWR_TCL_K(VWv, Q) k_sq_tiled<VWv, TCL_CFG[Q].wrn, TCL_CFG[Q].ut, TCL_CFG[Q].xr>
@@ -1209,7 +1368,7 @@ int step_tail(cwr_engine* e, int t, int flags) {
       HIP_TRY(e, hipGetLastError());
     }
   }
-  if (gk > 0) {
+  if (gk > 0 && !e->fused_begin) {                    // (k_begin_step has written them)
     k_ghost_writeback<<<cdiv(gk, BLOCK), BLOCK, 0, e->stream>>>(gk, e->d_bc + (size_t)(t + 1) * gk, e->d_c + (size_t)e->n_real * K);
     HIP_TRY(e, hipGetLastError());
   }
@@ -1287,6 +1446,7 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
                               (size_t)(e->n_real - e->n_core) * K * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
   e->dominant_mode = tiled ? 6 : (sq ? 5 : 4);
   st.sweep_kernel = e->dominant_mode;
+  const bool noted = check_by_note(e);
   for (;;) {
     want = std::min(want, std::max(2, sweep_limit - st.sweeps));       // max_iter bounds the first batch too
     batch = std::max(2, std::min((want + 1) & ~1, 4096));               // even: the result lands in the state vector
@@ -1382,7 +1542,7 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
             int rc = launch_passes(0, doubles);
             if (rc == CWR_OK) rc = launch_apply<4>(e, srcb(doubles), dstb(doubles), nullptr, e->d_b, nullptr, nullptr);
             if (rc == CWR_OK && !one_closing) rc = launch_apply<4>(e, srcb(doubles + 1), dstb(doubles + 1), nullptr, e->d_b, nullptr, nullptr);
-            if (rc == CWR_OK) rc = reduce_check(e);
+            if (rc == CWR_OK) rc = reduce_check(e, noted);
             hipGraph_t g = nullptr;
             const hipError_t ec = hipStreamEndCapture(e->stream, &g);
             if (!(rc == CWR_OK && ec == hipSuccess && g && hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess)) { ex = nullptr; (void)hipGetLastError(); }
@@ -1555,12 +1715,13 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
       ++since_exchange;
     }
     st.sweeps += batch; st.launches += launches;
-    if (!batch_graph) TRY(reduce_check(e));
+    if (!batch_graph) TRY(reduce_check(e, noted));
+    if (noted) ++e->note_expected;                                        // (one notifying reduction per batch, replayed graph or not)
     bool speculated = false;
     // (partitioned engines too: every rank takes the same decisions from the all-reduced check, so a speculative tail --
     // whose exchange is a collective -- is entered and, if the check fails, repeated by all ranks alike)
     if (e->spec_t >= 0) { TRY(step_tail(e, e->spec_t, e->spec_flags)); speculated = true; }
-    TRY(gather_check(e, h.data()));
+    TRY(gather_check(e, h.data(), noted));
     // (a rank met the zero-coefficient precondition: its right-hand side is NaN-poisoned, every rank leaves here with the same code)
     if (e->comm && e->ghost_bad_any) { st.status = CWR_ERR_GHOST_COEFF; return CWR_ERR_GHOST_COEFF; }
     bool ok = true;
@@ -1763,25 +1924,48 @@ int solve_bicgstab(cwr_engine* e, double tol2, int max_iter, SolveStats& st) {
 // ====================================================================================================
 extern "C" {
 
-int32_t cwr_abi_version(void) { return 5; }
+int32_t cwr_abi_version(void) { return 6; }
 
 int32_t cwr_tile_rows(int32_t n_constituents) {
   if (n_constituents < 1 || n_constituents > 256) return 0;
   // (a work-item build with CWR_TCL_SPLIT=1 splits long rows itself and its tiles hold a variable number of rows, so a fixed
   // window would straddle tiles -- measured 38 -> 52 us per pass with sorted 256-row windows: no arrangement wanted then)
   if (CWR_WORK_ITEMS && n_constituents == 1 && getenv("CWR_TCL_SPLIT") && atoi(getenv("CWR_TCL_SPLIT")) != 0) return 0;
-  return tile_rows_for(n_constituents, nullptr);
+  return tile_rows_for(pad_constituents(n_constituents), nullptr);
+}
+
+// From how many rows an engine with K constituents chains its tiles (the rule of ensure_sq_pattern, evaluated for the usual four
+// resident blocks per CU): what a host wrapper that chooses the cell numbering BEFORE it creates the engine asks, so that numbering
+// (lanes along the flow for chains, the Hilbert curve for ping-pong passes) and engine follow ONE threshold, CWR_CHAIN_MIN_TILES
+// included (the wrapper used to carry its own copy of the constant and a hard-coded grid).
+int32_t cwr_chain_min_rows(int32_t n_constituents) {
+  if (n_constituents < 1 || n_constituents > 256) return 0;
+  double min_tiles = 1.75;
+  if (const char* v = getenv("CWR_CHAIN_MIN_TILES")) min_tiles = std::max(1.0, atof(v));
+  if (const char* v = getenv("CWR_NO_CHAINS")) if (atoi(v) != 0) return INT32_MAX;
+  int n_cu = 256;
+  hipDeviceProp_t prop;
+  int dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+  else (void)hipGetLastError();
+  int per_cu = 4;
+  if (const char* v = getenv("CWR_TCL_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(8, atoi(v)));
+  int grid = (n_cu * per_cu / N_XCD) * N_XCD;
+  if (const char* v = getenv("CWR_TCL_GRID")) grid = std::max(N_XCD, std::min(grid, atoi(v) / N_XCD * N_XCD));
+  const double rows = std::ceil(min_tiles * grid) * (double)tile_rows_for(pad_constituents(n_constituents), nullptr);
+  return rows >= 2147483647.0 ? INT32_MAX : (int32_t)rows;
 }
 
 const char* cwr_last_error(const cwr_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
 
-int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_edges, int32_t K,
+int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_edges, int32_t K_user,
                    const int32_t* face1, const int32_t* face2, int32_t device, cwr_engine** out) {
   if (!out) return fail(nullptr, CWR_ERR_BAD_ARG, "out is NULL");
   *out = nullptr;
-  if (n_owned <= 0 || n_halo < 0 || n_edges < 0 || K <= 0 || K > 256 || !face1 || !face2 ||
+  if (n_owned <= 0 || n_halo < 0 || n_edges < 0 || K_user <= 0 || K_user > 256 || !face1 || !face2 ||
       n_cells < n_owned + n_halo)
     return fail(nullptr, CWR_ERR_BAD_ARG, "cwr_create: bad sizes or NULL topology");
+  const int K = pad_constituents(K_user);       // the engine's internal row width (zero columns behind the caller's: see there)
   const int n_real = n_owned + n_halo;
   if ((double)n_cells * K * 8.0 >= 4294967296.0)
     return fail(nullptr, CWR_ERR_BAD_ARG, "cwr_create: n_cells * K * 8 bytes must stay below 4 GiB per engine (32-bit row offsets); partition the mesh");
@@ -1830,7 +2014,7 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   eng->h_edge.assign(ent_edge.begin(), ent_edge.begin() + nnz);
   eng->n_core = n_owned;
   eng->n_owned = n_owned; eng->n_halo = n_halo; eng->n_real = n_real; eng->n_cells = n_cells;
-  eng->n_ghost = n_cells - n_real; eng->E = n_edges; eng->K = K; eng->nnz = nnz;
+  eng->n_ghost = n_cells - n_real; eng->E = n_edges; eng->K = K; eng->Ku = K_user; eng->nnz = nnz;
   eng->VW = (K % 2 == 0) ? 2 : 1;
   eng->G = K / eng->VW;
   eng->R = BLOCK / eng->G;
@@ -1888,7 +2072,7 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
 
 #define CREATE_TRY(call) do { int _rc = (call); if (_rc != CWR_OK) { g_create_error = eng->err; cwr_destroy(eng); return _rc; } } while (0)
 #define CREATE_HIP(call) do { hipError_t _st = (call); if (_st != hipSuccess) { g_create_error = std::string(#call) + ": " + hipGetErrorString(_st); cwr_destroy(eng); return CWR_ERR_HIP; } } while (0)
-  CREATE_HIP(hipSetDevice(device));
+  CREATE_HIP(enter_device(device));
   CREATE_HIP(hipStreamCreateWithFlags(&eng->stream, hipStreamNonBlocking));
   if (eng->apply_lds > 48 * 1024) {
     CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_apply<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)eng->apply_lds));
@@ -1924,6 +2108,19 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   CREATE_TRY(dev_alloc(eng, &eng->d_chk, 4 * (size_t)K + 2));      // (+ ew_rel, read by k_apply MODE 4)
   CREATE_HIP(hipMemset(eng->d_chk, 0, (4 * (size_t)K + 2) * sizeof(double)));
   CREATE_TRY(dev_alloc(eng, &eng->d_keep, (size_t)n_cells * K));
+  if (const char* v = getenv("CWR_NO_NOTE")) eng->use_note = atoi(v) == 0;
+  if (const char* v = getenv("CWR_NO_FUSED_BEGIN")) eng->fused_begin = atoi(v) == 0;
+  if (eng->use_note) {
+    // (a runtime that cannot map host memory leaves h_note null: the checks are downloaded as before)
+    void* hp = nullptr;
+    if (hipHostMalloc(&hp, (4 * (size_t)K + 2) * sizeof(double), hipHostMallocMapped) == hipSuccess && hp) {
+      std::memset(hp, 0, (4 * (size_t)K + 2) * sizeof(double));
+      eng->h_note = static_cast<double*>(hp);
+      eng->h_note_seq = reinterpret_cast<unsigned long long*>(eng->h_note + 4 * (size_t)K);
+      CREATE_TRY(dev_alloc(eng, &eng->d_note_state, 2));
+      CREATE_HIP(hipMemset(eng->d_note_state, 0, 2 * sizeof(unsigned long long)));
+    } else (void)hipGetLastError();
+  }
   if (const char* v = getenv("CWR_NO_ELEMENTWISE")) eng->ew_enabled = atoi(v) == 0;
   CREATE_TRY(dev_alloc(eng, &eng->d_c, (size_t)n_cells * K));
   CREATE_TRY(dev_alloc(eng, &eng->d_r, nK));
@@ -1934,7 +2131,7 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   CREATE_TRY(dev_alloc(eng, &eng->d_t, nK));
   CREATE_TRY(dev_alloc(eng, &eng->d_b, nK));
   // (the 8 step counters live behind the solver scalars: one memset clears both at the start of a step)
-  CREATE_TRY(dev_alloc(eng, &eng->d_scal, eng->scal_count() + 5));      // (+ 8 int32 counters + the precondition flag as a double)
+  CREATE_TRY(dev_alloc(eng, &eng->d_scal, eng->scal_alloc()));      // (+ 8 int32 counters + the precondition flag as a double)
   eng->d_counters = reinterpret_cast<int32_t*>(eng->d_scal + eng->scal_count());
   CREATE_TRY(dev_alloc(eng, &eng->d_partial, (size_t)2 * std::max(eng->apply_grid, 256 * 8) * 4 * K));   // (x 2: a sweep in two launches, see n_apply_inner)
   if (getenv("CWR_VERBOSE")) fprintf(stderr, "[cwr] K=%d VW=%d G=%d U=%d tiles=%d stage_cap=%d lds=%zu grid=%d\n", K, eng->VW, eng->G, eng->U, eng->ntiles, eng->stage_cap, eng->apply_lds, eng->apply_grid);
@@ -1959,7 +2156,7 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   CREATE_HIP(hipMemsetAsync(eng->d_c, 0, (size_t)n_cells * K * sizeof(double), eng->stream));
   for (double* v : {eng->d_r, eng->d_r0, eng->d_p, eng->d_v, eng->d_s, eng->d_t, eng->d_b})
     CREATE_HIP(hipMemsetAsync(v, 0, nK * sizeof(double), eng->stream));
-  CREATE_HIP(hipMemsetAsync(eng->d_scal, 0, (eng->scal_count() + 5) * sizeof(double), eng->stream));
+  CREATE_HIP(hipMemsetAsync(eng->d_scal, 0, eng->scal_alloc() * sizeof(double), eng->stream));
   CREATE_HIP(hipStreamSynchronize(eng->stream));
 #undef CREATE_TRY
 #undef CREATE_HIP
@@ -1993,6 +2190,8 @@ void cwr_destroy(cwr_engine* e) {
                   e->d_bc, e->d_rec, e->d_diag, e->d_c, e->d_r, e->d_r0, e->d_p, e->d_v, e->d_s, e->d_t, e->d_b,
                   e->d_scal, e->d_partial, e->d_fadv, e->d_fdif, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf, e->d_ptr2, e->d_col2, e->d_row2, e->d_rec2, e->d_w, e->d_react, e->d_info, e->d_tcl_ptr, e->d_tcl_cols, e->d_loc2, e->d_w2, e->d_pair_ptr, e->d_slots, e->d_line_ptr, e->d_line_faces, e->d_ledger, e->d_mass_out, e->d_chk, e->d_face_orig, e->d_row_ghost, e->d_keep, e->d_in_rows, e->d_in_vals, e->d_face_pos, e->d_trow, e->d_vptr, e->d_meta, e->d_tile_inner, e->d_tile_outer, e->d_apply_inner, e->d_apply_outer, e->d_face_inner, e->d_face_outer, e->d_chkx, e->d_sq_fast, e->d_sched, e->d_link_ptr, e->d_link_ent, e->d_link_flux, e->d_scols, e->d_scols_io, e->sched_in.d, e->sched_out.d};
   for (void* p : ptrs) if (p) hipFree(p);
+  if (e->d_note_state) hipFree(e->d_note_state);
+  if (e->h_note) hipHostFree(e->h_note);
   if (e->stream) hipStreamDestroy(e->stream);
   delete e;
 }
@@ -2002,7 +2201,7 @@ int32_t cwr_load_flow_field(cwr_engine* e, int32_t T, const float* face_flow, co
   if (!e) return CWR_ERR_BAD_ARG;
   if (T < 2 || !face_flow || !edge_velocity || !volume || !dt || !dist)
     return fail(e, CWR_ERR_BAD_ARG, "cwr_load_flow_field: need >= 2 time levels and non-NULL arrays");
-  HIP_TRY(e, hipSetDevice(e->dev));
+  HIP_TRY(e, enter_device(e->dev));
   TRY(alloc_flow(e, T));
   const size_t TE = (size_t)T * e->E;
   // the host arrays arrive in the reference's face order: upload to temporaries, gather into the internal face order
@@ -2037,7 +2236,7 @@ int32_t cwr_load_coefficients(cwr_engine* e, int32_t T, const float* adv, const 
   if (!e) return CWR_ERR_BAD_ARG;
   if (T < 2 || !adv || !dif || !vel || !volume || !dt)
     return fail(e, CWR_ERR_BAD_ARG, "cwr_load_coefficients: need >= 2 time levels and non-NULL arrays");
-  HIP_TRY(e, hipSetDevice(e->dev));
+  HIP_TRY(e, enter_device(e->dev));
   TRY(alloc_flow(e, T));
   const size_t TE = (size_t)T * e->E;
   DevTmp<float> t_tmpf; DevTmp<double> t_tmpd;                     // reference face order -> internal face order
@@ -2063,7 +2262,7 @@ int32_t cwr_load_coefficients(cwr_engine* e, int32_t T, const float* adv, const 
 int32_t cwr_get_coefficients(cwr_engine* e, int32_t t, float* adv, double* dif) {
   if (!e) return CWR_ERR_BAD_ARG;
   TRY(check_level(e, t, false));
-  HIP_TRY(e, hipSetDevice(e->dev));
+  HIP_TRY(e, enter_device(e->dev));
   DevTmp<float> t_tmpf; DevTmp<double> t_tmpd;                     // internal face order -> reference face order
   float*& d_tmpf = t_tmpf.p; double*& d_tmpd = t_tmpd.p;
   int rc = CWR_OK;
@@ -2083,22 +2282,22 @@ int32_t cwr_get_coefficients(cwr_engine* e, int32_t t, float* adv, double* dif) 
 int32_t cwr_load_boundary(cwr_engine* e, int32_t T, const double* ghost_conc) {
   if (!e) return CWR_ERR_BAD_ARG;
   if (T < 1 || (!ghost_conc && e->n_ghost > 0)) return fail(e, CWR_ERR_BAD_ARG, "cwr_load_boundary: bad arguments");
-  HIP_TRY(e, hipSetDevice(e->dev));
+  HIP_TRY(e, enter_device(e->dev));
   const size_t cnt = (size_t)T * e->n_ghost * e->K;
   if (e->T_bc != T) {
     hipFree(e->d_bc); e->d_bc = nullptr; e->T_bc = 0;
     TRY(dev_alloc(e, &e->d_bc, cnt));
     e->T_bc = T;
   }
-  TRY(upload(e, e->d_bc, ghost_conc, cnt));
+  TRY(upload_cols(e, e->d_bc, ghost_conc, (size_t)T * e->n_ghost));
   return CWR_OK;
 }
 
 int32_t cwr_set_boundary_level(cwr_engine* e, int32_t t, const double* level) {
   if (!e) return CWR_ERR_BAD_ARG;
   if (t < 0 || t >= e->T_bc) return fail(e, CWR_ERR_STATE, "cwr_set_boundary_level: level outside the loaded boundary array");
-  HIP_TRY(e, hipSetDevice(e->dev));
-  TRY(upload(e, e->d_bc + (size_t)t * e->n_ghost * e->K, level, (size_t)e->n_ghost * e->K));
+  HIP_TRY(e, enter_device(e->dev));
+  TRY(upload_cols(e, e->d_bc + (size_t)t * e->n_ghost * e->K, level, (size_t)e->n_ghost));
   return CWR_OK;
 }
 
@@ -2110,7 +2309,7 @@ int32_t cwr_load_real_inputs(cwr_engine* e, int32_t n_entries, const int32_t* le
     if (level[i] < 1) return fail(e, CWR_ERR_BAD_ARG, "cwr_load_real_inputs: level must be >= 1 (level 0 is the initial state: cwr_set_state)");
     if (i > 0 && level[i] < level[i - 1]) return fail(e, CWR_ERR_BAD_ARG, "cwr_load_real_inputs: entries must be sorted by level");
   }
-  HIP_TRY(e, hipSetDevice(e->dev));
+  HIP_TRY(e, enter_device(e->dev));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   hipFree(e->d_in_rows); hipFree(e->d_in_vals);
   e->d_in_rows = nullptr; e->d_in_vals = nullptr; e->in_levels.clear();
@@ -2118,7 +2317,7 @@ int32_t cwr_load_real_inputs(cwr_engine* e, int32_t n_entries, const int32_t* le
   TRY(dev_alloc(e, &e->d_in_rows, (size_t)n_entries));
   TRY(dev_alloc(e, &e->d_in_vals, (size_t)n_entries * e->K));
   TRY(upload(e, e->d_in_rows, row, (size_t)n_entries));
-  TRY(upload(e, e->d_in_vals, values, (size_t)n_entries * e->K));
+  TRY(upload_cols(e, e->d_in_vals, values, (size_t)n_entries));
   for (int i = 0; i < n_entries; ++i) {
     auto it = e->in_levels.find(level[i]);
     if (it == e->in_levels.end()) e->in_levels[level[i]] = std::make_pair(i, 1); else it->second.second += 1;
@@ -2128,20 +2327,24 @@ int32_t cwr_load_real_inputs(cwr_engine* e, int32_t n_entries, const int32_t* le
 
 int32_t cwr_set_state(cwr_engine* e, const double* conc_owned) {
   if (!e || !conc_owned) return e ? fail(e, CWR_ERR_BAD_ARG, "cwr_set_state: NULL") : CWR_ERR_BAD_ARG;
-  HIP_TRY(e, hipSetDevice(e->dev));
+  HIP_TRY(e, enter_device(e->dev));
   e->halo_fresh = false;
-  TRY(upload(e, e->d_c, conc_owned, (size_t)e->n_core * e->K));
+  TRY(upload_cols(e, e->d_c, conc_owned, (size_t)e->n_core));
   return CWR_OK;
 }
 
 int32_t cwr_react_linear(cwr_engine* e, const double* M) {
   if (!e || !M) return e ? fail(e, CWR_ERR_BAD_ARG, "cwr_react_linear: NULL") : CWR_ERR_BAD_ARG;
   if (e->K > BLOCK) return fail(e, CWR_ERR_BAD_ARG, "cwr_react_linear: K too large");
-  HIP_TRY(e, hipSetDevice(e->dev));
+  HIP_TRY(e, enter_device(e->dev));
   const int K = e->K;
   e->halo_fresh = false;
   if (!e->d_react) TRY(dev_alloc(e, &e->d_react, (size_t)K * K));
-  TRY(upload(e, e->d_react, M, (size_t)K * K));
+  {
+    std::vector<double> Mp((size_t)K * K, 0.0);                  // (the caller's Ku x Ku block; padded columns stay zero)
+    for (int i = 0; i < e->Ku; ++i) for (int j = 0; j < e->Ku; ++j) Mp[(size_t)i * K + j] = M[(size_t)i * e->Ku + j];
+    TRY(upload(e, e->d_react, Mp.data(), (size_t)K * K));
+  }
   const int rows_pb = BLOCK / K;
   const size_t lds = ((size_t)rows_pb * K + (size_t)K * K) * sizeof(double);
   const int grid = std::max(1, std::min(cdiv(e->n_core, rows_pb), 256 * 8));
@@ -2160,21 +2363,23 @@ int32_t cwr_state_device_ptr(cwr_engine* e, void** state, void** stream) {
   return CWR_OK;
 }
 
+int32_t cwr_state_row_stride(const cwr_engine* e) { return e ? e->K : 0; }
+
 int32_t cwr_get_state(cwr_engine* e, double* conc_all) {
   if (!e || !conc_all) return e ? fail(e, CWR_ERR_BAD_ARG, "cwr_get_state: NULL") : CWR_ERR_BAD_ARG;
-  HIP_TRY(e, hipSetDevice(e->dev));
-  TRY(download(e, conc_all, e->d_c, (size_t)e->n_cells * e->K));
+  HIP_TRY(e, enter_device(e->dev));
+  TRY(download_cols(e, conc_all, e->d_c, (size_t)e->n_cells));
   return CWR_OK;
 }
 
 int32_t cwr_apply(cwr_engine* e, int32_t t, const double* x, double* y) {
   if (!e || !x || !y) return e ? fail(e, CWR_ERR_BAD_ARG, "cwr_apply: NULL") : CWR_ERR_BAD_ARG;
   TRY(check_level(e, t, true));
-  HIP_TRY(e, hipSetDevice(e->dev));
-  TRY(upload(e, e->d_p, x, (size_t)e->n_real * e->K));
+  HIP_TRY(e, enter_device(e->dev));
+  TRY(upload_cols(e, e->d_p, x, (size_t)e->n_real));
   TRY(prep_step(e, t));
   TRY(launch_apply<0>(e, e->d_p, e->d_v, nullptr, nullptr, nullptr, nullptr));
-  TRY(download(e, y, e->d_v, (size_t)e->n_owned * e->K));
+  TRY(download_cols(e, y, e->d_v, (size_t)e->n_owned));
   return CWR_OK;
 }
 
@@ -2182,15 +2387,15 @@ int32_t cwr_rhs(cwr_engine* e, int32_t t, const double* x_t, double* b) {
   if (!e || !x_t || !b) return e ? fail(e, CWR_ERR_BAD_ARG, "cwr_rhs: NULL") : CWR_ERR_BAD_ARG;
   TRY(check_level(e, t, true));
   if (e->T_bc < t + 2) return fail(e, CWR_ERR_STATE, "cwr_rhs: boundary values of level t+1 not loaded");
-  HIP_TRY(e, hipSetDevice(e->dev));
-  TRY(upload(e, e->d_s, x_t, (size_t)e->n_owned * e->K));
+  HIP_TRY(e, enter_device(e->dev));
+  TRY(upload_cols(e, e->d_s, x_t, (size_t)e->n_owned));
   HIP_TRY(e, hipMemsetAsync(e->d_counters, 0, 8 * sizeof(int32_t), e->stream));
   TRY(launch_rhs(e, t, e->d_s, e->d_t, false));
   int32_t cnt[8];
   TRY(download(e, cnt, e->d_counters, (size_t)8));
   if (cnt[2]) return fail(e, CWR_ERR_GHOST_COEFF, "active ghost face with a zero advection/diffusion coefficient at level t+1 "
                           "(the reference raises a shape-mismatch ValueError, linalg.py:349-351)");
-  TRY(download(e, b, e->d_t, (size_t)e->n_owned * e->K));
+  TRY(download_cols(e, b, e->d_t, (size_t)e->n_owned));
   return CWR_OK;
 }
 
@@ -2202,7 +2407,7 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
   TRY(check_level(e, t, true));
   if (e->T_bc < t + 2) return fail(e, CWR_ERR_STATE, "cwr_step: boundary values of level t+1 not loaded (cwr_load_boundary)");
   if (!(tol > 0.0) || max_iter < 1) return fail(e, CWR_ERR_BAD_ARG, "cwr_step: tol must be > 0 and max_iter >= 1");
-  HIP_TRY(e, hipSetDevice(e->dev));
+  HIP_TRY(e, enter_device(e->dev));
   const int K = e->K;
   const double tol2 = tol * tol;
   e->profiling = (flags & CWR_STEP_PROFILE) != 0;
@@ -2242,8 +2447,8 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
   if (!e->comm && (size_t)(t + 1) < e->bad_level.size() && e->bad_level[(size_t)t + 1])
     return fail(e, CWR_ERR_GHOST_COEFF, "active ghost face with a zero advection/diffusion coefficient at level t+1 "
                 "(the reference raises a shape-mismatch ValueError, linalg.py:349-351)");
-  TRY(prep_step(e, t));
-  HIP_TRY(e, hipMemsetAsync(e->d_scal, 0, (e->scal_count() + 5) * sizeof(double), e->stream));   // (+ the counters and the precondition flag behind them)
+  if (!e->fused_begin) TRY(prep_step(e, t));
+  HIP_TRY(e, hipMemsetAsync(e->d_scal, 0, e->scal_alloc() * sizeof(double), e->stream));   // (+ the counters and the precondition flag behind them)
   // the inner halo layers need x_t for their right-hand sides; the exchange that closed the previous step (for its face
   // fluxes) already delivered it unless the state was touched in between.  Every rank makes the same calls, so every
   // rank takes the same branch.
@@ -2251,7 +2456,9 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
   if (!e->halo_fresh || e->ptr_exported) TRY(exchange_halo(e, e->d_c));
   e->halo_fresh = false;
   // keep x_t and the ghost rows (k_rhs writes both aside): a failed solve restores them
-  TRY(launch_rhs(e, t, e->d_c, e->d_b, true, e->d_keep));
+  // (round 5: operator set-up, right-hand side, kept rows and the ghost rows' values of level t+1 in one launch)
+  if (e->fused_begin) TRY(launch_begin_step(e, t));
+  else TRY(launch_rhs(e, t, e->d_c, e->d_b, true, e->d_keep));
   // the tail writes real rows then: it must not run speculatively (partitioned: on any rank -- the tail is collective)
   const bool has_inputs = e->in_levels.count(t + 1) != 0 || ((size_t)(t + 1) < e->in_any.size() && e->in_any[(size_t)t + 1]);
   SolveStats st;
@@ -2338,8 +2545,8 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
 int32_t cwr_get_mass_flux(cwr_engine* e, double* adv, double* dif, double* tot) {
   if (!e) return CWR_ERR_BAD_ARG;
   if (!e->flux_valid) return fail(e, CWR_ERR_STATE, "cwr_get_mass_flux: the last step was not taken with CWR_STEP_MASS_FLUX");
-  HIP_TRY(e, hipSetDevice(e->dev));
-  const size_t cnt = (size_t)e->E * e->K;
+  HIP_TRY(e, enter_device(e->dev));
+  const size_t cnt = (size_t)e->E * e->Ku;
   if (cnt == 0) return CWR_OK;
   DevTmp<double> tmp;                                   // internal face order -> reference face order, on the device
   TRY(dev_alloc(e, &tmp.p, cnt));
@@ -2348,7 +2555,7 @@ int32_t cwr_get_mass_flux(cwr_engine* e, double* adv, double* dif, double* tot) 
   const double* srcs[3] = {e->d_fadv, e->d_fdif, e->d_fadv};
   for (int q = 0; q < 3; ++q) {
     if (!outs[q]) continue;
-    k_face_rows_out<<<grid, BLOCK, 0, e->stream>>>((int64_t)cnt, e->K, e->d_face_orig, srcs[q], q == 2 ? e->d_fdif : nullptr, tmp.p);
+    k_face_rows_out<<<grid, BLOCK, 0, e->stream>>>((int64_t)cnt, e->Ku, e->K, e->d_face_orig, srcs[q], q == 2 ? e->d_fdif : nullptr, tmp.p);
     HIP_TRY(e, hipGetLastError());
     TRY(download(e, outs[q], tmp.p, cnt));
   }
@@ -2380,7 +2587,7 @@ int32_t cwr_get_error_factors(cwr_engine* e, int32_t n_times, double* factors) {
 // Tiling of the dominant sweep kernel: out = {tiled pass ready, tiles, blocks of its persistent grid, rows per tile}
 int32_t cwr_tiling_info(cwr_engine* e, int32_t out[4]) {
   if (!e || !out) return e ? fail(e, CWR_ERR_BAD_ARG, "cwr_tiling_info: NULL") : CWR_ERR_BAD_ARG;
-  HIP_TRY(e, hipSetDevice(e->dev));
+  HIP_TRY(e, enter_device(e->dev));
   if (e->use_sq && !e->sq_failed && e->K >= e->sq_min_k) TRY(ensure_sq_pattern(e));
   out[0] = e->tcl_ready ? 1 : 0; out[1] = e->tcl_ntiles; out[2] = e->tcl_grid; out[3] = e->tcl_TR;
   return CWR_OK;
@@ -2390,7 +2597,7 @@ int32_t cwr_tiling_info(cwr_engine* e, int32_t out[4]) {
 // (n_lists must be the grid of the tiled pass, every tile must appear exactly once).  depth = 0 removes it.
 int32_t cwr_set_tile_schedule(cwr_engine* e, int32_t n_lists, int32_t depth, const int32_t* sched) {
   if (!e) return CWR_ERR_BAD_ARG;
-  HIP_TRY(e, hipSetDevice(e->dev));
+  HIP_TRY(e, enter_device(e->dev));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   if (depth <= 0) { e->sched_depth = 0; e->sched_user = false; e->sched_level = -1; return CWR_OK; }
   if (!sched || !e->tcl_ready || n_lists != e->tcl_grid) return fail(e, CWR_ERR_BAD_ARG, "cwr_set_tile_schedule: n_lists must equal the grid of the tiled pass (cwr_tiling_info)");
@@ -2408,7 +2615,7 @@ int32_t cwr_set_tile_schedule(cwr_engine* e, int32_t n_lists, int32_t depth, con
 // [depth][n_lists]; info = {depth, n_lists, level it was built for (-1: none / the caller's), schedules built so far}
 int32_t cwr_get_tile_schedule(cwr_engine* e, int32_t info[4], int32_t* out, int64_t out_cap) {
   if (!e || !info) return e ? fail(e, CWR_ERR_BAD_ARG, "cwr_get_tile_schedule: NULL") : CWR_ERR_BAD_ARG;
-  HIP_TRY(e, hipSetDevice(e->dev));
+  HIP_TRY(e, enter_device(e->dev));
   info[0] = e->sched_depth; info[1] = e->sched_depth > 0 ? e->tcl_grid : 0; info[2] = e->sched_user ? -1 : e->sched_level; info[3] = (int32_t)e->n_sched_builds;
   const size_t cnt = (size_t)e->sched_depth * e->tcl_grid;
   if (out && cnt > 0) {
@@ -2421,7 +2628,7 @@ int32_t cwr_get_tile_schedule(cwr_engine* e, int32_t info[4], int32_t* out, int6
 int32_t cwr_time_apply(cwr_engine* e, int32_t t, int32_t variant, int32_t reps, double* avg_us) {
   if (!e || !avg_us || reps < 1) return e ? fail(e, CWR_ERR_BAD_ARG, "cwr_time_apply: bad arguments") : CWR_ERR_BAD_ARG;
   TRY(check_level(e, t, true));
-  HIP_TRY(e, hipSetDevice(e->dev));
+  HIP_TRY(e, enter_device(e->dev));
   TRY(prep_step(e, t));
   const size_t nK = (size_t)e->n_real * e->K;
   // operands: the current state and its image, so the numbers are those of a real step
@@ -2496,7 +2703,7 @@ int32_t cwr_set_boundary_lines(cwr_engine* e, int32_t n_lines, const int32_t* li
   if (nf > 0 && !line_faces) return fail(e, CWR_ERR_BAD_ARG, "cwr_set_boundary_lines: line_faces is NULL");
   for (int i = 0; i < nf; ++i)
     if (line_faces[i] < 0 || line_faces[i] >= e->E) return fail(e, CWR_ERR_BAD_ARG, "cwr_set_boundary_lines: face id out of range");
-  HIP_TRY(e, hipSetDevice(e->dev));
+  HIP_TRY(e, enter_device(e->dev));
   hipFree(e->d_line_ptr); hipFree(e->d_line_faces); hipFree(e->d_ledger);
   e->d_line_ptr = nullptr; e->d_line_faces = nullptr; e->d_ledger = nullptr; e->n_lines = 0;
   TRY(dev_alloc(e, &e->d_line_ptr, (size_t)n_lines + 1));
@@ -2515,7 +2722,7 @@ int32_t cwr_set_boundary_lines(cwr_engine* e, int32_t n_lines, const int32_t* li
 int32_t cwr_reset_mass_balance(cwr_engine* e) {
   if (!e) return CWR_ERR_BAD_ARG;
   if (e->n_lines <= 0) return fail(e, CWR_ERR_STATE, "cwr_reset_mass_balance: no boundary lines set");
-  HIP_TRY(e, hipSetDevice(e->dev));
+  HIP_TRY(e, enter_device(e->dev));
   HIP_TRY(e, hipMemsetAsync(e->d_ledger, 0, (size_t)e->n_lines * 3 * e->K * sizeof(double), e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   return CWR_OK;
@@ -2524,8 +2731,8 @@ int32_t cwr_reset_mass_balance(cwr_engine* e) {
 int32_t cwr_get_mass_balance(cwr_engine* e, double* ledger) {
   if (!e || !ledger) return e ? fail(e, CWR_ERR_BAD_ARG, "cwr_get_mass_balance: NULL") : CWR_ERR_BAD_ARG;
   if (e->n_lines <= 0) return fail(e, CWR_ERR_STATE, "cwr_get_mass_balance: no boundary lines set");
-  HIP_TRY(e, hipSetDevice(e->dev));
-  TRY(download(e, ledger, e->d_ledger, (size_t)e->n_lines * 3 * e->K));
+  HIP_TRY(e, enter_device(e->dev));
+  TRY(download_cols(e, ledger, e->d_ledger, (size_t)e->n_lines * 3));
   return CWR_OK;
 }
 
@@ -2533,14 +2740,17 @@ int32_t cwr_domain_mass(cwr_engine* e, int32_t t_level, double* out) {
   if (!e || !out) return e ? fail(e, CWR_ERR_BAD_ARG, "cwr_domain_mass: NULL") : CWR_ERR_BAD_ARG;
   TRY(check_level(e, t_level, false));
   if (e->K > BLOCK) return fail(e, CWR_ERR_BAD_ARG, "cwr_domain_mass: K too large");
-  HIP_TRY(e, hipSetDevice(e->dev));
+  HIP_TRY(e, enter_device(e->dev));
   const int K = e->K, per = BLOCK / K;
   const int grid = std::max(1, std::min(cdiv(e->n_core, per), 512));
   if (!e->d_mass_out) TRY(dev_alloc(e, &e->d_mass_out, (size_t)513 * (K + 1)));
   k_domain_mass<<<grid, BLOCK, 0, e->stream>>>(e->n_core, K, e->d_vol + (size_t)t_level * e->n_cells, e->d_c, e->d_mass_out);
   k_fold_partials<<<1, BLOCK, 0, e->stream>>>(grid, K + 1, e->d_mass_out, e->d_mass_out + (size_t)512 * (K + 1));
   HIP_TRY(e, hipGetLastError());
-  TRY(download(e, out, e->d_mass_out + (size_t)512 * (K + 1), (size_t)K + 1));
+  std::vector<double> h((size_t)K + 1);
+  TRY(download(e, h.data(), e->d_mass_out + (size_t)512 * (K + 1), (size_t)K + 1));
+  for (int k = 0; k < e->Ku; ++k) out[k] = h[(size_t)k];
+  out[e->Ku] = h[(size_t)K];                          // (the volume sum sits behind the engine's K columns)
   return CWR_OK;
 }
 
@@ -2569,10 +2779,10 @@ int32_t cwr_output_open(cwr_engine* e, int32_t n_slots, int32_t with_flux, int32
   if (row_order)
     for (int i = 0; i < n_out; ++i)
       if (row_order[i] < 0 || row_order[i] >= e->n_cells) return fail(e, CWR_ERR_BAD_ARG, "cwr_output_open: row_order entry out of range");
-  HIP_TRY(e, hipSetDevice(e->dev));
+  HIP_TRY(e, enter_device(e->dev));
   e->out_n = n_out; e->out_flux = with_flux != 0; e->out_next = 0;
-  e->out_state_cnt = (size_t)n_out * e->K;
-  e->out_slot_cnt = e->out_state_cnt + (e->out_flux ? (size_t)3 * e->E * e->K : 0);
+  e->out_state_cnt = (size_t)n_out * e->Ku;
+  e->out_slot_cnt = e->out_state_cnt + (e->out_flux ? (size_t)3 * e->E * e->Ku : 0);
   HIP_TRY(e, hipStreamCreateWithFlags(&e->out_stream, hipStreamNonBlocking));
   int rc = CWR_OK;
   if (hipEventCreateWithFlags(&e->out_snap_ready, hipEventDisableTiming) != hipSuccess ||
@@ -2587,7 +2797,7 @@ int32_t cwr_output_open(cwr_engine* e, int32_t n_slots, int32_t with_flux, int32
     }
   }
   if (rc != CWR_OK) { cwr_output_close(e); return rc; }
-  const size_t lds = (size_t)e->K * (SNAP_ROWS + 1) * sizeof(double);
+  const size_t lds = (size_t)e->Ku * (SNAP_ROWS + 1) * sizeof(double);
   if (lds > 48 * 1024) HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_snapshot_t), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   return CWR_OK;
 }
@@ -2598,7 +2808,7 @@ namespace {
 int output_push_impl(cwr_engine* e, int32_t* slot, double* state_dst, double* flux_dst) {
   if (!e->out_stream) return fail(e, CWR_ERR_STATE, "cwr_output_push: cwr_output_open first");
   if (e->out_flux && !e->flux_valid) return fail(e, CWR_ERR_STATE, "cwr_output_push: the last step was not taken with CWR_STEP_MASS_FLUX");
-  HIP_TRY(e, hipSetDevice(e->dev));
+  HIP_TRY(e, enter_device(e->dev));
   const int s = e->out_next;
   cwr_engine::OutSlot& sl = e->out_slots[(size_t)s];
   for (int waited = 0; sl.busy.load(std::memory_order_acquire); ++waited) {           // the consumer still holds this slot
@@ -2607,16 +2817,16 @@ int output_push_impl(cwr_engine* e, int32_t* slot, double* state_dst, double* fl
   }
   // the device snapshot is rewritten only after the previous copy out of it has finished
   if (e->out_copy_pending) HIP_TRY(e, hipStreamWaitEvent(e->stream, e->out_copy_done, 0));
-  const size_t lds = (size_t)e->K * (SNAP_ROWS + 1) * sizeof(double);
+  const size_t lds = (size_t)e->Ku * (SNAP_ROWS + 1) * sizeof(double);
   const int grid = std::max(1, std::min(cdiv(e->out_n, SNAP_ROWS), 256 * 8));
-  k_snapshot_t<<<grid, BLOCK, lds, e->stream>>>(e->out_n, e->K, e->d_out_order, e->d_c, nullptr, e->d_snap);
+  k_snapshot_t<<<grid, BLOCK, lds, e->stream>>>(e->out_n, e->Ku, e->K, e->d_out_order, e->d_c, nullptr, e->d_snap);
   if (e->out_flux) {
     const int gridf = std::max(1, std::min(cdiv(e->E, SNAP_ROWS), 256 * 8));
-    const size_t EK = (size_t)e->E * e->K;
+    const size_t EK = (size_t)e->E * e->Ku;
     // (output index = the reference's face id; its row sits at the face's internal position)
-    k_snapshot_t<<<gridf, BLOCK, lds, e->stream>>>(e->E, e->K, e->d_face_pos, e->d_fadv, nullptr, e->d_snap + e->out_state_cnt);
-    k_snapshot_t<<<gridf, BLOCK, lds, e->stream>>>(e->E, e->K, e->d_face_pos, e->d_fdif, nullptr, e->d_snap + e->out_state_cnt + EK);
-    k_snapshot_t<<<gridf, BLOCK, lds, e->stream>>>(e->E, e->K, e->d_face_pos, e->d_fadv, e->d_fdif, e->d_snap + e->out_state_cnt + 2 * EK);
+    k_snapshot_t<<<gridf, BLOCK, lds, e->stream>>>(e->E, e->Ku, e->K, e->d_face_pos, e->d_fadv, nullptr, e->d_snap + e->out_state_cnt);
+    k_snapshot_t<<<gridf, BLOCK, lds, e->stream>>>(e->E, e->Ku, e->K, e->d_face_pos, e->d_fdif, nullptr, e->d_snap + e->out_state_cnt + EK);
+    k_snapshot_t<<<gridf, BLOCK, lds, e->stream>>>(e->E, e->Ku, e->K, e->d_face_pos, e->d_fadv, e->d_fdif, e->d_snap + e->out_state_cnt + 2 * EK);
   }
   HIP_TRY(e, hipGetLastError());
   HIP_TRY(e, hipEventRecord(e->out_snap_ready, e->stream));
@@ -2683,7 +2893,7 @@ int32_t cwr_output_release(cwr_engine* e, int32_t slot) {
 
 int32_t cwr_synchronize(cwr_engine* e) {
   if (!e) return CWR_ERR_BAD_ARG;
-  HIP_TRY(e, hipSetDevice(e->dev));
+  HIP_TRY(e, enter_device(e->dev));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   return CWR_OK;
 }
@@ -2693,7 +2903,7 @@ int32_t cwr_apply_bytes(const cwr_engine* e, int64_t* bytes_read, int64_t* bytes
   // algorithmic bytes of one launch of the last step's dominant operator kernel: adjacency records (16 B each; of J^2
   // when the double sweep is active), CSR row pointers, diagonal (plain sweep only), the input vector (every real row
   // once), the bhat / c2 / r0 operand; one output row per computed row
-  const int64_t K = e->K;
+  const int64_t K = e->Ku;                             // (the caller's constituents: padded columns are not counted as useful bytes)
   const bool sq = (e->dominant_mode == 5 || e->dominant_mode == 6);
   const int64_t entries = sq ? e->nnz2 : e->nnz;
   const int64_t rows = (e->dominant_mode == 6) ? e->n_tcl : (sq ? e->n_sq : e->n_owned);
@@ -2729,7 +2939,11 @@ int32_t cwr_attach_comm(cwr_engine* e, int32_t rank, int32_t world, const uint8_
   }
   const int n_send = n_peers ? send_ptr[n_peers] : 0;
   const int n_recv = n_peers ? recv_ptr[n_peers] : 0;
-  if (n_recv != e->n_real - n_core)
+  // (world == 1 without peers: a STAND-ALONE rank -- the row layout of one rank of a larger partition (core, replayed layers, read-only
+  // layer) with nobody to exchange with: the rows outside the core keep what the caller put there.  The launch structure of a rank's
+  // step without its exchanges: tools/rank_step_profile.py)
+  const bool standalone = world == 1 && n_peers == 0;
+  if (n_recv != e->n_real - n_core && !standalone)
     return fail(e, CWR_ERR_BAD_ARG, "cwr_attach_comm: receive lists must cover every real row outside the core exactly once");
   for (int i = 0; i < n_send; ++i)
     if (!send_cells || send_cells[i] < 0 || send_cells[i] >= n_core)
@@ -2744,7 +2958,7 @@ int32_t cwr_attach_comm(cwr_engine* e, int32_t rank, int32_t world, const uint8_
   }
   std::string err;
   if (!g_rccl.load(err)) return fail(e, CWR_ERR_RCCL, err);
-  HIP_TRY(e, hipSetDevice(e->dev));
+  HIP_TRY(e, enter_device(e->dev));
   NcclUniqueId id; std::memcpy(id.internal, unique_id, 128);
   NCCL_TRY(e, g_rccl.CommInitRank(&e->comm, world, id, rank));
   e->rank = rank; e->world = world;
@@ -2800,6 +3014,7 @@ int32_t cwr_attach_comm(cwr_engine* e, int32_t rank, int32_t world, const uint8_
   HIP_TRY(e, hipEventCreateWithFlags(&e->ev_red_out, hipEventDisableTiming));
   if (const char* v = getenv("CWR_COMM_TWO_STREAMS")) e->one_comm_stream = atoi(v) == 0;
   TRY(sync_jnorms(e));
+  TRY(refine_error_factors(e));                                   // (collective: the row-wise bound of the global matrix, see there)
   return sync_input_levels(e);
 }
 
@@ -2808,7 +3023,7 @@ int32_t cwr_comm_selftest(cwr_engine* e, int32_t count, int64_t* overlapped_exch
   if (overlapped_exchanges) *overlapped_exchanges = e->n_overlapped;
   if (count <= 0) return CWR_OK;                               // (statistics only)
   if (!e->comm) return fail(e, CWR_ERR_STATE, "cwr_comm_selftest: no communicator attached");
-  HIP_TRY(e, hipSetDevice(e->dev));
+  HIP_TRY(e, enter_device(e->dev));
   // a grouped ncclSend / ncclRecv of this rank to ITSELF on the communication stream, bracketed by the two events of
   // the overlapped exchange: the call signatures and the stream / event plumbing of exchange_begin / exchange_finish,
   // executable with a single rank (the one-GPU box cannot host two RCCL ranks)

@@ -187,13 +187,18 @@ __device__ __forceinline__ void block_reduce_cols(double (&val)[NV], int G, int 
 // fixed order (strided per thread, then an LDS tree), one block per dot d.  `outs` holds the destination
 // row of each dot (they are not contiguous for the start-up residual: ||r||^2 and ||bhat||^2).
 struct ReduceOuts { double* p[4]; };
+// (round 5) The convergence check without a copy and without draining the stream: the folded scalars are ALSO stored into a page-locked
+// host buffer the GPU can write (host_out[d * K + k]); the last of the ND blocks to finish publishes a sequence number behind them
+// (system-scope release), and the host spins on that word.  The sequence lives in device memory (dev_seq) because these launches
+// are captured into hipGraphs: a by-value argument would freeze it.  All null: no notification.
+struct ReduceNote { double* host_out; unsigned long long* host_seq; unsigned int* arrive; unsigned long long* dev_seq; };
 constexpr int RBLOCK = 1024;
 __global__ void __launch_bounds__(RBLOCK) k_reduce_partials(int nslots, int ND, int K, const double* __restrict__ partial,
-                                                          ReduceOuts outs, int max_from) {
+                                                          ReduceOuts outs, int max_from, ReduceNote note) {
   __shared__ double sm[RBLOCK];
   const int d = blockIdx.x;
   double* out = outs.p[d];
-  if (out == nullptr) return;                   // uniform per block
+  if (out == nullptr) return;                   // uniform per block (never with a notification: the host passes every dot then)
   const int S = RBLOCK / K;                     // slot lanes per column
   const int tid = threadIdx.x;
   const int k = tid % K, l = tid / K;
@@ -210,31 +215,45 @@ __global__ void __launch_bounds__(RBLOCK) k_reduce_partials(int nslots, int ND, 
       __syncthreads();
       len = h;
     }
-    if (tid < K) out[tid] = sm[tid];
-    return;
-  }
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;   // four independent chains keep four loads in flight
-  if (l < S) {
-    int slot = l;
-    for (; slot + 3 * S < nslots; slot += 4 * S) {
-      s0 += base[(size_t)slot * stride];
-      s1 += base[(size_t)(slot + S) * stride];
-      s2 += base[(size_t)(slot + 2 * S) * stride];
-      s3 += base[(size_t)(slot + 3 * S) * stride];
+  } else {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;   // four independent chains keep four loads in flight
+    if (l < S) {
+      int slot = l;
+      for (; slot + 3 * S < nslots; slot += 4 * S) {
+        s0 += base[(size_t)slot * stride];
+        s1 += base[(size_t)(slot + S) * stride];
+        s2 += base[(size_t)(slot + 2 * S) * stride];
+        s3 += base[(size_t)(slot + 3 * S) * stride];
+      }
+      for (; slot < nslots; slot += S) s0 += base[(size_t)slot * stride];
     }
-    for (; slot < nslots; slot += S) s0 += base[(size_t)slot * stride];
-  }
-  sm[tid] = (s0 + s1) + (s2 + s3);
-  __syncthreads();
-  // the slot lanes of a column are folded in a fixed tree (lane l takes lane l + ceil(len / 2)): log2(S) steps instead of one
-  // thread adding S values one after the other -- at K = 1 that was 1 024 dependent additions, 10 of the launch's 16 us
-  for (int len = S; len > 1;) {
-    const int h = (len + 1) >> 1;
-    if (l < len - h) sm[tid] += sm[tid + h * K];
+    sm[tid] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    len = h;
+    // the slot lanes of a column are folded in a fixed tree (lane l takes lane l + ceil(len / 2)): log2(S) steps instead of one
+    // thread adding S values one after the other -- at K = 1 that was 1 024 dependent additions, 10 of the launch's 16 us
+    for (int len = S; len > 1;) {
+      const int h = (len + 1) >> 1;
+      if (l < len - h) sm[tid] += sm[tid + h * K];
+      __syncthreads();
+      len = h;
+    }
   }
   if (tid < K) out[tid] = sm[tid];
+  if (note.host_seq) {
+    if (tid < K) note.host_out[(size_t)d * K + tid] = sm[tid];
+    __threadfence_system();                     // this block's values are out before it says so
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned prev = atomicAdd(note.arrive, 1u);
+      if (prev == (unsigned)ND - 1u) {          // the last block: every other block's values are visible (fence / atomic / fence)
+        __threadfence_system();
+        *note.arrive = 0u;                      // (the next notifying launch is stream-ordered behind this one)
+        const unsigned long long sq = *note.dev_seq + 1ull;
+        *note.dev_seq = sq;
+        __hip_atomic_store(note.host_seq, sq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
 }
 
 // Internal face order: the engine stores every per-face array sorted by the smaller cell id of the face, so that the
@@ -250,12 +269,27 @@ __global__ void __launch_bounds__(BLOCK) k_faces_in(int64_t total, int E, const 
 }
 // rows of K values: dst[orig[p], :] = src[p, :] (per-face K-vectors from the internal face order to the reference's)
 // (src2: a second array added element by element -- total_mass_flux = advection + diffusion is formed on the way out, see k_mass_flux)
-__global__ void __launch_bounds__(BLOCK) k_face_rows_out(int64_t total, int K, const int32_t* __restrict__ orig,
+__global__ void __launch_bounds__(BLOCK) k_face_rows_out(int64_t total, int K, int Kp, const int32_t* __restrict__ orig,
                                                        const double* __restrict__ src, const double* __restrict__ src2,
                                                        double* __restrict__ dst) {
+  // K: the caller's constituents (the rows of dst), Kp >= K: the engine's internal row width (zero columns behind K: cwr_create)
   for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * BLOCK) {
     const int64_t p = i / K; const int k = (int)(i - p * K);
-    dst[(size_t)orig[p] * K + k] = src2 ? src[i] + src2[i] : src[i];
+    const size_t j = (size_t)p * Kp + k;
+    dst[(size_t)orig[p] * K + k] = src2 ? src[j] + src2[j] : src[j];
+  }
+}
+// rows of K values <-> rows of Kp >= K values (the engine carries zero columns behind the caller's K where that is faster)
+__global__ void __launch_bounds__(BLOCK) k_pad_cols(int64_t total, int K, int Kp, const double* __restrict__ src, double* __restrict__ dst) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * BLOCK) {
+    const int64_t r = i / Kp; const int k = (int)(i - r * Kp);
+    dst[i] = k < K ? src[r * K + k] : 0.0;
+  }
+}
+__global__ void __launch_bounds__(BLOCK) k_strip_cols(int64_t total, int K, int Kp, const double* __restrict__ src, double* __restrict__ dst) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * BLOCK) {
+    const int64_t r = i / K; const int k = (int)(i - r * K);
+    dst[i] = src[r * Kp + k];
   }
 }
 template <typename T>
@@ -290,7 +324,7 @@ __global__ void __launch_bounds__(BLOCK) k_derive_coeff(
 // (linalg.py:76-103 dry dummy, V/dt, diffusion diagonals; :113-115 outflow incl. ghost faces;
 //  :139-141 inflow seen from the neighbour).  One thread per owned cell.
 constexpr int PREP_CAP = 1536;      // adjacency entries of a 256-row block staged in LDS (4-6 per row on HEC-RAS meshes)
-__global__ void __launch_bounds__(BLOCK) k_prep_step(
+__device__ __forceinline__ void prep_block_rows(
     int n_owned, const int32_t* __restrict__ ptr, const int32_t* __restrict__ ent_edge,
     const int32_t* __restrict__ ent_nb, const float* __restrict__ adv_t, const double* __restrict__ dif_t,
     const float* __restrict__ vol_next, double dt, FaceRec* __restrict__ rec, double* __restrict__ diag,
@@ -362,6 +396,14 @@ __global__ void __launch_bounds__(BLOCK) k_prep_step(
   }
 }
 
+__global__ void __launch_bounds__(BLOCK) k_prep_step(
+    int n_owned, const int32_t* __restrict__ ptr, const int32_t* __restrict__ ent_edge,
+    const int32_t* __restrict__ ent_nb, const float* __restrict__ adv_t, const double* __restrict__ dif_t,
+    const float* __restrict__ vol_next, double dt, FaceRec* __restrict__ rec, double* __restrict__ diag,
+    double* __restrict__ w) {
+  prep_block_rows(n_owned, ptr, ent_edge, ent_nb, adv_t, dif_t, vol_next, dt, rec, diag, w);
+}
+
 // The reference's zero-coefficient ValueError (linalg.py:349-351) depends on the flow field only: flags[t] = 1 when
 // level t has an active ghost face (edge_velocity != 0) of a computed row whose advection coefficient (inflow) or
 // diffusion coefficient (either direction, D != 0) is exactly 0 -- the condition k_rhs tests at level t+1 of a step.
@@ -428,22 +470,16 @@ __global__ void __launch_bounds__(BLOCK) k_fill(int64_t total, double v, double*
 // b[c,k] = V[t,c]*x[c,k]/dt + G_in[c,k] + G_out[c,k]; boundary terms from level t+1, selected by the
 // sign of edge_velocity[t+1]; the highest active ghost-face id of a cell wins in each set
 // (linalg.py:349-351,378: assignment, not accumulation).  SCALE: divide by diag (Jacobi row scaling).
+// rows c = c_first, c_first + c_step, ... < c_end of the right-hand side (one lane group per row; col = the lane's first constituent)
 template <int VW, bool SCALE>
-__global__ void __launch_bounds__(BLOCK) k_rhs(
-    int n_owned, int K, int G, const int32_t* __restrict__ ptr, const int32_t* __restrict__ ent_edge,
+__device__ __forceinline__ void rhs_rows(
+    int c_first, int c_end, int c_step, int K, int col, const int32_t* __restrict__ ptr, const int32_t* __restrict__ ent_edge,
     const int32_t* __restrict__ ent_nb, const float* __restrict__ vol_t, double dt,
     const float* __restrict__ vel_n, const float* __restrict__ adv_n, const double* __restrict__ dif_n,
     int use_diffusion, const double* __restrict__ bc_n, const double* __restrict__ x,
     const double* __restrict__ diag, const uint8_t* __restrict__ row_ghost, double* __restrict__ b,
-    int32_t* __restrict__ counters, double* __restrict__ x_keep, int keep_from, int keep_rows, double* __restrict__ ew_out, double ew_val,
-    double* __restrict__ bad_flag) {
-  const int R = BLOCK / G;
-  const int r = threadIdx.x / G, g = threadIdx.x - r * G;
-  // this step's relative element-wise tolerance, for every MODE 4 sweep that follows (k_apply reads it from memory)
-  if (ew_out && blockIdx.x == 0 && threadIdx.x == 0) ew_out[0] = ew_val;
-  if (r >= R) return;
-  const int col = g * VW;
-  for (int c = blockIdx.x * R + r; c < n_owned; c += gridDim.x * R) {      // grid-stride: a block works many row groups
+    int32_t* __restrict__ counters, double* __restrict__ x_keep, double* __restrict__ bad_flag) {
+  for (int c = c_first; c < c_end; c += c_step) {
   double xv[VW], gin[VW], gout[VW];
   bool bad = false;
   ldv<VW>(x + (size_t)c * K + col, xv);
@@ -487,13 +523,69 @@ __global__ void __launch_bounds__(BLOCK) k_rhs(
   }
   stv<VW>(b + (size_t)c * K + col, out);
   }
+}
+
+template <int VW, bool SCALE>
+__global__ void __launch_bounds__(BLOCK) k_rhs(
+    int n_owned, int K, int G, const int32_t* __restrict__ ptr, const int32_t* __restrict__ ent_edge,
+    const int32_t* __restrict__ ent_nb, const float* __restrict__ vol_t, double dt,
+    const float* __restrict__ vel_n, const float* __restrict__ adv_n, const double* __restrict__ dif_n,
+    int use_diffusion, const double* __restrict__ bc_n, const double* __restrict__ x,
+    const double* __restrict__ diag, const uint8_t* __restrict__ row_ghost, double* __restrict__ b,
+    int32_t* __restrict__ counters, double* __restrict__ x_keep, int keep_from, int keep_rows, double* __restrict__ ew_out, double ew_val,
+    double* __restrict__ bad_flag) {
+  const int R = BLOCK / G;
+  const int r = threadIdx.x / G, g = threadIdx.x - r * G;
+  // this step's relative element-wise tolerance, for every MODE 4 sweep that follows (k_apply reads it from memory)
+  if (ew_out && blockIdx.x == 0 && threadIdx.x == 0) ew_out[0] = ew_val;
+  if (r >= R) return;
+  const int col = g * VW;
+  rhs_rows<VW, SCALE>(blockIdx.x * R + r, n_owned, gridDim.x * R, K, col, ptr, ent_edge, ent_nb, vol_t, dt, vel_n, adv_n, dif_n, use_diffusion,
+                      bc_n, x, diag, row_ghost, b, counters, x_keep, bad_flag);      // grid-stride: a block works many row groups
   // the ghost rows of the state as the step found them (rows keep_from ...): kept with x_t for a failed step
   if (x_keep) {
-    const int col2 = g * VW;
     for (int c = keep_from + blockIdx.x * R + r; c < keep_from + keep_rows; c += gridDim.x * R) {
       double v[VW];
-      ldv<VW>(x + (size_t)c * K + col2, v);
-      stv<VW>(x_keep + (size_t)c * K + col2, v);
+      ldv<VW>(x + (size_t)c * K + col, v);
+      stv<VW>(x_keep + (size_t)c * K + col, v);
+    }
+  }
+}
+
+// (round 5) The opening of a step in ONE launch: the operator of level t for the block's 256 rows (k_prep_step), their scaled
+// right-hand sides with x_t kept aside (k_rhs), the kept copy of the rows behind the computed ones (halo, ghost) -- and the ghost
+// rows' values of level t+1 (k_ghost_writeback: transport.py:258-264), which no kernel of the solve reads and the step's closing
+// flux kernel needs; a failed step puts the kept rows back.  Three launches and a drained stream between each pair less per step:
+// what counts on engines of ~100 k cells, whose set-up kernels are all latency (profiles/r05_*).
+template <int VW>
+__global__ void __launch_bounds__(BLOCK) k_begin_step(
+    int n_owned, int n_real, int n_cells, int K, int G, const int32_t* __restrict__ ptr, const int32_t* __restrict__ ent_edge,
+    const int32_t* __restrict__ ent_nb, const float* __restrict__ adv_t, const double* __restrict__ dif_t,
+    const float* __restrict__ vol_next, double dt, FaceRec* __restrict__ rec, double* __restrict__ diag, double* __restrict__ w,
+    const float* __restrict__ vol_t, const float* __restrict__ vel_n, const float* __restrict__ adv_n, const double* __restrict__ dif_n,
+    int use_diffusion, const double* __restrict__ bc_n, double* __restrict__ x, const uint8_t* __restrict__ row_ghost,
+    double* __restrict__ b, int32_t* __restrict__ counters, double* __restrict__ x_keep, double* __restrict__ ew_out, double ew_val,
+    double* __restrict__ bad_flag) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) ew_out[0] = ew_val;
+  prep_block_rows(n_owned, ptr, ent_edge, ent_nb, adv_t, dif_t, vol_next, dt, rec, diag, w);
+  __syncthreads();                                   // diag of the block's rows is in memory (block scope)
+  const int R = BLOCK / G;
+  const int r = threadIdx.x / G, g = threadIdx.x - r * G;
+  if (r >= R) return;
+  const int col = g * VW;
+  const int c0 = blockIdx.x * BLOCK, c1 = min(c0 + BLOCK, n_owned);
+  rhs_rows<VW, true>(c0 + r, c1, R, K, col, ptr, ent_edge, ent_nb, vol_t, dt, vel_n, adv_n, dif_n, use_diffusion, bc_n, x, diag, row_ghost, b,
+                     counters, x_keep, bad_flag);
+  for (int c = n_owned + blockIdx.x * R + r; c < n_cells; c += gridDim.x * R) {
+    double v[VW];
+    ldv<VW>(x + (size_t)c * K + col, v);
+    stv<VW>(x_keep + (size_t)c * K + col, v);
+    if (c >= n_real) {                               // ghost row: boundary value of level t+1 where non-zero, NaN otherwise
+      double nv[VW];
+      ldv<VW>(bc_n + (size_t)(c - n_real) * K + col, nv);
+#pragma unroll
+      for (int q = 0; q < VW; ++q) nv[q] = (nv[q] != 0.0) ? nv[q] : __builtin_nan("");
+      stv<VW>(x + (size_t)c * K + col, nv);
     }
   }
 }
@@ -1513,8 +1605,9 @@ __global__ void __launch_bounds__(BLOCK) k_fold_partials(int nblocks, int width,
 // A block transposes SNAP_ROWS rows through LDS so that both the row reads (K consecutive doubles) and the column
 // writes (consecutive i) are coalesced.  Dynamic LDS: K * (SNAP_ROWS + 1) doubles.
 constexpr int SNAP_ROWS = 64;
-__global__ void __launch_bounds__(BLOCK) k_snapshot_t(int n_out, int K, const int32_t* __restrict__ order,
+__global__ void __launch_bounds__(BLOCK) k_snapshot_t(int n_out, int K, int Kp, const int32_t* __restrict__ order,
                                                     const double* __restrict__ x, const double* __restrict__ x2, double* __restrict__ out) {
+  // K: the caller's constituents (what is written), Kp >= K: the row width of x (the engine's internal width)
   extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
   double* s = reinterpret_cast<double*>(s_dyn);                    // [K][SNAP_ROWS + 1]
   const int tid = threadIdx.x;
@@ -1523,7 +1616,7 @@ __global__ void __launch_bounds__(BLOCK) k_snapshot_t(int n_out, int K, const in
     for (int q = tid; q < rows * K; q += BLOCK) {
       const int r = q / K, k = q - r * K;
       const int src = order ? order[i0 + r] : i0 + r;
-      s[k * (SNAP_ROWS + 1) + r] = x2 ? x[(size_t)src * K + k] + x2[(size_t)src * K + k] : x[(size_t)src * K + k];
+      s[k * (SNAP_ROWS + 1) + r] = x2 ? x[(size_t)src * Kp + k] + x2[(size_t)src * Kp + k] : x[(size_t)src * Kp + k];
     }
     __syncthreads();
     for (int q = tid; q < rows * K; q += BLOCK) {

@@ -86,19 +86,16 @@ def shared_hilbert_order(mesh: dict, n: int, rank: int, world: int, K: int = 16)
     return t.cpu().numpy()
 
 
-CHAIN_MIN_TILES = 1.75      # = cwr_engine.hip chain_min_tiles (CWR_CHAIN_MIN_TILES overrides the engine's; the numbering follows this constant)
-
-
 def curve_kind(n: int, K: int, world: int = 1) -> str:
     """'lanes' or 'hilbert': which numbering _curve_order (and the facade, model.py) builds for n real cells, K constituents and
-    `world` ranks.  Lanes along the flow are for engines that will CHAIN their tiles -- from CHAIN_MIN_TILES = 1.75 tiles per block of the
-    persistent grid up (1 024 blocks: about 115 k cells per engine at K = 16, 460 k at K = 1; three tiles per block until the lane
-    boundaries were smoothed: profiles/r04_x); below that the passes ping-pong between two
-    vectors, which lose on anisotropic tiles, and the isotropic Hilbert curve is kept -- on one GPU too since round 4 (ADVICE r03;
-    same-box pairs in profiles/r04_f_small_engines.txt: 0.699 vs 0.754 ms per step at 119 k cells x 16, equal within 3 % at K = 1)."""
+    `world` ranks.  Lanes along the flow are for engines that will CHAIN their tiles; the ENGINE says from how many rows it does
+    (engine.chain_min_rows = cwr_chain_min_rows: 1.75 tiles per block of its persistent grid -- about 115 k cells per engine at K = 16,
+    460 k at K = 1 --, CWR_CHAIN_MIN_TILES / CWR_TCL_GRID included: one threshold for the numbering and the engine).
+    Below that the passes ping-pong between two vectors, which lose on anisotropic tiles, and the isotropic Hilbert curve is kept -- on
+    one GPU too since round 4 (profiles/r04_f_small_engines.txt: 0.699 vs 0.754 ms per step at 119 k cells x 16)."""
+    from .engine import chain_min_rows
     want = os.environ.get('CWR_TILE_ORDER', 'auto')
-    lanes = want == 'lanes' or (want == 'auto' and not os.environ.get('CWR_NO_CHAINS') and
-                                n // max(1, world) >= CHAIN_MIN_TILES * 1024 * tile_rows(K))
+    lanes = want == 'lanes' or (want == 'auto' and not os.environ.get('CWR_NO_CHAINS') and n // max(1, world) >= chain_min_rows(K))
     return 'lanes' if lanes else 'hilbert'
 
 
@@ -123,10 +120,14 @@ class PartitionedTransport:
     single-GPU engine (no halo, no communicator)."""
 
     def __init__(self, mesh: dict, inputs3: np.ndarray, rank: int, world: int, device: int = 0,
-                 unique_id: bytes | None = None, halo_depth: int = 1, renumber: str | None = 'hilbert'):
+                 unique_id: bytes | None = None, halo_depth: int = 1, renumber: str | None = 'hilbert',
+                 standalone: bool = False):
         """renumber='hilbert': work in a space-filling-curve numbering of the real cells (ordering.py); every
         array handed in or out of this class stays in the reference's numbering.
-        halo_depth=0: choose the depth from the size of a rank's range (auto_halo_depth)."""
+        halo_depth=0: choose the depth from the size of a rank's range (auto_halo_depth).
+        standalone=True (measurement only, tools/rank_step_profile.py): build rank `rank` of `world` -- its real partition, core +
+        replayed layers + read-only layer -- WITHOUT a communicator: the halo rows keep what they hold, no exchange, no all-reduce.
+        What such an engine computes per step is the compute side of that rank's step."""
         n = int(np.asarray(mesh['edges_face1']).max()) + 1
         if halo_depth == 0:
             halo_depth = auto_halo_depth(n, world)
@@ -166,7 +167,13 @@ class PartitionedTransport:
                                     fields['face_to_face_dist'], float(mesh['diffusion_coefficient']))
         ghost_global = lm.cell_global[lm.n_real:]
         self.engine.load_boundary(np.ascontiguousarray(inputs3[:, ghost_global, :]))
-        if world > 1:
+        self.standalone = bool(standalone) and world > 1
+        if self.standalone:
+            # a communicator of ONE rank without peers (cwr_attach_comm): the engine takes the row layout and the launch structure of a
+            # rank (n_core, replayed layers, exchange-free stretches) and never exchanges
+            self.engine.attach_comm(0, 1, TransportEngine.comm_unique_id(), np.zeros(0, np.int32), np.zeros(1, np.int32), np.zeros(0, np.int32),
+                                    np.zeros(1, np.int32), np.zeros(0, np.int32), n_core=lm.n_core, exchange_every=lm.depth)
+        if world > 1 and not self.standalone:
             if unique_id is None:
                 raise ValueError('world > 1 needs the RCCL unique id broadcast from rank 0')
             self.engine.attach_comm(rank, world, unique_id, lm.peers, lm.send_ptr, lm.send_cells, lm.recv_ptr,
@@ -189,7 +196,7 @@ class PartitionedTransport:
                 lvs.append(np.full(len(ce), t, dtype=np.int32)); ces.append(ce); vas.append(blk[ce])
         if lvs:
             self.engine.load_real_inputs(np.concatenate(lvs), np.concatenate(ces), np.concatenate(vas))
-        elif world > 1:                                           # (collective for partitioned engines: also with no entries)
+        elif world > 1 and not self.standalone:                   # (collective for partitioned engines: also with no entries)
             self.engine.load_real_inputs(np.zeros(0, np.int32), np.zeros(0, np.int64), np.zeros((0, self.K)))
 
     def step(self, t: int, **kw):

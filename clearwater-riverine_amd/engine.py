@@ -34,13 +34,13 @@ STEP_DETERMINISTIC = 32
 
 INFO_LOOSE_RESIDUAL = 1        # BiCGSTAB stagnated within 100 x tol and was accepted
 INFO_ELEMENTWISE_MISSED = 2    # the element-wise rule was still violated after the tightened BiCGSTAB rounds
-INFO_ELEMENTWISE_CLAMPED = 4   # ||J||_inf so close to 1 that the rule's scale was held at 1e-3 (bound weaker by 1e-3 / s)
+INFO_ELEMENTWISE_CLAMPED = 4   # error factor F > 300 (CFL of several hundred): the rule's scale 0.3 / F was held at 1e-3 (bound weaker by F / 300)
 
 # every symbol include/cwr_transport.h declares (tests check that the library exports them all)
 ABI_SYMBOLS = (
-    'cwr_abi_version', 'cwr_tile_rows', 'cwr_create', 'cwr_destroy', 'cwr_last_error', 'cwr_load_flow_field',
+    'cwr_abi_version', 'cwr_tile_rows', 'cwr_chain_min_rows', 'cwr_create', 'cwr_destroy', 'cwr_last_error', 'cwr_load_flow_field',
     'cwr_load_coefficients', 'cwr_get_coefficients', 'cwr_load_boundary', 'cwr_set_boundary_level',
-    'cwr_set_state', 'cwr_get_state', 'cwr_load_real_inputs', 'cwr_react_linear', 'cwr_state_device_ptr', 'cwr_apply', 'cwr_rhs', 'cwr_step', 'cwr_get_mass_flux',
+    'cwr_set_state', 'cwr_get_state', 'cwr_load_real_inputs', 'cwr_react_linear', 'cwr_state_device_ptr', 'cwr_state_row_stride', 'cwr_apply', 'cwr_rhs', 'cwr_step', 'cwr_get_mass_flux',
     'cwr_get_jacobi_norms', 'cwr_set_jacobi_norms', 'cwr_get_error_factors', 'cwr_tiling_info', 'cwr_set_tile_schedule', 'cwr_get_tile_schedule',
     'cwr_time_apply', 'cwr_profile_read', 'cwr_synchronize', 'cwr_apply_bytes',
     'cwr_comm_unique_id', 'cwr_attach_comm', 'cwr_comm_selftest',
@@ -98,6 +98,10 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.cwr_abi_version.argtypes = []
     lib.cwr_tile_rows.restype = i32
     lib.cwr_tile_rows.argtypes = [i32]
+    lib.cwr_chain_min_rows.restype = i32
+    lib.cwr_chain_min_rows.argtypes = [i32]
+    lib.cwr_state_row_stride.restype = i32
+    lib.cwr_state_row_stride.argtypes = [vp]
     lib.cwr_last_error.restype = C.c_char_p
     lib.cwr_last_error.argtypes = [vp]
     lib.cwr_destroy.restype = None
@@ -168,6 +172,12 @@ def _ptr(a: np.ndarray | None):
 def tile_rows(n_constituents: int) -> int:
     """Rows of one tile of the engine's sweep kernel for this many constituents (cwr_tile_rows)."""
     return int(load_library().cwr_tile_rows(int(n_constituents)))
+
+
+def chain_min_rows(n_constituents: int) -> int:
+    """Rows from which an engine with this many constituents chains its tiles (cwr_chain_min_rows: the engine's own threshold,
+    CWR_CHAIN_MIN_TILES included) -- what decides between the lane-major and the Hilbert numbering (distributed.curve_kind)."""
+    return int(load_library().cwr_chain_min_rows(int(n_constituents)))
 
 
 class TransportEngine:
@@ -337,8 +347,13 @@ class TransportEngine:
         M = _arr(reaction_matrix, np.float64, (self.K, self.K), 'reaction_matrix')
         self._check(self._lib.cwr_react_linear(self._h, _ptr(M)))
 
+    def state_row_stride(self) -> int:
+        """Doubles per row of the state behind state_device_ptr(): K, or more when the engine carries zero columns behind the
+        caller's constituents (cwr_create pads K = 3, 5, 7, 9-11, 13-15, ... to the next count its kernels run well at)."""
+        return int(self._lib.cwr_state_row_stride(self._h))
+
     def state_device_ptr(self):
-        """(device pointer of the (n_cells, K) float64 state, hipStream_t) as integers."""
+        """(device pointer of the (n_cells, state_row_stride()) float64 state, hipStream_t) as integers."""
         st, sm = C.c_void_p(), C.c_void_p()
         self._check(self._lib.cwr_state_device_ptr(self._h, C.byref(st), C.byref(sm)))
         return st.value, sm.value
@@ -389,8 +404,8 @@ class TransportEngine:
                 what.append('the element-wise convergence rule was not met (the norm criterion holds)')
             if info.flags & INFO_ELEMENTWISE_CLAMPED and not getattr(self, '_clamp_warned', False):
                 self._clamp_warned = True                # a property of the flow field and dt: said once per engine, flagged every step
-                what.append('||J||_inf of this step is above 0.9967: the scale of the element-wise rule was held at 1e-3, its '
-                            'max-norm error bound is weaker by 1e-3 / (0.3 (1 - ||J||) / ||J||)')
+                what.append('the a-posteriori error factor F of this step (error_factors(): row-wise bound or ||J||/(1 - ||J||)) is above '
+                            '300: the scale of the element-wise rule was held at 1e-3, its max-norm error bound is weaker by F / 300')
             if what:
                 warnings.warn(f'transport step {t}: ' + '; '.join(what), RuntimeWarning, stacklevel=2)
         return StepResult(info.iterations, info.sweeps, info.restarts, info.operator_launches, info.solver,

@@ -88,9 +88,10 @@ enum {
   CWR_INFO_LOOSE_RESIDUAL = 1,     /* BiCGSTAB stagnated within 100 x tol after 6 verified restarts and was accepted */
   CWR_INFO_ELEMENTWISE_MISSED = 2, /* the element-wise rule |x'-x| <= 1e6 tol |x| + tol max|x| (scaled, see cwr_step) was still
                                       violated after 3 tightened BiCGSTAB rounds; the norm criterion holds */
-  CWR_INFO_ELEMENTWISE_CLAMPED = 4 /* ||J||_inf of this step is so close to 1 (> 0.9967: CFL of several hundred) that the scale of the
-                                      element-wise rule, s = 0.3 (1 - ||J||_inf) / ||J||_inf, fell below 1e-3 and was held there: the
-                                      max-norm forward-error bound of cwr_step is then 0.3 (1e6 tol + tol) max|x| x (1e-3 / s) */
+  CWR_INFO_ELEMENTWISE_CLAMPED = 4 /* the a-posteriori error factor F of this step (cwr_get_error_factors: the row-wise bound
+                                      max((I - J)^-1 1) - 1, or ||J||_inf / (1 - ||J||_inf) where that is smaller) is above 300 -- CFL of
+                                      several hundred -- so the scale of the element-wise rule, s = 0.3 / F, fell below 1e-3 and was held
+                                      there: the max-norm forward-error bound of cwr_step is then 0.3 (1e6 tol + tol) max|x| x (1e-3 / s) */
 };
 
 int32_t cwr_abi_version(void);
@@ -100,6 +101,12 @@ int32_t cwr_abi_version(void);
  * within two face steps): the kernel's waves loop to the longest of their rows.  0 = no arrangement wanted.  Purely a speed
  * matter. */
 int32_t cwr_tile_rows(int32_t n_constituents);
+/* Rows from which an engine with K constituents links its tiles into chains along the flow and relaxes in place (see "tiling and
+ * the chained passes" below): 1.75 tiles per block of its persistent grid (CWR_CHAIN_MIN_TILES), four resident blocks per CU.  A
+ * host wrapper that chooses the cell numbering before it creates the engine -- lanes along the flow for engines that chain, an
+ * isotropic space-filling curve for those that do not -- asks this, so that numbering and engine follow one threshold.  No handle
+ * and no GPU needed (without a device: 256 CUs).  Purely a speed matter. */
+int32_t cwr_chain_min_rows(int32_t n_constituents);
 
 /* ---- construction -------------------------------------------------------------------------------
  * Replaces LHS.__init__ (linalg.py:18-32: internal / real face index sets) and RHS.__init__
@@ -109,6 +116,10 @@ int32_t cwr_tile_rows(int32_t n_constituents);
  *   [n_owned + n_halo, n_cells)       ghost (boundary) cells
  * On one GPU n_owned = nreal + 1 and the numbering is the reference's own.
  * face1/face2: (n_edges) int32, face1 must be a real cell (as in every HEC-RAS file the reference reads).
+ * n_constituents = K of every (.., K) array at this boundary.  Internally the engine may carry more columns: K = 3, 5, 7 run as
+ * 4, 6, 8 and K > 8 as the next multiple of 4 (zero columns behind the caller's, which solve to zero and are stripped at every
+ * read-out: the kernels' wide mappings need an even K, best a multiple of 4, and the reference's cost is linear in K,
+ * transport.py:231; CWR_K_PAD=0 switches it off).  Visible only through cwr_state_device_ptr: cwr_state_row_stride.
  */
 int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_edges,
                    int32_t n_constituents, const int32_t* face1, const int32_t* face2,
@@ -170,7 +181,7 @@ int32_t cwr_load_real_inputs(cwr_engine* e, int32_t n_entries, const int32_t* le
  * cwr_react_linear: c[cell, :] <- M c[cell, :] on every owned cell, M (K, K) row-major host array (first-order
  *   decay on the diagonal, pairwise exchange off it) -- the built-in stand-in for a TSM/NSM kinetics kernel;
  * cwr_state_device_ptr: the device pointer of the (n_cells, K) float64 state and the engine's hipStream_t, for a
- *   caller-supplied HIP reaction kernel launched between two cwr_step() calls.  Rows are in the cell numbering this
+ *   caller-supplied HIP reaction kernel launched between two cwr_step() calls (row stride: cwr_state_row_stride).  Rows are in the cell numbering this
  *   engine was CREATED with: rows [0, n_owned) are the real cells face1/face2 of cwr_create refer to (a host wrapper that
  *   renumbers cells before cwr_create -- engine.py's cell_order -- must hand its row map to the kernel's author:
  *   TransportEngine.state_row_order()).  The pointer never changes; once it has been handed out the engine assumes the
@@ -178,6 +189,9 @@ int32_t cwr_load_real_inputs(cwr_engine* e, int32_t n_entries, const int32_t* le
  *   exchange).  Work enqueued on the returned stream is ordered with the engine's own kernels. */
 int32_t cwr_react_linear(cwr_engine* e, const double* reaction_matrix);
 int32_t cwr_state_device_ptr(cwr_engine* e, void** state, void** stream);
+/* Doubles per row of that state: n_constituents, or the padded count the engine runs with (cwr_create); columns >= n_constituents
+ * hold zeros (NaN on ghost rows) and must be left alone. */
+int32_t cwr_state_row_stride(const cwr_engine* e);
 
 /* ---- the face-flux operator (exported for parity tests and roofline timing) ---------------------
  * y = A x with A the matrix LHS.update_values(mesh, t) + csr_matrix build (linalg.py:34-156,
@@ -196,13 +210,15 @@ int32_t cwr_rhs(cwr_engine* e, int32_t t, const double* x_t, double* b);
  * tol: target for ||D^-1 (b - A x)||_2 / ||D^-1 b||_2 per constituent (e.g. 1e-12); max_iter bounds
  * sweeps and BiCGSTAB iterations each.  info may be NULL.
  * On top of the norm criterion every cell and constituent must satisfy |x'_i - x_i| <= s (1e6 tol |x'_i| + tol max|x'|)
- * for one more Jacobi sweep x -> x', s = 0.3 (1 - rho) / rho with rho = ||J||_inf of this step's Jacobi iteration matrix
- * (exact, from the flow field: cwr_get_jacobi_norms), kept within [1e-3, 0.1].  Jacobi's a-posteriori bound
- * ||x* - x'||_inf <= rho / (1 - rho) ||x' - x||_inf then gives a RIGOROUS max-norm forward error of 0.3 (1e6 tol + tol) max|x|
- * (3e-7 of the largest concentration at tol = 1e-12); that every cell is also within 1e-6 of ITS OWN value down to the
- * 1e-12 max|x| floor -- plume fronts many decades below the peak, which a 2-norm cannot see -- is what the per-cell form of
- * the rule buys empirically (tests: element-wise against spsolve output up to CFL 180).  When s would fall below 1e-3 the
- * step runs at 1e-3 and sets CWR_INFO_ELEMENTWISE_CLAMPED.
+ * for one more Jacobi sweep x -> x', with s = 0.3 / F kept within [1e-3, 0.1] and F the a-posteriori factor of this step's Jacobi
+ * iteration matrix J, ||x* - x'||_inf <= F ||x' - x||_inf (cwr_get_error_factors): the ROW-WISE bound max((I - J)^-1 1) - 1, taken
+ * from a few sweeps of the Neumann series when the flow field is loaded (partitioned engines: over the ranks, so that every rank
+ * holds the factor of the global matrix), or the norm form ||J||_inf / (1 - ||J||_inf) where that is smaller.  That gives a
+ * RIGOROUS max-norm forward error of 0.3 (1e6 tol + tol) max|x| (3e-7 of the largest concentration at tol = 1e-12) -- also on
+ * meshes with dry or nearly dry cells, whose worst row sum (> 1 beside a dry cell) admits no norm bound; that every cell is also
+ * within 1e-6 of ITS OWN value down to the 1e-12 max|x| floor -- plume fronts many decades below the peak, which a 2-norm cannot
+ * see -- is what the per-cell form of the rule buys empirically (tests: element-wise against spsolve output up to CFL 180).  When
+ * s would fall below 1e-3 (F > 300) the step runs at 1e-3 and sets CWR_INFO_ELEMENTWISE_CLAMPED.
  * A step that fails (CWR_ERR_NOT_CONVERGED, CWR_ERR_NONFINITE, CWR_ERR_GHOST_COEFF) leaves the state exactly as it
  * found it: it may be retried with another tolerance, iteration budget or solver.
  * The call returns as soon as convergence is known: the ghost write-back and flux kernels that close the step may still
@@ -222,12 +238,14 @@ int32_t cwr_get_mass_flux(cwr_engine* e, double* advection, double* diffusion, d
  * (No reference counterpart: spsolve is direct, transport.py:249.) */
 int32_t cwr_get_jacobi_norms(cwr_engine* e, int32_t n_times, double* norms);
 int32_t cwr_set_jacobi_norms(cwr_engine* e, int32_t n_times, const double* norms);
-/* The factor the element-wise rule of cwr_step is really scaled by: factors[t] = F_t with ||x* - x'||_inf <= F_t ||x' - x||_inf for
+/* The factor the element-wise rule of cwr_step is scaled by: factors[t] = F_t with ||x* - x'||_inf <= F_t ||x' - x||_inf for
  * a Jacobi sweep x -> x' of step t (x*: the solution spsolve returns, transport.py:249).  ||J||_inf / (1 - ||J||_inf) where that is
- * finite; single engines replace it by the row-wise bound max((I - J)^-1 1) - 1 <= max(w_m - 1) / (1 - ||J^m 1||_inf), taken from
- * a few sweeps of the Neumann series when the flow field is loaded, where that is smaller: meshes with dry or nearly dry cells,
- * whose worst row sum (> 1 beside a dry cell) says nothing about the error of a sweep.  cwr_set_jacobi_norms resets the factors to
- * the norm form of the caller's values. */
+ * finite, replaced by the row-wise bound max((I - J)^-1 1) - 1 <= max(w_m - 1) / (1 - ||J^m 1||_inf), taken from a few sweeps of the
+ * Neumann series when the flow field is loaded, where that is smaller: meshes with dry or nearly dry cells, whose worst row sum
+ * (> 1 beside a dry cell) says nothing about the error of a sweep.  Partitioned engines run those sweeps over the ranks (one halo
+ * exchange per `exchange_every` sweeps, one all-reduce per check -- at load / attach time only: both calls are collective) and
+ * hold the factors of the GLOBAL matrix, the ones a single engine holds.  cwr_set_jacobi_norms resets the factors to the norm
+ * form of the caller's values. */
 int32_t cwr_get_error_factors(cwr_engine* e, int32_t n_times, double* factors);
 
 /* ---- measurement --------------------------------------------------------------------------------
@@ -244,10 +262,11 @@ int32_t cwr_synchronize(cwr_engine* e);
 int32_t cwr_apply_bytes(const cwr_engine* e, int64_t* bytes_read, int64_t* bytes_written);
 
 /* ---- tiling and the chained passes (diagnostics / tuning; no reference counterpart: spsolve is direct, transport.py:249) ----
- * The dominant sweep kernel walks tiles of cwr_tile_rows(K) rows with a persistent grid.  From three tiles per block up the
+ * The dominant sweep kernel walks tiles of cwr_tile_rows(K) rows with a persistent grid.  From 1.75 tiles per block up
+ * (CWR_CHAIN_MIN_TILES; cwr_tiling_info returns tiles and blocks: a host wrapper that chooses the cell numbering asks it) the
  * engine links the tiles into chains along the flow of the level being solved and relaxes IN PLACE along them (block
  * Gauss-Seidel along the flow without any block waiting for another; what consecutive tiles of a block's list share is
- * carried over in LDS; re-derived every CWR_CHAIN_REFRESH = 64 levels; CWR_NO_CHAINS=1: the deterministic ping-pong passes).
+ * carried over in LDS; re-derived every CWR_CHAIN_REFRESH = 64 levels; CWR_NO_CHAINS=1: ping-pong passes in tile order).
  * cwr_tiling_info: out = {tiled pass available, tiles, blocks of its grid, rows per tile}.
  * cwr_set_tile_schedule: install a caller's schedule instead: sched[it * n_lists + b] = it-th tile of block b, -1 = end of
  *   the list; n_lists must equal the grid, every tile must appear exactly once (checked).  depth = 0: back to the engine's own.
@@ -268,8 +287,18 @@ int32_t cwr_get_tile_schedule(cwr_engine* e, int32_t info[4], int32_t* out, int6
  *   peers[i]                      rank of the i-th neighbour
  *   send_ptr[i] .. send_ptr[i+1]  slice of send_cells (local core ids) packed for peers[i]
  *   recv_ptr[i] .. recv_ptr[i+1]  slice of recv_cells (local ids in [n_core, n_owned + n_halo)) filled by peers[i]
- * Exchanges are ncclGroupStart/Send/Recv/End on the engine stream between a pack and an unpack kernel;
- * inner products are completed with ncclAllReduce.  BiCGSTAB exchanges before every operator launch. */
+ * Every RCCL call of an engine -- ncclGroupStart/Send/Recv/End between a pack and an unpack kernel, the ncclAllReduce of the inner
+ * products and checks -- is issued on ONE communication stream of the engine's own, ordered against the engine's stream by
+ * events; an exchange runs beside the interior tiles of the pass (sweep, flux kernel) that needs it.  BiCGSTAB exchanges before
+ * every operator launch.
+ * world == 1 with n_peers == 0 attaches a STAND-ALONE rank: the row layout and launch structure of one rank of a larger partition
+ * (n_core < n_owned: replayed layers; n_halo read-only rows) that never exchanges -- the rows outside the core keep what the caller
+ * put there (measurement of a rank's compute side: tools/rank_step_profile.py).
+ * Hosting: one process per GPU is the supported arrangement.  Several engines in ONE process, each driven by its own thread, work
+ * as far as this library goes (every entry point switches its thread to the thread-local stream-capture mode, so one engine's
+ * hipGraph capture does not refuse the other's calls) -- but the streams of one process share its copy-engine rings, which
+ * execute in order: a communication layer that parks a copy behind a wait on a peer (the test stand-in does; RCCL's kernels do
+ * not) can then block its process mate's copies. */
 int32_t cwr_comm_unique_id(uint8_t id_out[128]);
 int32_t cwr_attach_comm(cwr_engine* e, int32_t rank, int32_t world, const uint8_t unique_id[128], int32_t n_core,
                         int32_t exchange_every, int32_t n_peers, const int32_t* peers, const int32_t* send_ptr,

@@ -159,9 +159,9 @@ def test_without_chains_runs_are_bitwise_reproducible_and_with_them_within_the_t
     assert rel_err(runs[True][0], runs[True][1]) <= 1e-10
 
 
-def test_the_deterministic_step_flag_selects_ping_pong_passes_per_step(gpu_lib, monkeypatch):
+def test_the_deterministic_step_flag_selects_the_deterministic_passes_per_step(gpu_lib, monkeypatch):
     """regression-stable output without an environment variable.  On ONE engine that chains by default, steps taken with
-    deterministic=True (CWR_STEP_DETERMINISTIC) run the ping-pong passes -- cwr_step_info.chained says which ran -- and two engines
+    deterministic=True (CWR_STEP_DETERMINISTIC) run the passes between two vectors (the tile chains still walked: chained == 2) -- cwr_step_info.chained says which ran -- and two engines
     driven that way agree bit for bit, while the default steps of the same engines agree to the solver tolerance only.  The facade
     forwards its constructor keyword."""
     import clearwater_riverine_amd as cw

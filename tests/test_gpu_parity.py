@@ -147,13 +147,18 @@ def test_facade_multi_constituent_and_override(gpu_lib, K, solver, path, monkeyp
         assert flux_err(model.constituent_dict[nm].total_mass_flux[:12], ref.constituent_dict[nm].total_mass_flux[:12]) <= 1e-8
 
 
-@pytest.mark.parametrize('K', [2, 5, 7, 8, 12, 20, 24, 32, 64])
-def test_step_parity_across_constituent_counts_on_tiled_meshes(gpu_lib, K, monkeypatch):
+@pytest.mark.parametrize('K,pad', [(2, True), (3, True), (5, True), (5, False), (7, True), (7, False), (8, True), (10, True), (10, False), (12, True),
+                                   (13, True), (20, True), (24, True), (32, True), (64, True)])
+def test_step_parity_across_constituent_counts_on_tiled_meshes(gpu_lib, K, pad, monkeypatch):
     """Every lane mapping of the sweep kernels (VW = 1 for odd K, 2, and the four-wide split-row mapping of
     K % 16 == 0; wide rows that do not fit the tiled pass fall back to the un-tiled J^2 pass) against the oracle's
-    spsolve, on a mesh of many 64-row tiles with merged (5-6 face) cells and a dry cell."""
+    spsolve, on a mesh of many 64-row tiles with merged (5-6 face) cells and a dry cell.
+    Round 5: K = 3, 5, 7, 10, 13 run as 4, 6, 8, 12, 16 inside the engine (zero columns behind the caller's, stripped at every
+    read-out: cwr_create); pad = False (CWR_K_PAD=0) keeps the native odd / 5-lane mappings exercised."""
     import clearwater_riverine_amd as cw
     monkeypatch.setenv('CWR_NO_SMALL', '1')
+    if not pad:
+        monkeypatch.setenv('CWR_K_PAD', '0')
     mesh, inputs3 = synthetic_case(K, nx=96, ny=48, n_steps=3, seed=13, n_merge=150, n_dry=1, dt=30.0,
                                    diffusion_coefficient=0.4)
     n = mesh['nreal'] + 1
@@ -171,6 +176,15 @@ def test_step_parity_across_constituent_counts_on_tiled_meshes(gpu_lib, K, monke
     for kk, nm in ((0, names[0]), (1, names[-1])):
         assert rel_err(model.mesh[nm], ref.constituent_dict[f'c{kk}'].state) <= TOL_CONC
         assert flux_err(model.constituent_dict[nm].total_mass_flux[:3], ref.constituent_dict[f'c{kk}'].total_mass_flux[:3]) <= 1e-8
+    want_stride = {3: 4, 5: 6, 7: 8, 10: 12, 13: 16}.get(K, K) if pad else K
+    assert model.engine.state_row_stride() == want_stride
+    # the blocking read-outs strip the padded columns too (the facade above read through the output ring)
+    st = model.engine.get_state()
+    assert st.shape == (len(mesh['face_x']), K) and rel_err(st[:, K - 1], ref.constituent_dict['c1'].state[3]) <= TOL_CONC
+    adv, dif, tot = model.engine.get_mass_flux()
+    assert tot.shape == (len(mesh['edges_face1']), K) and flux_err(tot[:, 0], ref.constituent_dict['c0'].total_mass_flux[2]) <= 1e-8
+    mass, vol = model.engine.domain_mass(3)
+    assert mass.shape == (K,) and np.isclose(mass[K - 1], float(np.sum(np.asarray(mesh['volume'])[3, :n].astype(np.float64) * st[:n, K - 1])), rtol=1e-9)
 
 
 @pytest.mark.parametrize('K', [1, 12])

@@ -230,8 +230,14 @@ def test_curve_kind_follows_the_size_of_a_rank_and_the_environment(monkeypatch):
     # 125 k cells per rank: 1.9 tiles per block -- chained since the lane boundaries were smoothed (1.75 tiles per block; was 3)
     assert curve_kind(1_000_000, 16, 8) == 'lanes' and curve_kind(120_000, 16, 1) == 'lanes'
     assert curve_kind(1_000_000, 1, 2) == 'lanes' and curve_kind(1_000_000, 1, 4) == 'hilbert'       # (256-row tiles at K = 1)
-    lim = int(1.75 * 1024 * tr)
+    from clearwater_riverine_amd.engine import chain_min_rows
+    lim = chain_min_rows(16)
+    assert lim == int(1.75 * 1024) * tr                          # (four resident blocks on each of 256 CUs; no GPU here: the default)
     assert curve_kind(lim * 2, 16, 2) == 'lanes' and curve_kind(lim * 2 - 2, 16, 2) == 'hilbert'
+    # the numbering follows the ENGINE's threshold: CWR_CHAIN_MIN_TILES moves both (round 5; it used to move the engine's only)
+    monkeypatch.setenv('CWR_CHAIN_MIN_TILES', '3')
+    assert chain_min_rows(16) == 3 * 1024 * tr and curve_kind(120_000, 16, 1) == 'hilbert' and curve_kind(250_000, 16, 1) == 'lanes'
+    monkeypatch.delenv('CWR_CHAIN_MIN_TILES')
     monkeypatch.setenv('CWR_NO_CHAINS', '1')
     assert curve_kind(1_000_000, 16, 1) == 'hilbert'
     monkeypatch.setenv('CWR_TILE_ORDER', 'lanes')
