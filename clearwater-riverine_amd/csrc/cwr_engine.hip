@@ -96,10 +96,33 @@ struct cwr_engine {
   uint8_t* d_row_ghost = nullptr;          // 1 where a computed row has a boundary (ghost) face
   std::vector<int32_t> bad_level;          // per time level: the zero-coefficient precondition is violated (k_check_ghost_levels)
   std::vector<int32_t> h_face_pos;         // reference face id -> internal face index
-  // flow field, all levels resident in HBM
+  // flow field: all T levels resident in HBM (W == T), or -- windowed (round 5: cwr_flow_window_open / _load) -- a ring of W < T
+  // levels, level t in slot t % W, filled on a stream of its own beside the steps
   int T = 0, T_bc = 0;
+  int W = 0;                               // levels the device arrays hold
+  int flow_cap = 0;                        // ... and are allocated for
+  bool windowed = false;
   float *d_adv = nullptr, *d_vel = nullptr, *d_vol = nullptr;
   double* d_dif = nullptr;
+  size_t slot(int t) const { return windowed ? (size_t)(t % W) : (size_t)t; }
+  float* adv_l(int t) const { return d_adv + slot(t) * (size_t)E; }
+  double* dif_l(int t) const { return d_dif + slot(t) * (size_t)E; }
+  float* vel_l(int t) const { return d_vel + slot(t) * (size_t)E; }
+  float* vol_l(int t) const { return d_vol + slot(t) * (size_t)n_cells; }
+  std::vector<int32_t> slot_level;         // windowed: the level every slot holds (-1: none)
+  hipStream_t flow_stream = nullptr;       // windowed: upload, derivation, norms of the incoming levels
+  std::vector<hipEvent_t> ev_level;        // [W] recorded on flow_stream when the slot's level is complete
+  hipEvent_t ev_evict = nullptr;           // engine stream -> flow stream: every user of the level being replaced is done
+  float *d_in_f = nullptr, *d_flow_l = nullptr;   // staging of ONE level: reference face order in, face flows in internal order
+  double* d_dist = nullptr;                // face_to_face_dist in internal face order (kept by windowed engines)
+  unsigned long long* d_jn = nullptr;      // [T] ||J||_inf bit patterns per step (windowed)
+  int32_t* d_bad = nullptr;                // [T] zero-coefficient flags per level (windowed)
+  double* d_lvl_view = nullptr;            // the device's address of h_lvl
+  double* h_lvl = nullptr;                 // page-locked [T][2]: {||J||_inf of step t, flag of level t}: where flow_stream leaves them
+  std::vector<char> lvl_final;             // windowed: jnorm / err_factor / bad_level of index t are final on the host
+  // the Neumann vectors of refine_error_factors: ONE column (k_neumann), two of them, and the maxima of every sweep
+  double *d_wa = nullptr, *d_wb = nullptr;
+  unsigned long long* d_wmax = nullptr;
   std::vector<double> dt;
   double D = 0.0;
   double* d_bc = nullptr;
@@ -115,6 +138,7 @@ struct cwr_engine {
   // (round 5) the check scalars of a single engine reach the host without a copy and without draining the stream: k_reduce_partials
   // stores them into this page-locked buffer and publishes a sequence number behind them (ReduceNote); the host spins on it
   double* h_note = nullptr;        // [4 K] doubles + the sequence word (hipHostMalloc, mapped)
+  double* d_note_view = nullptr;   // the device's address of h_note
   unsigned long long* h_note_seq = nullptr;
   unsigned long long* d_note_state = nullptr;   // device: [0] the sequence counter, [1] (as unsigned int) the arrival counter
   unsigned long long note_expected = 0;         // notifications enqueued so far
@@ -412,8 +436,8 @@ int resident_blocks(const void* fn, size_t lds) {
 int prep_step(cwr_engine* e, int t) {
   if (e->prepared_t == t) return CWR_OK;
   k_prep_step<<<cdiv(e->n_owned, BLOCK), BLOCK, 0, e->stream>>>(
-      e->n_owned, e->d_ptr, e->d_ent_edge, e->d_ent_nb, e->d_adv + (size_t)t * e->E,
-      e->d_dif + (size_t)t * e->E, e->d_vol + (size_t)(t + 1) * e->n_cells, e->dt[t], e->d_rec, e->d_diag, e->d_w);
+      e->n_owned, e->d_ptr, e->d_ent_edge, e->d_ent_nb, e->adv_l(t),
+      e->dif_l(t), e->vol_l(t + 1), e->dt[t], e->d_rec, e->d_diag, e->d_w);
   HIP_TRY(e, hipGetLastError());
   e->prepared_t = t;
   return CWR_OK;
@@ -424,7 +448,8 @@ int reduce_partials(cwr_engine* e, int nslots, int ND, double* o0, double* o1 = 
   ReduceOuts outs; outs.p[0] = o0; outs.p[1] = o1; outs.p[2] = o2; outs.p[3] = o3;
   ReduceNote note{nullptr, nullptr, nullptr, nullptr};
   if (notify && e->h_note && ND == 4 && o0 && o1 && o2 && o3)
-    note = ReduceNote{e->h_note, e->h_note_seq, reinterpret_cast<unsigned int*>(e->d_note_state + 1), e->d_note_state};
+    note = ReduceNote{e->d_note_view, reinterpret_cast<unsigned long long*>(e->d_note_view + 4 * (size_t)e->K),
+                      reinterpret_cast<unsigned int*>(e->d_note_state + 1), e->d_note_state};
   k_reduce_partials<<<ND, RBLOCK, 0, e->stream>>>(nslots, ND, e->K, e->d_partial, outs, max_from, note);
   HIP_TRY(e, hipGetLastError());
   return CWR_OK;
@@ -627,11 +652,10 @@ bool elementwise_ok(const cwr_engine* e, const double* h, double* ratio) {
 
 int launch_rhs(cwr_engine* e, int t, const double* x, double* b, bool scale, double* keep = nullptr) {
   const int grid = std::max(1, std::min(cdiv(e->n_owned, e->R), 256 * 16));
-  const size_t E = e->E;
-  const float* vol_t = e->d_vol + (size_t)t * e->n_cells;
-  const float* vel_n = e->d_vel + (size_t)(t + 1) * E;
-  const float* adv_n = e->d_adv + (size_t)(t + 1) * E;
-  const double* dif_n = e->d_dif + (size_t)(t + 1) * E;
+  const float* vol_t = e->vol_l(t);
+  const float* vel_n = e->vel_l(t + 1);
+  const float* adv_n = e->adv_l(t + 1);
+  const double* dif_n = e->dif_l(t + 1);
   const double* bc_n = e->d_bc + (size_t)(t + 1) * e->n_ghost * e->K;
   const int used = (e->D != 0.0) ? 1 : 0;
 #define CWR_RHS(VWv, SC) k_rhs<VWv, SC><<<grid, BLOCK, 0, e->stream>>>(e->n_owned, e->K, e->G, e->d_ptr, e->d_ent_edge, \
@@ -646,11 +670,10 @@ int launch_rhs(cwr_engine* e, int t, const double* x, double* b, bool scale, dou
 
 // the opening of step t in one launch (k_begin_step): what prep_step + launch_rhs(scale, keep) + the ghost write-back of step_tail did
 int launch_begin_step(cwr_engine* e, int t) {
-  const size_t E = e->E;
   const int used = (e->D != 0.0) ? 1 : 0;
 #define CWR_BEGIN(VWv) k_begin_step<VWv><<<cdiv(e->n_owned, BLOCK), BLOCK, 0, e->stream>>>(e->n_owned, e->n_real, e->n_cells, e->K, e->G, e->d_ptr, \
-    e->d_ent_edge, e->d_ent_nb, e->d_adv + (size_t)t * E, e->d_dif + (size_t)t * E, e->d_vol + (size_t)(t + 1) * e->n_cells, e->dt[t], e->d_rec, \
-    e->d_diag, e->d_w, e->d_vol + (size_t)t * e->n_cells, e->d_vel + (size_t)(t + 1) * E, e->d_adv + (size_t)(t + 1) * E, e->d_dif + (size_t)(t + 1) * E, \
+    e->d_ent_edge, e->d_ent_nb, e->adv_l(t), e->dif_l(t), e->vol_l(t + 1), e->dt[t], e->d_rec, \
+    e->d_diag, e->d_w, e->vol_l(t), e->vel_l(t + 1), e->adv_l(t + 1), e->dif_l(t + 1), \
     used, e->d_bc + (size_t)(t + 1) * e->n_ghost * e->K, e->d_c, e->d_row_ghost, e->d_b, e->d_counters, e->d_keep, e->d_chk + 4 * (size_t)e->K, e->ew_rel, \
     e->bad_flag())
   if (e->VW == 2) CWR_BEGIN(2); else CWR_BEGIN(1);
@@ -690,6 +713,31 @@ int check_level(cwr_engine* e, int t, bool need_next) {
   if (e->T <= 0) return fail(e, CWR_ERR_STATE, "no flow field loaded (cwr_load_flow_field / cwr_load_coefficients)");
   if (t < 0 || t + (need_next ? 1 : 0) >= e->T)
     return fail(e, CWR_ERR_STATE, "time level " + std::to_string(t) + " out of range for " + std::to_string(e->T) + " levels");
+  if (e->windowed)
+    for (int q = t; q <= t + (need_next ? 1 : 0); ++q) {
+      if (e->slot_level[e->slot(q)] != q)
+        return fail(e, CWR_ERR_STATE, "time level " + std::to_string(q) + " is not in the flow-field window (cwr_flow_window_load: slot " +
+                    std::to_string(e->slot(q)) + " holds level " + std::to_string(e->slot_level[e->slot(q)]) + ")");
+      HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_level[e->slot(q)], 0));   // (whatever the caller enqueues next reads the arrived level)
+    }
+  return CWR_OK;
+}
+
+// Windowed engines: before step t runs, its two levels must have arrived (the engine's stream waits for the flow stream's events)
+// and the host needs what the flow stream left for it -- ||J||_inf of step t, the zero-coefficient flag of level t + 1 -- and the
+// row-wise error factor where the norm form is not good enough (refine_level: synchronously here, the price of a level whose
+// worst row says nothing; uniform fields never pay it).  The same numbers a resident engine holds after cwr_load_flow_field.
+int refine_level(cwr_engine* e, int t);
+int finalize_level(cwr_engine* e, int t) {
+  if (!e->windowed || e->lvl_final[(size_t)t]) return CWR_OK;      // (check_level has made the engine's stream wait for both levels)
+  HIP_TRY(e, hipEventSynchronize(e->ev_level[e->slot(t + 1)]));    // (the later of the two: the flow stream works in load order)
+  HIP_TRY(e, hipEventSynchronize(e->ev_level[e->slot(t)]));
+  const double rho = e->h_lvl[2 * (size_t)t];
+  e->jnorm[(size_t)t] = rho;
+  e->bad_level[(size_t)t + 1] = e->h_lvl[2 * ((size_t)t + 1) + 1] != 0.0 ? 1 : 0;
+  e->err_factor[(size_t)t] = (rho >= 0.0 && rho < 1.0) ? rho / (1.0 - rho) : INFINITY;
+  if (e->neumann_sweeps > 0) TRY(refine_level(e, t));
+  e->lvl_final[(size_t)t] = 1;
   return CWR_OK;
 }
 
@@ -702,15 +750,16 @@ void collect_profile(cwr_engine* e) {
 }
 
 int alloc_flow(cwr_engine* e, int T) {
-  if (e->T != T) {
+  if (e->flow_cap != T) {
     hipFree(e->d_adv); hipFree(e->d_dif); hipFree(e->d_vel); hipFree(e->d_vol);
-    e->d_adv = nullptr; e->d_dif = nullptr; e->d_vel = nullptr; e->d_vol = nullptr; e->T = 0;
+    e->d_adv = nullptr; e->d_dif = nullptr; e->d_vel = nullptr; e->d_vol = nullptr; e->T = 0; e->flow_cap = 0;
     TRY(dev_alloc(e, &e->d_adv, (size_t)T * e->E));
     TRY(dev_alloc(e, &e->d_dif, (size_t)T * e->E));
     TRY(dev_alloc(e, &e->d_vel, (size_t)T * e->E));
     TRY(dev_alloc(e, &e->d_vol, (size_t)T * e->n_cells));
+    e->flow_cap = T;
   }
-  e->T = T;
+  e->T = T; e->W = T; e->windowed = false;
   e->prepared_t = -1;
   return CWR_OK;
 }
@@ -759,7 +808,7 @@ int compute_jnorms(cwr_engine* e) {
     const int nt = std::min(32768, T - 1 - t0);
     k_jnorm<<<dim3((unsigned)cdiv(e->n_owned, BLOCK), (unsigned)nt), BLOCK, 0, e->stream>>>(
         e->n_owned, e->E, e->n_cells, e->d_ptr, e->d_ent_edge, e->d_ent_nb, e->d_adv + (size_t)t0 * e->E, e->d_dif + (size_t)t0 * e->E,
-        e->d_vol + (size_t)t0 * e->n_cells, t_dt.p + t0, t_jn.p + t0);
+        e->d_vol + (size_t)(t0 + 1) * e->n_cells, t_dt.p + t0, t_jn.p + t0, 0.0);
     HIP_TRY(e, hipGetLastError());
   }
   static_assert(sizeof(unsigned long long) == sizeof(double), "bit patterns");
@@ -802,30 +851,66 @@ int sync_jnorms(cwr_engine* e) {
 // neighbours.  w is bounded rigorously from the Neumann series: w_m = sum_{k<=m} J^k 1 (m sweeps of w <- 1 + J w from 1),
 // r_m = w_{m+1} - w_m = J^{m+1} 1 >= 0, and w - w_{m+1} = (I - J)^-1 J r_m <= ||r_m||_inf (w - 1), so
 //     max(w) - 1 <= max(w_{m+1} - 1) / (1 - ||r_m||_inf)          once ||r_m||_inf < 1.
-// Evaluated once per loaded level with the engine's own sweep kernel (all K columns carry the same numbers).
+// Evaluated per loaded level with a matrix-free one-column sweep of its own (k_neumann: J's entries formed on the fly from the
+// level's coefficients; round 4 ran the K-wide solver sweep on K identical columns).
 // Partitioned engines (round 5): the same sweeps over the rank's computed rows (core + replayed layers) with one halo exchange per
 // `exch_every` sweeps -- the deep halo serves the Neumann vector exactly as it serves the solver's sweeps -- and ONE all-reduce per
 // check that carries every rank's (||r_m||_inf, max w) in a slot of its own: every rank ends with the factor of the GLOBAL matrix, the
 // one a single engine would hold, and takes the same stop decisions.  COLLECTIVE then: called where the flow field is loaded with a
 // communicator attached, or where the communicator is attached to an engine that holds a flow field (cwr_attach_comm).
-int bound_check(cwr_engine* e, double* r, double* wmax) {
-  const size_t K = (size_t)e->K;
+constexpr int NEU_FIRST = 12, NEU_NEXT = 8;      // sweeps before the first / every later host decision
+
+int neumann_buffers(cwr_engine* e) {
+  if (e->d_wa) return CWR_OK;
+  TRY(dev_alloc(e, &e->d_wa, (size_t)e->n_real));
+  TRY(dev_alloc(e, &e->d_wb, (size_t)e->n_real));
+  TRY(dev_alloc(e, &e->d_wmax, (size_t)2 * (e->neumann_sweeps + NEU_FIRST + NEU_NEXT)));
+  return CWR_OK;
+}
+
+// one-column halo exchange of the Neumann vector (partitioned engines; the solver's send / receive buffers serve: nothing else
+// runs while a flow field is being loaded or a communicator attached)
+int exchange_halo_1col(cwr_engine* e, double* vec, double* vec2) {
+  if (!e->comm || e->peers.empty()) return CWR_OK;
+  hipStream_t cs = (e->one_comm_stream && e->comm_stream) ? e->comm_stream : e->stream;
+  if (e->n_send > 0) {
+    k_pack_rows<<<cdiv(e->n_send, BLOCK), BLOCK, 0, e->stream>>>((int64_t)e->n_send, 1, e->d_send_cells, vec, e->d_sendbuf);
+    HIP_TRY(e, hipGetLastError());
+  }
+  if (cs != e->stream) { HIP_TRY(e, hipEventRecord(e->ev_packed, e->stream)); HIP_TRY(e, hipStreamWaitEvent(cs, e->ev_packed, 0)); }
+  NCCL_TRY(e, g_rccl.GroupStart());
+  for (size_t i = 0; i < e->peers.size(); ++i) {
+    const size_t ns = (size_t)(e->send_ptr[i + 1] - e->send_ptr[i]), nr = (size_t)(e->recv_ptr[i + 1] - e->recv_ptr[i]);
+    if (ns) NCCL_TRY(e, g_rccl.Send(e->d_sendbuf + (size_t)e->send_ptr[i], ns, NCCL_FLOAT64, e->peers[i], e->comm, cs));
+    if (nr) NCCL_TRY(e, g_rccl.Recv(e->d_recvbuf + (size_t)e->recv_ptr[i], nr, NCCL_FLOAT64, e->peers[i], e->comm, cs));
+  }
+  NCCL_TRY(e, g_rccl.GroupEnd());
+  if (e->n_recv > 0) {
+    k_unpack_rows<<<cdiv(e->n_recv, BLOCK), BLOCK, 0, cs>>>((int64_t)e->n_recv, 1, e->d_recv_cells, e->d_recvbuf, vec, vec2);
+    HIP_TRY(e, hipGetLastError());
+  }
+  if (cs != e->stream) { HIP_TRY(e, hipEventRecord(e->ev_halo, cs)); HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_halo, 0)); }
+  return CWR_OK;
+}
+
+// (||w_{m+1} - w_m||_inf, max w_{m+1}) of sweep `q` of the level in progress, over every rank
+int bound_check(cwr_engine* e, int q, double* r, double* wmax) {
+  double h[2];
+  static_assert(sizeof(unsigned long long) == sizeof(double), "bit patterns");
   if (!e->comm || (e->world == 1 && !e->force_coll)) {
-    std::vector<double> h(4 * K);
-    TRY(download(e, h.data(), e->d_chk, 4 * K));
-    *r = h[2 * K]; *wmax = h[3 * K];
+    TRY(download(e, reinterpret_cast<unsigned long long*>(h), e->d_wmax + 2 * (size_t)q, 2));
+    *r = h[0]; *wmax = h[1];
     return CWR_OK;
   }
   const size_t W = (size_t)e->world, n = 2 * W;                 // (d_chkx holds (2 + 2 W) K + 1 doubles)
   HIP_TRY(e, hipMemsetAsync(e->d_chkx, 0, n * sizeof(double), e->stream));
-  HIP_TRY(e, hipMemcpyAsync(e->d_chkx + 2 * (size_t)e->rank, e->d_chk + 2 * K, sizeof(double), hipMemcpyDeviceToDevice, e->stream));
-  HIP_TRY(e, hipMemcpyAsync(e->d_chkx + 2 * (size_t)e->rank + 1, e->d_chk + 3 * K, sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(e->d_chkx + 2 * (size_t)e->rank, e->d_wmax + 2 * (size_t)q, 2 * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
   TRY(allreduce(e, e->d_chkx, n));
   std::vector<double> all(n);
   TRY(download(e, all.data(), e->d_chkx, n));
   double rr = 0.0, ww = 0.0;
-  for (size_t q = 0; q < W; ++q) {                              // (a NaN on any rank is everybody's NaN: no bound from there)
-    const double a = all[2 * q], b = all[2 * q + 1];
+  for (size_t k = 0; k < W; ++k) {                              // (no bound on any rank is no bound for anybody)
+    const double a = all[2 * k], b = all[2 * k + 1];
     rr = (a != a || rr != rr) ? NAN : std::max(rr, a);
     ww = (b != b || ww != ww) ? NAN : std::max(ww, b);
   }
@@ -833,62 +918,56 @@ int bound_check(cwr_engine* e, double* r, double* wmax) {
   return CWR_OK;
 }
 
+// the row-wise factor of ONE step (level t, whose coefficients and V of level t + 1 must be on the device), synchronously
+int refine_level(cwr_engine* e, int t) {
+  if (e->err_factor[(size_t)t] <= 3.0) return CWR_OK;
+  // (the scale s = 0.3 / F of the element-wise rule is held within [1e-3, 0.1]: a factor below 3 changes nothing, so a level whose
+  // norm form is already there needs no sweeps, and the sweeps stop as soon as the bound is.  Partitioned: err_factor comes from the
+  // all-reduced norms, so every rank skips the same levels)
+  TRY(neumann_buffers(e));
+  const bool part = e->comm && (e->world > 1 || e->force_coll);
+  const int nr = e->n_real;
+  const int cap = e->neumann_sweeps + NEU_FIRST + NEU_NEXT;
+  k_fill<<<std::max(1, std::min(cdiv(nr, BLOCK), 2048)), BLOCK, 0, e->stream>>>((int64_t)nr, 1.0, e->d_wa, e->d_wb);
+  HIP_TRY(e, hipGetLastError());
+  HIP_TRY(e, hipMemsetAsync(e->d_wmax, 0, (size_t)2 * cap * sizeof(unsigned long long), e->stream));
+  double* x = e->d_wa; double* y = e->d_wb;
+  double best = e->err_factor[(size_t)t];
+  int since_exchange = 0;                                                    // (w_0 = 1 on every row, halo rows included: exact everywhere)
+  int q = 0;
+  for (int done = 0; done < e->neumann_sweeps;) {
+    const int batch = done == 0 ? NEU_FIRST : NEU_NEXT;                      // (one host round trip decides most levels: see the stop rules below)
+    for (int i = 0; i < batch; ++i, ++q) {
+      if (part && since_exchange >= e->exch_every) { TRY(exchange_halo_1col(e, x, y)); since_exchange = 0; }
+      k_neumann<<<cdiv(e->n_owned, BLOCK), BLOCK, 0, e->stream>>>(e->n_owned, e->n_core, e->d_ptr, e->d_ent_edge, e->d_ent_nb, e->adv_l(t), e->dif_l(t),
+                                                              e->vol_l(t + 1), e->dt[(size_t)t], x, y, e->d_wmax + 2 * (size_t)q);
+      HIP_TRY(e, hipGetLastError());
+      std::swap(x, y); ++since_exchange;
+    }
+    done += batch;
+    double r = 0.0, wmax = 0.0;
+    TRY(bound_check(e, q - 1, &r, &wmax));
+    // r = ||w_{m+1} - w_m||_inf, wmax = max(w_{m+1}) (over the core rows of every rank)
+    if (!std::isfinite(r) || !std::isfinite(wmax)) break;                    // NaN in the field: no bound from here
+    if (r < 1.0) best = std::min(best, (wmax - 1.0) / (1.0 - r));
+    if (r <= 0.1 || best <= 3.0) break;                                      // within 11 % of max(w) - 1, or below what matters
+    // a field whose rows are uniformly stiff gains nothing over its norm bound and would take the most sweeps to say so: where the
+    // norm form is usable (s not clamped) and ||J^12 1|| is still above 0.3 (bulk row sums >= 0.9), stop (Ohio-sized band at CFL 18, 912 levels: 0.4 -> 0.1 s)
+    if (done >= NEU_FIRST && r > 0.3 && e->err_factor[(size_t)t] < 300.0) break;
+  }
+  e->err_factor[(size_t)t] = best;
+  return CWR_OK;
+}
+
 int refine_error_factors(cwr_engine* e) {
   const int T = e->T;
-  if (T < 2 || e->neumann_sweeps <= 0 || e->err_factor.size() != (size_t)T) return CWR_OK;
+  if (T < 2 || e->neumann_sweeps <= 0 || e->err_factor.size() != (size_t)T || e->windowed) return CWR_OK;   // (windowed: per level, at the step)
   // an engine with halo rows and no communicator (yet): its halo rows would stay at w = 1 -- no bound of the global matrix;
   // cwr_attach_comm calls again
   if ((!e->comm || e->peers.empty()) && e->n_halo != 0) return CWR_OK;    // (a stand-alone rank likewise: its halo rows are frozen)
-  const bool part = e->comm && (e->world > 1 || e->force_coll);
-  const int K = e->K;
-  const size_t nK = (size_t)e->n_real * K;
-  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv((int64_t)nK, BLOCK), 256 * 8));
-  const bool was_prof = e->profiling; e->profiling = false;
-  const int keep_mode = e->dominant_mode; e->dominant_mode = -1;
-  int rc = CWR_OK;
-  for (int t = 0; t + 1 < T && rc == CWR_OK; ++t) {
-    // (the scale s = 0.3 / F of the element-wise rule is held within [1e-3, 0.1]: a factor below 3 changes nothing, so a level whose
-    // norm form is already there needs no sweeps, and the sweeps stop as soon as the bound is.  Partitioned: err_factor comes from the
-    // all-reduced norms, so every rank skips the same levels)
-    if (e->err_factor[(size_t)t] <= 3.0) continue;
-    rc = prep_step(e, t);
-    if (rc != CWR_OK) break;
-    k_fill<<<grid, BLOCK, 0, e->stream>>>((int64_t)nK, 1.0, e->d_r0, e->d_r);
-    if (hipMemsetAsync(e->d_chk + 4 * (size_t)K, 0, sizeof(double), e->stream) != hipSuccess) { rc = fail(e, CWR_ERR_HIP, "hipMemsetAsync failed"); break; }
-    double* x = e->d_r; double* y = e->d_v;
-    double best = e->err_factor[(size_t)t];
-    int since_exchange = 0;                                                  // (w_0 = 1 on every row, halo rows included: exact everywhere)
-    if (part) {
-      k_fill<<<grid, BLOCK, 0, e->stream>>>((int64_t)nK, 1.0, e->d_v, nullptr);    // (the partner's read-only layer too)
-      if (hipGetLastError() != hipSuccess) { rc = fail(e, CWR_ERR_HIP, "k_fill failed"); break; }
-    }
-    for (int done = 0; done < e->neumann_sweeps && rc == CWR_OK;) {
-      const int batch = done == 0 ? 12 : 8;                                  // (one host round trip decides most levels: see the stop rules below)
-      for (int q = 0; q < batch && rc == CWR_OK; ++q) {
-        if (part && since_exchange >= e->exch_every) { rc = exchange_halo(e, x, y); since_exchange = 0; if (rc != CWR_OK) break; }
-        rc = launch_apply<4>(e, x, y, nullptr, e->d_r0, nullptr, nullptr);
-        std::swap(x, y); ++since_exchange;
-      }
-      done += batch;
-      if (rc == CWR_OK) rc = reduce_check(e);
-      double r = 0.0, wmax = 0.0;
-      if (rc == CWR_OK) rc = bound_check(e, &r, &wmax);
-      if (rc != CWR_OK) break;
-      // r = ||w_{m+1} - w_m||_inf, wmax = max(w_{m+1}) (every column alike; over the core rows of every rank)
-      if (!std::isfinite(r) || !std::isfinite(wmax)) break;                  // NaN in the field: no bound from here
-      if (r < 1.0) best = std::min(best, (wmax - 1.0) / (1.0 - r));
-      if (r <= 0.1 || best <= 3.0) break;                                    // within 11 % of max(w) - 1, or below what matters
-      // a field whose rows are uniformly stiff gains nothing over its norm bound and would take the most sweeps to say so: where the
-      // norm form is usable (s not clamped) and ||J^12 1|| is still above 0.3 (bulk row sums >= 0.9), stop (Ohio-sized band at CFL 18, 912 levels: 0.4 -> 0.1 s)
-      if (done >= 12 && r > 0.3 && e->err_factor[(size_t)t] < 300.0) break;
-    }
-    e->err_factor[(size_t)t] = best;
-  }
-  e->profiling = was_prof;
-  e->dominant_mode = keep_mode;
-  e->prepared_t = -1;
+  for (int t = 0; t + 1 < T; ++t) TRY(refine_level(e, t));
   e->step_exchanges = e->step_overlapped = 0;
-  return rc;
+  return CWR_OK;
 }
 
 // Partitioned engines: a level at which ANY rank has real-cell inputs is taken non-speculatively by EVERY rank -- the step's
@@ -1206,7 +1285,7 @@ int build_chain_schedule(cwr_engine* e, int t) {
   TRY(build_tile_links(e));
   if (e->n_links == 0) { e->sched_level = t; return CWR_OK; }                // a single tile, or variable tiles: nothing to chain
   const int nt = e->tcl_ntiles, L = e->n_links;
-  k_link_flux<<<cdiv(L, BLOCK), BLOCK, 0, e->stream>>>(L, e->d_link_ptr, e->d_link_ent, e->d_adv + (size_t)t * e->E, e->d_link_flux);
+  k_link_flux<<<cdiv(L, BLOCK), BLOCK, 0, e->stream>>>(L, e->d_link_ptr, e->d_link_ent, e->adv_l(t), e->d_link_flux);
   HIP_TRY(e, hipGetLastError());
   std::vector<float> flux((size_t)L);
   TRY(download(e, flux.data(), e->d_link_flux, (size_t)L));
@@ -1377,8 +1456,8 @@ int step_tail(cwr_engine* e, int t, int flags) {
       const size_t cnt = (size_t)e->E * K;
       TRY(dev_alloc(e, &e->d_fadv, cnt)); TRY(dev_alloc(e, &e->d_fdif, cnt));
     }
-    const float* adv_t = e->d_adv + (size_t)t * e->E;
-    const double* dif_t = e->d_dif + (size_t)t * e->E;
+    const float* adv_t = e->adv_l(t);
+    const double* dif_t = e->dif_l(t);
     auto flux = [&](const int32_t* list, int n_list) -> int {
       const int nf = list ? n_list : e->E;
       if (nf <= 0) return CWR_OK;
@@ -1943,11 +2022,9 @@ int32_t cwr_chain_min_rows(int32_t n_constituents) {
   double min_tiles = 1.75;
   if (const char* v = getenv("CWR_CHAIN_MIN_TILES")) min_tiles = std::max(1.0, atof(v));
   if (const char* v = getenv("CWR_NO_CHAINS")) if (atoi(v) != 0) return INT32_MAX;
-  int n_cu = 256;
-  hipDeviceProp_t prop;
-  int dev = 0;
-  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
-  else (void)hipGetLastError();
+  // (no HIP call here: the question is asked before an engine exists, also by processes that must not open the GPU -- a test runner
+  // counting its processes on the card, bench.py's launcher.  gfx950 / MI355X: 256 CUs, what cwr_create finds on the device)
+  const int n_cu = 256;
   int per_cu = 4;
   if (const char* v = getenv("CWR_TCL_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(8, atoi(v)));
   int grid = (n_cu * per_cu / N_XCD) * N_XCD;
@@ -2113,10 +2190,13 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   if (eng->use_note) {
     // (a runtime that cannot map host memory leaves h_note null: the checks are downloaded as before)
     void* hp = nullptr;
-    if (hipHostMalloc(&hp, (4 * (size_t)K + 2) * sizeof(double), hipHostMallocMapped) == hipSuccess && hp) {
+    void* dp = nullptr;
+    if (hipHostMalloc(&hp, (4 * (size_t)K + 2) * sizeof(double), hipHostMallocMapped) == hipSuccess && hp &&
+        hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess && dp) {
       std::memset(hp, 0, (4 * (size_t)K + 2) * sizeof(double));
       eng->h_note = static_cast<double*>(hp);
       eng->h_note_seq = reinterpret_cast<unsigned long long*>(eng->h_note + 4 * (size_t)K);
+      eng->d_note_view = static_cast<double*>(dp);                 // (the same address on this platform; asked for, not assumed)
       CREATE_TRY(dev_alloc(eng, &eng->d_note_state, 2));
       CREATE_HIP(hipMemset(eng->d_note_state, 0, 2 * sizeof(unsigned long long)));
     } else (void)hipGetLastError();
@@ -2190,6 +2270,12 @@ void cwr_destroy(cwr_engine* e) {
                   e->d_bc, e->d_rec, e->d_diag, e->d_c, e->d_r, e->d_r0, e->d_p, e->d_v, e->d_s, e->d_t, e->d_b,
                   e->d_scal, e->d_partial, e->d_fadv, e->d_fdif, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf, e->d_ptr2, e->d_col2, e->d_row2, e->d_rec2, e->d_w, e->d_react, e->d_info, e->d_tcl_ptr, e->d_tcl_cols, e->d_loc2, e->d_w2, e->d_pair_ptr, e->d_slots, e->d_line_ptr, e->d_line_faces, e->d_ledger, e->d_mass_out, e->d_chk, e->d_face_orig, e->d_row_ghost, e->d_keep, e->d_in_rows, e->d_in_vals, e->d_face_pos, e->d_trow, e->d_vptr, e->d_meta, e->d_tile_inner, e->d_tile_outer, e->d_apply_inner, e->d_apply_outer, e->d_face_inner, e->d_face_outer, e->d_chkx, e->d_sq_fast, e->d_sched, e->d_link_ptr, e->d_link_ent, e->d_link_flux, e->d_scols, e->d_scols_io, e->sched_in.d, e->sched_out.d};
   for (void* p : ptrs) if (p) hipFree(p);
+  for (void* p : {(void*)e->d_in_f, (void*)e->d_flow_l, (void*)e->d_dist, (void*)e->d_jn, (void*)e->d_bad, (void*)e->d_wa, (void*)e->d_wb, (void*)e->d_wmax})
+    if (p) hipFree(p);
+  if (e->h_lvl) hipHostFree(e->h_lvl);
+  if (e->flow_stream) { hipStreamSynchronize(e->flow_stream); hipStreamDestroy(e->flow_stream); }
+  for (hipEvent_t ev : e->ev_level) if (ev) hipEventDestroy(ev);
+  if (e->ev_evict) hipEventDestroy(e->ev_evict);
   if (e->d_note_state) hipFree(e->d_note_state);
   if (e->h_note) hipHostFree(e->h_note);
   if (e->stream) hipStreamDestroy(e->stream);
@@ -2231,6 +2317,116 @@ int32_t cwr_load_flow_field(cwr_engine* e, int32_t T, const float* face_flow, co
   return compute_jnorms(e);
 }
 
+// ---- windowed flow-field residency ("time-series streaming") ------------------------------------------------------
+// cwr_load_flow_field keeps all T levels in HBM: adv f32 + dif f64 + vel f32 per face and vol f32 per cell, ~37 MB per level at 1 M
+// cells -- ~7 000 levels are the ceiling there, and the reference's own fixture has 10 801 stamps (tests/data/simple_test_cases/
+// plan01_10x5), its reader windows a file by datetime_range (io/hdf.py:149-191) and utilities.py:513-541 derives per level.  Here
+// the device holds a RING of W levels; cwr_flow_window_load uploads further levels on a stream of its own, derives their
+// coefficients, the zero-coefficient flag and ||J||_inf there, beside the steps, and cwr_step(t) runs for any t whose levels t and
+// t + 1 are in the ring.
+int32_t cwr_flow_window_open(cwr_engine* e, int32_t T, int32_t W, const double* dt, const double* dist, double D) {
+  if (!e) return CWR_ERR_BAD_ARG;
+  if (T < 2 || W < 2 || !dt || !dist) return fail(e, CWR_ERR_BAD_ARG, "cwr_flow_window_open: need >= 2 time levels, a window of >= 2 levels and non-NULL arrays");
+  if (e->comm) return fail(e, CWR_ERR_STATE, "cwr_flow_window_open: windowed residency is for single engines (a partitioned engine holds 1 / N of every level)");
+  HIP_TRY(e, enter_device(e->dev));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  W = std::min(W, T);
+  TRY(alloc_flow(e, W));                             // (W levels of the four arrays)
+  e->T = T; e->W = W; e->windowed = W < T;
+  e->dt.assign(dt, dt + T);
+  e->D = D;
+  e->slot_level.assign((size_t)W, -1);
+  e->jnorm.assign((size_t)T, NAN); e->jnorm[(size_t)T - 1] = 0.0;
+  e->err_factor.assign((size_t)T, INFINITY);
+  e->bad_level.assign((size_t)T, 0);
+  e->lvl_final.assign((size_t)T, 0);
+  e->windowed = true;                                // (also with W == T: the levels still arrive one load at a time)
+  for (void* p : {(void*)e->d_in_f, (void*)e->d_flow_l, (void*)e->d_dist, (void*)e->d_jn, (void*)e->d_bad}) if (p) hipFree(p);
+  e->d_in_f = e->d_flow_l = nullptr; e->d_dist = nullptr; e->d_jn = nullptr; e->d_bad = nullptr;
+  if (e->h_lvl) { hipHostFree(e->h_lvl); e->h_lvl = nullptr; }
+  TRY(dev_alloc(e, &e->d_in_f, (size_t)std::max(e->E, e->n_cells)));
+  TRY(dev_alloc(e, &e->d_flow_l, (size_t)e->E));
+  TRY(dev_alloc(e, &e->d_dist, (size_t)e->E));
+  TRY(dev_alloc(e, &e->d_jn, (size_t)T));
+  TRY(dev_alloc(e, &e->d_bad, (size_t)T));
+  HIP_TRY(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_lvl), (size_t)2 * T * sizeof(double), hipHostMallocMapped));
+  std::memset(e->h_lvl, 0, (size_t)2 * T * sizeof(double));
+  { void* dp = nullptr; HIP_TRY(e, hipHostGetDevicePointer(&dp, e->h_lvl, 0)); e->d_lvl_view = static_cast<double*>(dp); }
+  HIP_TRY(e, hipMemsetAsync(e->d_jn, 0, (size_t)T * sizeof(unsigned long long), e->stream));
+  HIP_TRY(e, hipMemsetAsync(e->d_bad, 0, (size_t)T * sizeof(int32_t), e->stream));
+  {
+    DevTmp<double> tmp;                              // face_to_face_dist: reference face order -> internal
+    TRY(dev_alloc(e, &tmp.p, (size_t)e->E));
+    TRY(upload(e, tmp.p, dist, (size_t)e->E));
+    if (e->E > 0) k_faces_in<double><<<cdiv(e->E, BLOCK), BLOCK, 0, e->stream>>>((int64_t)e->E, e->E, e->d_face_orig, tmp.p, e->d_dist);
+    HIP_TRY(e, hipGetLastError());
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+  }
+  if (!e->flow_stream) HIP_TRY(e, hipStreamCreateWithFlags(&e->flow_stream, hipStreamNonBlocking));
+  if (!e->ev_evict) HIP_TRY(e, hipEventCreateWithFlags(&e->ev_evict, hipEventDisableTiming));
+  for (hipEvent_t ev : e->ev_level) hipEventDestroy(ev);
+  e->ev_level.assign((size_t)W, nullptr);
+  for (auto& ev : e->ev_level) HIP_TRY(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  e->sched_level = -1;
+  return CWR_OK;
+}
+
+int32_t cwr_flow_window_load(cwr_engine* e, int32_t t0, int32_t n_levels, const float* face_flow, const float* edge_velocity, const float* volume) {
+  if (!e) return CWR_ERR_BAD_ARG;
+  if (!e->windowed || !e->flow_stream) return fail(e, CWR_ERR_STATE, "cwr_flow_window_load: cwr_flow_window_open first");
+  if (t0 < 0 || n_levels < 1 || t0 + n_levels > e->T || n_levels > e->W || !face_flow || !edge_velocity || !volume)
+    return fail(e, CWR_ERR_BAD_ARG, "cwr_flow_window_load: levels outside the run, more levels than the window holds, or NULL arrays");
+  HIP_TRY(e, enter_device(e->dev));
+  const size_t E = (size_t)e->E, nc = (size_t)e->n_cells;
+  hipStream_t fs = e->flow_stream;
+  e->prepared_t = -1;
+  // the slots about to be overwritten may still be read by what the engine's stream holds (a step's closing flux kernel reads the
+  // coefficients of its level): the flow stream waits for everything enqueued there so far
+  HIP_TRY(e, hipEventRecord(e->ev_evict, e->stream));
+  HIP_TRY(e, hipStreamWaitEvent(fs, e->ev_evict, 0));
+  const int gE = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv((int64_t)E, BLOCK), 256 * 16));
+  for (int i = 0; i < n_levels; ++i) {
+    const int L = t0 + i;
+    const size_t sl = e->slot(L);
+    const int old = e->slot_level[sl];
+    e->slot_level[sl] = L;
+    if (old >= 0 && old != L) {                      // what was derived WITH the level that leaves must be derived again if it ever returns
+      e->lvl_final[(size_t)old] = 0;
+      if (old > 0) e->lvl_final[(size_t)old - 1] = 0;
+    }
+    e->lvl_final[(size_t)L] = 0;
+    if (L > 0) e->lvl_final[(size_t)L - 1] = 0;
+    // face flows and velocities arrive in the reference's face order: one staging level, gathered into the internal order
+    HIP_TRY(e, hipMemcpyAsync(e->d_in_f, face_flow + (size_t)i * E, E * sizeof(float), hipMemcpyHostToDevice, fs));
+    if (E > 0) k_faces_in<float><<<gE, BLOCK, 0, fs>>>((int64_t)E, e->E, e->d_face_orig, e->d_in_f, e->d_flow_l);
+    HIP_TRY(e, hipMemcpyAsync(e->d_in_f, edge_velocity + (size_t)i * E, E * sizeof(float), hipMemcpyHostToDevice, fs));
+    if (E > 0) {
+      k_faces_in<float><<<gE, BLOCK, 0, fs>>>((int64_t)E, e->E, e->d_face_orig, e->d_in_f, e->vel_l(L));
+      k_derive_coeff<<<gE, BLOCK, 0, fs>>>((int64_t)E, e->E, e->d_flow_l, e->vel_l(L), e->d_dist, (float)e->D, e->adv_l(L), e->dif_l(L));
+    }
+    HIP_TRY(e, hipMemcpyAsync(e->vol_l(L), volume + (size_t)i * nc, nc * sizeof(float), hipMemcpyHostToDevice, fs));
+    // the zero-coefficient flag of level L (the reference's ValueError, linalg.py:349-351) ...
+    HIP_TRY(e, hipMemsetAsync(e->d_bad + L, 0, sizeof(int32_t), fs));
+    if (E > 0) k_check_ghost_levels<<<gE, BLOCK, 0, fs>>>((int64_t)E, e->E, e->n_owned, e->n_real, e->d_f1, e->d_f2, e->vel_l(L), e->adv_l(L),
+                                                         e->dif_l(L), e->D != 0.0 ? 1 : 0, e->d_bad + L);
+    HIP_TRY(e, hipGetLastError());
+    k_note_level<<<1, 1, 0, fs>>>(e->d_bad + L, nullptr, e->d_lvl_view + 2 * (size_t)L + 1);
+    // ... and ||J||_inf of the steps this level completes: step L - 1 (its coefficients, this level's volumes) and step L (when
+    // level L + 1 is already here: levels loaded out of order)
+    for (int st : {L - 1, L}) {
+      if (st < 0 || st + 1 >= e->T) continue;
+      if (e->slot_level[e->slot(st)] != st || e->slot_level[e->slot(st + 1)] != st + 1) continue;
+      HIP_TRY(e, hipMemsetAsync(e->d_jn + st, 0, sizeof(unsigned long long), fs));
+      k_jnorm<<<dim3((unsigned)cdiv(e->n_owned, BLOCK), 1u), BLOCK, 0, fs>>>(e->n_owned, e->E, e->n_cells, e->d_ptr, e->d_ent_edge, e->d_ent_nb,
+          e->adv_l(st), e->dif_l(st), e->vol_l(st + 1), nullptr, e->d_jn + st, e->dt[(size_t)st]);
+      k_note_level<<<1, 1, 0, fs>>>(nullptr, e->d_jn + st, e->d_lvl_view + 2 * (size_t)st);
+    }
+    HIP_TRY(e, hipGetLastError());
+    HIP_TRY(e, hipEventRecord(e->ev_level[sl], fs));
+  }
+  return CWR_OK;
+}
+
 int32_t cwr_load_coefficients(cwr_engine* e, int32_t T, const float* adv, const double* dif, const float* vel,
                               const float* volume, const double* dt, double D) {
   if (!e) return CWR_ERR_BAD_ARG;
@@ -2268,12 +2464,12 @@ int32_t cwr_get_coefficients(cwr_engine* e, int32_t t, float* adv, double* dif) 
   int rc = CWR_OK;
   if (adv) {
     rc = dev_alloc(e, &d_tmpf, (size_t)std::max(e->E, 1));
-    if (rc == CWR_OK) { k_faces_out<float><<<cdiv(std::max(e->E, 1), BLOCK), BLOCK, 0, e->stream>>>(e->E, e->d_face_orig, e->d_adv + (size_t)t * e->E, d_tmpf);
+    if (rc == CWR_OK) { k_faces_out<float><<<cdiv(std::max(e->E, 1), BLOCK), BLOCK, 0, e->stream>>>(e->E, e->d_face_orig, e->adv_l(t), d_tmpf);
                         rc = download(e, adv, d_tmpf, (size_t)e->E); }
   }
   if (rc == CWR_OK && dif) {
     rc = dev_alloc(e, &d_tmpd, (size_t)std::max(e->E, 1));
-    if (rc == CWR_OK) { k_faces_out<double><<<cdiv(std::max(e->E, 1), BLOCK), BLOCK, 0, e->stream>>>(e->E, e->d_face_orig, e->d_dif + (size_t)t * e->E, d_tmpd);
+    if (rc == CWR_OK) { k_faces_out<double><<<cdiv(std::max(e->E, 1), BLOCK), BLOCK, 0, e->stream>>>(e->E, e->d_face_orig, e->dif_l(t), d_tmpd);
                         rc = download(e, dif, d_tmpd, (size_t)e->E); }
   }
   return rc;
@@ -2408,6 +2604,7 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
   if (e->T_bc < t + 2) return fail(e, CWR_ERR_STATE, "cwr_step: boundary values of level t+1 not loaded (cwr_load_boundary)");
   if (!(tol > 0.0) || max_iter < 1) return fail(e, CWR_ERR_BAD_ARG, "cwr_step: tol must be > 0 and max_iter >= 1");
   HIP_TRY(e, enter_device(e->dev));
+  TRY(finalize_level(e, t));
   const int K = e->K;
   const double tol2 = tol * tol;
   e->profiling = (flags & CWR_STEP_PROFILE) != 0;
@@ -2531,7 +2728,7 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
   if (flags & CWR_STEP_MASS_BALANCE) {
     if (e->n_lines <= 0) return fail(e, CWR_ERR_STATE, "cwr_step: CWR_STEP_MASS_BALANCE without cwr_set_boundary_lines");
     k_line_mass<<<e->n_lines, BLOCK, 0, e->stream>>>(K, e->n_core, e->d_line_ptr, e->d_line_faces, e->d_f1, e->d_f2,
-        e->d_adv + (size_t)t * e->E, e->d_dif + (size_t)t * e->E, e->dt[t], e->d_c, e->d_ledger);
+        e->adv_l(t), e->dif_l(t), e->dt[t], e->d_c, e->d_ledger);
     HIP_TRY(e, hipGetLastError());
   }
   // no synchronisation here: convergence is known, and the tail kernels are ordered on the engine's stream before
@@ -2655,8 +2852,8 @@ int32_t cwr_time_apply(cwr_engine* e, int32_t t, int32_t variant, int32_t reps, 
     const double* xin = (i & 1) ? e->d_s : e->d_p;
     double* yo = (i & 1) ? e->d_t : e->d_v;
     const int g1 = cdiv(e->n_owned, e->R), g2 = cdiv(e->E, e->R);
-    const float* adv_t = e->d_adv + (size_t)t * e->E;
-    const double* dif_t = e->d_dif + (size_t)t * e->E;
+    const float* adv_t = e->adv_l(t);
+    const double* dif_t = e->dif_l(t);
     if (e->VW == 2) {
       k_scatter_diag<2><<<g1, BLOCK, 0, e->stream>>>(e->n_owned, e->K, e->G, e->d_diag, xin, yo);
       k_scatter_faces<2><<<g2, BLOCK, 0, e->stream>>>(e->E, e->n_owned, e->n_real, e->K, e->G, e->d_f1, e->d_f2, adv_t, dif_t, xin, yo);
@@ -2744,7 +2941,7 @@ int32_t cwr_domain_mass(cwr_engine* e, int32_t t_level, double* out) {
   const int K = e->K, per = BLOCK / K;
   const int grid = std::max(1, std::min(cdiv(e->n_core, per), 512));
   if (!e->d_mass_out) TRY(dev_alloc(e, &e->d_mass_out, (size_t)513 * (K + 1)));
-  k_domain_mass<<<grid, BLOCK, 0, e->stream>>>(e->n_core, K, e->d_vol + (size_t)t_level * e->n_cells, e->d_c, e->d_mass_out);
+  k_domain_mass<<<grid, BLOCK, 0, e->stream>>>(e->n_core, K, e->vol_l(t_level), e->d_c, e->d_mass_out);
   k_fold_partials<<<1, BLOCK, 0, e->stream>>>(grid, K + 1, e->d_mass_out, e->d_mass_out + (size_t)512 * (K + 1));
   HIP_TRY(e, hipGetLastError());
   std::vector<double> h((size_t)K + 1);
@@ -2895,6 +3092,7 @@ int32_t cwr_synchronize(cwr_engine* e) {
   if (!e) return CWR_ERR_BAD_ARG;
   HIP_TRY(e, enter_device(e->dev));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
+  if (e->flow_stream) HIP_TRY(e, hipStreamSynchronize(e->flow_stream));   // (windowed flow field: every enqueued level has arrived)
   return CWR_OK;
 }
 
@@ -2956,6 +3154,7 @@ int32_t cwr_attach_comm(cwr_engine* e, int32_t rank, int32_t world, const uint8_
       seen[recv_cells[i]] = 1;
     }
   }
+  if (e->windowed) return fail(e, CWR_ERR_STATE, "cwr_attach_comm: this engine holds a windowed flow field (single engines only)");
   std::string err;
   if (!g_rccl.load(err)) return fail(e, CWR_ERR_RCCL, err);
   HIP_TRY(e, enter_device(e->dev));

@@ -430,7 +430,8 @@ __global__ void __launch_bounds__(BLOCK) k_check_ghost_levels(
 __global__ void __launch_bounds__(BLOCK) k_jnorm(
     int n_owned, int E, int n_cells, const int32_t* __restrict__ ptr, const int32_t* __restrict__ ent_edge,
     const int32_t* __restrict__ ent_nb, const float* __restrict__ adv, const double* __restrict__ dif,
-    const float* __restrict__ vol, const double* __restrict__ dt, unsigned long long* __restrict__ jn) {
+    const float* __restrict__ vol_next, const double* __restrict__ dt, unsigned long long* __restrict__ jn, double dt_one) {
+  // adv / dif: level t of the launch's first step at offset 0 (stride E); vol_next: V of level t + 1 at offset 0 (stride n_cells)
   __shared__ double s_m[BLOCK / 64];
   const int t = blockIdx.y;
   const int c = blockIdx.x * BLOCK + threadIdx.x;
@@ -438,8 +439,8 @@ __global__ void __launch_bounds__(BLOCK) k_jnorm(
   if (c < n_owned) {
     const float* adv_t = adv + (size_t)t * E;
     const double* dif_t = dif + (size_t)t * E;
-    const double vn = (double)vol[(size_t)(t + 1) * n_cells + c];
-    double dg = vn / dt[t] + (vn == 0.0 ? 1.0 : 0.0), off = 0.0;
+    const double vn = (double)vol_next[(size_t)t * n_cells + c];
+    double dg = vn / (dt ? dt[t] : dt_one) + (vn == 0.0 ? 1.0 : 0.0), off = 0.0;     // (dt == nullptr: one step, its dt by value)
     const int j1 = ptr[c + 1];
     for (int j = ptr[c]; j < j1; ++j) {
       const int code = ent_edge[j];
@@ -462,8 +463,59 @@ __global__ void __launch_bounds__(BLOCK) k_jnorm(
   }
 }
 
+// windowed flow fields: the per-level scalars the host needs at the step, left in page-locked memory by the flow stream
+// (flag: the zero-coefficient flag of a level as 0.0 / 1.0; jn: the bit pattern of ||J||_inf of a step)
+__global__ void k_note_level(const int32_t* __restrict__ flag, const unsigned long long* __restrict__ jn, double* __restrict__ out) {
+  if (flag) out[0] = flag[0] ? 1.0 : 0.0;
+  if (jn) out[0] = __longlong_as_double((long long)jn[0]);
+  __threadfence_system();
+}
+
 __global__ void __launch_bounds__(BLOCK) k_fill(int64_t total, double v, double* __restrict__ a, double* __restrict__ b) {
   for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * BLOCK) { a[i] = v; if (b) b[i] = v; }
+}
+
+// One sweep w' = 1 + J w of the Neumann series of (I - J)^-1 1 (the row-wise a-posteriori factor of the element-wise rule: see
+// refine_error_factors in cwr_engine.hip), MATRIX-FREE and on ONE column: J's entries are formed on the fly from the level's
+// coefficients exactly as k_prep_step forms them -- no operator buffers, no K-wide vectors -- so the sweeps of an incoming level can
+// run on the flow-field stream beside the steps of a windowed run.  One thread per computed row; rows >= n_owned of w (a rank's
+// read-only layer) are input only.  max[0] = max over rows < n_dot of (w' - w) (>= 0: the series is monotone), max[1] = max w',
+// folded with integer atomicMax on the bit patterns (non-negative doubles order like their bits; the host zeroes the two words).
+__global__ void __launch_bounds__(BLOCK) k_neumann(
+    int n_owned, int n_dot, const int32_t* __restrict__ ptr, const int32_t* __restrict__ ent_edge, const int32_t* __restrict__ ent_nb,
+    const float* __restrict__ adv_t, const double* __restrict__ dif_t, const float* __restrict__ vol_next, double dt,
+    const double* __restrict__ win, double* __restrict__ wout, unsigned long long* __restrict__ maxima) {
+  __shared__ double s_r[BLOCK / 64], s_w[BLOCK / 64];
+  const int c = blockIdx.x * BLOCK + threadIdx.x;
+  double r = 0.0, wv = 0.0;
+  if (c < n_owned) {
+    const double vn = (double)vol_next[c];
+    double dg = vn / dt + (vn == 0.0 ? 1.0 : 0.0), sum = 0.0;
+    const int j1 = ptr[c + 1];
+    for (int j = ptr[c]; j < j1; ++j) {
+      const int code = ent_edge[j];
+      const float a = adv_t[code >> 1];
+      const double d = dif_t[code >> 1];
+      const double a_c = (code & 1) ? -(double)a : (double)a;
+      dg += d + fmax(a_c, 0.0);
+      const int nb = ent_nb[j];
+      if (nb >= 0) sum += (d - fmin(a_c, 0.0)) * win[nb];
+    }
+    wv = 1.0 + sum / dg;
+    wout[c] = wv;
+    if (c < n_dot) { r = wv - win[c]; if (!(r >= 0.0)) r = (r != r) ? INFINITY : 0.0; }   // (NaN in the field: no bound)
+    if (!(wv >= 0.0)) wv = INFINITY;
+    if (c >= n_dot) wv = 0.0;
+  }
+  for (int o = 32; o >= 1; o >>= 1) { r = fmax(r, __shfl_xor(r, o, 64)); wv = fmax(wv, __shfl_xor(wv, o, 64)); }
+  if ((threadIdx.x & 63) == 0) { s_r[threadIdx.x >> 6] = r; s_w[threadIdx.x >> 6] = wv; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double mr = s_r[0], mw = s_w[0];
+    for (int q = 1; q < BLOCK / 64; ++q) { mr = fmax(mr, s_r[q]); mw = fmax(mw, s_w[q]); }
+    atomicMax(maxima, (unsigned long long)__double_as_longlong(mr));
+    atomicMax(maxima + 1, (unsigned long long)__double_as_longlong(mw));
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ a-3

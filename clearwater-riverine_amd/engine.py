@@ -39,7 +39,7 @@ INFO_ELEMENTWISE_CLAMPED = 4   # error factor F > 300 (CFL of several hundred): 
 # every symbol include/cwr_transport.h declares (tests check that the library exports them all)
 ABI_SYMBOLS = (
     'cwr_abi_version', 'cwr_tile_rows', 'cwr_chain_min_rows', 'cwr_create', 'cwr_destroy', 'cwr_last_error', 'cwr_load_flow_field',
-    'cwr_load_coefficients', 'cwr_get_coefficients', 'cwr_load_boundary', 'cwr_set_boundary_level',
+    'cwr_load_coefficients', 'cwr_flow_window_open', 'cwr_flow_window_load', 'cwr_get_coefficients', 'cwr_load_boundary', 'cwr_set_boundary_level',
     'cwr_set_state', 'cwr_get_state', 'cwr_load_real_inputs', 'cwr_react_linear', 'cwr_state_device_ptr', 'cwr_state_row_stride', 'cwr_apply', 'cwr_rhs', 'cwr_step', 'cwr_get_mass_flux',
     'cwr_get_jacobi_norms', 'cwr_set_jacobi_norms', 'cwr_get_error_factors', 'cwr_tiling_info', 'cwr_set_tile_schedule', 'cwr_get_tile_schedule',
     'cwr_time_apply', 'cwr_profile_read', 'cwr_synchronize', 'cwr_apply_bytes',
@@ -110,6 +110,8 @@ def load_library(path: str | None = None) -> C.CDLL:
         'cwr_create': [i32, i32, i32, i32, i32, vp, vp, i32, P(vp)],
         'cwr_load_flow_field': [vp, i32, vp, vp, vp, vp, vp, f64],
         'cwr_load_coefficients': [vp, i32, vp, vp, vp, vp, vp, f64],
+        'cwr_flow_window_open': [vp, i32, i32, vp, vp, f64],
+        'cwr_flow_window_load': [vp, i32, i32, vp, vp, vp],
         'cwr_get_coefficients': [vp, i32, vp, vp],
         'cwr_load_boundary': [vp, i32, vp],
         'cwr_set_boundary_level': [vp, i32, vp],
@@ -278,6 +280,35 @@ class TransportEngine:
         self._check(self._lib.cwr_load_coefficients(self._h, T, _ptr(adv), _ptr(dif), _ptr(ev), _ptr(vol),
                                                     _ptr(dtv), float(diffusion_coefficient)))
         self.n_times = T
+
+    def flow_window_open(self, n_times: int, window_levels: int, dt, face_to_face_dist, diffusion_coefficient):
+        """Windowed residency of the flow field (cwr_flow_window_open): a ring of `window_levels` of the run's `n_times` levels."""
+        dtv = _arr(dt, np.float64, (int(n_times),), 'dt')
+        dist = _arr(face_to_face_dist, np.float64, (self.n_edges,), 'face_to_face_dist')
+        self._check(self._lib.cwr_flow_window_open(self._h, int(n_times), int(window_levels), _ptr(dtv), _ptr(dist), float(diffusion_coefficient)))
+        self.n_times = int(n_times)
+        self._window_keep = {}
+
+    def volume_in_engine_order(self, volume) -> np.ndarray:
+        """(T, n_cells) volumes with the columns in the engine's cell numbering (what flow_window_load(..., engine_order=True) takes):
+        a windowed run permutes the whole array once instead of one level per step."""
+        vol = _arr(volume, np.float32)
+        return vol if self._order is None else np.ascontiguousarray(vol[:, self._cols])
+
+    def flow_window_load(self, t0: int, face_flow, edge_velocity, volume, engine_order: bool = False):
+        """Levels t0 .. t0 + n - 1 into the ring (cwr_flow_window_load): (n, n_edges) f32 x 2 and (n, n_cells) f32, enqueued on the
+        engine's flow stream.  The arrays handed to the library are kept alive here until the slot is loaded again."""
+        ff = _arr(face_flow, np.float32)
+        n = ff.shape[0]
+        ff = _arr(ff, np.float32, (n, self.n_edges), 'face_flow')
+        ev = _arr(edge_velocity, np.float32, (n, self.n_edges), 'edge_velocity')
+        vol = _arr(volume, np.float32, (n, self.n_cells), 'volume')
+        if self._order is not None and not engine_order:
+            vol = np.ascontiguousarray(vol[:, self._cols])
+        self._check(self._lib.cwr_flow_window_load(self._h, int(t0), int(n), _ptr(ff), _ptr(ev), _ptr(vol)))
+        self._window_keep[int(t0)] = (ff, ev, vol)               # (the copies are asynchronous for page-locked arrays)
+        for k in [k for k in self._window_keep if k < int(t0) - 4 * max(1, n)]:
+            del self._window_keep[k]
 
     def get_coefficients(self, t: int):
         adv = np.empty(self.n_edges, np.float32)

@@ -224,7 +224,8 @@ class ClearwaterRiverine:
                  mesh: Optional[dict] = None, input_arrays: Optional[Dict[str, np.ndarray]] = None,
                  device: int = 0, tol: float = 1e-12, max_iter: int = 5000, store_history: bool = True,
                  solver: str = 'auto', renumber: bool = True, output_store: Optional[str] = None,
-                 output_flux: bool = False, host_state: bool = True, deterministic: bool = False):
+                 output_flux: bool = False, host_state: bool = True, deterministic: bool = False,
+                 flow_window: Optional[int] = None):
         self.gdf = None
         self.time_step = 0                                       # transport.py:102
         self.verbose = bool(verbose)
@@ -317,8 +318,26 @@ class ClearwaterRiverine:
             curve = lane_order(m, n, tile_rows=tile_rows(K)) if lanes else hilbert_order(m['face_x'], m['face_y'], n)
         order = balance_windows(curve, f1, f2, window=tile_rows(K)) if curve is not None else None
         self.engine = TransportEngine(f1, f2, ncell, K, device=device, cell_order=order)
-        self.engine.load_flow_field(m[FLOW_ACROSS_FACE], m[EDGE_VELOCITY], m[VOLUME], m[CHANGE_IN_TIME],
-                                    m[FACE_TO_FACE_DISTANCE], m.attrs['diffusion_coefficient'])
+        # Flow field: all T levels resident in HBM, or -- flow_window=W, or by itself when T levels exceed CWR_FLOW_RESIDENT_LIMIT_MB
+        # (default 65 536) of device memory -- a ring of W levels that update() refills one level per step on the engine's flow stream,
+        # beside the steps (cwr_flow_window_open / _load: SURVEY 8 f-1; the reference windows a file by datetime_range, io/hdf.py:149-191,
+        # and its own fixture has 10 801 stamps).  Same results, bit for bit with deterministic=True.
+        import os
+        per_level = E * 16 + ncell * 4
+        limit = int(os.environ.get('CWR_FLOW_RESIDENT_LIMIT_MB', '65536')) << 20
+        if flow_window is None and T * per_level > limit:
+            flow_window = max(4, int(limit // per_level))
+        self._flow_window = None if flow_window is None else max(2, min(int(flow_window), T))
+        self._win_hi = 0                                         # levels [.., _win_hi) have been handed to the engine
+        if self._flow_window is None:
+            self.engine.load_flow_field(m[FLOW_ACROSS_FACE], m[EDGE_VELOCITY], m[VOLUME], m[CHANGE_IN_TIME],
+                                        m[FACE_TO_FACE_DISTANCE], m.attrs['diffusion_coefficient'])
+        else:
+            self._flow_arrays = (np.ascontiguousarray(m[FLOW_ACROSS_FACE], dtype=np.float32), np.ascontiguousarray(m[EDGE_VELOCITY], dtype=np.float32),
+                                 self.engine.volume_in_engine_order(m[VOLUME]))          # (volumes permuted to the engine's cell order once)
+            self._flow_pinned = [a for a in self._flow_arrays if a.nbytes >= (1 << 20) and self.engine.host_register(a)]   # (asynchronous uploads)
+            self.engine.flow_window_open(T, self._flow_window, m[CHANGE_IN_TIME], m[FACE_TO_FACE_DISTANCE], m.attrs['diffusion_coefficient'])
+            self._fill_flow_window(0)
         ghost = np.stack([self.constituent_dict[c].input_array[:, n:] for c in self.constituents], axis=2)
         self.engine.load_boundary(ghost)
         # rows of input_array that carry non-zero values in REAL cells (the IC row, normally only t = 0):
@@ -355,6 +374,18 @@ class ClearwaterRiverine:
                                           attrs={'diffusion_coefficient': m.attrs['diffusion_coefficient']})
 
     # ------------------------------------------------------------------ helpers
+    def _fill_flow_window(self, t: int):
+        """Windowed flow field: hand the engine every level up to t + W - 1 that it does not hold yet (the slot of level L held level
+        L - W, which no step from t on reads).  Enqueued on the engine's flow stream: returns at once."""
+        if self._flow_window is None:
+            return
+        hi = min(self._T, t + self._flow_window)
+        if hi > self._win_hi:
+            ff, ev, vol = self._flow_arrays
+            lo = self._win_hi
+            self.engine.flow_window_load(lo, ff[lo:hi], ev[lo:hi], vol[lo:hi], engine_order=True)
+            self._win_hi = hi
+
     def _row(self, name: str, t: int) -> np.ndarray:
         st = self.mesh[name]
         return st[t] if self.store_history else st[t % 2]
@@ -410,6 +441,7 @@ class ClearwaterRiverine:
             if self._stream is not None:                         # level 0 is host data (input_array row 0)
                 for cname in self.constituents:
                     self._stream.writer.write_level(cname, t, np.ascontiguousarray(self._row(cname, t), dtype=np.float64))
+        self._fill_flow_window(t)
         want_flux = self.store_history or (self._stream is not None and self._stream.with_flux)
         # (a step that raises leaves the device state at level t -- the engine restores it -- and time_step unchanged:
         # update() may simply be called again, e.g. with a larger max_iter)
@@ -495,6 +527,12 @@ class ClearwaterRiverine:
         for b in getattr(self, '_pinned', []):
             self.engine.host_unregister(b)
         self._pinned = []
+        if getattr(self, '_flow_pinned', None):
+            if self.engine._h:
+                self.engine.synchronize()
+            for b in self._flow_pinned:
+                self.engine.host_unregister(b)
+            self._flow_pinned = []
 
     def __del__(self):
         # the page locks must go BEFORE the blocks' pages are unmapped: a stale registration of a recycled address range makes

@@ -104,8 +104,8 @@ int32_t cwr_tile_rows(int32_t n_constituents);
 /* Rows from which an engine with K constituents links its tiles into chains along the flow and relaxes in place (see "tiling and
  * the chained passes" below): 1.75 tiles per block of its persistent grid (CWR_CHAIN_MIN_TILES), four resident blocks per CU.  A
  * host wrapper that chooses the cell numbering before it creates the engine -- lanes along the flow for engines that chain, an
- * isotropic space-filling curve for those that do not -- asks this, so that numbering and engine follow one threshold.  No handle
- * and no GPU needed (without a device: 256 CUs).  Purely a speed matter. */
+ * isotropic space-filling curve for those that do not -- asks this, so that numbering and engine follow one threshold.  No handle,
+ * no GPU and no HIP call (the MI355X's 256 CUs are assumed).  Purely a speed matter. */
 int32_t cwr_chain_min_rows(int32_t n_constituents);
 
 /* ---- construction -------------------------------------------------------------------------------
@@ -145,6 +145,24 @@ int32_t cwr_load_flow_field(cwr_engine* e, int32_t n_times, const float* face_fl
 int32_t cwr_load_coefficients(cwr_engine* e, int32_t n_times, const float* advection_coeff,
                               const double* coeff_to_diffusion, const float* edge_velocity,
                               const float* volume, const double* dt, double diffusion_coefficient);
+/* Windowed residency ("time-series streaming"): the device holds a RING of window_levels levels instead of all
+ * n_times (~37 MB per level at 1 M cells: a 10 801-stamp file as the reference's tests/data/simple_test_cases/plan01_10x5 does
+ * not fit whole; the reference's reader windows a file by datetime_range, io/hdf.py:149-191, and derives per level,
+ * utilities.py:513-541).  Single engines.
+ * cwr_flow_window_open: n_times levels in the run, a ring of window_levels >= 2 of them (level t lives in slot t % window_levels);
+ *   dt (n_times), face_to_face_dist (n_edges) and D as for cwr_load_flow_field.  Replaces a loaded flow field.
+ * cwr_flow_window_load: levels t0 .. t0 + n_levels - 1 (face_flow, edge_velocity: (n_levels, n_edges) f32; volume: (n_levels,
+ *   n_cells) f32) into their slots, replacing what those held.  Only ENQUEUED, on a stream of the engine's own: upload, coefficient
+ *   derivation, the zero-coefficient flag of every level and ||J||_inf of every step the arrived levels complete run beside the
+ *   steps (behind every kernel already enqueued that may still read the levels being replaced); the host arrays must stay
+ *   untouched until a later cwr_step / cwr_synchronize has returned, and only page-locked arrays (cwr_host_register) make the upload
+ *   itself asynchronous.  cwr_step(t) needs levels t and t + 1 in the ring (CWR_ERR_STATE otherwise) and waits for them on the
+ *   device; results are those of the all-resident engine, bit for bit with CWR_STEP_DETERMINISTIC.  The row-wise error factor of a
+ *   step (cwr_get_error_factors) is taken when the step runs, and only where its norm form exceeds 3. */
+int32_t cwr_flow_window_open(cwr_engine* e, int32_t n_times, int32_t window_levels, const double* dt,
+                             const double* face_to_face_dist, double diffusion_coefficient);
+int32_t cwr_flow_window_load(cwr_engine* e, int32_t t0, int32_t n_levels, const float* face_flow,
+                             const float* edge_velocity, const float* volume);
 /* Read back the device-resident coefficients of level t (parity check of the on-device derivation). */
 int32_t cwr_get_coefficients(cwr_engine* e, int32_t t, float* advection_coeff, double* coeff_to_diffusion);
 
