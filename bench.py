@@ -113,6 +113,9 @@ def launch_ranks(n: int, argv: list[str], timeout_s: float = 1500.0) -> int:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
     script = os.environ.get('CWR_BENCH_CHILD', os.path.abspath(__file__))     # (tests substitute a stub child)
+    # HSA_ENABLE_IPC_MODE_LEGACY=0 (kept from the environment when set): this image's host driver supports dmabuf IPC only -- without it
+    # RCCL's sharing of device buffers between the rank processes fails with `hipIpcGetMemHandle: invalid argument` (the image exports it
+    # already; the launcher makes sure a rank started from a scrubbed environment has it too.  The torchrun route inherits the image's own.)
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
@@ -218,6 +221,9 @@ def main():
                     help='N > 1: halo layers = Jacobi sweeps between two exchanges (0: from the per-rank size, distributed.auto_halo_depth)')
     ap.add_argument('--deterministic', action='store_true',
                     help='CWR_STEP_DETERMINISTIC: passes between two vectors, bitwise reproducible run to run (the default passes are chained in place)')
+    ap.add_argument('--flow-window', type=int, default=0,
+                    help='N = 1: keep only this many levels of the flow field on the device and upload one level per step beside the steps '
+                         '(cwr_flow_window_open / _load; host arrays page-locked); 0: all levels resident (the headline configuration)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-pmc', action='store_true', help='skip the two rocprofv3 counter passes that measure roofline.traffic')
     ap.add_argument('--cpu-budget-s', type=float, default=100.0, help='wall-clock budget of the CPU baseline leg')
@@ -272,7 +278,9 @@ def main():
         mesh = synthetic.bench_mesh(n_levels, dt=args.dt, diffusion_coefficient=args.diffusion)
         mesh_name = 'unstructured floodplain mesh: 1026x1026 jittered quads, 5 % merged into 6-sided cells, shuffled numbering'
         mesh_key = 'bench_merged_1m'
-    inputs3 = (synthetic.distinct_input_array(mesh, K, seed=synthetic.BENCH_SEED) if args.inputs == 'distinct'
+    # (distinct inputs: a provider of the slices a rank needs -- its own cells' initial rows, the series of the ghost cells it holds --
+    # instead of the dense (T, ncell, K) block: 3.3 GB per rank at 1 M cells x 16, 13 GB at 4 M)
+    inputs3 = (synthetic.DistinctInputs(mesh, K, seed=synthetic.BENCH_SEED) if args.inputs == 'distinct'
                else synthetic.boundary_input_array(mesh, K))
     n = mesh['nreal'] + 1
 
@@ -280,7 +288,7 @@ def main():
     if world > 1:
         uid = broadcast_bytes(TransportEngine.comm_unique_id() if rank == 0 else None, 128, src=0)
     pt = PartitionedTransport(mesh, inputs3, rank, world, device=local_rank, unique_id=uid, halo_depth=args.halo_depth,
-                              renumber=None if args.renumber == 'none' else args.renumber)
+                              renumber=None if args.renumber == 'none' else args.renumber, flow_window=args.flow_window or None)
     eng = pt.engine
 
     def barrier():
@@ -377,7 +385,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        v, el, nn, done = cpu_baseline(mesh, inputs3[:, :, 0], args.cpu_budget_s, args.cpu_steps)
+        v, el, nn, done = cpu_baseline(mesh, inputs3.column(0) if hasattr(inputs3, 'column') else inputs3[:, :, 0], args.cpu_budget_s, args.cpu_steps)
         cpu = {'value': round(v, 5), 'unit': 'Mcell-updates/s', 'cores': 1, 'kind': 'port',
                'sample': f'the same mesh ({nn} cells, {mesh_name}), constituent 0 only, {done} step(s) of {el / done:.1f} s each '
                          f'(budget {args.cpu_budget_s:.0f} s; imports warmed on a 200-cell mesh); numpy COO assembly + '
@@ -401,7 +409,8 @@ def main():
                                    f'advection-diffusion step, dt={args.dt} s, D={args.diffusion}',
                        'cells': n, 'faces': int(len(mesh['edges_face1'])), 'constituents': K,
                        'numbering': pt.numbering + (' + tile-balanced windows' if pt.numbering != 'reference' else ''), 'partition': f'contiguous cell ranges x{world}' + (f', halo depth {pt.local.depth}' if world > 1 else ''),
-                       'tol': args.tol},
+                       'tol': args.tol, 'flow_field': (f'ring of {args.flow_window} levels, one level uploaded per step beside the steps'
+                                                       if args.flow_window and world == 1 else 'all levels resident in HBM')},
             'solver': {'method': ('J^2 passes of fused Jacobi sweeps, tiles chained along the flow and relaxed in place (block Gauss-Seidel '
                                   'along the flow, no inter-block waiting)' if chained else
                                   'J^2 passes of fused Jacobi sweeps between two vectors, tiles chained along the flow (a tile takes its '

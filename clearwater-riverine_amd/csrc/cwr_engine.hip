@@ -142,6 +142,9 @@ struct cwr_engine {
   unsigned long long* h_note_seq = nullptr;
   unsigned long long* d_note_state = nullptr;   // device: [0] the sequence counter, [1] (as unsigned int) the arrival counter
   unsigned long long note_expected = 0;         // notifications enqueued so far
+  int fixed_sweeps = 0;            // CWR_TEST_FIXED_SWEEPS=N (measurement hook, tools/rank_step_profile.py): every step runs ONE batch of N sweeps
+                                   // and takes its result whatever the check says -- the launch sequence of a converging step of that length, for a rank
+                                   // stepped alone, whose halo rows nobody refreshes (its own iteration cannot converge: see the tool)
   bool use_note = true;            // CWR_NO_NOTE=1: the download of round 4 (A/B)
   bool fused_begin = true;         // k_begin_step: operator set-up + right-hand side + kept rows + ghost write-back in one launch (CWR_NO_FUSED_BEGIN=1: round 4's three)
   double* d_chkx = nullptr;      // partitioned engines: [rr | bb | world x (m1 | m2)] -- the one all-reduce of a check (gather_check)
@@ -595,6 +598,8 @@ int wait_check_note(cwr_engine* e, double* h) {
     if ((spin & 0xFFFFu) == 0) {
       // a fault on the stream would otherwise leave the host spinning: ask the runtime every 65 536 spins
       const hipError_t st = hipStreamQuery(e->stream);
+      (void)hipGetLastError();         // (hipErrorNotReady is the normal answer here, and HIP remembers it as the thread's last error: a
+                                       //  library that checks hipGetLastError() afterwards -- RCCL's initialisation does -- would trip over it)
       if (st != hipSuccess && st != hipErrorNotReady) return fail(e, CWR_ERR_HIP, std::string("convergence check: ") + hipGetErrorString(st));
       if (st == hipSuccess && __atomic_load_n(e->h_note_seq, __ATOMIC_ACQUIRE) < want) {
         // (the stream is idle and the word has not moved: settle once more, then give up loudly)
@@ -1508,6 +1513,7 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
   // sweeps: the even-passes shape rounds up to 2 (mod 4) and has its slack built in)
   const int margin = e->two_closing ? 0 : e->sweep_margin;
   int want = (e->last_sweeps > 0) ? std::max(2, e->last_sweeps + margin) : 8;
+  if (e->fixed_sweeps > 0) want = e->fixed_sweeps;
   int batch = 0;
   const int sweep_limit = forced ? max_iter : std::min(max_iter, e->jacobi_limit);
   bool sq = false;
@@ -1813,6 +1819,7 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
       if (rr > tol2 * bb) ok = false;
       worst = std::max(worst, bb > 0.0 ? rr / (tol2 * bb) : (rr > 0.0 ? (double)INFINITY : 0.0));
     }
+    if (e->fixed_sweeps > 0) { e->last_sweeps = 0; e->tail_done = speculated; return CWR_OK; }   // (measurement hook: see fixed_sweeps)
     // element-wise rule: every |x'_i - x_i| within ew_rel |x'_i| + ew_abs max|x'| (plume fronts far below the peak are
     // invisible to the 2-norm).  Folded into `worst` (a squared ratio) so that the sweep prediction serves both rules.
     double ew_ratio = 0.0;
@@ -2185,6 +2192,7 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   CREATE_TRY(dev_alloc(eng, &eng->d_chk, 4 * (size_t)K + 2));      // (+ ew_rel, read by k_apply MODE 4)
   CREATE_HIP(hipMemset(eng->d_chk, 0, (4 * (size_t)K + 2) * sizeof(double)));
   CREATE_TRY(dev_alloc(eng, &eng->d_keep, (size_t)n_cells * K));
+  if (const char* v = getenv("CWR_TEST_FIXED_SWEEPS")) eng->fixed_sweeps = std::max(0, atoi(v));
   if (const char* v = getenv("CWR_NO_NOTE")) eng->use_note = atoi(v) == 0;
   if (const char* v = getenv("CWR_NO_FUSED_BEGIN")) eng->fused_begin = atoi(v) == 0;
   if (eng->use_note) {
@@ -3158,6 +3166,7 @@ int32_t cwr_attach_comm(cwr_engine* e, int32_t rank, int32_t world, const uint8_
   std::string err;
   if (!g_rccl.load(err)) return fail(e, CWR_ERR_RCCL, err);
   HIP_TRY(e, enter_device(e->dev));
+  (void)hipGetLastError();             // (no stale error of this thread may reach the communication library's own checks)
   NcclUniqueId id; std::memcpy(id.internal, unique_id, 128);
   NCCL_TRY(e, g_rccl.CommInitRank(&e->comm, world, id, rank));
   e->rank = rank; e->world = world;

@@ -121,7 +121,7 @@ class PartitionedTransport:
 
     def __init__(self, mesh: dict, inputs3: np.ndarray, rank: int, world: int, device: int = 0,
                  unique_id: bytes | None = None, halo_depth: int = 1, renumber: str | None = 'hilbert',
-                 standalone: bool = False):
+                 standalone: bool = False, flow_window: int | None = None):
         """renumber='hilbert': work in a space-filling-curve numbering of the real cells (ordering.py); every
         array handed in or out of this class stays in the reference's numbering.
         halo_depth=0: choose the depth from the size of a rank's range (auto_halo_depth).
@@ -163,10 +163,25 @@ class PartitionedTransport:
         fields = slice_fields(lm, mesh, np.asarray(dist_e), ref_cells)
         self.engine = TransportEngine(lm.face1, lm.face2, lm.n_cells, self.K, n_owned=lm.n_rows,
                                       n_halo=lm.n_halo, device=device)
-        self.engine.load_flow_field(fields['face_flow'], fields['edge_velocity'], fields['volume'], dt,
-                                    fields['face_to_face_dist'], float(mesh['diffusion_coefficient']))
+        # flow_window=W (single engines): a ring of W levels on the device, refilled one level per step on the engine's flow stream
+        # (cwr_flow_window_open / _load); the rank's slices stay on the host, page-locked so that the uploads are asynchronous
+        self._window = None
+        if flow_window and world == 1:
+            T = len(np.asarray(dt))
+            self._window = max(2, min(int(flow_window), T))
+            self._fields = (fields['face_flow'], fields['edge_velocity'], fields['volume'])
+            self._pinned = [a for a in self._fields if self.engine.host_register(a)]
+            self._T, self._win_lo, self._win_hi = T, 0, 0
+            self.engine.flow_window_open(T, self._window, dt, fields['face_to_face_dist'], float(mesh['diffusion_coefficient']))
+            self.fill_window(0)
+        else:
+            self.engine.load_flow_field(fields['face_flow'], fields['edge_velocity'], fields['volume'], dt,
+                                        fields['face_to_face_dist'], float(mesh['diffusion_coefficient']))
         ghost_global = lm.cell_global[lm.n_real:]
-        self.engine.load_boundary(np.ascontiguousarray(inputs3[:, ghost_global, :]))
+        # inputs3: the dense (T, ncell, K) input array, or a provider of the slices a rank needs (synthetic.DistinctInputs: initial_rows /
+        # ghost_columns / real_input_entries) -- the dense array of the bench workload is 3.3 GB per rank at 1 M cells, 13 GB at 4 M
+        lazy = hasattr(inputs3, 'ghost_columns')
+        self.engine.load_boundary(np.ascontiguousarray(inputs3.ghost_columns(ghost_global) if lazy else inputs3[:, ghost_global, :]))
         self.standalone = bool(standalone) and world > 1
         if self.standalone:
             # a communicator of ONE rank without peers (cwr_attach_comm): the engine takes the row layout and the launch structure of a
@@ -182,12 +197,16 @@ class PartitionedTransport:
             # is then the one of the global matrix, as on one GPU -- cwr_get_jacobi_norms)
         # initial condition of the owned cells (row 0 of input_array, constituents.py:94-98)
         core_ref = ref_cells[:lm.n_core]
-        self.engine.set_state(np.ascontiguousarray(inputs3[0, core_ref, :]))
+        self.engine.set_state(np.ascontiguousarray(inputs3.initial_rows(core_ref) if lazy else inputs3[0, core_ref, :]))
         # non-zero input_array entries on REAL cells at levels >= 1 (point sources / fixed concentrations inside the domain):
         # the reference writes them into the solved level before the mass fluxes and uses them as x_t of the next step
         # (transport.py:258-264, linalg.py:199-200); every rank loads the entries of the cells it owns
         lvs, ces, vas = [], [], []
-        for t in range(1, inputs3.shape[0]):
+        if lazy:
+            lv, ce, va = inputs3.real_input_entries(core_ref)
+            if len(lv):
+                lvs.append(np.asarray(lv, np.int32)); ces.append(np.asarray(ce)); vas.append(np.asarray(va))
+        for t in range(1, 0 if lazy else inputs3.shape[0]):
             if not inputs3[t, :n].any():                          # (one contiguous scan per level; the usual case: nothing)
                 continue
             blk = np.asarray(inputs3[t, core_ref, :])
@@ -199,7 +218,23 @@ class PartitionedTransport:
         elif world > 1 and not self.standalone:                   # (collective for partitioned engines: also with no entries)
             self.engine.load_real_inputs(np.zeros(0, np.int32), np.zeros(0, np.int64), np.zeros((0, self.K)))
 
+    def fill_window(self, t: int):
+        """Windowed flow field: make levels t .. t + W - 1 resident (levels below t are not read by step t or any later one).  Only
+        enqueued; a jump back in time reloads from level t."""
+        if self._window is None:
+            return
+        if t < self._win_lo or t >= self._win_hi:                # (first call, or a jump: nothing of the ring is of use)
+            self._win_hi = t
+        self._win_lo = t
+        hi = min(self._T, t + self._window)
+        if hi > self._win_hi:
+            ff, ev, vol = self._fields
+            lo = self._win_hi
+            self.engine.flow_window_load(lo, ff[lo:hi], ev[lo:hi], vol[lo:hi], engine_order=True)
+            self._win_hi = hi
+
     def step(self, t: int, **kw):
+        self.fill_window(t)
         return self.engine.step(t, **kw)
 
     def owned_state(self) -> np.ndarray:

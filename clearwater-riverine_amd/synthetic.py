@@ -305,52 +305,117 @@ def boundary_input_array(mesh: dict, n_const: int, *, ic: float | np.ndarray = 1
     return arr
 
 
-def distinct_input_array(mesh: dict, n_const: int, *, seed: int = 0) -> np.ndarray:
-    """(T, ncell, K) input array (constituents.py:78-164 convention, as boundary_input_array) in which every
-    constituent has its own initial field and its own boundary series, so that the K batched systems have
-    different right-hand sides, fronts and convergence histories.  Four families by k % 4:
+class DistinctInputs:
+    """The input array of distinct_input_array WITHOUT materialising it: (T, ncell, K) float64 is 3.3 GB at 1 M cells x 16 x 26
+    levels, and a rank of a partitioned run needs its own cells' initial rows and the boundary series of the ghost cells it holds.
+    Every constituent has its own initial field and its own boundary series, so that the K batched systems have different
+    right-hand sides, fronts and convergence histories.  Four families by k % 4:
       0  smooth field  A (1 + 0.5 sin(2 pi p x / Lx + phi) cos(2 pi q y / Ly)), sinusoidal inlet (period, phase by k)
       1  uniform field, inlet = base + a Gaussian pulse in time (a spill / E. coli spike)
       2  linear gradient along x, constant inlet, no outlet value
       3  plume: EXACTLY zero outside a disc (so the implicit solution has fronts decaying to 1e-300), small
          constant inlet value -- the case an element-wise parity check exists for
-    Every value is >= 0; zero on a ghost cell keeps its reference meaning "no boundary value"."""
-    rng = np.random.default_rng(seed)
-    T = len(mesh['time_seconds'])
-    ncell = len(mesh['face_x'])
-    n = mesh['nreal'] + 1
-    x = np.asarray(mesh['face_x'][:n], dtype=np.float64)
-    y = np.asarray(mesh['face_y'][:n], dtype=np.float64)
-    x0, x1, y0, y1 = x.min(), x.max(), y.min(), y.max()
-    Lx, Ly = max(x1 - x0, 1.0), max(y1 - y0, 1.0)
-    xs, ys = (x - x0) / Lx, (y - y0) / Ly
-    tsec = np.asarray(mesh['time_seconds'], dtype=np.float64)
-    span = max(tsec[-1] - tsec[0], 1.0)
-    inlet = np.asarray(mesh['inlet_ghost_cells'], dtype=np.int64)
-    outlet = np.asarray(mesh['outlet_ghost_cells'], dtype=np.int64)
-    arr = np.zeros((T, ncell, n_const))
-    for k in range(n_const):
-        fam = k % 4
-        amp = 1.0 + 0.75 * k
-        phi = 2 * np.pi * rng.random()
-        if fam == 0:
-            p, q = 1 + (k // 4) % 3, 1 + (k // 8) % 2
-            arr[0, :n, k] = amp * (1.0 + 0.5 * np.sin(2 * np.pi * p * xs + phi) * np.cos(2 * np.pi * q * ys))
-            series = amp * (60.0 + 40.0 * np.sin(2 * np.pi * tsec / (600.0 * (1 + 0.25 * k)) + phi))
-            arr[:, outlet[::2], k] = 5.0 * amp
-        elif fam == 1:
-            arr[0, :n, k] = amp
-            tc = tsec[0] + (0.3 + 0.4 * rng.random()) * span
-            series = amp * (2.0 + 80.0 * np.exp(-0.5 * ((tsec - tc) / (0.15 * span)) ** 2))
-            arr[:, outlet[1::2], k] = 0.5 * amp
-        elif fam == 2:
-            arr[0, :n, k] = amp * (0.2 + 2.0 * xs)
-            series = np.full(T, 0.2 * amp)
-        else:
-            cx, cy = 0.2 + 0.6 * rng.random(), 0.2 + 0.6 * rng.random()
-            r2 = ((xs - cx) * Lx) ** 2 + ((ys - cy) * Ly) ** 2
-            rad = 0.08 * min(Lx, Ly)
-            arr[0, :n, k] = np.where(r2 < rad * rad, 50.0 * amp * np.exp(-4.0 * r2 / (rad * rad)), 0.0)
-            series = np.full(T, 1e-3 * amp)
-        arr[:, inlet, k] = series[:, None]
-    return arr
+    Every value is >= 0; zero on a ghost cell keeps its reference meaning "no boundary value" (constituents.py:78-164 convention).
+    distributed.PartitionedTransport takes an instance in place of the dense array (initial_rows / ghost_columns / real_input_entries)."""
+
+    def __init__(self, mesh: dict, n_const: int, *, seed: int = 0):
+        rng = np.random.default_rng(seed)
+        self.T = len(mesh['time_seconds'])
+        self.ncell = len(mesh['face_x'])
+        self.K = int(n_const)
+        self.n = mesh['nreal'] + 1
+        self.shape = (self.T, self.ncell, self.K)
+        n = self.n
+        x = np.asarray(mesh['face_x'][:n], dtype=np.float64)
+        y = np.asarray(mesh['face_y'][:n], dtype=np.float64)
+        x0, x1, y0, y1 = x.min(), x.max(), y.min(), y.max()
+        self.Lx, self.Ly = max(x1 - x0, 1.0), max(y1 - y0, 1.0)
+        self._xs, self._ys = (x - x0) / self.Lx, (y - y0) / self.Ly
+        tsec = np.asarray(mesh['time_seconds'], dtype=np.float64)
+        span = max(tsec[-1] - tsec[0], 1.0)
+        self.inlet = np.asarray(mesh['inlet_ghost_cells'], dtype=np.int64)
+        self.outlet = np.asarray(mesh['outlet_ghost_cells'], dtype=np.int64)
+        self._par = []                                   # per constituent: (family, amplitude, phase, extras)
+        self._series = np.zeros((self.T, self.K))        # inlet series
+        self._out_val = np.zeros(self.K)                 # value on the outlet ghosts the constituent uses ...
+        self._out_sel = [None] * self.K                  # ... and which of them (slice of self.outlet)
+        for k in range(self.K):
+            fam = k % 4
+            amp = 1.0 + 0.75 * k
+            phi = 2 * np.pi * rng.random()
+            extra = None
+            if fam == 0:
+                extra = (1 + (k // 4) % 3, 1 + (k // 8) % 2)
+                self._series[:, k] = amp * (60.0 + 40.0 * np.sin(2 * np.pi * tsec / (600.0 * (1 + 0.25 * k)) + phi))
+                self._out_val[k], self._out_sel[k] = 5.0 * amp, slice(0, None, 2)
+            elif fam == 1:
+                tc = tsec[0] + (0.3 + 0.4 * rng.random()) * span
+                self._series[:, k] = amp * (2.0 + 80.0 * np.exp(-0.5 * ((tsec - tc) / (0.15 * span)) ** 2))
+                self._out_val[k], self._out_sel[k] = 0.5 * amp, slice(1, None, 2)
+            elif fam == 2:
+                self._series[:, k] = 0.2 * amp
+            else:
+                extra = (0.2 + 0.6 * rng.random(), 0.2 + 0.6 * rng.random())
+                self._series[:, k] = 1e-3 * amp
+            self._par.append((fam, amp, phi, extra))
+
+    def initial_rows(self, cells) -> np.ndarray:
+        """(len(cells), K): row 0 of the input array on these REAL cells (the initial condition)."""
+        cells = np.asarray(cells, dtype=np.int64)
+        xs, ys = self._xs[cells], self._ys[cells]
+        out = np.empty((len(cells), self.K))
+        for k, (fam, amp, phi, extra) in enumerate(self._par):
+            if fam == 0:
+                p, q = extra
+                out[:, k] = amp * (1.0 + 0.5 * np.sin(2 * np.pi * p * xs + phi) * np.cos(2 * np.pi * q * ys))
+            elif fam == 1:
+                out[:, k] = amp
+            elif fam == 2:
+                out[:, k] = amp * (0.2 + 2.0 * xs)
+            else:
+                cx, cy = extra
+                r2 = ((xs - cx) * self.Lx) ** 2 + ((ys - cy) * self.Ly) ** 2
+                rad = 0.08 * min(self.Lx, self.Ly)
+                out[:, k] = np.where(r2 < rad * rad, 50.0 * amp * np.exp(-4.0 * r2 / (rad * rad)), 0.0)
+        return out
+
+    def ghost_columns(self, ghost_cells) -> np.ndarray:
+        """(T, len(ghost_cells), K): the boundary series on these ghost cells (zero: no boundary value)."""
+        g = np.asarray(ghost_cells, dtype=np.int64)
+        out = np.zeros((self.T, len(g), self.K))
+        is_in = np.isin(g, self.inlet)
+        out[:, is_in, :] = self._series[:, None, :]
+        for k in range(self.K):
+            if self._out_sel[k] is not None:
+                out[:, np.isin(g, self.outlet[self._out_sel[k]]), k] = self._out_val[k]
+        return out
+
+    def real_input_entries(self, cells):
+        """Non-zero entries on real cells at levels >= 1 (none: the initial row is the only one that carries real-cell values)."""
+        return np.zeros(0, np.int32), np.zeros(0, np.int64), np.zeros((0, self.K))
+
+    def column(self, k: int) -> np.ndarray:
+        """(T, ncell): constituent k of the dense array."""
+        arr = np.zeros((self.T, self.ncell))
+        one = self.initial_rows(np.arange(self.n))[:, k] if self.K == 1 else None
+        arr[0, :self.n] = one if one is not None else self._initial_column(k)
+        arr[:, self.n:] = self.ghost_columns(np.arange(self.n, self.ncell))[:, :, k]
+        return arr
+
+    def _initial_column(self, k: int) -> np.ndarray:
+        sub = DistinctInputs.__new__(DistinctInputs)
+        sub.__dict__.update(self.__dict__)
+        sub.K, sub._par = 1, [self._par[k]]
+        return sub.initial_rows(np.arange(self.n))[:, 0]
+
+    def dense(self) -> np.ndarray:
+        arr = np.zeros(self.shape)
+        arr[0, :self.n, :] = self.initial_rows(np.arange(self.n))
+        arr[:, self.n:, :] = self.ghost_columns(np.arange(self.n, self.ncell))
+        return arr
+
+
+def distinct_input_array(mesh: dict, n_const: int, *, seed: int = 0) -> np.ndarray:
+    """(T, ncell, K) input array (constituents.py:78-164 convention, as boundary_input_array) in which every constituent has its
+    own initial field and its own boundary series: DistinctInputs, materialised."""
+    return DistinctInputs(mesh, n_const, seed=seed).dense()

@@ -4,7 +4,7 @@
     python3 tools/trace_budget.py <..._kernel_trace.csv> [--steps N] [--label TEXT]
 
 Reads the kernel trace (Kernel_Name, Start_Timestamp, End_Timestamp in ns), takes the LAST `--steps` steps (a step starts at its
-k_prep_step launch -- one per cwr_step; falls back to k_rhs) and prints, per step on average:
+k_begin_step launch -- one per cwr_step; older builds: k_prep_step / k_rhs) and prints, per step on average:
   * every kernel: launches per step, average duration, total per step;
   * the passes (k_sq_tiled) in particular: count x average = total;
   * idle time of the stream: gaps between consecutive kernels INSIDE a step (end of one -> start of the next), split into the gap in front
@@ -39,7 +39,7 @@ def main():
         for r in csv.DictReader(fh):
             rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), short(r['Kernel_Name'])))
     rows.sort()
-    marker = 'k_prep_step' if any(n.startswith('k_prep_step') for _, _, n in rows) else 'k_rhs'
+    marker = next((m for m in ('k_begin_step', 'k_prep_step', 'k_rhs') if any(n.startswith(m) for _, _, n in rows)), 'k_rhs')
     starts = [i for i, (_, _, n) in enumerate(rows) if n.startswith(marker)]
     if len(starts) < args.steps + 1:
         sys.exit(f'only {len(starts)} steps in the trace, need {args.steps + 1}')
@@ -64,10 +64,14 @@ def main():
             gap_head += g
         else:
             gap_in += g; n_in += 1
+    spans = []
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        spans.append(max(e for _, e, _ in sel[a:b]) - sel[a][0])
+    span = sum(spans) / len(spans)
     print(f'== {args.label or args.trace}')
-    print(f'   steps analysed: {args.steps}; wall per step (first kernel to first kernel) {wall / 1e3:9.1f} us; kernels busy {busy / 1e3:9.1f} us; '
-          f'idle between steps (check round trip + next launch) {gap_head / args.steps / 1e3:7.1f} us; idle between kernels of a step {gap_in / args.steps / 1e3:7.1f} us '
-          f'({n_in / args.steps:.1f} gaps of {gap_in / max(n_in, 1) / 1e3:.2f} us)')
+    print(f'   steps analysed: {args.steps}; step span (first kernel start -> last kernel end) {span / 1e3:9.1f} us = kernels busy {busy / 1e3:9.1f} us + idle between '
+          f'kernels of a step {gap_in / args.steps / 1e3:7.1f} us ({n_in / args.steps:.1f} gaps of {gap_in / max(n_in, 1) / 1e3:.2f} us); idle between steps (check round '
+          f'trip + next launch; + the state injection of a stand-alone rank) {gap_head / args.steps / 1e3:7.1f} us; first kernel to first kernel {wall / 1e3:9.1f} us')
     print(f'   {"kernel":60s} {"per step":>9s} {"avg us":>9s} {"us/step":>9s} {"share":>7s}')
     for n, (cnt, tot) in sorted(per.items(), key=lambda kv: -kv[1][1]):
         print(f'   {n:60s} {cnt / args.steps:9.2f} {tot / cnt / 1e3:9.2f} {tot / args.steps / 1e3:9.1f} {tot / args.steps / wall * 100:6.1f}%')
