@@ -286,6 +286,8 @@ struct cwr_engine {
   int32_t* d_scols_io = nullptr;
   std::vector<int32_t> h_tile_inner, h_tile_outer;
   std::vector<int32_t> h_tcl_ptr, h_tcl_cols;             // host copies of the tiles' column lists
+  std::vector<int32_t> h_trow;                            // ... and of their row ranges
+  bool tiles_cut = false;                                 // some windows were cut into smaller tiles (build_tiling's limits): tile != row / TR
   std::vector<int32_t> sched_nxt;          // chain successor of every tile in the installed schedule (unchanged -> no rebuild)
   int own_cap = 0;                         // rows of the LDS staging area for a tile's results (tile rows when reuse is on)
   bool use_chains = true;
@@ -1132,6 +1134,23 @@ int ensure_sq_pattern(cwr_engine* e) {
     const int nvmax = split ? TCL_NVMAX : 0;
     host::Tiling tl;
     if (!host::build_tiling(n_t, tr, seg, nvmax, e->K, e->n_real, ptr2, col2, tl)) continue;
+    {
+      // (round 5) a FEW windows heavier than the cheapest kernel configuration allows (a rank's window in which the replayed strips of
+      // two neighbours meet) are cut into smaller tiles instead of deciding the configuration of all: see build_tiling
+      const int q_first = want4 ? 3 : TCL_NARROW[0];
+      const int col_lim = want4 ? TCL_CFG[q_first].xr * (BLOCK / (e->K / 2)) : TCL_CFG[q_first].xr * e->R;
+      const int ent_lim = TCL_CFG[q_first].wrn * BLOCK;
+      if (!split && !getenv("CWR_NO_TILE_CUT") && (tl.max_cols > col_lim || tl.cap2 > ent_lim)) {
+        host::Tiling cut; int heavy = 0;
+        if (host::build_tiling(n_t, tr, seg, nvmax, e->K, e->n_real, ptr2, col2, cut, col_lim, ent_lim, &heavy) &&
+            heavy > 0 && heavy * 50 <= tl.ntiles() && cut.max_cols <= col_lim && cut.cap2 <= ent_lim) {
+          if (getenv("CWR_VERBOSE")) fprintf(stderr, "[cwr] tiled J^2: %d of %d windows cut into smaller tiles (they held up to %d distinct x rows / %d entries; limits %d / %d)\n",
+                                             heavy, tl.ntiles(), tl.max_cols, tl.cap2, col_lim, ent_lim);
+          tl = std::move(cut);
+          e->tiles_cut = true;
+        }
+      }
+    }
     const std::vector<int32_t>&trow = tl.trow, &vptr = tl.vptr, &tptr = tl.tptr, &tcols = tl.tcols;
     const std::vector<uint16_t>&vtab = tl.vtab, &loc2 = tl.loc2;
     const int nt = tl.ntiles(), max_cols = tl.max_cols, cap2 = tl.cap2;
@@ -1173,6 +1192,7 @@ int ensure_sq_pattern(cwr_engine* e) {
       e->tcl_total_cols = tcols.size();
       e->own_cap = own_cap;
       if (own_cap > 0) { e->h_tcl_ptr = tptr; e->h_tcl_cols = tcols; }
+      e->h_trow = trow;
       e->tcl_grid = grid_for(lds);
       TRY(dev_alloc(e, &e->d_tcl_ptr, (size_t)nt + 1));
       TRY(dev_alloc(e, &e->d_trow, (size_t)nt + 1));
@@ -1231,7 +1251,7 @@ int ensure_sq_pattern(cwr_engine* e) {
 int build_tile_links(cwr_engine* e) {
   if (e->n_links > 0 || !e->tcl_ready || e->tcl_seg < (1 << 20)) return CWR_OK;     // (fixed-size tiles only: tile = row / TR)
   host::TileLinks lk;
-  host::build_links(e->n_tcl, e->tcl_TR, e->tcl_ntiles, e->h_ptr, e->h_nb, e->h_edge, lk);
+  host::build_links(e->n_tcl, e->tcl_TR, e->tcl_ntiles, e->h_ptr, e->h_nb, e->h_edge, lk, e->tiles_cut ? &e->h_trow : nullptr);
   e->link_src = lk.src; e->link_dst = lk.dst;
   const std::vector<int32_t>&lptr = lk.lptr, &lent = lk.lent;
   e->n_links = (int)e->link_src.size();

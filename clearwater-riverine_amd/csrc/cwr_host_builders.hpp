@@ -111,10 +111,30 @@ struct Tiling {
 // Tiles of up to `tr` lane-group slots over rows [0, n_t): a row of more than `seg` entries occupies one slot per chunk (work
 // items; seg = 1 << 20, nvmax = 0: plain fixed-size tiles).  Returns false when a single row needs more slots than a tile has or
 // a tile's positions do not fit 16 bits.  n_cols = rows a column id may name (the real rows of the engine).
+// (round 5) col_limit / ent_limit: a window of tr rows whose tile would touch more distinct x rows or hold more J^2 entries than
+// that is cut into halves (recursively) -- the tiles of the next window still start at its multiple of tr.  A rank of a partition has a
+// few such windows where its replayed strips of two neighbours meet in one window (two clusters of rows, two neighbourhoods): without the
+// cut the ONE heavy tile decided the kernel configuration of every tile (a 7- or 8-rows-per-lane-group prefetch: 3 resident blocks per
+// CU instead of 4 -- 29 instead of 25 us per pass on a middle rank of 8 of the 1 M-cell mesh, 85 instead of 69 at 4 M:
+// profiles/r05_rank_budget.txt).  heavy (optional): windows that were cut.
 inline bool build_tiling(int n_t, int tr, int seg, int nvmax, int K, int n_cols, const std::vector<int32_t>& ptr2,
-                         const std::vector<int32_t>& col2, Tiling& out) {
+                         const std::vector<int32_t>& col2, Tiling& out, int col_limit = 1 << 30, int ent_limit = 1 << 30, int* heavy = nullptr) {
   out = Tiling();
   out.trow.assign(1, 0); out.vptr.assign(1, 0);
+  if (heavy) *heavy = 0;
+  const bool limited = col_limit < (1 << 30) || ent_limit < (1 << 30);
+  std::vector<int32_t> stamp_l;
+  int stamp_id = 0;
+  if (limited) stamp_l.assign((size_t)n_cols, -1);
+  // distinct x rows / entries of the rows [c0, c1)
+  auto fits = [&](int c0, int c1) {
+    if (ptr2[(size_t)c1] - ptr2[(size_t)c0] > ent_limit) return false;
+    ++stamp_id;
+    int cols = 0;
+    for (int c = c0; c < c1; ++c) if (stamp_l[(size_t)c] != stamp_id) { stamp_l[(size_t)c] = stamp_id; ++cols; }
+    for (int q = ptr2[(size_t)c0]; q < ptr2[(size_t)c1]; ++q) { const int k = col2[(size_t)q]; if (stamp_l[(size_t)k] != stamp_id) { stamp_l[(size_t)k] = stamp_id; ++cols; } }
+    return cols <= col_limit;
+  };
   for (int c = 0; c < n_t;) {
     int rows = 0, virt = 0;
     while (c + rows < n_t && rows < 256) {
@@ -125,6 +145,22 @@ inline bool build_tiling(int n_t, int tr, int seg, int nvmax, int K, int n_cols,
       ++rows; virt += extra;
     }
     if (rows == 0) return false;                                   // a single row needs more slots than a tile has
+    if (limited && nvmax == 0 && rows > 1 && !fits(c, c + rows)) {
+      // cut the window: halves, and halves of those, until every piece fits (a single row that does not is the caller's problem:
+      // the configuration test behind this call fails and the next larger configuration is tried)
+      if (heavy) ++*heavy;
+      std::vector<std::pair<int, int>> todo{{c, c + rows}}, done;
+      while (!todo.empty()) {
+        const auto seg_ = todo.back(); todo.pop_back();
+        if (seg_.second - seg_.first <= 1 || fits(seg_.first, seg_.second)) { done.push_back(seg_); continue; }
+        const int mid = (seg_.first + seg_.second) / 2;
+        todo.push_back({mid, seg_.second}); todo.push_back({seg_.first, mid});
+      }
+      std::sort(done.begin(), done.end());
+      for (const auto& d : done) { out.trow.push_back(d.second); out.vptr.push_back((int32_t)out.vtab.size()); }
+      c += rows;
+      continue;
+    }
     c += rows;
     out.trow.push_back(c); out.vptr.push_back((int32_t)out.vtab.size());
   }
@@ -176,7 +212,7 @@ inline void split_interior(int n_core, const Tiling& tl, std::vector<int32_t>& i
 }
 
 // ---- chained passes: links, chains, schedule, carry-over codes ----------------------------------------------------------------
-// Directed tile links over FIXED-size tiles (tile = row / TR): for every ordered pair of distinct tiles that share a face, the
+// Directed tile links (tile = row / TR, or the row ranges of `trow`): for every ordered pair of distinct tiles that share a face, the
 // adjacency entries (edge code = face index << 1 | side, as in ent_edge) through which a cell of src meets a cell of dst, sorted by
 // (src, dst), entries of a link in their adjacency order.
 struct TileLinks {
@@ -184,14 +220,22 @@ struct TileLinks {
   int n() const { return (int)src.size(); }
 };
 inline void build_links(int n, int TR, int nt, const std::vector<int32_t>& ptr, const std::vector<int32_t>& nb,
-                        const std::vector<int32_t>& edge, TileLinks& out) {
+                        const std::vector<int32_t>& edge, TileLinks& out, const std::vector<int32_t>* trow = nullptr) {
+  // trow (optional): the tiles' row ranges when they are not all TR rows long (windows cut by build_tiling's limits)
+  std::vector<int32_t> tile_of_row;
+  if (trow) {
+    tile_of_row.assign((size_t)n, 0);
+    for (int t = 0; t + 1 < (int)trow->size(); ++t)
+      for (int c = (*trow)[(size_t)t]; c < (*trow)[(size_t)t + 1] && c < n; ++c) tile_of_row[(size_t)c] = t;
+  }
+  auto tile = [&](int c) { return trow ? tile_of_row[(size_t)c] : c / TR; };
   struct Ent { int64_t key; int32_t code; };
   std::vector<Ent> ents;
   for (int c = 0; c < n; ++c)
     for (int j = ptr[(size_t)c]; j < ptr[(size_t)c + 1]; ++j) {
       const int m = nb[(size_t)j];
-      if (m < 0 || m >= n || m / TR == c / TR) continue;
-      ents.push_back({(int64_t)(c / TR) * nt + (m / TR), edge[(size_t)j]});         // flow leaving c's side of the face
+      if (m < 0 || m >= n || tile(m) == tile(c)) continue;
+      ents.push_back({(int64_t)tile(c) * nt + tile(m), edge[(size_t)j]});           // flow leaving c's side of the face
     }
   std::stable_sort(ents.begin(), ents.end(), [](const Ent& a, const Ent& b) { return a.key < b.key; });
   out = TileLinks();

@@ -67,7 +67,11 @@ int main(int argc, char** argv) {
   out["ptr2"] = sq.ptr2; out["col2"] = sq.col2; out["pair_ptr"] = sq.pair_ptr; out["slots"] = widen(sq.slots); out["fast"] = widen(sq.fast);
 
   Tiling tl;
-  const bool tiled = build_tiling(sq.n_sq, tr, seg, nvmax, K, n_real, sq.ptr2, sq.col2, tl);
+  // params[8], [9] (optional): limits on the distinct x rows / J^2 entries of a tile -- heavier windows are cut (round 5)
+  const int col_limit = par.size() > 8 ? par.at(8) : (1 << 30), ent_limit = par.size() > 9 ? par.at(9) : (1 << 30);
+  int heavy = 0;
+  const bool tiled = build_tiling(sq.n_sq, tr, seg, nvmax, K, n_real, sq.ptr2, sq.col2, tl, col_limit, ent_limit, &heavy);
+  out["heavy"] = {heavy};
   out["tiled"] = {tiled ? 1 : 0};
   if (!tiled) { write_bag(argv[2], out); return 0; }
   out["trow"] = tl.trow; out["vptr"] = tl.vptr; out["vtab"] = widen(tl.vtab); out["tptr"] = tl.tptr; out["tcols"] = tl.tcols;
@@ -80,7 +84,7 @@ int main(int argc, char** argv) {
   if (seg >= (1 << 20)) {                              // fixed-size tiles: links, chains, schedules, carry-over codes
     const int nt = tl.ntiles();
     TileLinks lk;
-    build_links(sq.n_sq, tr, nt, ptr, nb, edge, lk);
+    build_links(sq.n_sq, tr, nt, ptr, nb, edge, lk, heavy > 0 ? &tl.trow : nullptr);
     out["link_src"] = lk.src; out["link_dst"] = lk.dst; out["link_ptr"] = lk.lptr; out["link_ent"] = lk.lent;
     // k_link_flux on the CPU: the flow leaving the source side, summed in entry order, stored as float
     std::vector<float> flux((size_t)lk.n());

@@ -71,9 +71,9 @@ def adjacency(f1, f2, n_owned, n_real):
     return np.cumsum(ptr).astype(np.int32), nb[o].astype(np.int32), code[o].astype(np.int32)
 
 
-def run(driver, tmp_path, ptr, nb, edge, adv, n_owned, n_core, n_real, K, tr, grid, seg=1 << 20, nvmax=0):
+def run(driver, tmp_path, ptr, nb, edge, adv, n_owned, n_core, n_real, K, tr, grid, seg=1 << 20, nvmax=0, limits=()):
     fin, fout = str(tmp_path / 'in.bin'), str(tmp_path / 'out.bin')
-    write_bag(fin, {'params': np.array([n_owned, n_core, n_real, K, tr, grid, seg, nvmax]), 'ptr': ptr, 'nb': nb, 'edge': edge,
+    write_bag(fin, {'params': np.array([n_owned, n_core, n_real, K, tr, grid, seg, nvmax, *limits]), 'ptr': ptr, 'nb': nb, 'edge': edge,
                     'adv': np.asarray(adv, dtype=np.float32)})
     env = dict(os.environ, ASAN_OPTIONS='detect_leaks=1:abort_on_error=1', UBSAN_OPTIONS='print_stacktrace=1')
     res = subprocess.run([driver, fin, fout], capture_output=True, text=True, env=env, timeout=600)
@@ -275,3 +275,47 @@ def test_work_item_tiles_cover_every_row_once(driver, tmp_path):
         codes = vtab[vptr[t]:vptr[t + 1]]
         want = [r | (ch << 8) for r in range(rows) for ch in range(1, extra[r] + 1)]
         assert list(codes) == want
+
+
+def test_heavy_windows_are_cut_into_smaller_tiles_and_the_rest_keep_their_windows(driver, tmp_path):
+    """Round 5: a middle rank of a partition has windows of 64 rows in which the replayed strips of two neighbours meet -- two clusters,
+    two neighbourhoods, more distinct x rows than the cheapest kernel configuration holds.  With limits build_tiling cuts such a window
+    into halves (recursively); every other tile is its whole window, every piece respects the limits, the links follow the row ranges
+    (ASan / UBSan build) and the schedules over the cut tiling are valid (checked by the driver itself)."""
+    mesh = cw.synthetic.make_mesh(120, 64, 3, seed=7, n_merge=300, dt=40.0, diffusion_coefficient=0.5)
+    n = mesh['nreal'] + 1
+    K, tr = 16, 64
+    mesh = renumber_mesh(mesh, lane_order(mesh, n, tile_rows=tr))
+    lm = partition_mesh(mesh['edges_face1'], mesh['edges_face2'], n, 8, 3, depth=8, align=tr)
+    n_owned, n_real = lm.n_rows, lm.n_rows + lm.n_halo
+    ptr, nb, edge = adjacency(lm.face1, lm.face2, n_owned, n_real)
+    adv = np.asarray(mesh['face_flow'][1], dtype=np.float32)[lm.edge_global]
+    plain = run(driver, tmp_path, ptr, nb, edge, adv, n_owned, lm.n_core, n_real, K, tr, 8)
+    cols_plain = np.diff(plain['tptr'])
+    lim = int(np.sort(cols_plain)[-4])                              # a limit that the three heaviest windows exceed
+    assert cols_plain.max() > lim
+    out = run(driver, tmp_path, ptr, nb, edge, adv, n_owned, lm.n_core, n_real, K, tr, 8, limits=(lim, 1 << 20))
+    n_sq = int(out['n_sq'][0])
+    trow, tptr, tcols, ptr2, col2 = out['trow'], out['tptr'], out['tcols'], out['ptr2'], out['col2']
+    heavy = int(out['heavy'][0])
+    assert 1 <= heavy <= 3 + 1 and len(trow) - 1 > len(plain['trow']) - 1
+    assert trow[0] == 0 and trow[-1] == n_sq and (np.diff(trow) > 0).all()
+    # every multiple of tr is a tile boundary: the windows the numbering was arranged in survive
+    assert set(range(0, n_sq, tr)) <= set(trow.tolist())
+    for t in range(len(trow) - 1):
+        c0, c1 = int(trow[t]), int(trow[t + 1])
+        want = np.unique(np.concatenate([np.arange(c0, c1), col2[ptr2[c0]:ptr2[c1]]]))
+        got = tcols[tptr[t]:tptr[t + 1]]
+        assert np.array_equal(np.sort(got), want) and np.array_equal(got[:c1 - c0], np.arange(c0, c1))
+        assert len(got) <= lim or c1 - c0 == 1
+    # links: between the tiles of the cut tiling (row ranges), never inside one
+    tile_of = np.repeat(np.arange(len(trow) - 1), np.diff(trow))
+    src, dst = out['link_src'], out['link_dst']
+    assert (src != dst).all() and src.max() < len(trow) - 1
+    pairs = set()
+    for c in range(n_sq):
+        for j in range(ptr[c], ptr[c + 1]):
+            m = nb[j]
+            if 0 <= m < n_sq and tile_of[m] != tile_of[c]:
+                pairs.add((int(tile_of[c]), int(tile_of[m])))
+    assert pairs == set(zip(src.tolist(), dst.tolist()))
