@@ -61,7 +61,7 @@ def cpu_baseline(mesh: dict, input_col: np.ndarray, budget_s: float, max_steps: 
 def pmc_traffic(which: str, K: int, kernel: str = 'k_sq_tiled'):
     """HBM-side bytes per launch of the dominant kernel, measured NOW: two counter-only rocprofv3 passes (--pmc FETCH_SIZE,
     --pmc WRITE_SIZE; the guide's HBM section: separate passes, read = 2 x FETCH_SIZE x 1024 on gfx950, written =
-    WRITE_SIZE x 1024) over scratch/pmc_target.py -- two steps of this very workload -- as child processes.  Called before
+    WRITE_SIZE x 1024) over tools/pmc_target.py -- two steps of this very workload -- as child processes.  Called before
     this process touches the GPU.  Returns (read, written) or None when rocprofv3 is not there or a pass fails."""
     import csv
     import glob
@@ -76,7 +76,7 @@ def pmc_traffic(which: str, K: int, kernel: str = 'k_sq_tiled'):
         try:
             env = dict(os.environ, TMPDIR='/tmp')
             subprocess.run(['rocprofv3', '--pmc', counter, '--output-format', 'csv', '-d', d, '-o', 'pmc', '--',
-                            sys.executable, os.path.join(ROOT, 'scratch', 'pmc_target.py'), which, str(K)],
+                            sys.executable, os.path.join(ROOT, 'tools', 'pmc_target.py'), which, str(K)],
                            check=True, capture_output=True, timeout=240, env=env, cwd='/tmp')
             tot, n = 0.0, 0
             for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
@@ -342,7 +342,7 @@ def main():
         traffic_source = None
         if live_traffic is not None and r.sweep_kernel == 6:
             traffic_rw, traffic = live_traffic, sum(live_traffic)
-            traffic_source = 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over scratch/pmc_target.py in this run'
+            traffic_source = 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over tools/pmc_target.py in this run'
         try:                                             # otherwise the committed PMC measurement of this exact config, if any
             with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as fh:
                 ent = json.load(fh).get(mesh_key, {}).get(str(K)) if world == 1 and args.solver == 'auto' else None

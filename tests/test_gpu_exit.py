@@ -2,7 +2,7 @@
 
 pytest, smoke() and bench.py all release their engines before they exit, so none of them says anything about a host program that
 simply ends -- with a TransportEngine still referenced from a module global, a facade whose history blocks are page-locked, or a
-streamed-output writer thread still attached.  Every mode of scratch/exit_probe.py runs as a FRESH child process here; the child
+streamed-output writer thread still attached.  Every mode of tools/exit_probe.py runs as a FRESH child process here; the child
 must exit with status 0 and an empty stderr (no traceback from a finalizer, no 'Exception ignored in', no fault)."""
 import os
 import subprocess
@@ -13,7 +13,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PROBE = os.path.join(ROOT, 'scratch', 'exit_probe.py')
+PROBE = os.path.join(ROOT, 'tools', 'exit_probe.py')
 
 
 @pytest.mark.parametrize('mode', ['engine', 'engine_global', 'facade', 'facade_closed', 'facade_stream'])

@@ -1,4 +1,4 @@
-"""Target of the PMC passes (rocprofv3 --pmc ... -- python3 scratch/pmc_target.py <mesh> <K>): two steps of the bench
+"""Target of the PMC passes (rocprofv3 --pmc ... -- python3 tools/pmc_target.py <mesh> <K>): two steps of the bench
 workload, nothing else.  bench.py runs it as a child BEFORE it touches the GPU itself; profiles/*pmc* come from it too."""
 import os
 import sys

@@ -35,26 +35,26 @@ if [ "$part" = A ]; then
   for c in FETCH_SIZE "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
     for K in 16 1; do
       d=/tmp/pmc_${K}_$(echo $c | cut -c1-5); rm -rf $d
-      rocprofv3 --pmc $c --output-format csv -d $d -o pmc -- python3 scratch/pmc_target.py merged $K > /dev/null 2> $d.err
+      rocprofv3 --pmc $c --output-format csv -d $d -o pmc -- python3 tools/pmc_target.py merged $K > /dev/null 2> $d.err
       echo "== K=$K counters: $c" >> $O/pmc_raw_summary.txt
-      python scratch/pmc_summarize.py $d k_ >> $O/pmc_raw_summary.txt
+      python tools/pmc_summarize.py $d k_ >> $O/pmc_raw_summary.txt
     done
   done
   show $O/bench_*.json
 else
-  python scratch/config5.py > $O/config5.txt 2>&1
+  python tools/config5.py > $O/config5.txt 2>&1
   python tests/models/ohio_like.py > $O/ohio_like.txt 2>&1
   : > $O/stiff.txt
-  python scratch/r03_stiff.py 16 6 40 pingpong 2 chains auto 2>&1 | grep -v Warn >> $O/stiff.txt
-  python scratch/r03_stiff.py 16 3 400 pingpong 2 chains auto 2>&1 | grep -v Warn >> $O/stiff.txt
-  python scratch/r03_stiff.py 16 3 1000 pingpong 2 chains auto 2>&1 | grep -v Warn >> $O/stiff.txt
-  python scratch/r03_stiff.py 16 2 3600 chains auto 2>&1 | grep -v Warn >> $O/stiff.txt
-  python scratch/r03_stiff.py 1 8 40 pingpong auto chains auto 2>&1 | grep -v Warn >> $O/stiff.txt
+  python tools/r03_stiff.py 16 6 40 pingpong 2 chains auto 2>&1 | grep -v Warn >> $O/stiff.txt
+  python tools/r03_stiff.py 16 3 400 pingpong 2 chains auto 2>&1 | grep -v Warn >> $O/stiff.txt
+  python tools/r03_stiff.py 16 3 1000 pingpong 2 chains auto 2>&1 | grep -v Warn >> $O/stiff.txt
+  python tools/r03_stiff.py 16 2 3600 chains auto 2>&1 | grep -v Warn >> $O/stiff.txt
+  python tools/r03_stiff.py 1 8 40 pingpong auto chains auto 2>&1 | grep -v Warn >> $O/stiff.txt
   : > $O/small_engines.txt
   C="warmup= r04=CWR_NO_NOTE:1,CWR_NO_FUSED_BEGIN:1 r05="
   for cs in "sq354 16" "sq245 16" "sq354 1" "band200x50 12" "band160x50 12" "band160x50 1"; do
-    timeout -k 10 300 python scratch/r04_small.py $cs $C >> $O/small_engines.txt 2>&1
+    timeout -k 10 300 python tools/r04_small.py $cs $C >> $O/small_engines.txt 2>&1
   done
-  MID_DT=400 timeout -k 10 300 python scratch/r04_small.py sq354 16 $C >> $O/small_engines.txt 2>&1
+  MID_DT=400 timeout -k 10 300 python tools/r04_small.py sq354 16 $C >> $O/small_engines.txt 2>&1
   tail -2 $O/config5.txt; tail -5 $O/ohio_like.txt; cat $O/stiff.txt; grep -v "warmup\|^\[cwr\]\|Warn" $O/small_engines.txt
 fi

@@ -5,7 +5,7 @@ set -o pipefail
 cd "$(dirname "$0")/.." || exit 1
 tag=${1:-r05f}
 out=gpurun_out/${tag}_small_ab.txt; : > $out
-run() { timeout -k 10 500 python scratch/r04_small.py "$@" >> $out 2>&1 || echo "FAILED $* rc=$?" >> $out; }
+run() { timeout -k 10 500 python tools/r04_small.py "$@" >> $out 2>&1 || echo "FAILED $* rc=$?" >> $out; }
 AB="warmup= r04=CWR_NO_NOTE:1,CWR_NO_FUSED_BEGIN:1 note_only=CWR_NO_FUSED_BEGIN:1 fused_only=CWR_NO_NOTE:1 r05= r04b=CWR_NO_NOTE:1,CWR_NO_FUSED_BEGIN:1 r05b="
 run sq354 16 $AB
 run sq354 1 $AB
