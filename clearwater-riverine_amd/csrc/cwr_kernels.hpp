@@ -432,11 +432,12 @@ __global__ void __launch_bounds__(BLOCK) k_jnorm(
     const int32_t* __restrict__ ent_nb, const float* __restrict__ adv, const double* __restrict__ dif,
     const float* __restrict__ vol_next, const double* __restrict__ dt, unsigned long long* __restrict__ jn, double dt_one) {
   // adv / dif: level t of the launch's first step at offset 0 (stride E); vol_next: V of level t + 1 at offset 0 (stride n_cells)
+  // grid (row blocks, levels): the rows are walked grid-stride, so the host bounds the blocks per level -- one same-address atomic per
+  // block is what the launch waits for (3 906 blocks per level at 1 M cells: 39 us per level; <= 1 024 now)
   __shared__ double s_m[BLOCK / 64];
   const int t = blockIdx.y;
-  const int c = blockIdx.x * BLOCK + threadIdx.x;
   double rho = 0.0;
-  if (c < n_owned) {
+  for (int c = blockIdx.x * BLOCK + threadIdx.x; c < n_owned; c += gridDim.x * BLOCK) {
     const float* adv_t = adv + (size_t)t * E;
     const double* dif_t = dif + (size_t)t * E;
     const double vn = (double)vol_next[(size_t)t * n_cells + c];
@@ -450,8 +451,9 @@ __global__ void __launch_bounds__(BLOCK) k_jnorm(
       dg += d + fmax(a_c, 0.0);
       if (ent_nb[j] >= 0) off += d - fmin(a_c, 0.0);
     }
-    rho = off / dg;
-    if (!(rho >= 0.0)) rho = INFINITY;               // NaN in the field: no bound
+    double rr = off / dg;
+    if (!(rr >= 0.0)) rr = INFINITY;               // NaN in the field: no bound
+    rho = fmax(rho, rr);
   }
   for (int o = 32; o >= 1; o >>= 1) rho = fmax(rho, __shfl_xor(rho, o, 64));
   if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = rho;
@@ -463,11 +465,39 @@ __global__ void __launch_bounds__(BLOCK) k_jnorm(
   }
 }
 
+// One level of a windowed flow field on its way in (cwr_flow_window_load), in ONE pass over the faces: the face flows and velocities
+// arrive in the reference's face order (in_flow, in_vel) and leave in the internal one -- k_faces_in twice --, the coefficients are
+// derived (k_derive_coeff: utilities.py:514-535, the same float32 / float64 steps) and the level's zero-coefficient flag is set
+// (k_check_ghost_levels: linalg.py:349-351).  The first thread zeroes the flag and the norm word of the step this level completes
+// first (everything later on the stream sets / folds into them).
+__global__ void __launch_bounds__(BLOCK) k_level_in(
+    int E, int n_owned, int n_real, const int32_t* __restrict__ orig, const int32_t* __restrict__ f1, const int32_t* __restrict__ f2,
+    const float* __restrict__ in_flow, const float* __restrict__ in_vel, const double* __restrict__ dist, float Df, int use_diffusion,
+    float* __restrict__ vel, float* __restrict__ adv, double* __restrict__ dif, int32_t* __restrict__ flag) {
+  for (int p = blockIdx.x * BLOCK + threadIdx.x; p < E; p += gridDim.x * BLOCK) {
+    const int src = orig[p];
+    const float f = in_flow[src], v = in_vel[src];
+    const float sg = (v != v) ? v : (fabsf(v) > 0.0f ? 1.0f : 0.0f);
+    const float a = f * sg;
+    float area = a / v;
+    if (area != area) area = 0.0f;
+    const float ad = area * Df;
+    const double d = (double)ad / dist[p];
+    vel[p] = v; adv[p] = a; dif[p] = d;
+    if (f2[p] >= n_real && f1[p] < n_owned && ((v < 0.0f) || (v > 0.0f))) {
+      const bool d0 = use_diffusion && fabs(d) == 0.0;
+      if (v < 0.0f ? (fabs((double)a) == 0.0 || d0) : d0) flag[0] = 1;
+    }
+  }
+}
+
 // windowed flow fields: the per-level scalars the host needs at the step, left in page-locked memory by the flow stream
-// (flag: the zero-coefficient flag of a level as 0.0 / 1.0; jn: the bit pattern of ||J||_inf of a step)
-__global__ void k_note_level(const int32_t* __restrict__ flag, const unsigned long long* __restrict__ jn, double* __restrict__ out) {
-  if (flag) out[0] = flag[0] ? 1.0 : 0.0;
-  if (jn) out[0] = __longlong_as_double((long long)jn[0]);
+// (the zero-coefficient flag of a level as 0.0 / 1.0; ||J||_inf of up to two steps from their bit patterns)
+__global__ void k_note_level(const int32_t* __restrict__ flag, double* __restrict__ flag_out, const unsigned long long* __restrict__ jn_a,
+                             double* __restrict__ out_a, const unsigned long long* __restrict__ jn_b, double* __restrict__ out_b) {
+  flag_out[0] = flag[0] ? 1.0 : 0.0;
+  if (jn_a) out_a[0] = __longlong_as_double((long long)jn_a[0]);
+  if (jn_b) out_b[0] = __longlong_as_double((long long)jn_b[0]);
   __threadfence_system();
 }
 
@@ -485,10 +515,12 @@ __global__ void __launch_bounds__(BLOCK) k_neumann(
     int n_owned, int n_dot, const int32_t* __restrict__ ptr, const int32_t* __restrict__ ent_edge, const int32_t* __restrict__ ent_nb,
     const float* __restrict__ adv_t, const double* __restrict__ dif_t, const float* __restrict__ vol_next, double dt,
     const double* __restrict__ win, double* __restrict__ wout, unsigned long long* __restrict__ maxima) {
+  // maxima == nullptr: a sweep nobody checks (all but the last of a batch) -- no reduction at all.  Grid-stride over the rows with a
+  // bounded grid: the two same-address atomics per block are what a checked sweep waits for (3 906 blocks at 1 M cells: 111 us per
+  // sweep, profiles/r05_final_kernel_stats_bench_K16.csv of the first build; <= 1 024 blocks and only the last sweep of a batch now).
   __shared__ double s_r[BLOCK / 64], s_w[BLOCK / 64];
-  const int c = blockIdx.x * BLOCK + threadIdx.x;
   double r = 0.0, wv = 0.0;
-  if (c < n_owned) {
+  for (int c = blockIdx.x * BLOCK + threadIdx.x; c < n_owned; c += gridDim.x * BLOCK) {
     const double vn = (double)vol_next[c];
     double dg = vn / dt + (vn == 0.0 ? 1.0 : 0.0), sum = 0.0;
     const int j1 = ptr[c + 1];
@@ -501,12 +533,16 @@ __global__ void __launch_bounds__(BLOCK) k_neumann(
       const int nb = ent_nb[j];
       if (nb >= 0) sum += (d - fmin(a_c, 0.0)) * win[nb];
     }
-    wv = 1.0 + sum / dg;
-    wout[c] = wv;
-    if (c < n_dot) { r = wv - win[c]; if (!(r >= 0.0)) r = (r != r) ? INFINITY : 0.0; }   // (NaN in the field: no bound)
-    if (!(wv >= 0.0)) wv = INFINITY;
-    if (c >= n_dot) wv = 0.0;
+    double w1 = 1.0 + sum / dg;
+    wout[c] = w1;
+    if (maxima && c < n_dot) {
+      double dr = w1 - win[c];
+      if (!(dr >= 0.0)) dr = (dr != dr) ? INFINITY : 0.0;      // (NaN in the field: no bound)
+      if (!(w1 >= 0.0)) w1 = INFINITY;
+      r = fmax(r, dr); wv = fmax(wv, w1);
+    }
   }
+  if (!maxima) return;                                          // (uniform)
   for (int o = 32; o >= 1; o >>= 1) { r = fmax(r, __shfl_xor(r, o, 64)); wv = fmax(wv, __shfl_xor(wv, o, 64)); }
   if ((threadIdx.x & 63) == 0) { s_r[threadIdx.x >> 6] = r; s_w[threadIdx.x >> 6] = wv; }
   __syncthreads();

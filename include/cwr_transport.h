@@ -152,13 +152,15 @@ int32_t cwr_load_coefficients(cwr_engine* e, int32_t n_times, const float* advec
  * cwr_flow_window_open: n_times levels in the run, a ring of window_levels >= 2 of them (level t lives in slot t % window_levels);
  *   dt (n_times), face_to_face_dist (n_edges) and D as for cwr_load_flow_field.  Replaces a loaded flow field.
  * cwr_flow_window_load: levels t0 .. t0 + n_levels - 1 (face_flow, edge_velocity: (n_levels, n_edges) f32; volume: (n_levels,
- *   n_cells) f32) into their slots, replacing what those held.  Only ENQUEUED, on a stream of the engine's own: upload, coefficient
- *   derivation, the zero-coefficient flag of every level and ||J||_inf of every step the arrived levels complete run beside the
- *   steps (behind every kernel already enqueued that may still read the levels being replaced); the host arrays must stay
- *   untouched until a later cwr_step / cwr_synchronize has returned, and only page-locked arrays (cwr_host_register) make the upload
- *   itself asynchronous.  cwr_step(t) needs levels t and t + 1 in the ring (CWR_ERR_STATE otherwise) and waits for them on the
+ *   n_cells) f32) into their slots, replacing what those held.  Only NOTED by this call: the next cwr_step sends the levels to a stream
+ *   of the engine's own -- behind its batch of passes, while the host would otherwise wait for the convergence check, unless the step
+ *   itself needs them (then first) -- where upload, coefficient derivation, the zero-coefficient flag of every level and ||J||_inf of
+ *   every step the arrived levels complete run beside the steps (behind every kernel already enqueued that may still read the levels
+ *   being replaced).  Any other call that needs a level (cwr_get_coefficients, cwr_apply, ...) and cwr_synchronize send them at once.
+ *   The host arrays must stay untouched until a cwr_step that reads the levels, or cwr_synchronize, has returned, and only
+ *   page-locked arrays (cwr_host_register) make the upload itself asynchronous.  cwr_step(t) needs levels t and t + 1 in the ring (CWR_ERR_STATE otherwise) and waits for them on the
  *   device; results are those of the all-resident engine, bit for bit with CWR_STEP_DETERMINISTIC.  The row-wise error factor of a
- *   step (cwr_get_error_factors) is taken when the step runs, and only where its norm form exceeds 3. */
+ *   step (cwr_get_error_factors) is taken when the step runs, and only where its norm form exceeds 4. */
 int32_t cwr_flow_window_open(cwr_engine* e, int32_t n_times, int32_t window_levels, const double* dt,
                              const double* face_to_face_dist, double diffusion_coefficient);
 int32_t cwr_flow_window_load(cwr_engine* e, int32_t t0, int32_t n_levels, const float* face_flow,

@@ -250,17 +250,21 @@ def test_eight_ranks_through_the_stand_in(gpu_lib, K, depth, monkeypatch):
     allows 6 processes on its card, so the 8 ranks are 4 processes x 2 rank threads (_host_main): eight complete engines, eight
     communicators, the real partition of 8 with its middle ranks (up to six peers, two cut sides, few or no interior tiles) and its
     end ranks.  Oracle parity, every rank the same solver decisions and the same exchange / overlap / check counts per step.
-    Two ranks in ONE process is an arrangement of this test only (the product runs one engine per process), and the HIP runtime
-    limits it twice: (i) while one rank thread captures a hipGraph the other thread's copies are refused ("operation not permitted
-    when stream is capturing") -> CWR_NO_GRAPHS=1; (ii) stream wait-values of two ranks of one process block each other (the
-    second rank of every process never got past its first exchange: gpurun_out/r04g_eight.log) -> the stand-in runs in its
-    HOST-synchronous mode here.  Up to 4 ranks (one process each) the stream-asynchronous mode is what every other test of this
-    file uses, the poison tests included."""
+    Two ranks in ONE process is an arrangement of this test only (the product runs one engine per process), and it limits the test
+    in one way: the streams of one process share its in-order copy-engine rings, so the stream-asynchronous stand-in, which parks a
+    copy behind a wait on a peer, lets one rank's receive block its process mate's send (gpurun_out/r04e / r04g)
+    -> the stand-in runs in its HOST-synchronous mode here.  hipGraphs are ON again since round 5 (K = 16): while one rank thread
+    captured, the runtime refused the other thread's calls ("operation not permitted when stream is capturing", r04f) as long as
+    that thread's capture-interaction mode was the default; every ABI entry now puts its thread into the thread-local mode.
+    Up to 6 ranks (one process each) the stream-asynchronous mode is what every other test uses, the poison tests included."""
     build_mock()
     world = 8
     monkeypatch.setenv('CWR_NO_SMALL', '1')
     monkeypatch.setenv('CWR_TEST_BIG', '1')
-    monkeypatch.setenv('CWR_NO_GRAPHS', '1')
+    if K == 1:
+        monkeypatch.setenv('CWR_NO_GRAPHS', '1')         # (one of the two cases keeps round 4's arrangement)
+    else:
+        monkeypatch.delenv('CWR_NO_GRAPHS', raising=False)
     monkeypatch.setenv('CWR_MOCK_ASYNC', '0')
     monkeypatch.setenv('CWR_MOCK_TIMEOUT_S', '45')
     results = run_ranks(world, _host_main, (K, 'jacobi', depth), per_host=2)
