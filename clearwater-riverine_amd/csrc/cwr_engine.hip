@@ -143,7 +143,7 @@ struct cwr_engine {
                                  // element-wise measures max(|x'-x| - ew_rel |x'|), max |x'| (k_apply MODE 4)
   // (round 5) the check scalars of a single engine reach the host without a copy and without draining the stream: k_reduce_partials
   // stores them into this page-locked buffer and publishes a sequence number behind them (ReduceNote); the host spins on it
-  double* h_note = nullptr;        // [4 K] doubles + the sequence word (hipHostMalloc, mapped)
+  double* h_note = nullptr;        // [5 K] doubles + the sequence word (hipHostMalloc, mapped)
   double* d_note_view = nullptr;   // the device's address of h_note
   unsigned long long* h_note_seq = nullptr;
   unsigned long long* d_note_state = nullptr;   // device: [0] the sequence counter, [1] (as unsigned int) the arrival counter
@@ -327,7 +327,11 @@ struct cwr_engine {
   int sweep_margin = 1;
   bool two_closing = false;      // CWR_TWO_CLOSING=1: round 1's batch shape on one GPU too (even passes + two closing sweeps; A/B)
   bool use_small = true;         // one-workgroup-per-constituent LDS-resident solve for meshes that fit one CU
-  double* d_info = nullptr;      // [K][3] results of k_small_jacobi
+  double* d_info = nullptr;      // [K][5] results of k_small_jacobi
+  int32_t* d_small_rows = nullptr;   // [rpt][1024] the row at position p of k_small_jacobi's internal order (-1: none)
+  int32_t* d_small_recs = nullptr;   // [8][rpt][1024] record index of the q-th real neighbour of that row (-1: none)
+  uint32_t* d_small_offs = nullptr;  // [4][rpt][1024] byte offsets of neighbours 2 qq / 2 qq + 1 in the LDS column (16 bits each)
+  int small_rpt = 0;                 // rows per thread the two tables were built for (0: not built)
   int nt_stream = 0;            // nt loads for the streamed operands (records, bhat/c2/r0): pays for wide rows only
   std::string err;
 
@@ -459,7 +463,7 @@ int reduce_partials(cwr_engine* e, int nslots, int ND, double* o0, double* o1 = 
   ReduceOuts outs; outs.p[0] = o0; outs.p[1] = o1; outs.p[2] = o2; outs.p[3] = o3;
   ReduceNote note{nullptr, nullptr, nullptr, nullptr};
   if (notify && e->h_note && ND == 4 && o0 && o1 && o2 && o3)
-    note = ReduceNote{e->d_note_view, reinterpret_cast<unsigned long long*>(e->d_note_view + 4 * (size_t)e->K),
+    note = ReduceNote{e->d_note_view, reinterpret_cast<unsigned long long*>(e->d_note_view + 5 * (size_t)e->K),
                       reinterpret_cast<unsigned int*>(e->d_note_state + 1), e->d_note_state};
   k_reduce_partials<<<ND, RBLOCK, 0, e->stream>>>(nslots, ND, e->K, e->d_partial, outs, max_from, note);
   HIP_TRY(e, hipGetLastError());
@@ -598,7 +602,7 @@ bool check_by_note(const cwr_engine* e) { return e->use_note && e->h_note && (!e
 // Wait for the `note_expected`-th notification of k_reduce_partials and take the check scalars from the host buffer.  The host
 // spins on a word of page-locked memory: no copy is enqueued and the stream is not drained -- whatever was enqueued BEHIND the
 // reduction (the step's speculative tail) runs on while the host already decides and enqueues the next step.
-int wait_check_note(cwr_engine* e, double* h) {
+int wait_check_note(cwr_engine* e, double* h, size_t count = 0) {
   const unsigned long long want = e->note_expected;
   for (unsigned long long spin = 1;; ++spin) {
     if (__atomic_load_n(e->h_note_seq, __ATOMIC_ACQUIRE) >= want) break;
@@ -616,7 +620,7 @@ int wait_check_note(cwr_engine* e, double* h) {
       }
     }
   }
-  std::memcpy(h, e->h_note, 4 * (size_t)e->K * sizeof(double));
+  std::memcpy(h, e->h_note, (count ? count : 4 * (size_t)e->K) * sizeof(double));
   return CWR_OK;
 }
 
@@ -1894,32 +1898,124 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
   }
 }
 
+// The tables of k_small_jacobi (see there).  The column lives in LDS in an INTERNAL order, position p = slot i * 1024 + thread:
+//   1. Cuthill-McKee order of the adjacency (breadth-first levels from a pseudo-peripheral cell; the engine knows no coordinates
+//      here): the q-th nearest-position neighbour of consecutive positions is then a run of consecutive positions -- the 32 lanes of
+//      a half-wave gather from 32 different LDS banks whatever the caller's numbering was (profiles/r05_small_mesh.txt: 38 % of the
+//      LDS cycles were bank conflicts with the rows in the caller's order);
+//   2. on top of it a stable sort by the class of the REAL-neighbour count (7-8, 5-6, up to 4): the 64 rows a wave relaxes
+//      together gather the same number of neighbours.
+// Per row the real neighbours in ascending position (ghost faces carry no weight in J: no slot): their record index (for the
+// step's weights) and their byte offset in the column, two offsets per word.
+int ensure_small_tables(cwr_engine* e, int rpt) {
+  if (e->small_rpt == rpt) return CWR_OK;
+  const int n = e->n_owned;
+  std::vector<int32_t> deg((size_t)n, 0);
+  for (int c = 0; c < n; ++c) {
+    for (int j = e->h_ptr[(size_t)c]; j < e->h_ptr[(size_t)c + 1]; ++j) deg[(size_t)c] += e->h_nb[(size_t)j] >= 0;
+    if (deg[(size_t)c] > SMALL_DEG) { e->use_small = false; return CWR_OK; }
+  }
+  // breadth-first order from `start` over the cells not yet placed; returns the last cell reached (farthest level)
+  std::vector<int32_t> order; order.reserve((size_t)n);
+  std::vector<char> seen((size_t)n, 0);
+  auto bfs = [&](int start, std::vector<int32_t>& out, std::vector<char>& mark) -> int {
+    const size_t first = out.size();
+    out.push_back(start); mark[(size_t)start] = 1;
+    std::vector<int32_t> nbs;
+    for (size_t head = first; head < out.size(); ++head) {
+      const int c = out[head];
+      nbs.clear();
+      for (int j = e->h_ptr[(size_t)c]; j < e->h_ptr[(size_t)c + 1]; ++j) {
+        const int nb = e->h_nb[(size_t)j];
+        if (nb >= 0 && nb < n && !mark[(size_t)nb]) { mark[(size_t)nb] = 1; nbs.push_back(nb); }
+      }
+      std::sort(nbs.begin(), nbs.end(), [&](int32_t a, int32_t b) { return deg[(size_t)a] != deg[(size_t)b] ? deg[(size_t)a] < deg[(size_t)b] : a < b; });
+      out.insert(out.end(), nbs.begin(), nbs.end());
+    }
+    return out.back();
+  };
+  for (int c0 = 0; c0 < n; ++c0) {
+    if (seen[(size_t)c0]) continue;
+    // pseudo-peripheral start of this component: the far end of a search from its first cell, then the far end of that one
+    std::vector<char> tmp_mark(seen);
+    std::vector<int32_t> tmp;
+    int far = bfs(c0, tmp, tmp_mark);
+    tmp_mark = seen; tmp.clear();
+    far = bfs(far, tmp, tmp_mark);
+    bfs(far, order, seen);
+  }
+  // (classes, not counts: the kernel gathers four neighbours unconditionally, then two, then two -- rows of up to four neighbours
+  // stay in Cuthill-McKee order among themselves, which keeps the runs of consecutive positions whole at the mesh's edges)
+  auto cls = [&](int32_t c) { return deg[(size_t)c] > 6 ? 0 : (deg[(size_t)c] > 4 ? 1 : 2); };
+  std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return cls(a) < cls(b); });
+  std::vector<int32_t> pos((size_t)n);
+  for (int p = 0; p < n; ++p) pos[(size_t)order[(size_t)p]] = p;
+  const size_t slots_n = (size_t)rpt * SMALL_THREADS;
+  std::vector<int32_t> rows(slots_n, -1), recs((size_t)SMALL_DEG * slots_n, -1);
+  std::vector<uint32_t> offs((size_t)(SMALL_DEG / 2) * slots_n, 0);
+  std::vector<std::pair<int32_t, int32_t>> nb;   // (position, record)
+  for (int p = 0; p < n; ++p) {
+    const int c = order[(size_t)p];
+    rows[(size_t)p] = c;                          // p = i * 1024 + thread
+    nb.clear();
+    for (int j = e->h_ptr[(size_t)c]; j < e->h_ptr[(size_t)c + 1]; ++j)
+      if (e->h_nb[(size_t)j] >= 0) nb.emplace_back(pos[(size_t)e->h_nb[(size_t)j]], j);
+    std::sort(nb.begin(), nb.end());
+    for (int q = 0; q < SMALL_DEG; ++q) {
+      const uint32_t off = (uint32_t)(q < (int)nb.size() ? nb[(size_t)q].first : p) * 8u;     // empty slot: the row itself, weight zero
+      if (q < (int)nb.size()) recs[(size_t)q * slots_n + (size_t)p] = nb[(size_t)q].second;
+      offs[(size_t)(q / 2) * slots_n + (size_t)p] |= (q & 1) ? (off << 16) : off;
+    }
+  }
+  for (int32_t** d : {&e->d_small_rows, &e->d_small_recs})
+    if (*d) { (void)hipFree(*d); *d = nullptr; }
+  if (e->d_small_offs) { (void)hipFree(e->d_small_offs); e->d_small_offs = nullptr; }
+  HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&e->d_small_rows), rows.size() * sizeof(int32_t)));
+  HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&e->d_small_recs), recs.size() * sizeof(int32_t)));
+  HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&e->d_small_offs), offs.size() * sizeof(uint32_t)));
+  HIP_TRY(e, hipMemcpy(e->d_small_rows, rows.data(), rows.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  HIP_TRY(e, hipMemcpy(e->d_small_recs, recs.data(), recs.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  HIP_TRY(e, hipMemcpy(e->d_small_offs, offs.data(), offs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  e->small_rpt = rpt;
+  return CWR_OK;
+}
+
 // Meshes that fit one CU's LDS: the whole Jacobi solve of every constituent in ONE launch (k_small_jacobi).
 // handled = false: not applicable; need_bicg = true: the sweeps did not converge within the limit.
 int solve_small(cwr_engine* e, double tol2, int max_iter, bool forced, SolveStats& st, bool& handled, bool& need_bicg) {
   handled = false; need_bicg = false;
-  // only where the rows' face records fit registers (<= 4 rows per thread, <= 8 faces per row): then a sweep touches LDS
-  // only (0.3 ms per step at 2 943 cells).  Streaming the records from L2 instead was measured SLOWER than the
-  // multi-launch path (4.3 vs 1.5 ms at 8-10 k cells), so larger meshes do not come here.
-  if (e->comm || !e->use_small || e->n_halo != 0 || e->n_owned > SMALL_THREADS * 4 || e->max_degree > SMALL_DEG) return CWR_OK;
+  // only where the rows' weights fit registers (<= 4 rows per thread, <= 8 real neighbours per row): then a sweep touches LDS
+  // only.  Streaming the records from L2 instead was measured SLOWER than the multi-launch path (4.3 vs 1.5 ms at 8-10 k
+  // cells), so larger meshes do not come here.
+  if (e->comm || !e->use_small || e->n_halo != 0 || e->n_owned > SMALL_THREADS * 4) return CWR_OK;
   const int K = e->K, n = e->n_owned;
+  const int rpt = cdiv(n, SMALL_THREADS) == 3 ? 3 : (n <= SMALL_THREADS ? 1 : (n <= 2 * SMALL_THREADS ? 2 : 4));
+  TRY(ensure_small_tables(e, rpt));
+  if (!e->use_small) return CWR_OK;              // a row with more than 8 real neighbours: the multi-launch path
   if (!e->d_info) TRY(dev_alloc(e, &e->d_info, (size_t)5 * K));
-  const size_t lds = ((size_t)n + 64) * sizeof(double);     // the column + the scratch of block_reduce3 (3 x 16 wave results)
+  const size_t lds = (2 * (size_t)rpt * SMALL_THREADS + 64) * sizeof(double);  // two columns + the scratch of block_reduce3 (3 x 16 wave results)
   const int limit = forced ? max_iter : std::min(max_iter, e->jacobi_limit);
-  const int rpt = cdiv(n, SMALL_THREADS);
-#define CWR_SMALL(RPTv, REGSv) do {                                                                                   \
+  // (round 5) the five numbers per constituent reach the host through the notification buffer of the sweeps' check: no download,
+  // and -- what counts at 0.35 ms per step -- no copy's round trip behind the one launch
+  const bool noted = check_by_note(e);
+  ReduceNote note{nullptr, nullptr, nullptr, nullptr};
+  if (noted) note = ReduceNote{e->d_note_view, reinterpret_cast<unsigned long long*>(e->d_note_view + 5 * (size_t)K),
+                               reinterpret_cast<unsigned int*>(e->d_note_state + 1), e->d_note_state};
+#define CWR_SMALL(RPTv) do {                                                                                          \
     static bool attr_done = false;                                                                                    \
-    if (!attr_done) { HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_small_jacobi<RPTv, REGSv>),     \
+    if (!attr_done) { HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_small_jacobi<RPTv>),            \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_done = true; }        \
-    k_small_jacobi<RPTv, REGSv><<<K, SMALL_THREADS, lds, e->stream>>>(n, K, e->d_ptr, e->d_rec, e->d_diag, e->d_b,    \
-        e->d_c, tol2, e->ew_enabled ? e->ew_rel : 1.0, e->ew_enabled ? e->ew_abs : 1.0, limit, 4, e->d_info); } while (0)
-  if (rpt <= 1) CWR_SMALL(1, true);
-  else if (rpt <= 2) CWR_SMALL(2, true);
-  else CWR_SMALL(4, true);
+    k_small_jacobi<RPTv><<<K, SMALL_THREADS, lds, e->stream>>>(n, K, e->d_small_rows, e->d_small_recs, e->d_small_offs, e->d_rec, e->d_diag, e->d_b, \
+        e->d_c, tol2, e->ew_enabled ? e->ew_rel : 1.0, e->ew_enabled ? e->ew_abs : 1.0, limit, 4, e->d_info, note); } while (0)
+  if (rpt == 1) CWR_SMALL(1);
+  else if (rpt == 2) CWR_SMALL(2);
+  else if (rpt == 3) CWR_SMALL(3);
+  else CWR_SMALL(4);
 #undef CWR_SMALL
   HIP_TRY(e, hipGetLastError());
   std::vector<double> h((size_t)5 * K);
-  TRY(download(e, h.data(), e->d_info, (size_t)5 * K));
+  if (noted) { ++e->note_expected; TRY(wait_check_note(e, h.data(), (size_t)5 * K)); }
+  else TRY(download(e, h.data(), e->d_info, (size_t)5 * K));
   handled = true;
   st.launches += 1;
   st.sweep_kernel = 7;
@@ -2235,11 +2331,11 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
     // (a runtime that cannot map host memory leaves h_note null: the checks are downloaded as before)
     void* hp = nullptr;
     void* dp = nullptr;
-    if (hipHostMalloc(&hp, (4 * (size_t)K + 2) * sizeof(double), hipHostMallocMapped) == hipSuccess && hp &&
+    if (hipHostMalloc(&hp, (5 * (size_t)K + 2) * sizeof(double), hipHostMallocMapped) == hipSuccess && hp &&
         hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess && dp) {
-      std::memset(hp, 0, (4 * (size_t)K + 2) * sizeof(double));
-      eng->h_note = static_cast<double*>(hp);
-      eng->h_note_seq = reinterpret_cast<unsigned long long*>(eng->h_note + 4 * (size_t)K);
+      std::memset(hp, 0, (5 * (size_t)K + 2) * sizeof(double));
+      eng->h_note = static_cast<double*>(hp);                      // (4 K check rows of the sweeps, or the 5 K numbers of k_small_jacobi)
+      eng->h_note_seq = reinterpret_cast<unsigned long long*>(eng->h_note + 5 * (size_t)K);
       eng->d_note_view = static_cast<double*>(dp);                 // (the same address on this platform; asked for, not assumed)
       CREATE_TRY(dev_alloc(eng, &eng->d_note_state, 2));
       CREATE_HIP(hipMemset(eng->d_note_state, 0, 2 * sizeof(unsigned long long)));
@@ -2312,7 +2408,7 @@ void cwr_destroy(cwr_engine* e) {
   for (hipEvent_t ev : e->ev) hipEventDestroy(ev);
   void* ptrs[] = {e->d_f1, e->d_f2, e->d_ptr, e->d_ent_edge, e->d_ent_nb, e->d_adv, e->d_vel, e->d_vol, e->d_dif,
                   e->d_bc, e->d_rec, e->d_diag, e->d_c, e->d_r, e->d_r0, e->d_p, e->d_v, e->d_s, e->d_t, e->d_b,
-                  e->d_scal, e->d_partial, e->d_fadv, e->d_fdif, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf, e->d_ptr2, e->d_col2, e->d_row2, e->d_rec2, e->d_w, e->d_react, e->d_info, e->d_tcl_ptr, e->d_tcl_cols, e->d_loc2, e->d_w2, e->d_pair_ptr, e->d_slots, e->d_line_ptr, e->d_line_faces, e->d_ledger, e->d_mass_out, e->d_chk, e->d_face_orig, e->d_row_ghost, e->d_keep, e->d_in_rows, e->d_in_vals, e->d_face_pos, e->d_trow, e->d_vptr, e->d_meta, e->d_tile_inner, e->d_tile_outer, e->d_apply_inner, e->d_apply_outer, e->d_face_inner, e->d_face_outer, e->d_chkx, e->d_sq_fast, e->d_sched, e->d_link_ptr, e->d_link_ent, e->d_link_flux, e->d_scols, e->d_scols_io, e->sched_in.d, e->sched_out.d};
+                  e->d_scal, e->d_partial, e->d_fadv, e->d_fdif, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf, e->d_ptr2, e->d_col2, e->d_row2, e->d_rec2, e->d_w, e->d_react, e->d_info, e->d_tcl_ptr, e->d_tcl_cols, e->d_loc2, e->d_w2, e->d_pair_ptr, e->d_slots, e->d_line_ptr, e->d_line_faces, e->d_ledger, e->d_mass_out, e->d_chk, e->d_face_orig, e->d_row_ghost, e->d_keep, e->d_in_rows, e->d_in_vals, e->d_face_pos, e->d_trow, e->d_vptr, e->d_meta, e->d_tile_inner, e->d_tile_outer, e->d_apply_inner, e->d_apply_outer, e->d_face_inner, e->d_face_outer, e->d_chkx, e->d_sq_fast, e->d_sched, e->d_link_ptr, e->d_link_ent, e->d_link_flux, e->d_scols, e->d_scols_io, e->sched_in.d, e->sched_out.d, e->d_small_rows, e->d_small_recs, e->d_small_offs};
   for (void* p : ptrs) if (p) hipFree(p);
   for (void* p : {(void*)e->d_in_f, (void*)e->d_flow_l, (void*)e->d_dist, (void*)e->d_jn, (void*)e->d_bad, (void*)e->d_wa, (void*)e->d_wb, (void*)e->d_wmax})
     if (p) hipFree(p);

@@ -1718,64 +1718,87 @@ __global__ void __launch_bounds__(BLOCK) k_snapshot_t(int n_out, int K, int Kp, 
 // ------------------------------------------------------------------------------------------------ small meshes
 // The reference's own meshes (Ohio River 2 943 cells, Sumwere Creek 367) fit one CU's LDS.  There a sweep launch
 // is pure latency (4-6 us for a few microseconds of work), so the WHOLE Jacobi solve of one constituent runs in one
-// 1024-thread workgroup: the column of x lives in LDS, every thread keeps its rows' bhat and 1/diag in registers,
-// face records stream from L2, two barriers per sweep; ||x'-x||^2 (the exact scaled residual of the sweep's input)
-// is block-reduced every `check_every` sweeps.  One workgroup per constituent (columns are independent systems).
+// 1024-thread workgroup: the column of x lives in LDS, every thread keeps its rows' bhat and Jacobi weights in registers;
+// ||x'-x||^2 (the exact scaled residual of the sweep's input) is block-reduced every `check_every` sweeps.  One workgroup per
+// constituent (columns are independent systems).
+//
+// Round 5 (profiles/r05_small_mesh.txt: the kernel was 317 of the step's 342 us at 2 943 cells, 2.3 us per sweep, and the time
+// was the LDS gather -- 4 rows x 8 padded slots per thread where the mesh has 4.1 neighbours per row):
+//   * the rows are dealt to the threads SORTED BY NEIGHBOUR COUNT (host: ensure_small_tables), so the 64 rows a wave relaxes
+//     together have the same count: four neighbours are gathered without a branch, the fifth to eighth only by the waves whose
+//     rows have them -- LDS reads fall from RPT x 8 to about the neighbours there are; ghost faces (weight zero in J) take no slot;
+//   * the column lives in LDS in that internal order (Cuthill-McKee under the count sort), neighbours taken in ascending position:
+//     the lanes of a half-wave gather from different banks (38 % of the LDS cycles were bank conflicts before);
+//   * 3 rows per thread exist as a variant (2 943 cells = 2.9 x 1024);
+//   * two columns in LDS (read one, write the other): ONE barrier per sweep instead of two; the thread's own previous value stays in
+//     a register.
+// The order of a row's sum is the ascending position of its neighbours: fixed per engine, so run to run the same bits.
 constexpr int SMALL_THREADS = 1024;
-constexpr int SMALL_RPT_MAX = 8;                 // rows per thread: meshes up to 8 192 real cells
-constexpr int SMALL_DEG = 8;                     // register-resident records: faces per row
+constexpr int SMALL_DEG = 8;                     // register-resident weights: real neighbours per row
 // RPT  rows per thread (compile time: static register indexing).
-// REGS the rows' face records (neighbour, coefficient / diag) live in registers too -- then a sweep touches LDS only.
-template <int RPT, bool REGS>
+// rows  [RPT][1024]      the row at position p = i * 1024 + thread: -1 = none
+// recs  [8][RPT][1024]   the record index (into rec) of the q-th REAL neighbour of that row: -1 = none
+// offs  [4][RPT][1024]   byte offsets of neighbours 2 qq (low half) and 2 qq + 1 (high half) in a column; empty: the row's own
+template <int RPT>
 __global__ void __launch_bounds__(SMALL_THREADS) k_small_jacobi(
-    int n, int K, const int32_t* __restrict__ ptr, const FaceRec* __restrict__ rec, const double* __restrict__ diag,
-    const double* __restrict__ bhat, double* __restrict__ x, double tol2, double ew_rel, double ew_abs, int max_sweeps,
-    int check_every, double* __restrict__ info /* [K][5]: sweeps, ||x'-x||^2, ||bhat||^2, max(|dx| - ew_rel |x'|), max |x'| */) {
-  extern __shared__ double s_x[];                // n doubles, then reduction scratch
-  double* s_red = s_x + n;
+    int n, int K, const int32_t* __restrict__ rows, const int32_t* __restrict__ recs, const uint32_t* __restrict__ offs,
+    const FaceRec* __restrict__ rec,
+    const double* __restrict__ diag, const double* __restrict__ bhat, double* __restrict__ x, double tol2, double ew_rel, double ew_abs,
+    int max_sweeps, int check_every, double* __restrict__ info /* [K][5]: sweeps, ||x'-x||^2, ||bhat||^2, max(|dx| - ew_rel |x'|), max |x'| */,
+    ReduceNote note /* (round 5) the same five numbers per constituent into page-locked host memory + a sequence word: no download */) {
+  extern __shared__ double s_x[];                // two columns of RPT x 1024 doubles (compile-time stride: the column a sweep
+  constexpr int COL = RPT * SMALL_THREADS;       // reads or writes is an immediate offset of its LDS instructions), then scratch
+  double* s_red = s_x + 2 * COL;
   const int k = blockIdx.x;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  double bh[RPT], rdg[RPT];
-  int j0[RPT], j1[RPT];
-  int rnb[REGS ? RPT * SMALL_DEG : 1];
-  double rw[REGS ? RPT * SMALL_DEG : 1];
+  constexpr bool OWN_IN_REG = RPT <= 3;          // the row's previous value: a register, or (4 rows per thread: 128 VGPRs are short) LDS
+  double bh[RPT], xo[OWN_IN_REG ? RPT : 1];
+  int row[RPT], dmax[RPT];
+  unsigned roff2[RPT * SMALL_DEG / 2];           // BYTE offsets of the neighbours in a column (< 32 768: two per register)
+  double rw[RPT * SMALL_DEG];
   double bb = 0.0;
 #pragma unroll
   for (int i = 0; i < RPT; ++i) {
-    const int c = tid + i * SMALL_THREADS;
-    bh[i] = 0.0; rdg[i] = 0.0; j0[i] = 0; j1[i] = 0;
-    if (c < n) {
-      s_x[c] = x[(size_t)c * K + k];
+    const int c = rows[i * SMALL_THREADS + tid];
+    row[i] = c; bh[i] = 0.0;
+    if constexpr (OWN_IN_REG) xo[i] = 0.0;
+    double rdg = 0.0;
+    s_x[i * SMALL_THREADS + tid] = 0.0;           // (empty positions: bhat = 0, weights 0 -- they stay zero and need no branch)
+    s_x[COL + i * SMALL_THREADS + tid] = 0.0;
+    if (c >= 0) {
+      const double x0 = x[(size_t)c * K + k];
+      if constexpr (OWN_IN_REG) xo[i] = x0;
+      s_x[i * SMALL_THREADS + tid] = x0;
       bh[i] = bhat[(size_t)c * K + k];
-      rdg[i] = 1.0 / diag[c];
-      j0[i] = ptr[c]; j1[i] = ptr[c + 1];
+      rdg = 1.0 / diag[c];
       bb += bh[i] * bh[i];
     }
-    if constexpr (REGS) {
+    int cnt = 0;
 #pragma unroll
-      for (int q = 0; q < SMALL_DEG; ++q) {
-        rnb[i * SMALL_DEG + q] = min(c, n - 1);  // padded slot: own row, zero weight
-        rw[i * SMALL_DEG + q] = 0.0;
-        if (c < n && j0[i] + q < j1[i]) {
-          const FaceRec fr = rec[j0[i] + q];
-          if (fr.nb >= 0) { rnb[i * SMALL_DEG + q] = fr.nb; rw[i * SMALL_DEG + q] = (fr.d - fmin((double)fr.a_c, 0.0)) * rdg[i]; }
-        }
+    for (int q = 0; q < SMALL_DEG; ++q) {
+      const int j = recs[(q * RPT + i) * SMALL_THREADS + tid];
+      rw[i * SMALL_DEG + q] = 0.0;                // empty slot: weight zero, the row's own offset
+      if (j >= 0) {
+        const FaceRec fr = rec[j];
+        rw[i * SMALL_DEG + q] = (fr.d - fmin((double)fr.a_c, 0.0)) * rdg;
+        cnt = q + 1;
       }
+      if ((q & 1) == 0) roff2[(i * SMALL_DEG + q) / 2] = offs[((q / 2) * RPT + i) * SMALL_THREADS + tid];
     }
+    for (int off = 32; off >= 1; off >>= 1) cnt = max(cnt, __shfl_xor(cnt, off, 64));
+    dmax[i] = __builtin_amdgcn_readfirstlane(cnt);            // wave-uniform: the gather loop's bound for this row slot
   }
   auto block_sum = [&](double v) -> double {      // fixed-order reduction: shuffles inside a wave, then the 16 wave sums
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
     __syncthreads();
     if (lane == 0) s_red[wave] = v;
     __syncthreads();
-    double t = 0.0;
-    for (int w = 0; w < SMALL_THREADS / 64; ++w) t += s_red[w];
-    return t;
+    double t = lane < SMALL_THREADS / 64 ? s_red[lane] : 0.0;      // (16 wave sums, folded in a fixed order on every wave alike)
+    for (int off = 8; off >= 1; off >>= 1) t += __shfl_xor(t, off, 64);
+    return __shfl(t, 0, 64);
   };
-  // the three measures of a check in ONE round (sum, max, max): two barriers instead of six, and -- for hipcc's
-  // allocation -- 45 VGPRs less than three separate reductions (which pushed the 4-rows-per-thread variant into scratch:
-  // 1.04 instead of 0.3 ms per step on the 2 943-cell mesh)
+  // the three measures of a check in ONE round (sum, max, max): two barriers instead of six
   auto block_reduce3 = [&](double& a, double& b, double& c) {
     for (int off = 32; off >= 1; off >>= 1) {
       a += __shfl_xor(a, off, 64);
@@ -1794,46 +1817,63 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_small_jacobi(
     }
     a = __shfl(a, 0, 64); b = __shfl(b, 0, 64); c = __shfl(c, 0, 64);
   };
-  bb = block_sum(bb);
+  bb = block_sum(bb);                             // (its barriers also publish the first column)
   int sweep = 0;
   double rr = 0.0, m1 = INFINITY, m2 = 0.0;      // (m1 = +inf until an element-wise verification has run)
-  // one sweep x -> x' in LDS.  MEASURE: also the element-wise measures of this sweep (the lean variant is the hot loop:
-  // computing them in every sweep cost the 4-rows-per-thread kernel its registers -- 0.5 instead of 0.3 ms per step at
-  // 2 943 cells -- so they are taken in ONE extra verification sweep after the norm criterion holds)
-  auto sweep_once = [&](auto measure, double& dx2, double& e1, double& e2) {
-    double xn[RPT];
+  char* const lds = reinterpret_cast<char*>(s_x);
+  int dir = 0;                                   // the column holding the current iterate
+  // one sweep: column DIR -> column 1 - DIR in LDS; the caller's barrier publishes it.  MEASURE: also the element-wise measures of
+  // this sweep (taken in ONE extra verification sweep after the norm criterion holds: the hot loop stays lean)
+  auto sweep_dir = [&](auto measure, auto dirc, double& dx2, double& e1, double& e2) {
+    constexpr int DIR = decltype(dirc)::value;
+    const char* const cur = lds + DIR * COL * 8;
+    char* const nxt = lds + (1 - DIR) * COL * 8;
+    auto xat = [&](int i, int q) -> double {       // (i, q compile-time after unrolling: static register indexing)
+      const unsigned pr = roff2[(i * SMALL_DEG + q) / 2];
+      return *reinterpret_cast<const double*>(cur + ((q & 1) ? (pr >> 16) : (pr & 0xffffu)));
+    };
+    // the first four neighbours of every row slot in ONE basic block -- no branch between the LDS reads, so they are all in flight
+    // together (a scalar branch per neighbour made every read wait for its own latency: 1.35 us per sweep at 2 943 cells);
+    // slots beyond a row's count hold weight zero and the row's own offset (empty row slots: offset 0): harmless reads
+    double sum[RPT];                               // sum = (J x)[row]: x' = bhat + sum, neighbours in record order
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
-      const int c = tid + i * SMALL_THREADS;
-      xn[i] = 0.0;
-      if (c < n) {
-        double sum = 0.0;                          // sum = (J x)[c] * diag-free form: x' = bhat + sum
-        if constexpr (REGS) {
+      sum[i] = 0.0;
 #pragma unroll
-          for (int q = 0; q < SMALL_DEG; ++q) sum += rw[i * SMALL_DEG + q] * s_x[rnb[i * SMALL_DEG + q]];
-        } else {
-          for (int j = j0[i]; j < j1[i]; ++j) {
-            const FaceRec fr = rec[j];
-            const bool ok = fr.nb >= 0;
-            const double cf = ok ? (fr.d - fmin((double)fr.a_c, 0.0)) * rdg[i] : 0.0;
-            sum += cf * s_x[ok ? fr.nb : c];
-          }
-        }
-        xn[i] = bh[i] + sum;
-        const double dx = xn[i] - s_x[c];
-        dx2 += dx * dx;
-        if constexpr (decltype(measure)::value) {
-          e1 = fmax(e1, fabs(dx) - ew_rel * fabs(xn[i]));
-          e2 = fmax(e2, fabs(xn[i]));
+      for (int q = 0; q < 4; ++q) sum[i] += rw[i * SMALL_DEG + q] * xat(i, q);
+    }
+    // neighbours five to eight: only the waves whose rows have them (the rows are dealt sorted by count: a few waves of slot 0).
+    // (4 rows per thread: hipcc keeps THESE weights in scratch -- 128 VGPRs are short by that much -- and the common path free of it)
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      if (dmax[i] > 4) {
+        sum[i] += rw[i * SMALL_DEG + 4] * xat(i, 4);
+        sum[i] += rw[i * SMALL_DEG + 5] * xat(i, 5);
+        if (dmax[i] > 6) {
+          sum[i] += rw[i * SMALL_DEG + 6] * xat(i, 6);
+          sum[i] += rw[i * SMALL_DEG + 7] * xat(i, 7);
         }
       }
     }
-    __syncthreads();                             // every read of the old column is done
 #pragma unroll
-    for (int i = 0; i < RPT; ++i) {
-      const int c = tid + i * SMALL_THREADS;
-      if (c < n) s_x[c] = xn[i];
+    for (int i = 0; i < RPT; ++i) {                // (empty positions compute 0 = 0 + 0 and write it: no branch)
+      const double xn = bh[i] + sum[i];
+      const double dx = xn - (OWN_IN_REG ? xo[i] : *reinterpret_cast<const double*>(cur + (i * SMALL_THREADS + tid) * 8));
+      dx2 += dx * dx;
+      if constexpr (decltype(measure)::value) {
+        if (row[i] >= 0) {                         // (an empty position would put 0 - ew_rel * 0 = 0 into a maximum that may be negative)
+          e1 = fmax(e1, fabs(dx) - ew_rel * fabs(xn));
+          e2 = fmax(e2, fabs(xn));
+        }
+      }
+      if constexpr (OWN_IN_REG) xo[i] = xn;
+      *reinterpret_cast<double*>(nxt + (i * SMALL_THREADS + tid) * 8) = xn;
     }
+  };
+  auto sweep_once = [&](auto measure, double& dx2, double& e1, double& e2) {
+    if (dir == 0) sweep_dir(measure, std::integral_constant<int, 0>{}, dx2, e1, e2);
+    else sweep_dir(measure, std::integral_constant<int, 1>{}, dx2, e1, e2);
+    dir ^= 1;
   };
   for (;;) {
     double dx2 = 0.0, e1 = -INFINITY, e2 = 0.0;
@@ -1856,11 +1896,23 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_small_jacobi(
     }
   }
 #pragma unroll
-  for (int i = 0; i < RPT; ++i) {
-    const int c = tid + i * SMALL_THREADS;
-    if (c < n) x[(size_t)c * K + k] = s_x[c];
+  for (int i = 0; i < RPT; ++i)
+    if (row[i] >= 0) x[(size_t)row[i] * K + k] = OWN_IN_REG ? xo[i] : s_x[dir * COL + i * SMALL_THREADS + tid];
+  if (tid == 0) {
+    info[k * 5 + 0] = (double)sweep; info[k * 5 + 1] = rr; info[k * 5 + 2] = bb; info[k * 5 + 3] = m1; info[k * 5 + 4] = m2;
+    if (note.host_seq) {
+      note.host_out[k * 5 + 0] = (double)sweep; note.host_out[k * 5 + 1] = rr; note.host_out[k * 5 + 2] = bb; note.host_out[k * 5 + 3] = m1; note.host_out[k * 5 + 4] = m2;
+      __threadfence_system();
+      const unsigned prev = atomicAdd(note.arrive, 1u);
+      if (prev == (unsigned)K - 1u) {              // the last constituent's workgroup: every other one's numbers are out
+        __threadfence_system();
+        *note.arrive = 0u;
+        const unsigned long long sq = *note.dev_seq + 1ull;
+        *note.dev_seq = sq;
+        __hip_atomic_store(note.host_seq, sq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
   }
-  if (tid == 0) { info[k * 5 + 0] = (double)sweep; info[k * 5 + 1] = rr; info[k * 5 + 2] = bb; info[k * 5 + 3] = m1; info[k * 5 + 4] = m2; }
 }
 
 // ------------------------------------------------------------------------------------------------ a-8 on device

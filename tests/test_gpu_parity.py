@@ -285,3 +285,25 @@ def test_meshes_with_eight_sided_cells_match_the_oracle(gpu_lib, K, small, monke
     for kk, col in enumerate(cols):
         assert rel_err(model.mesh[names[col]], ref.constituent_dict[f'c{kk}'].state) <= TOL_CONC
         assert flux_err(model.constituent_dict[names[col]].total_mass_flux[:3], ref.constituent_dict[f'c{kk}'].total_mass_flux[:3]) <= 1e-8
+
+
+@pytest.mark.parametrize('nx,ny,rpt', [(25, 20, 1), (50, 38, 2), (72, 42, 3), (90, 45, 4)])
+def test_one_launch_solver_at_every_rows_per_thread_variant(gpu_lib, nx, ny, rpt):
+    """k_small_jacobi deals the rows to its 1 024 threads sorted by neighbour count, 1 / 2 / 3 / 4 rows per thread (round 5): meshes
+    of each size class with 8-sided, 6-sided, plain and dry cells, K = 3 (carried as 4), against the oracle's spsolve -- states,
+    fluxes, and the same answer as the multi-launch path to solver tolerance."""
+    import clearwater_riverine_amd as cw
+    K, steps = 3, 4
+    mesh, inputs3 = synthetic_case(K, nx=nx, ny=ny, n_steps=steps, seed=17 + rpt, n_merge=nx * ny // 30, n_merge4=nx * ny // 60, n_dry=3,
+                                   dt=30.0, diffusion_coefficient=0.2)
+    n = mesh['nreal'] + 1
+    assert (n + 1023) // 1024 == rpt
+    ref = oracle_run(mesh, inputs3, steps)
+    names = [f'c{k}' for k in range(K)]
+    model = cw.ClearwaterRiverine(mesh=dict(mesh), input_arrays={nm: inputs3[:, :, k].copy() for k, nm in enumerate(names)})
+    for _ in range(steps):
+        model.update()
+        assert model.last_step.sweep_kernel == 7 and model.last_step.max_rel_residual <= 1e-12
+    for k, nm in enumerate(names):
+        assert rel_err(model.mesh[nm], ref.constituent_dict[nm].state) <= TOL_CONC
+        assert flux_err(model.constituent_dict[nm].total_mass_flux[:steps], ref.constituent_dict[nm].total_mass_flux[:steps]) <= 1e-8
