@@ -191,6 +191,8 @@ struct cwr_engine {
   int32_t* d_out_order = nullptr;
   int out_n = 0, out_next = 0;
   bool out_flux = false, out_copy_pending = false;
+  size_t out_direct_limit = 4u << 20;   // snapshots up to this many bytes are written in place into page-locked destinations (CWR_OUTPUT_DIRECT_MB)
+  long out_direct_pushes = 0, out_copy_pushes = 0;   // (CWR_OUTPUT_DEBUG=1: printed by cwr_output_close)
   size_t out_state_cnt = 0, out_slot_cnt = 0;
   double* d_scal = nullptr;      // acc[3][ACC_N][K] | rho[3][K] | bb[K]
   int32_t* d_counters = nullptr; // 8 ints
@@ -2326,6 +2328,7 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   CREATE_TRY(dev_alloc(eng, &eng->d_keep, (size_t)n_cells * K));
   if (const char* v = getenv("CWR_TEST_FIXED_SWEEPS")) eng->fixed_sweeps = std::max(0, atoi(v));
   if (const char* v = getenv("CWR_NO_NOTE")) eng->use_note = atoi(v) == 0;
+  if (const char* v = getenv("CWR_OUTPUT_DIRECT_MB")) eng->out_direct_limit = (size_t)std::max(0, atoi(v)) << 20;   // 0: always the copy engine
   if (const char* v = getenv("CWR_NO_FUSED_BEGIN")) eng->fused_begin = atoi(v) == 0;
   if (eng->use_note) {
     // (a runtime that cannot map host memory leaves h_note null: the checks are downloaded as before)
@@ -3131,7 +3134,9 @@ int32_t cwr_output_close(cwr_engine* e) {
   if (!e) return CWR_ERR_BAD_ARG;
   if (!e->out_stream || g_down.load()) return CWR_OK;
   hipSetDevice(e->dev);
+  hipStreamSynchronize(e->stream);               // (snapshots written in place run on the engine's stream)
   hipStreamSynchronize(e->out_stream);
+  if (getenv("CWR_OUTPUT_DEBUG")) fprintf(stderr, "cwr_output_close: %ld snapshots written in place, %ld through the copy engine\n", e->out_direct_pushes, e->out_copy_pushes);
   for (auto& sl : e->out_slots) { if (sl.h) hipHostFree(sl.h); if (sl.done) hipEventDestroy(sl.done); }
   e->out_slots.clear();
   if (e->out_snap_ready) hipEventDestroy(e->out_snap_ready);
@@ -3188,20 +3193,43 @@ int output_push_impl(cwr_engine* e, int32_t* slot, double* state_dst, double* fl
     if (waited > 120000) return fail(e, CWR_ERR_STATE, "cwr_output_push: output ring full for 120 s (slot never released)");
     std::this_thread::sleep_for(std::chrono::milliseconds(1));
   }
+  // Small snapshots into page-locked destinations (the facade's history blocks at the reference's own mesh sizes) are written
+  // IN PLACE by the snapshot kernels through the destinations' device aliases: no staging buffer, no copy commands, no second
+  // stream -- at 2 943 cells x 12 the copies' submission and completion cost more than the 2 MB they moved
+  // (profiles/r05_small_mesh.txt).  Larger ones keep the copy engine (a kernel writing across PCIe holds CUs for the duration).
+  double* dst_dev = nullptr; double* dstf_dev = nullptr;
+  bool direct = false;
+  if (state_dst && e->out_direct_limit > 0 && e->out_slot_cnt * sizeof(double) <= e->out_direct_limit) {
+    void* p = nullptr; void* pf = nullptr;
+    if (hipHostGetDevicePointer(&p, state_dst, 0) == hipSuccess && p &&
+        (!(e->out_flux && flux_dst) || (hipHostGetDevicePointer(&pf, flux_dst, 0) == hipSuccess && pf))) {
+      direct = true; dst_dev = static_cast<double*>(p); dstf_dev = static_cast<double*>(pf);
+    } else {
+      (void)hipGetLastError();                     // pageable destination: the copy path below
+    }
+  }
   // the device snapshot is rewritten only after the previous copy out of it has finished
-  if (e->out_copy_pending) HIP_TRY(e, hipStreamWaitEvent(e->stream, e->out_copy_done, 0));
+  if (!direct && e->out_copy_pending) HIP_TRY(e, hipStreamWaitEvent(e->stream, e->out_copy_done, 0));
   const size_t lds = (size_t)e->Ku * (SNAP_ROWS + 1) * sizeof(double);
   const int grid = std::max(1, std::min(cdiv(e->out_n, SNAP_ROWS), 256 * 8));
-  k_snapshot_t<<<grid, BLOCK, lds, e->stream>>>(e->out_n, e->Ku, e->K, e->d_out_order, e->d_c, nullptr, e->d_snap);
-  if (e->out_flux) {
+  k_snapshot_t<<<grid, BLOCK, lds, e->stream>>>(e->out_n, e->Ku, e->K, e->d_out_order, e->d_c, nullptr, direct ? dst_dev : e->d_snap, nullptr, nullptr);
+  if (e->out_flux && (!direct || dstf_dev)) {
     const int gridf = std::max(1, std::min(cdiv(e->E, SNAP_ROWS), 256 * 8));
     const size_t EK = (size_t)e->E * e->Ku;
+    double* fo = direct ? dstf_dev : e->d_snap + e->out_state_cnt;
     // (output index = the reference's face id; its row sits at the face's internal position)
-    k_snapshot_t<<<gridf, BLOCK, lds, e->stream>>>(e->E, e->Ku, e->K, e->d_face_pos, e->d_fadv, nullptr, e->d_snap + e->out_state_cnt);
-    k_snapshot_t<<<gridf, BLOCK, lds, e->stream>>>(e->E, e->Ku, e->K, e->d_face_pos, e->d_fdif, nullptr, e->d_snap + e->out_state_cnt + EK);
-    k_snapshot_t<<<gridf, BLOCK, lds, e->stream>>>(e->E, e->Ku, e->K, e->d_face_pos, e->d_fadv, e->d_fdif, e->d_snap + e->out_state_cnt + 2 * EK);
+    k_snapshot_t<<<gridf, BLOCK, lds, e->stream>>>(e->E, e->Ku, e->K, e->d_face_pos, e->d_fadv, e->d_fdif, fo, fo + EK, fo + 2 * EK);
   }
   HIP_TRY(e, hipGetLastError());
+  ++(direct ? e->out_direct_pushes : e->out_copy_pushes);
+  if (direct) {
+    sl.dst_state = state_dst; sl.dst_flux = flux_dst;
+    HIP_TRY(e, hipEventRecord(sl.done, e->stream));
+    sl.busy.store(true, std::memory_order_release);
+    e->out_next = (s + 1) % (int)e->out_slots.size();
+    *slot = s;
+    return CWR_OK;
+  }
   HIP_TRY(e, hipEventRecord(e->out_snap_ready, e->stream));
   HIP_TRY(e, hipStreamWaitEvent(e->out_stream, e->out_snap_ready, 0));
   if (state_dst) {
@@ -3251,7 +3279,16 @@ int32_t cwr_output_wait(cwr_engine* e, int32_t slot, const double** state, const
   cwr_engine::OutSlot& sl = e->out_slots[(size_t)slot];
   if (!sl.busy.load(std::memory_order_acquire)) return fail(e, CWR_ERR_STATE, "cwr_output_wait: slot holds no snapshot");
   // (no hipSetDevice: events carry their device; this may run on a consumer thread)
-  if (hipEventSynchronize(sl.done) != hipSuccess) return fail(e, CWR_ERR_HIP, "cwr_output_wait: event synchronize failed");
+  // (a short spin first: a snapshot of the reference's own mesh sizes lands within tens of microseconds, less than a blocking
+  // wait's wake-up)
+  bool landed = false;
+  for (int spin = 0; spin < 4000 && !landed; ++spin) {
+    const hipError_t q = hipEventQuery(sl.done);
+    if (q == hipSuccess) landed = true;
+    else if (q != hipErrorNotReady) return fail(e, CWR_ERR_HIP, "cwr_output_wait: event query failed");
+  }
+  (void)hipGetLastError();                       // (hipErrorNotReady of the queries is no error)
+  if (!landed && hipEventSynchronize(sl.done) != hipSuccess) return fail(e, CWR_ERR_HIP, "cwr_output_wait: event synchronize failed");
   if (state) *state = sl.dst_state ? sl.dst_state : sl.h;
   if (flux) *flux = !e->out_flux ? nullptr : (sl.dst_state ? sl.dst_flux : sl.h + e->out_state_cnt);
   return CWR_OK;

@@ -1692,26 +1692,35 @@ __global__ void __launch_bounds__(BLOCK) k_fold_partials(int nblocks, int width,
 // Output snapshot, constituent-major: out[k * n_out + i] = x[row(i) * K + k], row(i) = order ? order[i] : i.
 // A block transposes SNAP_ROWS rows through LDS so that both the row reads (K consecutive doubles) and the column
 // writes (consecutive i) are coalesced.  Dynamic LDS: K * (SNAP_ROWS + 1) doubles.
+// With x2 / out2 / out3 (the face fluxes): out = x, out2 = x2, out3 = x + x2 in ONE launch (round 5; three launches before) --
+// `tot = adv + dif` is the same IEEE addition wherever it is made.  The outputs may be device memory (the ring's snapshot
+// buffer, copied out by the copy engine) or the device alias of page-locked host memory (small snapshots: written in place).
 constexpr int SNAP_ROWS = 64;
 __global__ void __launch_bounds__(BLOCK) k_snapshot_t(int n_out, int K, int Kp, const int32_t* __restrict__ order,
-                                                    const double* __restrict__ x, const double* __restrict__ x2, double* __restrict__ out) {
+                                                    const double* __restrict__ x, const double* __restrict__ x2, double* __restrict__ out,
+                                                    double* __restrict__ out2, double* __restrict__ out3) {
   // K: the caller's constituents (what is written), Kp >= K: the row width of x (the engine's internal width)
   extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
   double* s = reinterpret_cast<double*>(s_dyn);                    // [K][SNAP_ROWS + 1]
   const int tid = threadIdx.x;
+  const int nv = x2 ? 3 : 1;
   for (int i0 = blockIdx.x * SNAP_ROWS; i0 < n_out; i0 += gridDim.x * SNAP_ROWS) {
     const int rows = min(SNAP_ROWS, n_out - i0);
-    for (int q = tid; q < rows * K; q += BLOCK) {
-      const int r = q / K, k = q - r * K;
-      const int src = order ? order[i0 + r] : i0 + r;
-      s[k * (SNAP_ROWS + 1) + r] = x2 ? x[(size_t)src * Kp + k] + x2[(size_t)src * Kp + k] : x[(size_t)src * Kp + k];
+    for (int v = 0; v < nv; ++v) {                                 // (the second and third reading hit the cache lines of the first)
+      for (int q = tid; q < rows * K; q += BLOCK) {
+        const int r = q / K, k = q - r * K;
+        const int src = order ? order[i0 + r] : i0 + r;
+        const size_t at = (size_t)src * Kp + k;
+        s[k * (SNAP_ROWS + 1) + r] = v == 0 ? x[at] : (v == 1 ? x2[at] : x[at] + x2[at]);
+      }
+      __syncthreads();
+      double* o = v == 0 ? out : (v == 1 ? out2 : out3);
+      for (int q = tid; q < rows * K; q += BLOCK) {
+        const int k = q / rows, r = q - k * rows;
+        o[(size_t)k * n_out + i0 + r] = s[k * (SNAP_ROWS + 1) + r];
+      }
+      __syncthreads();
     }
-    __syncthreads();
-    for (int q = tid; q < rows * K; q += BLOCK) {
-      const int k = q / rows, r = q - k * rows;
-      out[(size_t)k * n_out + i0 + r] = s[k * (SNAP_ROWS + 1) + r];
-    }
-    __syncthreads();
   }
 }
 

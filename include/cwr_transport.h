@@ -363,7 +363,11 @@ int32_t cwr_output_push(cwr_engine* e, int32_t* slot);
  * (3, K, n_edges; required when the ring was opened with_flux) -- e.g. row t+1 of a (T, K, ncell) history block, so that no host
  * copy is left between the device and mesh[name][t+1] (transport.py:252-273).  The copies are asynchronous when the
  * destination is page-locked (cwr_host_register: hipHostRegister with the engine's HIP runtime) and staged by HIP otherwise;
- * cwr_output_wait(slot) returns the two destinations once they are complete. */
+ * cwr_output_wait(slot) returns the two destinations once they are complete.
+ * Round 5: a snapshot of up to 4 MB (CWR_OUTPUT_DIRECT_MB) whose destinations are page-locked is written in place by the snapshot
+ * kernels through the destinations' device aliases (no staging buffer, no copy command: at the reference's own mesh sizes the
+ * copies' submission cost more than the bytes); the destinations must then stay registered until cwr_output_wait has returned
+ * for the slot -- as before -- and cwr_output_close drains the engine's stream as well as the ring's. */
 int32_t cwr_output_push_into(cwr_engine* e, double* state_dst, double* flux_dst, int32_t* slot);
 int32_t cwr_host_register(void* ptr, int64_t bytes);
 int32_t cwr_host_unregister(void* ptr);

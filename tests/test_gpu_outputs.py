@@ -184,3 +184,38 @@ def test_output_ring_api_errors(gpu_lib):
         eng.output_wait(s)                                 # released: holds no snapshot
     eng.output_close()
     eng.close()
+
+
+def test_snapshots_written_in_place_equal_those_of_the_copy_engine(gpu_lib, monkeypatch, capfd):
+    """Round 5: snapshots of up to CWR_OUTPUT_DIRECT_MB (4) are written by the snapshot kernels straight into the facade's
+    page-locked history rows (no staging buffer, no copy command); larger ones -- or CWR_OUTPUT_DIRECT_MB=0 -- go through the copy
+    engine.  Same histories bit for bit, fluxes included (total = advection + diffusion formed in the one flux launch), and the
+    debug counters say which way each facade's snapshots went."""
+    import clearwater_riverine_amd as cw
+    K, steps = 3, 9
+    mesh = cw.synthetic.make_mesh(60, 24, steps, seed=23, n_merge=40, dt=40.0, diffusion_coefficient=0.5)
+    inputs3 = cw.synthetic.distinct_input_array(mesh, K, seed=23)
+    monkeypatch.setenv('CWR_OUTPUT_DEBUG', '1')
+    hist = {}
+    for label, mb in (('in place', None), ('copy engine', '0')):
+        if mb is None:
+            monkeypatch.delenv('CWR_OUTPUT_DIRECT_MB', raising=False)
+        else:
+            monkeypatch.setenv('CWR_OUTPUT_DIRECT_MB', mb)
+        mdl = cw.ClearwaterRiverine(mesh=dict(mesh), input_arrays={f'c{k}': inputs3[:, :, k].copy() for k in range(K)}, deterministic=True)
+        for _ in range(steps):
+            mdl.update()
+        hist[label] = ({nm: np.array(mdl.mesh[nm]) for nm in mdl.constituents},
+                       {nm: [np.array(getattr(mdl.constituent_dict[nm], a)) for a in ('advection_mass_flux', 'diffusion_mass_flux', 'total_mass_flux')]
+                        for nm in mdl.constituents})
+        capfd.readouterr()
+        mdl.close_output(); mdl.engine.close()
+        err = capfd.readouterr().err
+        want = f'{steps} snapshots written in place, 0 through' if mb is None else f'0 snapshots written in place, {steps} through'
+        assert want in err, err
+    for nm in hist['in place'][0]:
+        assert np.array_equal(hist['in place'][0][nm], hist['copy engine'][0][nm], equal_nan=True)
+        for a, b in zip(hist['in place'][1][nm], hist['copy engine'][1][nm]):
+            assert np.array_equal(a, b, equal_nan=True)
+        adv, dif, tot = hist['in place'][1][nm]
+        assert np.array_equal(tot[:steps], adv[:steps] + dif[:steps], equal_nan=True)
