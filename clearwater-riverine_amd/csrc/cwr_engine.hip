@@ -333,7 +333,19 @@ struct cwr_engine {
   int32_t* d_small_rows = nullptr;   // [rpt][1024] the row at position p of k_small_jacobi's internal order (-1: none)
   int32_t* d_small_recs = nullptr;   // [8][rpt][1024] record index of the q-th real neighbour of that row (-1: none)
   uint32_t* d_small_offs = nullptr;  // [4][rpt][1024] byte offsets of neighbours 2 qq / 2 qq + 1 in the LDS column (16 bits each)
-  int small_rpt = 0;                 // rows per thread the two tables were built for (0: not built)
+  int small_rpt = 0;                 // rows per thread of the plan (0: not built)
+  bool small_planned = false;
+  int small_P = 1, small_D = 0, small_S = 0, small_R = 0;   // parts per constituent, halo layers, padded send / receive list lengths
+  int small_parts = 0;               // CWR_SMALL_PARTS: parts per constituent (0: the fewest that fit)
+  int small_depth = 12;              // CWR_SMALL_DEPTH: halo layers = sweeps between two exchanges of a plan of several parts
+                                     // (profiles/r05_mid_mesh.txt: an exchange costs ~4 us, a sweep ~1.1: 10 k x 12 0.54 / 0.44 / 0.41 ms per step at 4 / 8 / 12)
+  int small_max_parts = 8;           // CWR_SMALL_MAX_PARTS
+  int small_spin_ms = 500;           // CWR_SMALL_SPIN_MS: bound of a part's wait for the others
+  int small_max_cells = 16384;       // CWR_SMALL_MAX_CELLS: meshes up to this size may take the one-launch solver with several parts
+                                     // (18 k cells: no faster than the multi-launch passes; 0 = meshes of up to 4 096 cells only)
+  int32_t *d_small_send_pos = nullptr, *d_small_send_cnt = nullptr, *d_small_recv_src = nullptr, *d_small_recv_pos = nullptr, *d_small_recv_cnt = nullptr;
+  double *d_small_pub = nullptr, *d_small_red = nullptr;
+  unsigned long long* d_small_arrive = nullptr;
   int nt_stream = 0;            // nt loads for the streamed operands (records, bhat/c2/r0): pays for wide rows only
   std::string err;
 
@@ -1900,85 +1912,42 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
   }
 }
 
-// The tables of k_small_jacobi (see there).  The column lives in LDS in an INTERNAL order, position p = slot i * 1024 + thread:
-//   1. Cuthill-McKee order of the adjacency (breadth-first levels from a pseudo-peripheral cell; the engine knows no coordinates
-//      here): the q-th nearest-position neighbour of consecutive positions is then a run of consecutive positions -- the 32 lanes of
-//      a half-wave gather from 32 different LDS banks whatever the caller's numbering was (profiles/r05_small_mesh.txt: 38 % of the
-//      LDS cycles were bank conflicts with the rows in the caller's order);
-//   2. on top of it a stable sort by the class of the REAL-neighbour count (7-8, 5-6, up to 4): the 64 rows a wave relaxes
-//      together gather the same number of neighbours.
-// Per row the real neighbours in ascending position (ghost faces carry no weight in J: no slot): their record index (for the
-// step's weights) and their byte offset in the column, two offsets per word.
-int ensure_small_tables(cwr_engine* e, int rpt) {
-  if (e->small_rpt == rpt) return CWR_OK;
-  const int n = e->n_owned;
-  std::vector<int32_t> deg((size_t)n, 0);
-  for (int c = 0; c < n; ++c) {
-    for (int j = e->h_ptr[(size_t)c]; j < e->h_ptr[(size_t)c + 1]; ++j) deg[(size_t)c] += e->h_nb[(size_t)j] >= 0;
-    if (deg[(size_t)c] > SMALL_DEG) { e->use_small = false; return CWR_OK; }
+// The tables of k_small_jacobi (see there and host::build_small_plan): built once per engine, uploaded, with the exchange buffers of
+// a plan of several parts.  use_small goes false when no plan exists (a row with more than 8 real neighbours, a mesh too large).
+int ensure_small_plan(cwr_engine* e) {
+  if (e->small_planned) return CWR_OK;
+  e->small_planned = true;
+  host::SmallPlan pl;
+  if (!host::build_small_plan(e->n_owned, e->h_ptr, e->h_nb, SMALL_THREADS, 4, e->small_parts, e->small_depth, e->small_max_parts, pl)) {
+    e->use_small = false;
+    return CWR_OK;
   }
-  // breadth-first order from `start` over the cells not yet placed; returns the last cell reached (farthest level)
-  std::vector<int32_t> order; order.reserve((size_t)n);
-  std::vector<char> seen((size_t)n, 0);
-  auto bfs = [&](int start, std::vector<int32_t>& out, std::vector<char>& mark) -> int {
-    const size_t first = out.size();
-    out.push_back(start); mark[(size_t)start] = 1;
-    std::vector<int32_t> nbs;
-    for (size_t head = first; head < out.size(); ++head) {
-      const int c = out[head];
-      nbs.clear();
-      for (int j = e->h_ptr[(size_t)c]; j < e->h_ptr[(size_t)c + 1]; ++j) {
-        const int nb = e->h_nb[(size_t)j];
-        if (nb >= 0 && nb < n && !mark[(size_t)nb]) { mark[(size_t)nb] = 1; nbs.push_back(nb); }
-      }
-      std::sort(nbs.begin(), nbs.end(), [&](int32_t a, int32_t b) { return deg[(size_t)a] != deg[(size_t)b] ? deg[(size_t)a] < deg[(size_t)b] : a < b; });
-      out.insert(out.end(), nbs.begin(), nbs.end());
-    }
-    return out.back();
+  auto up32 = [&](int32_t** d, const void* h, size_t count) -> int {
+    if (count == 0) count = 1;
+    HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(d), count * sizeof(int32_t)));
+    if (h) HIP_TRY(e, hipMemcpy(*d, h, count * sizeof(int32_t), hipMemcpyHostToDevice));
+    return CWR_OK;
   };
-  for (int c0 = 0; c0 < n; ++c0) {
-    if (seen[(size_t)c0]) continue;
-    // pseudo-peripheral start of this component: the far end of a search from its first cell, then the far end of that one
-    std::vector<char> tmp_mark(seen);
-    std::vector<int32_t> tmp;
-    int far = bfs(c0, tmp, tmp_mark);
-    tmp_mark = seen; tmp.clear();
-    far = bfs(far, tmp, tmp_mark);
-    bfs(far, order, seen);
+  TRY(up32(&e->d_small_rows, pl.rows.data(), pl.rows.size()));
+  TRY(up32(&e->d_small_recs, pl.recs.data(), pl.recs.size()));
+  TRY(up32(reinterpret_cast<int32_t**>(&e->d_small_offs), pl.offs.data(), pl.offs.size()));
+  e->small_rpt = pl.rpt; e->small_P = pl.P; e->small_D = pl.depth; e->small_S = pl.S; e->small_R = pl.R;
+  if (pl.P > 1) {
+    // (recv_src travels as part * 2 S + slot: the two publication buffers of a part lie side by side)
+    std::vector<int32_t> src(pl.recv_src);
+    for (auto& v : src) v = (v / pl.S) * 2 * pl.S + v % pl.S;
+    TRY(up32(&e->d_small_send_pos, pl.send_pos.data(), pl.send_pos.size()));
+    TRY(up32(&e->d_small_send_cnt, pl.send_cnt.data(), pl.send_cnt.size()));
+    TRY(up32(&e->d_small_recv_src, src.data(), src.size()));
+    TRY(up32(&e->d_small_recv_pos, pl.recv_pos.data(), pl.recv_pos.size()));
+    TRY(up32(&e->d_small_recv_cnt, pl.recv_cnt.data(), pl.recv_cnt.size()));
+    const size_t K = (size_t)e->K;
+    HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&e->d_small_pub), K * pl.P * 2 * pl.S * sizeof(double)));
+    HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&e->d_small_red), K * pl.P * 2 * 4 * sizeof(double)));
+    HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&e->d_small_arrive), (K + 1) * sizeof(unsigned long long)));   // + the abort word
+    HIP_TRY(e, hipMemset(e->d_small_pub, 0, K * pl.P * 2 * pl.S * sizeof(double)));
+    HIP_TRY(e, hipMemset(e->d_small_red, 0, K * pl.P * 2 * 4 * sizeof(double)));
   }
-  // (classes, not counts: the kernel gathers four neighbours unconditionally, then two, then two -- rows of up to four neighbours
-  // stay in Cuthill-McKee order among themselves, which keeps the runs of consecutive positions whole at the mesh's edges)
-  auto cls = [&](int32_t c) { return deg[(size_t)c] > 6 ? 0 : (deg[(size_t)c] > 4 ? 1 : 2); };
-  std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return cls(a) < cls(b); });
-  std::vector<int32_t> pos((size_t)n);
-  for (int p = 0; p < n; ++p) pos[(size_t)order[(size_t)p]] = p;
-  const size_t slots_n = (size_t)rpt * SMALL_THREADS;
-  std::vector<int32_t> rows(slots_n, -1), recs((size_t)SMALL_DEG * slots_n, -1);
-  std::vector<uint32_t> offs((size_t)(SMALL_DEG / 2) * slots_n, 0);
-  std::vector<std::pair<int32_t, int32_t>> nb;   // (position, record)
-  for (int p = 0; p < n; ++p) {
-    const int c = order[(size_t)p];
-    rows[(size_t)p] = c;                          // p = i * 1024 + thread
-    nb.clear();
-    for (int j = e->h_ptr[(size_t)c]; j < e->h_ptr[(size_t)c + 1]; ++j)
-      if (e->h_nb[(size_t)j] >= 0) nb.emplace_back(pos[(size_t)e->h_nb[(size_t)j]], j);
-    std::sort(nb.begin(), nb.end());
-    for (int q = 0; q < SMALL_DEG; ++q) {
-      const uint32_t off = (uint32_t)(q < (int)nb.size() ? nb[(size_t)q].first : p) * 8u;     // empty slot: the row itself, weight zero
-      if (q < (int)nb.size()) recs[(size_t)q * slots_n + (size_t)p] = nb[(size_t)q].second;
-      offs[(size_t)(q / 2) * slots_n + (size_t)p] |= (q & 1) ? (off << 16) : off;
-    }
-  }
-  for (int32_t** d : {&e->d_small_rows, &e->d_small_recs})
-    if (*d) { (void)hipFree(*d); *d = nullptr; }
-  if (e->d_small_offs) { (void)hipFree(e->d_small_offs); e->d_small_offs = nullptr; }
-  HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&e->d_small_rows), rows.size() * sizeof(int32_t)));
-  HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&e->d_small_recs), recs.size() * sizeof(int32_t)));
-  HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&e->d_small_offs), offs.size() * sizeof(uint32_t)));
-  HIP_TRY(e, hipMemcpy(e->d_small_rows, rows.data(), rows.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-  HIP_TRY(e, hipMemcpy(e->d_small_recs, recs.data(), recs.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-  HIP_TRY(e, hipMemcpy(e->d_small_offs, offs.data(), offs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-  e->small_rpt = rpt;
   return CWR_OK;
 }
 
@@ -1989,13 +1958,24 @@ int solve_small(cwr_engine* e, double tol2, int max_iter, bool forced, SolveStat
   // only where the rows' weights fit registers (<= 4 rows per thread, <= 8 real neighbours per row): then a sweep touches LDS
   // only.  Streaming the records from L2 instead was measured SLOWER than the multi-launch path (4.3 vs 1.5 ms at 8-10 k
   // cells), so larger meshes do not come here.
-  if (e->comm || !e->use_small || e->n_halo != 0 || e->n_owned > SMALL_THREADS * 4) return CWR_OK;
+  // (round 5: meshes of up to ~20 000 cells -- BASELINE configs 1 / 2 at "~10 k cells" -- come here too: several workgroups per
+  // constituent, each with halo layers around its rows, exchanging every few sweeps: k_small_jacobi<RPT, true>)
+  if (e->comm || !e->use_small || e->n_halo != 0 || e->n_owned > std::max(SMALL_THREADS * 4, e->small_max_cells)) return CWR_OK;
   const int K = e->K, n = e->n_owned;
-  const int rpt = cdiv(n, SMALL_THREADS) == 3 ? 3 : (n <= SMALL_THREADS ? 1 : (n <= 2 * SMALL_THREADS ? 2 : 4));
-  TRY(ensure_small_tables(e, rpt));
-  if (!e->use_small) return CWR_OK;              // a row with more than 8 real neighbours: the multi-launch path
+  TRY(ensure_small_plan(e));
+  if (!e->use_small) return CWR_OK;              // no plan (a row with more than 8 real neighbours, too many parts): the multi-launch path
+  const int rpt = e->small_rpt, P = e->small_P;
   if (!e->d_info) TRY(dev_alloc(e, &e->d_info, (size_t)5 * K));
-  const size_t lds = (2 * (size_t)rpt * SMALL_THREADS + 64) * sizeof(double);  // two columns + the scratch of block_reduce3 (3 x 16 wave results)
+  size_t lds = (2 * (size_t)rpt * SMALL_THREADS + 64) * sizeof(double);  // two columns + the scratch of block_reduce3 (3 x 16 wave results)
+  if (P > 1) lds = std::max(lds, (size_t)84 * 1024);                     // more than half a CU's LDS: one workgroup per CU (the hand-off's measured form)
+  SmallCoop co{};
+  if (P > 1) {
+    if ((long long)K * P > 128) return CWR_OK;   // a part that is not resident would be waited for: one workgroup per CU, half the chip at most
+    HIP_TRY(e, hipMemsetAsync(e->d_small_arrive, 0, ((size_t)K + 1) * sizeof(unsigned long long), e->stream));
+    co = SmallCoop{P, e->small_D, e->small_S, e->small_R, e->d_small_send_pos, e->d_small_send_cnt, e->d_small_recv_src, e->d_small_recv_pos,
+                   e->d_small_recv_cnt, e->d_small_pub, e->d_small_red, e->d_small_arrive, reinterpret_cast<unsigned int*>(e->d_small_arrive + K),
+                   (long long)e->small_spin_ms * 100000ll};
+  }
   const int limit = forced ? max_iter : std::min(max_iter, e->jacobi_limit);
   // (round 5) the five numbers per constituent reach the host through the notification buffer of the sweeps' check: no download,
   // and -- what counts at 0.35 ms per step -- no copy's round trip behind the one launch
@@ -2003,21 +1983,36 @@ int solve_small(cwr_engine* e, double tol2, int max_iter, bool forced, SolveStat
   ReduceNote note{nullptr, nullptr, nullptr, nullptr};
   if (noted) note = ReduceNote{e->d_note_view, reinterpret_cast<unsigned long long*>(e->d_note_view + 5 * (size_t)K),
                                reinterpret_cast<unsigned int*>(e->d_note_state + 1), e->d_note_state};
-#define CWR_SMALL(RPTv) do {                                                                                          \
+#define CWR_SMALL(RPTv, COOPv) do {                                                                                   \
     static bool attr_done = false;                                                                                    \
-    if (!attr_done) { HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_small_jacobi<RPTv>),            \
+    if (!attr_done) { HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_small_jacobi<RPTv, COOPv>),     \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_done = true; }        \
-    k_small_jacobi<RPTv><<<K, SMALL_THREADS, lds, e->stream>>>(n, K, e->d_small_rows, e->d_small_recs, e->d_small_offs, e->d_rec, e->d_diag, e->d_b, \
-        e->d_c, tol2, e->ew_enabled ? e->ew_rel : 1.0, e->ew_enabled ? e->ew_abs : 1.0, limit, 4, e->d_info, note); } while (0)
-  if (rpt == 1) CWR_SMALL(1);
-  else if (rpt == 2) CWR_SMALL(2);
-  else if (rpt == 3) CWR_SMALL(3);
-  else CWR_SMALL(4);
+    k_small_jacobi<RPTv, COOPv><<<K * P, SMALL_THREADS, lds, e->stream>>>(n, K, e->d_small_rows, e->d_small_recs, e->d_small_offs, e->d_rec, \
+        e->d_diag, e->d_b, e->d_c, tol2, e->ew_enabled ? e->ew_rel : 1.0, e->ew_enabled ? e->ew_abs : 1.0, limit, 4, e->d_info, note, co); } while (0)
+  if (P == 1) {
+    if (rpt == 1) CWR_SMALL(1, false);
+    else if (rpt == 2) CWR_SMALL(2, false);
+    else if (rpt == 3) CWR_SMALL(3, false);
+    else CWR_SMALL(4, false);
+  } else {
+    if (rpt == 1) CWR_SMALL(1, true);
+    else if (rpt == 2) CWR_SMALL(2, true);
+    else if (rpt == 3) CWR_SMALL(3, true);
+    else CWR_SMALL(4, true);
+  }
 #undef CWR_SMALL
   HIP_TRY(e, hipGetLastError());
   std::vector<double> h((size_t)5 * K);
   if (noted) { ++e->note_expected; TRY(wait_check_note(e, h.data(), (size_t)5 * K)); }
   else TRY(download(e, h.data(), e->d_info, (size_t)5 * K));
+  for (int k = 0; k < K; ++k)
+    if (h[5 * (size_t)k] < 0.0) {
+      // a part was waited for longer than the bound (never seen; a CU shortage would do it): nobody wrote x -- the multi-launch
+      // path takes the step from the same start, and this engine stays with it
+      fprintf(stderr, "cwr: the one-launch solver's parts did not all arrive within %d ms; this engine uses the multi-launch passes from here on\n", e->small_spin_ms);
+      e->use_small = false;
+      return CWR_OK;
+    }
   handled = true;
   st.launches += 1;
   st.sweep_kernel = 7;
@@ -2328,6 +2323,11 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   CREATE_TRY(dev_alloc(eng, &eng->d_keep, (size_t)n_cells * K));
   if (const char* v = getenv("CWR_TEST_FIXED_SWEEPS")) eng->fixed_sweeps = std::max(0, atoi(v));
   if (const char* v = getenv("CWR_NO_NOTE")) eng->use_note = atoi(v) == 0;
+  if (const char* v = getenv("CWR_SMALL_PARTS")) eng->small_parts = std::max(0, std::min(16, atoi(v)));
+  if (const char* v = getenv("CWR_SMALL_DEPTH")) eng->small_depth = std::max(1, std::min(16, atoi(v)));
+  if (const char* v = getenv("CWR_SMALL_MAX_PARTS")) eng->small_max_parts = std::max(1, std::min(16, atoi(v)));
+  if (const char* v = getenv("CWR_SMALL_MAX_CELLS")) eng->small_max_cells = std::max(0, atoi(v));
+  if (const char* v = getenv("CWR_SMALL_SPIN_MS")) eng->small_spin_ms = std::max(1, atoi(v));
   if (const char* v = getenv("CWR_OUTPUT_DIRECT_MB")) eng->out_direct_limit = (size_t)std::max(0, atoi(v)) << 20;   // 0: always the copy engine
   if (const char* v = getenv("CWR_NO_FUSED_BEGIN")) eng->fused_begin = atoi(v) == 0;
   if (eng->use_note) {
@@ -2411,7 +2411,7 @@ void cwr_destroy(cwr_engine* e) {
   for (hipEvent_t ev : e->ev) hipEventDestroy(ev);
   void* ptrs[] = {e->d_f1, e->d_f2, e->d_ptr, e->d_ent_edge, e->d_ent_nb, e->d_adv, e->d_vel, e->d_vol, e->d_dif,
                   e->d_bc, e->d_rec, e->d_diag, e->d_c, e->d_r, e->d_r0, e->d_p, e->d_v, e->d_s, e->d_t, e->d_b,
-                  e->d_scal, e->d_partial, e->d_fadv, e->d_fdif, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf, e->d_ptr2, e->d_col2, e->d_row2, e->d_rec2, e->d_w, e->d_react, e->d_info, e->d_tcl_ptr, e->d_tcl_cols, e->d_loc2, e->d_w2, e->d_pair_ptr, e->d_slots, e->d_line_ptr, e->d_line_faces, e->d_ledger, e->d_mass_out, e->d_chk, e->d_face_orig, e->d_row_ghost, e->d_keep, e->d_in_rows, e->d_in_vals, e->d_face_pos, e->d_trow, e->d_vptr, e->d_meta, e->d_tile_inner, e->d_tile_outer, e->d_apply_inner, e->d_apply_outer, e->d_face_inner, e->d_face_outer, e->d_chkx, e->d_sq_fast, e->d_sched, e->d_link_ptr, e->d_link_ent, e->d_link_flux, e->d_scols, e->d_scols_io, e->sched_in.d, e->sched_out.d, e->d_small_rows, e->d_small_recs, e->d_small_offs};
+                  e->d_scal, e->d_partial, e->d_fadv, e->d_fdif, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf, e->d_ptr2, e->d_col2, e->d_row2, e->d_rec2, e->d_w, e->d_react, e->d_info, e->d_tcl_ptr, e->d_tcl_cols, e->d_loc2, e->d_w2, e->d_pair_ptr, e->d_slots, e->d_line_ptr, e->d_line_faces, e->d_ledger, e->d_mass_out, e->d_chk, e->d_face_orig, e->d_row_ghost, e->d_keep, e->d_in_rows, e->d_in_vals, e->d_face_pos, e->d_trow, e->d_vptr, e->d_meta, e->d_tile_inner, e->d_tile_outer, e->d_apply_inner, e->d_apply_outer, e->d_face_inner, e->d_face_outer, e->d_chkx, e->d_sq_fast, e->d_sched, e->d_link_ptr, e->d_link_ent, e->d_link_flux, e->d_scols, e->d_scols_io, e->sched_in.d, e->sched_out.d, e->d_small_rows, e->d_small_recs, e->d_small_offs, e->d_small_send_pos, e->d_small_send_cnt, e->d_small_recv_src, e->d_small_recv_pos, e->d_small_recv_cnt, e->d_small_pub, e->d_small_red, e->d_small_arrive};
   for (void* p : ptrs) if (p) hipFree(p);
   for (void* p : {(void*)e->d_in_f, (void*)e->d_flow_l, (void*)e->d_dist, (void*)e->d_jn, (void*)e->d_bad, (void*)e->d_wa, (void*)e->d_wb, (void*)e->d_wmax})
     if (p) hipFree(p);

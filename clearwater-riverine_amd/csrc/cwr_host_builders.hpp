@@ -15,6 +15,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <array>
 #include <cstddef>
 #include <vector>
 
@@ -350,6 +351,214 @@ inline const char* validate_schedule(int ntiles, int n_lists, int depth, const i
     }
   }
   return count == ntiles ? nullptr : "every tile must appear exactly once";
+}
+
+
+// ---- the one-launch solver of small and mid-size meshes (k_small_jacobi) -----------------------------------------------------
+// One 1024-thread workgroup relaxes up to RPT x 1024 rows whose column lives in its LDS; P workgroups ("parts") share the rows
+// of one constituent when the mesh is larger than that, each with `depth` layers of halo rows around its own, exchanged every
+// `depth` sweeps through global memory (the engine's multi-GPU partition in miniature: the iterates are those of the global
+// Jacobi iteration, bit for bit, whatever P is).
+//   order     Cuthill-McKee order of the adjacency (breadth-first levels from a pseudo-peripheral cell; no coordinates needed):
+//             the q-th nearest-position neighbour of consecutive positions is a run of consecutive positions, so the 32 lanes of a
+//             half-wave gather from different LDS banks; part p owns positions [p L, (p + 1) L) of it;
+//   layers    halo layer l of a part = the cells at graph distance l from its own; layers 1 .. depth-1 are relaxed redundantly
+//             (exact for depth - l sweeps after an exchange), layer `depth` is only read; all of them are refreshed by the exchange;
+//   classes   inside a part a stable sort by the class of the real-neighbour count (7-8, 5-6, up to 4): the 64 rows a wave
+//             relaxes together gather the same number of neighbours (four without a branch, then two, then two);
+//   per row   its real neighbours in ascending Cuthill-McKee position (ghost faces carry no weight in J: no slot): the record index
+//             (for the step's weights) and the byte offset in the part's column, two offsets per word.
+struct SmallPlan {
+  int P = 0, rpt = 0, depth = 0, threads = 0;
+  int S = 0, R = 0;                        // padded lengths of the send / receive lists (0 when P == 1)
+  std::vector<int32_t> rows;               // [P][rpt * threads]  global row | kind << 28 (1 own, 2 relaxed halo, 3 read-only halo); -1: none
+  std::vector<int32_t> recs;               // [P][8][rpt * threads]  record index of the q-th real neighbour (-1: none)
+  std::vector<uint32_t> offs;              // [P][4][rpt * threads]  byte offsets of neighbours 2 qq (low half) and 2 qq + 1 (high half)
+  std::vector<int32_t> send_pos, send_cnt; // [P][S] local position of the own row published in slot s; [P]
+  std::vector<int32_t> recv_src, recv_pos, recv_cnt;   // [P][R] part * S + slot read; local position written; [P]
+  std::vector<int32_t> n_local;            // [P] rows of a part, halo included
+};
+constexpr int SP_DEG = 8;                  // = cwr::SMALL_DEG
+
+inline void cuthill_mckee(int n, const std::vector<int32_t>& ptr, const std::vector<int32_t>& nb, const std::vector<int32_t>& deg,
+                          std::vector<int32_t>& order) {
+  order.clear(); order.reserve((size_t)n);
+  std::vector<char> seen((size_t)n, 0);
+  // breadth-first order from `start` over the cells not yet marked; returns the last cell reached (the farthest level)
+  auto bfs = [&](int start, std::vector<int32_t>& out, std::vector<char>& mark) -> int {
+    const size_t first = out.size();
+    out.push_back(start); mark[(size_t)start] = 1;
+    std::vector<int32_t> nbs;
+    for (size_t head = first; head < out.size(); ++head) {
+      const int c = out[head];
+      nbs.clear();
+      for (int j = ptr[(size_t)c]; j < ptr[(size_t)c + 1]; ++j) {
+        const int v = nb[(size_t)j];
+        if (v >= 0 && v < n && !mark[(size_t)v]) { mark[(size_t)v] = 1; nbs.push_back(v); }
+      }
+      std::sort(nbs.begin(), nbs.end(), [&](int32_t a, int32_t b) { return deg[(size_t)a] != deg[(size_t)b] ? deg[(size_t)a] < deg[(size_t)b] : a < b; });
+      out.insert(out.end(), nbs.begin(), nbs.end());
+    }
+    return out.back();
+  };
+  for (int c0 = 0; c0 < n; ++c0) {
+    if (seen[(size_t)c0]) continue;
+    // pseudo-peripheral start of this component: the far end of a search from its first cell, then the far end of that one
+    std::vector<char> tmp_mark(seen);
+    std::vector<int32_t> tmp;
+    int far = bfs(c0, tmp, tmp_mark);
+    tmp_mark = seen; tmp.clear();
+    far = bfs(far, tmp, tmp_mark);
+    bfs(far, order, seen);
+  }
+}
+
+// parts == 0: the fewest parts (up to max_parts) whose rows fit rpt_max rows per thread, preferring 3 rows per thread to 4.
+// Returns false when a row has more than 8 real neighbours or no admissible plan exists.
+inline bool build_small_plan(int n, const std::vector<int32_t>& ptr, const std::vector<int32_t>& nb, int threads, int rpt_max, int parts,
+                             int depth, int max_parts, SmallPlan& out) {
+  if (n <= 0) return false;
+  std::vector<int32_t> deg((size_t)n, 0);
+  for (int c = 0; c < n; ++c) {
+    for (int j = ptr[(size_t)c]; j < ptr[(size_t)c + 1]; ++j) deg[(size_t)c] += (nb[(size_t)j] >= 0 && nb[(size_t)j] < n);
+    if (deg[(size_t)c] > SP_DEG) return false;
+  }
+  for (size_t j = 0; j < nb.size(); ++j) if (nb[j] >= n) return false;      // (engines with halo cells of a partition do not come here)
+  std::vector<int32_t> order, gpos((size_t)n);
+  cuthill_mckee(n, ptr, nb, deg, order);
+  for (int p = 0; p < n; ++p) gpos[(size_t)order[(size_t)p]] = p;
+  auto cls = [&](int32_t c, int kind) { return kind == 3 ? 2 : (deg[(size_t)c] > 6 ? 0 : (deg[(size_t)c] > 4 ? 1 : 2)); };
+
+  auto attempt = [&](int P, int rpt, SmallPlan& pl) -> bool {
+    const int cap = rpt * threads;
+    if ((size_t)cap * 8 > 65535 + 8) return false;                          // byte offsets travel as 16-bit halves
+    const int D = P == 1 ? 0 : depth;
+    const int L = (n + P - 1) / P;
+    pl = SmallPlan();
+    pl.P = P; pl.rpt = rpt; pl.depth = D; pl.threads = threads;
+    pl.rows.assign((size_t)P * cap, -1);
+    pl.recs.assign((size_t)P * SP_DEG * cap, -1);
+    pl.offs.assign((size_t)P * (SP_DEG / 2) * cap, 0u);
+    pl.n_local.assign((size_t)P, 0);
+    std::vector<std::vector<int32_t>> local((size_t)P), kind((size_t)P);
+    std::vector<int32_t> lpos((size_t)n), dist((size_t)n);
+    std::vector<std::vector<int32_t>> want((size_t)P);                       // per OWNER: the rows other parts hold as halo (deduplicated below)
+    std::vector<std::vector<std::pair<int32_t, int32_t>>> halo_of((size_t)P); // per part: (global row, local position) of its halo rows
+    for (int p = 0; p < P; ++p) {
+      const int lo = std::min(n, p * L), hi = std::min(n, (p + 1) * L);
+      if (lo >= hi) return false;                                           // (an empty part: fewer parts would do)
+      std::fill(dist.begin(), dist.end(), -1);
+      std::vector<int32_t>& loc = local[(size_t)p];
+      std::vector<int32_t>& kd = kind[(size_t)p];
+      for (int q = lo; q < hi; ++q) { loc.push_back(order[(size_t)q]); kd.push_back(1); dist[(size_t)order[(size_t)q]] = 0; }
+      size_t layer_lo = 0, layer_hi = loc.size();
+      for (int l = 1; l <= D; ++l) {
+        std::vector<int32_t> next;
+        for (size_t i = layer_lo; i < layer_hi; ++i) {
+          const int c = loc[i];
+          for (int j = ptr[(size_t)c]; j < ptr[(size_t)c + 1]; ++j) {
+            const int v = nb[(size_t)j];
+            if (v >= 0 && dist[(size_t)v] < 0) { dist[(size_t)v] = l; next.push_back(v); }
+          }
+        }
+        std::sort(next.begin(), next.end(), [&](int32_t a, int32_t b) { return gpos[(size_t)a] < gpos[(size_t)b]; });
+        layer_lo = loc.size();
+        for (int32_t v : next) { loc.push_back(v); kd.push_back(l < D ? 2 : 3); }
+        layer_hi = loc.size();
+      }
+      if ((int)loc.size() > cap) return false;
+      // class sort (stable) of the part's rows, kinds carried along
+      std::vector<int32_t> idx(loc.size());
+      for (size_t i = 0; i < idx.size(); ++i) idx[i] = (int32_t)i;
+      std::stable_sort(idx.begin(), idx.end(), [&](int32_t a, int32_t b) { return cls(loc[(size_t)a], kd[(size_t)a]) < cls(loc[(size_t)b], kd[(size_t)b]); });
+      std::vector<int32_t> loc2(loc.size()), kd2(loc.size());
+      for (size_t i = 0; i < idx.size(); ++i) { loc2[i] = loc[(size_t)idx[i]]; kd2[i] = kd[(size_t)idx[i]]; }
+      loc.swap(loc2); kd.swap(kd2);
+      pl.n_local[(size_t)p] = (int32_t)loc.size();
+      std::fill(lpos.begin(), lpos.end(), -1);
+      for (size_t i = 0; i < loc.size(); ++i) lpos[(size_t)loc[i]] = (int32_t)i;
+      std::vector<std::array<int32_t, 3>> nbl;                               // (global Cuthill-McKee position, local position, record)
+      for (size_t i = 0; i < loc.size(); ++i) {
+        const int c = loc[i];
+        pl.rows[(size_t)p * cap + i] = c | (kd[i] << 28);
+        nbl.clear();
+        if (kd[i] != 3)
+          for (int j = ptr[(size_t)c]; j < ptr[(size_t)c + 1]; ++j) {
+            const int v = nb[(size_t)j];
+            if (v < 0) continue;
+            if (lpos[(size_t)v] < 0) return false;                          // (cannot happen: a relaxed row's neighbours are within `depth` layers)
+            nbl.push_back({gpos[(size_t)v], lpos[(size_t)v], j});
+          }
+        // the order of a row's sum is a property of the ROW (ascending Cuthill-McKee position of its neighbours), not of the part
+        // that relaxes it: a halo copy of a row is then the same bits as its owner's value
+        std::sort(nbl.begin(), nbl.end());
+        for (int q = 0; q < SP_DEG; ++q) {
+          const uint32_t off = (uint32_t)(q < (int)nbl.size() ? nbl[(size_t)q][1] : (int32_t)i) * 8u;   // empty slot: the row itself, weight zero
+          if (q < (int)nbl.size()) pl.recs[((size_t)p * SP_DEG + q) * cap + i] = nbl[(size_t)q][2];
+          pl.offs[((size_t)p * (SP_DEG / 2) + q / 2) * cap + i] |= (q & 1) ? (off << 16) : off;
+        }
+        if (kd[i] != 1) { halo_of[(size_t)p].emplace_back(c, (int32_t)i); want[(size_t)std::min(P - 1, gpos[(size_t)c] / L)].push_back(c); }
+      }
+    }
+    if (P == 1) return true;
+    // send lists: per owner the rows wanted by anyone, once each, in Cuthill-McKee order; slot = index in that list
+    std::vector<std::vector<int32_t>> slot_of((size_t)P);
+    size_t S = 1, R = 1;
+    for (int o = 0; o < P; ++o) {
+      std::vector<int32_t>& w = want[(size_t)o];
+      std::sort(w.begin(), w.end(), [&](int32_t a, int32_t b) { return gpos[(size_t)a] < gpos[(size_t)b]; });
+      w.erase(std::unique(w.begin(), w.end()), w.end());
+      S = std::max(S, w.size());
+      R = std::max(R, halo_of[(size_t)o].size());
+    }
+    pl.S = (int)S; pl.R = (int)R;
+    pl.send_pos.assign((size_t)P * S, 0); pl.send_cnt.assign((size_t)P, 0);
+    pl.recv_src.assign((size_t)P * R, 0); pl.recv_pos.assign((size_t)P * R, 0); pl.recv_cnt.assign((size_t)P, 0);
+    std::vector<int32_t> slot((size_t)n, -1);
+    for (int o = 0; o < P; ++o) {
+      const std::vector<int32_t>& w = want[(size_t)o];
+      // the owner's local position of each wanted row
+      const int cap = rpt * threads;
+      std::fill(lpos.begin(), lpos.end(), -1);
+      for (int i = 0; i < pl.n_local[(size_t)o]; ++i) {
+        const int32_t code = pl.rows[(size_t)o * cap + i];
+        if ((code >> 28) == 1) lpos[(size_t)(code & 0x0fffffff)] = i;
+      }
+      for (size_t s = 0; s < w.size(); ++s) {
+        if (lpos[(size_t)w[s]] < 0) return false;                            // (cannot happen: the owner holds its own rows)
+        pl.send_pos[(size_t)o * S + s] = lpos[(size_t)w[s]];
+        slot[(size_t)w[s]] = (int32_t)s;
+      }
+      pl.send_cnt[(size_t)o] = (int32_t)w.size();
+    }
+    for (int p = 0; p < P; ++p) {
+      std::vector<std::pair<int32_t, int32_t>> ent;                          // (source code, local position), sorted for coalesced reads
+      for (const auto& h : halo_of[(size_t)p]) {
+        const int o = std::min(P - 1, gpos[(size_t)h.first] / L);
+        if (o == p || slot[(size_t)h.first] < 0) return false;
+        ent.emplace_back(o * (int32_t)S + slot[(size_t)h.first], h.second);
+      }
+      std::sort(ent.begin(), ent.end());
+      for (size_t r = 0; r < ent.size(); ++r) { pl.recv_src[(size_t)p * R + r] = ent[r].first; pl.recv_pos[(size_t)p * R + r] = ent[r].second; }
+      pl.recv_cnt[(size_t)p] = (int32_t)ent.size();
+    }
+    return true;
+  };
+
+  if (parts > 0) {
+    for (int rpt = 1; rpt <= rpt_max; ++rpt)
+      if (attempt(parts, rpt, out)) return true;
+    return false;
+  }
+  if (n <= rpt_max * threads) {                                               // one workgroup: 1, 2, 3 or 4 rows per thread
+    const int rpt = (n + threads - 1) / threads;
+    return attempt(1, rpt, out);
+  }
+  if (depth < 1) return false;
+  for (int rpt : {3, 4})
+    for (int P = 2; P <= max_parts; ++P)
+      if (rpt <= rpt_max && (long long)P * rpt * threads >= n && attempt(P, rpt, out)) return true;
+  return false;
 }
 
 }  // namespace host

@@ -1748,17 +1748,42 @@ constexpr int SMALL_DEG = 8;                     // register-resident weights: r
 // rows  [RPT][1024]      the row at position p = i * 1024 + thread: -1 = none
 // recs  [8][RPT][1024]   the record index (into rec) of the q-th REAL neighbour of that row: -1 = none
 // offs  [4][RPT][1024]   byte offsets of neighbours 2 qq (low half) and 2 qq + 1 (high half) in a column; empty: the row's own
-template <int RPT>
+//
+// COOP (meshes of 4 097 .. ~20 000 cells, BASELINE configs 1 / 2 at "~10 k cells"): P workgroups share the rows of one constituent
+// (host::build_small_plan): each holds its own rows plus `D` layers of halo rows, relaxes D sweeps on its own (the halo layers
+// redundantly: the iterates are those of the global Jacobi iteration bit for bit) and then exchanges -- own rows that others
+// hold as halo, and the check's partial norms -- through global memory.  The hand-off is the measured-valid form of
+// MI355X_MICROARCH.md (inter-workgroup visibility, first row of the table): all payload stores and loads `sc1` (relaxed
+// agent-scope atomics), every storing wave waits vmcnt(0), workgroup barrier, ONE lane adds to the constituent's arrival counter
+// (agent scope), ONE lane polls it with sc1 loads, workgroup barrier, then the loads; one workgroup per CU (LDS request); two
+// publication buffers alternate, so a part one exchange ahead never overwrites what a neighbour still reads.  Every spin is
+// bounded: a part that waits longer than `spin_ticks` raises the abort word, every part leaves without touching x, and the
+// host takes the multi-launch path (and stops using this one).
+struct SmallCoop {
+  int P, D, S, R;
+  const int32_t* send_pos; const int32_t* send_cnt;       // [P][S], [P]
+  const int32_t* recv_src; const int32_t* recv_pos; const int32_t* recv_cnt;   // [P][R] (part * 2 S + slot), [P][R], [P]
+  double* pub;                      // [K][P][2][S]
+  double* red;                      // [K][P][2][4]
+  unsigned long long* arrive;       // [K], zero at launch
+  unsigned int* abort_word;         // zero at launch
+  long long spin_ticks;             // bound of a wait, in wall_clock64() ticks (100 MHz)
+};
+template <int RPT, bool COOP>
 __global__ void __launch_bounds__(SMALL_THREADS) k_small_jacobi(
     int n, int K, const int32_t* __restrict__ rows, const int32_t* __restrict__ recs, const uint32_t* __restrict__ offs,
     const FaceRec* __restrict__ rec,
     const double* __restrict__ diag, const double* __restrict__ bhat, double* __restrict__ x, double tol2, double ew_rel, double ew_abs,
     int max_sweeps, int check_every, double* __restrict__ info /* [K][5]: sweeps, ||x'-x||^2, ||bhat||^2, max(|dx| - ew_rel |x'|), max |x'| */,
-    ReduceNote note /* (round 5) the same five numbers per constituent into page-locked host memory + a sequence word: no download */) {
+    ReduceNote note /* (round 5) the same five numbers per constituent into page-locked host memory + a sequence word: no download */,
+    SmallCoop co) {
   extern __shared__ double s_x[];                // two columns of RPT x 1024 doubles (compile-time stride: the column a sweep
   constexpr int COL = RPT * SMALL_THREADS;       // reads or writes is an immediate offset of its LDS instructions), then scratch
   double* s_red = s_x + 2 * COL;
-  const int k = blockIdx.x;
+  const int P = COOP ? co.P : 1;
+  const int k = COOP ? blockIdx.x / P : blockIdx.x;
+  const int part = COOP ? blockIdx.x - k * P : 0;
+  rows += (size_t)part * COL; recs += (size_t)part * SMALL_DEG * COL; offs += (size_t)part * (SMALL_DEG / 2) * COL;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   constexpr bool OWN_IN_REG = RPT <= 3;          // the row's previous value: a register, or (4 rows per thread: 128 VGPRs are short) LDS
@@ -1767,9 +1792,12 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_small_jacobi(
   unsigned roff2[RPT * SMALL_DEG / 2];           // BYTE offsets of the neighbours in a column (< 32 768: two per register)
   double rw[RPT * SMALL_DEG];
   double bb = 0.0;
+  unsigned ownm = 0u;                            // bit i: row slot i holds one of this part's OWN rows (counted in the norms, written back)
 #pragma unroll
   for (int i = 0; i < RPT; ++i) {
-    const int c = rows[i * SMALL_THREADS + tid];
+    const int code = rows[i * SMALL_THREADS + tid];
+    const int c = code < 0 ? -1 : (code & 0x0fffffff);
+    const int kind = code < 0 ? 0 : (code >> 28);          // 1 own, 2 relaxed halo, 3 read-only halo
     row[i] = c; bh[i] = 0.0;
     if constexpr (OWN_IN_REG) xo[i] = 0.0;
     double rdg = 0.0;
@@ -1779,9 +1807,11 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_small_jacobi(
       const double x0 = x[(size_t)c * K + k];
       if constexpr (OWN_IN_REG) xo[i] = x0;
       s_x[i * SMALL_THREADS + tid] = x0;
-      bh[i] = bhat[(size_t)c * K + k];
-      rdg = 1.0 / diag[c];
-      bb += bh[i] * bh[i];
+      if (kind != 3) {
+        bh[i] = bhat[(size_t)c * K + k];
+        rdg = 1.0 / diag[c];
+      }
+      if (kind == 1) { bb += bh[i] * bh[i]; ownm |= 1u << i; }
     }
     int cnt = 0;
 #pragma unroll
@@ -1794,6 +1824,9 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_small_jacobi(
         cnt = q + 1;
       }
       if ((q & 1) == 0) roff2[(i * SMALL_DEG + q) / 2] = offs[((q / 2) * RPT + i) * SMALL_THREADS + tid];
+    }
+    if constexpr (COOP) {
+      if (kind == 3) { rw[i * SMALL_DEG] = 1.0; cnt = 1; }   // a read-only halo row copies itself (0 + 1.0 * x: exact) until the exchange refreshes it
     }
     for (int off = 32; off >= 1; off >>= 1) cnt = max(cnt, __shfl_xor(cnt, off, 64));
     dmax[i] = __builtin_amdgcn_readfirstlane(cnt);            // wave-uniform: the gather loop's bound for this row slot
@@ -1826,11 +1859,75 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_small_jacobi(
     }
     a = __shfl(a, 0, 64); b = __shfl(b, 0, 64); c = __shfl(c, 0, 64);
   };
-  bb = block_sum(bb);                             // (its barriers also publish the first column)
-  int sweep = 0;
-  double rr = 0.0, m1 = INFINITY, m2 = 0.0;      // (m1 = +inf until an element-wise verification has run)
   char* const lds = reinterpret_cast<char*>(s_x);
   int dir = 0;                                   // the column holding the current iterate
+  int xchg = 0;                                  // exchanges made (COOP)
+  bool aborted = false;
+  // COOP: publish the own rows others hold as halo and this part's three numbers, wait for every part of the constituent, refresh
+  // the halo rows of the current column, and combine the numbers (sum, max, max) in part order -- the same bits in every part.
+  // Called by all threads, after a workgroup barrier that followed the column's last write (block_sum / block_reduce3 end in one).
+  auto sync_exchange = [&](double& a, double& b, double& c) {
+    if constexpr (COOP) {
+      const int par = xchg & 1;
+      double* col = s_x + dir * COL;
+      double* mypub = co.pub + (((size_t)k * P + part) * 2 + par) * co.S;
+      const int ns = co.send_cnt[part];
+      for (int s2 = tid; s2 < ns; s2 += SMALL_THREADS)
+        __hip_atomic_store(mypub + s2, col[co.send_pos[(size_t)part * co.S + s2]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) {
+        double* myred = co.red + (((size_t)k * P + part) * 2 + par) * 4;
+        __hip_atomic_store(myred + 0, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(myred + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(myred + 2, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave, before the barrier its signalling lane joins
+      __syncthreads();
+      if (tid == 0) {
+        __hip_atomic_fetch_add(co.arrive + k, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long target = (unsigned long long)P * (unsigned long long)(xchg + 1);
+        const long long t0 = wall_clock64();
+        double flag = 0.0;
+        for (;;) {
+          if (__hip_atomic_load(co.arrive + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
+          if (__hip_atomic_load(co.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { flag = 1.0; break; }
+          if (wall_clock64() - t0 > co.spin_ticks) {              // a part never came (not resident?): everyone leaves
+            __hip_atomic_store(co.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            flag = 1.0; break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        s_red[56] = flag;
+      }
+      __syncthreads();
+      if (s_red[56] != 0.0) { aborted = true; return; }
+      const int nr = co.recv_cnt[part];
+      const double* kpub = co.pub + (size_t)k * P * 2 * co.S + (size_t)par * co.S;
+      for (int r = tid; r < nr; r += SMALL_THREADS)
+        col[co.recv_pos[(size_t)part * co.R + r]] = __hip_atomic_load(kpub + co.recv_src[(size_t)part * co.R + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (wave == 0) {
+        double ra = 0.0, rb = -INFINITY, rc = -INFINITY;
+        if (lane < P) {
+          const double* r4 = co.red + (((size_t)k * P + lane) * 2 + par) * 4;
+          ra = __hip_atomic_load(r4 + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          rb = __hip_atomic_load(r4 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          rc = __hip_atomic_load(r4 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        for (int off = 8; off >= 1; off >>= 1) {                 // (P <= 16 parts, folded in a fixed order)
+          ra += __shfl_xor(ra, off, 64);
+          rb = fmax(rb, __shfl_xor(rb, off, 64));
+          rc = fmax(rc, __shfl_xor(rc, off, 64));
+        }
+        if (lane == 0) { s_red[57] = ra; s_red[58] = rb; s_red[59] = rc; }
+      }
+      __syncthreads();                                           // the refreshed halo rows and the combined numbers, for everyone
+      a = s_red[57]; b = s_red[58]; c = s_red[59];
+      ++xchg;
+    }
+  };
+  bb = block_sum(bb);                             // (its barriers also publish the first column)
+  if constexpr (COOP) { double u = -INFINITY, v = -INFINITY; sync_exchange(bb, u, v); }
+  int sweep = 0, since = 0;
+  double rr = 0.0, m1 = INFINITY, m2 = 0.0;      // (m1 = +inf until an element-wise verification has run)
   // one sweep: column DIR -> column 1 - DIR in LDS; the caller's barrier publishes it.  MEASURE: also the element-wise measures of
   // this sweep (taken in ONE extra verification sweep after the norm criterion holds: the hot loop stays lean)
   auto sweep_dir = [&](auto measure, auto dirc, double& dx2, double& e1, double& e2) {
@@ -1868,9 +1965,10 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_small_jacobi(
     for (int i = 0; i < RPT; ++i) {                // (empty positions compute 0 = 0 + 0 and write it: no branch)
       const double xn = bh[i] + sum[i];
       const double dx = xn - (OWN_IN_REG ? xo[i] : *reinterpret_cast<const double*>(cur + (i * SMALL_THREADS + tid) * 8));
-      dx2 += dx * dx;
+      if constexpr (COOP) dx2 += ((ownm >> i) & 1u) ? dx * dx : 0.0;     // (halo rows belong to another part's norm)
+      else dx2 += dx * dx;
       if constexpr (decltype(measure)::value) {
-        if (row[i] >= 0) {                         // (an empty position would put 0 - ew_rel * 0 = 0 into a maximum that may be negative)
+        if ((ownm >> i) & 1u) {                    // (an empty position would put 0 - ew_rel * 0 = 0 into a maximum that may be negative)
           e1 = fmax(e1, fabs(dx) - ew_rel * fabs(xn));
           e2 = fmax(e2, fabs(xn));
         }
@@ -1884,19 +1982,22 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_small_jacobi(
     else sweep_dir(measure, std::integral_constant<int, 1>{}, dx2, e1, e2);
     dir ^= 1;
   };
-  for (;;) {
+  for (; !aborted;) {
     double dx2 = 0.0, e1 = -INFINITY, e2 = 0.0;
     sweep_once(std::false_type{}, dx2, e1, e2);
-    ++sweep;
-    const bool check = (sweep % check_every == 0) || sweep >= max_sweeps;
+    ++sweep; ++since;
+    // COOP: the halo layers carry co.D sweeps; the check rides on the exchange
+    const bool check = (COOP ? since >= co.D : (sweep % check_every == 0)) || sweep >= max_sweeps;
     if (check) {                                 // uniform
       rr = block_sum(dx2);                       // (its barriers also publish the new column)
+      if constexpr (COOP) { double u = -INFINITY, v = -INFINITY; sync_exchange(rr, u, v); since = 0; if (aborted) break; }
       if (!(rr == rr) || sweep >= max_sweeps) break;          // NaN, or out of sweeps
       if (!(rr > tol2 * bb)) {                   // the norm criterion holds: verify the element-wise rule with one more sweep
         dx2 = 0.0;
         sweep_once(std::true_type{}, dx2, e1, e2);
         ++sweep;
         block_reduce3(dx2, e1, e2);
+        if constexpr (COOP) { sync_exchange(dx2, e1, e2); since = 0; if (aborted) break; }
         rr = dx2; m1 = e1; m2 = e2;              // ||x'-x||^2 and the element-wise measures of this sweep (k_apply MODE 4)
         if (!(rr == rr) || (!(rr > tol2 * bb) && !(m1 > ew_abs * m2)) || sweep >= max_sweeps) break;
       }
@@ -1904,10 +2005,14 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_small_jacobi(
       __syncthreads();
     }
   }
+  if (aborted) {                                 // x untouched: the host takes the multi-launch path from the same start
+    if (tid == 0 && part == 0) { sweep = -1; rr = 0.0; }
+  } else {
 #pragma unroll
-  for (int i = 0; i < RPT; ++i)
-    if (row[i] >= 0) x[(size_t)row[i] * K + k] = OWN_IN_REG ? xo[i] : s_x[dir * COL + i * SMALL_THREADS + tid];
-  if (tid == 0) {
+    for (int i = 0; i < RPT; ++i)
+      if ((ownm >> i) & 1u) x[(size_t)row[i] * K + k] = OWN_IN_REG ? xo[i] : s_x[dir * COL + i * SMALL_THREADS + tid];
+  }
+  if (tid == 0 && part == 0) {
     info[k * 5 + 0] = (double)sweep; info[k * 5 + 1] = rr; info[k * 5 + 2] = bb; info[k * 5 + 3] = m1; info[k * 5 + 4] = m2;
     if (note.host_seq) {
       note.host_out[k * 5 + 0] = (double)sweep; note.host_out[k * 5 + 1] = rr; note.host_out[k * 5 + 2] = bb; note.host_out[k * 5 + 3] = m1; note.host_out[k * 5 + 4] = m2;

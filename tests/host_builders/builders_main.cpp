@@ -53,6 +53,20 @@ template <typename T> static std::vector<int32_t> widen(const std::vector<T>& v)
 int main(int argc, char** argv) {
   if (argc != 3) { std::fprintf(stderr, "usage: builders_main <in> <out>\n"); return 2; }
   Bag in = read_bag(argv[1]), out;
+  if (in.count("small_params")) {                      // the plan of the one-launch solver: n, threads, rpt_max, parts, depth, max_parts
+    const std::vector<int32_t>& sp = in.at("small_params");
+    SmallPlan pl;
+    const bool ok = build_small_plan(sp.at(0), in.at("ptr"), in.at("nb"), sp.at(1), sp.at(2), sp.at(3), sp.at(4), sp.at(5), pl);
+    out["ok"] = {ok ? 1 : 0};
+    if (ok) {
+      out["dims"] = {pl.P, pl.rpt, pl.depth, pl.threads, pl.S, pl.R};
+      out["rows"] = pl.rows; out["recs"] = pl.recs; out["offs"] = std::vector<int32_t>(pl.offs.begin(), pl.offs.end());
+      out["send_pos"] = pl.send_pos; out["send_cnt"] = pl.send_cnt; out["recv_src"] = pl.recv_src; out["recv_pos"] = pl.recv_pos;
+      out["recv_cnt"] = pl.recv_cnt; out["n_local"] = pl.n_local;
+    }
+    write_bag(argv[2], out);
+    return 0;
+  }
   const std::vector<int32_t>& par = in.at("params");   // n_owned, n_core, n_real, K, tr, grid, seg, nvmax
   const int n_owned = par.at(0), n_core = par.at(1), n_real = par.at(2), K = par.at(3), tr = par.at(4), grid = par.at(5), seg = par.at(6), nvmax = par.at(7);
   const std::vector<int32_t>&ptr = in.at("ptr"), &nb = in.at("nb"), &edge = in.at("edge"), &adv_bits = in.at("adv");

@@ -187,13 +187,17 @@ def test_step_parity_across_constituent_counts_on_tiled_meshes(gpu_lib, K, pad, 
     assert mass.shape == (K,) and np.isclose(mass[K - 1], float(np.sum(np.asarray(mesh['volume'])[3, :n].astype(np.float64) * st[:n, K - 1])), rtol=1e-9)
 
 
+@pytest.mark.mid_mesh_default
 @pytest.mark.parametrize('K', [1, 12])
-@pytest.mark.parametrize('n_target', [2943, 10000])
-def test_baseline_configs_2_and_3_river_band_mesh(gpu_lib, K, n_target):
+@pytest.mark.parametrize('n_target,path', [(2943, 'default'), (10000, 'default'), (10000, 'tiled passes')])
+def test_baseline_configs_2_and_3_river_band_mesh(gpu_lib, K, n_target, path, monkeypatch):
     """BASELINE configs 2 / 3: a river-band mesh of the Ohio River's size (2 943 cells; 10 000 nominal) with
     jittered, partly merged 5-6-sided cells and a locally shuffled numbering, dt = 3600 s (CFL ~ 18), one tracer and the
     12-constituent NSM-I state vector, through the facade against the oracle's spsolve.  2 943 cells take the one-launch
-    LDS-resident solver, 10 000 the tiled block-asynchronous passes."""
+    LDS-resident solver with one workgroup per constituent, 10 000 the same with several (round 5) -- or, with
+    CWR_SMALL_MAX_CELLS=0, the tiled block-asynchronous passes as before."""
+    if path == 'tiled passes':
+        monkeypatch.setenv('CWR_SMALL_MAX_CELLS', '0')
     import clearwater_riverine_amd as cw
     nx, ny, nm = (109, 28, 109) if n_target == 2943 else (200, 51, 200)
     mesh = cw.synthetic.make_mesh(nx, ny, 6, seed=20100529 % 100000, n_merge=nm, dx=75.0, dy=75.0, dt=3600.0, velocity=0.4,
@@ -208,7 +212,7 @@ def test_baseline_configs_2_and_3_river_band_mesh(gpu_lib, K, n_target):
     ref = oracle_run(mesh, inputs3[:, :, cols], 6)
     for _ in range(6):
         model.update()
-    assert model.last_step.sweep_kernel == (7 if n_target == 2943 else 6) and model.last_step.iterations == 0
+    assert model.last_step.sweep_kernel == (6 if path == 'tiled passes' else 7) and model.last_step.iterations == 0
     for kk, col in enumerate(cols):
         assert rel_err(model.mesh[names[col]], ref.constituent_dict[f'c{kk}'].state) <= TOL_CONC
         assert flux_err(model.constituent_dict[names[col]].total_mass_flux[:6], ref.constituent_dict[f'c{kk}'].total_mass_flux[:6]) <= 1e-8
@@ -307,3 +311,85 @@ def test_one_launch_solver_at_every_rows_per_thread_variant(gpu_lib, nx, ny, rpt
     for k, nm in enumerate(names):
         assert rel_err(model.mesh[nm], ref.constituent_dict[nm].state) <= TOL_CONC
         assert flux_err(model.constituent_dict[nm].total_mass_flux[:steps], ref.constituent_dict[nm].total_mass_flux[:steps]) <= 1e-8
+
+
+def _mid_case(nx, ny, K, steps, seed):
+    import clearwater_riverine_amd as cw
+    mesh = cw.synthetic.make_mesh(nx, ny, steps, seed=seed, n_merge=nx * ny // 30, n_merge4=nx * ny // 80, n_dry=4, dt=60.0,
+                                  diffusion_coefficient=0.3)
+    oracle.derive_coefficients(mesh)
+    return mesh, cw.synthetic.distinct_input_array(mesh, K, seed=seed)
+
+
+@pytest.mark.mid_mesh_default
+@pytest.mark.parametrize('nx,ny,parts,depth', [(110, 60, 0, 12), (150, 90, 0, 12), (150, 90, 8, 3), (100, 70, 3, 1), (128, 120, 0, 5)])
+def test_one_launch_solver_with_several_parts_matches_the_oracle(gpu_lib, nx, ny, parts, depth, monkeypatch):
+    """k_small_jacobi<RPT, true> (round 5): 6-15 k cells with 8-sided, 6-sided, plain and dry cells, K = 3 (carried as 4): several
+    workgroups per constituent with `depth` halo layers, an exchange through global memory every `depth` sweeps.  States and fluxes
+    against the oracle's spsolve over several steps; run twice: the same bits."""
+    import clearwater_riverine_amd as cw
+    K, steps = 3, 4
+    mesh, inputs3 = _mid_case(nx, ny, K, steps, seed=nx)
+    n = mesh['nreal'] + 1
+    assert 4096 < n <= 16384
+    monkeypatch.setenv('CWR_SMALL_PARTS', str(parts)); monkeypatch.setenv('CWR_SMALL_DEPTH', str(depth))
+    ref = oracle_run(mesh, inputs3, steps)
+    names = [f'c{k}' for k in range(K)]
+    runs = []
+    for _ in range(2):
+        model = cw.ClearwaterRiverine(mesh=dict(mesh), input_arrays={nm: inputs3[:, :, k].copy() for k, nm in enumerate(names)})
+        for _ in range(steps):
+            model.update()
+            assert model.last_step.sweep_kernel == 7 and model.last_step.max_rel_residual <= 1e-12 and model.last_step.flags == 0
+        runs.append({nm: np.array(model.mesh[nm]) for nm in names})
+        for nm in names:
+            assert rel_err(model.mesh[nm], ref.constituent_dict[nm].state) <= TOL_CONC
+            assert flux_err(model.constituent_dict[nm].total_mass_flux[:steps], ref.constituent_dict[nm].total_mass_flux[:steps]) <= 1e-8
+        model.close_output(); model.engine.close()
+    for nm in names:
+        assert np.array_equal(runs[0][nm], runs[1][nm], equal_nan=True)
+
+
+@pytest.mark.mid_mesh_default
+def test_the_parts_of_the_one_launch_solver_iterate_as_one(gpu_lib, monkeypatch):
+    """The halo layers are relaxed redundantly with each row's sum taken in one fixed order, so the iterates are those of the
+    global Jacobi iteration whatever the number of parts: 5 / 6 / 8 parts at the same depth (= the same check cadence) stop at
+    the same sweep with the same bits."""
+    import clearwater_riverine_amd as cw
+    K, steps = 2, 3
+    mesh, inputs3 = _mid_case(140, 70, K, steps, seed=77)
+    n = mesh['nreal'] + 1
+    out = {}
+    for parts in (5, 6, 8):
+        monkeypatch.setenv('CWR_SMALL_PARTS', str(parts)); monkeypatch.setenv('CWR_SMALL_DEPTH', '6')
+        eng = make_engine(mesh, inputs3)
+        eng.set_state(inputs3[0, :n, :])
+        sw = []
+        for t in range(steps):
+            r = eng.step(t, tol=1e-12)
+            assert r.sweep_kernel == 7
+            sw.append(r.sweeps)
+        out[parts] = (sw, eng.get_state())
+        eng.close()
+    for parts in (6, 8):
+        assert out[parts][0] == out[5][0]
+        assert np.array_equal(out[parts][1], out[5][1], equal_nan=True)
+
+
+@pytest.mark.mid_mesh_default
+def test_meshes_without_a_plan_take_the_tiled_passes(gpu_lib, monkeypatch):
+    """No admissible plan (here: at most two parts allowed for 10 k cells) -> the multi-launch path, silently, same answer."""
+    import clearwater_riverine_amd as cw
+    K, steps = 2, 2
+    mesh, inputs3 = _mid_case(140, 70, K, steps, seed=78)
+    n = mesh['nreal'] + 1
+    monkeypatch.setenv('CWR_SMALL_MAX_PARTS', '2')
+    eng = make_engine(mesh, inputs3)
+    eng.set_state(inputs3[0, :n, :])
+    ref = oracle_run(mesh, inputs3, steps)
+    for t in range(steps):
+        assert eng.step(t, tol=1e-12).sweep_kernel == 6
+    got = eng.get_state()
+    for k in range(K):
+        assert rel_err(got[:n, k], ref.constituent_dict[f'c{k}'].state[steps][:n]) <= TOL_CONC
+    eng.close()

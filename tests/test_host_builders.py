@@ -319,3 +319,122 @@ def test_heavy_windows_are_cut_into_smaller_tiles_and_the_rest_keep_their_window
             if 0 <= m < n_sq and tile_of[m] != tile_of[c]:
                 pairs.add((int(tile_of[c]), int(tile_of[m])))
     assert pairs == set(zip(src.tolist(), dst.tolist()))
+
+
+# ---- the plan of the one-launch solver (k_small_jacobi): parts, halo layers, exchange lists --------------------------------------
+def small_plan(driver, tmp_path, ptr, nb, n, threads, rpt_max, parts, depth, max_parts):
+    fin, fout = str(tmp_path / 'sp_in.bin'), str(tmp_path / 'sp_out.bin')
+    write_bag(fin, {'small_params': np.array([n, threads, rpt_max, parts, depth, max_parts]), 'ptr': ptr, 'nb': nb})
+    env = dict(os.environ, ASAN_OPTIONS='detect_leaks=1:abort_on_error=1', UBSAN_OPTIONS='print_stacktrace=1')
+    res = subprocess.run([driver, fin, fout], capture_output=True, text=True, env=env, timeout=600)
+    assert res.returncode == 0 and res.stderr == '', (res.returncode, res.stderr[-3000:])
+    return read_bag(fout)
+
+
+def jacobi_through_plan(out, ptr, nb, w, bh, x0, sweeps):
+    """The kernel's iteration restated with the plan's tables: every part relaxes all its rows (own + halo) in its own column, sums
+    in the plan's neighbour order, and the halo rows are refreshed from their owners every `depth` sweeps.  Returns the global x."""
+    P, rpt, depth, threads, S, R = (int(v) for v in out['dims'])
+    cap = rpt * threads
+    rows = out['rows'].reshape(P, cap)
+    recs = out['recs'].reshape(P, 8, cap)
+    offs = out['offs'].astype(np.int64).astype(np.uint32).reshape(P, 4, cap)
+    gid = np.where(rows >= 0, rows & 0x0fffffff, 0)
+    kind = np.where(rows >= 0, rows >> 28, 0)
+    col = np.zeros((P, cap))
+    for p in range(P):
+        col[p] = np.where(rows[p] >= 0, x0[gid[p]], 0.0)
+    pos = np.empty((P, 8, cap), dtype=np.int64)
+    for q in range(8):
+        half = offs[:, q // 2, :]
+        pos[:, q, :] = ((half >> 16) if (q & 1) else (half & 0xffff)).astype(np.int64) // 8
+    wt = np.where(recs >= 0, w[np.maximum(recs, 0)], 0.0)                    # weight of record j (zero for empty slots)
+    ro = kind == 3
+    wt[:, 0, :] = np.where(ro, 1.0, wt[:, 0, :])                            # read-only rows copy themselves
+    b = np.where((rows >= 0) & ~ro, bh[gid], 0.0)
+    since = 0
+    for _ in range(sweeps):
+        new = np.zeros_like(col)
+        for p in range(P):
+            s = np.zeros(cap)
+            for q in range(8):
+                s = s + wt[p, q] * col[p][pos[p, q]]
+            new[p] = b[p] + s
+        col = new
+        since += 1
+        if P > 1 and since == depth:
+            pub = np.zeros((P, S))
+            for p in range(P):
+                c = int(out['send_cnt'][p])
+                pub[p, :c] = col[p][out['send_pos'].reshape(P, S)[p, :c]]
+            for p in range(P):
+                c = int(out['recv_cnt'][p])
+                src = out['recv_src'].reshape(P, R)[p, :c]
+                col[p][out['recv_pos'].reshape(P, R)[p, :c]] = pub.reshape(-1)[src]
+            since = 0
+    x = np.full(len(x0), np.nan)
+    for p in range(P):
+        own = kind[p] == 1
+        x[gid[p][own]] = col[p][own]
+    return x, since
+
+
+@pytest.mark.parametrize('nx,ny,n_merge,parts,depth', [(40, 20, 30, 0, 4), (109, 28, 109, 0, 4), (200, 50, 150, 0, 4), (200, 50, 150, 6, 3),
+                                                      (120, 110, 300, 0, 4), (90, 45, 100, 3, 1), (64, 64, 0, 2, 2)])
+def test_small_solver_plan_reproduces_the_global_jacobi_iteration_bit_for_bit(driver, tmp_path, nx, ny, n_merge, parts, depth):
+    """build_small_plan under ASan / UBSan on meshes of one to seven parts: every row owned once, every slot a valid local
+    position, and -- the property the halo layers exist for -- the partitioned iteration with an exchange every `depth` sweeps
+    gives the SAME BITS as the global Jacobi iteration summed in the plan's neighbour order."""
+    import clearwater_riverine_amd as cw
+    mesh = cw.synthetic.make_mesh(nx, ny, 2, seed=nx + ny, n_merge=n_merge, n_merge4=n_merge // 3, n_dry=2, dt=40.0, diffusion_coefficient=0.5)
+    n = mesh['nreal'] + 1
+    ptr, nb, edge = adjacency(mesh['edges_face1'], mesh['edges_face2'], n, n)
+    out = small_plan(driver, tmp_path, ptr, nb, n, 1024, 4, parts, depth, 8)
+    assert out['ok'][0] == 1
+    P, rpt, D, threads, S, R = (int(v) for v in out['dims'])
+    cap = rpt * threads
+    assert (P == 1) == (n <= 4096 and parts in (0, 1)) and (parts == 0 or P == parts) and D == (0 if P == 1 else depth)
+    rows = out['rows'].reshape(P, cap)
+    kind = np.where(rows >= 0, rows >> 28, 0)
+    gid = rows & 0x0fffffff
+    owned = np.sort(np.concatenate([gid[p][kind[p] == 1] for p in range(P)]))
+    assert np.array_equal(owned, np.arange(n))                              # every row owned exactly once
+    for p in range(P):
+        nl = int(out['n_local'][p])
+        assert np.all(rows[p, :nl] >= 0) and np.all(rows[p, nl:] == -1)
+        assert len(np.unique(gid[p, :nl])) == nl                            # no row twice in a part
+        recs = out['recs'].reshape(P, 8, cap)[p]
+        for q in range(8):
+            live = recs[q] >= 0
+            assert not np.any(live[nl:]) and not np.any(live & (kind[p] == 3))
+            # the record belongs to the row, and the offset points at the local position of the record's neighbour
+            r = np.nonzero(live)[0]
+            owner_row = np.searchsorted(ptr, recs[q][r], side='right') - 1
+            assert np.array_equal(owner_row, gid[p][r])
+            half = out['offs'].astype(np.int64).astype(np.uint32).reshape(P, 4, cap)[p, q // 2]
+            lp = (((half >> 16) if (q & 1) else (half & 0xffff)).astype(np.int64) // 8)[r]
+            assert np.all(lp < nl) and np.array_equal(gid[p][lp], nb[recs[q][r]])
+    # the iteration: random weights of an M-matrix-like J (row sums < 1), random right-hand side
+    rng = np.random.default_rng(5)
+    w = rng.uniform(0.05, 0.2, len(nb)) * (nb >= 0)
+    bh = rng.uniform(0.5, 2.0, n)
+    x0 = rng.uniform(1.0, 5.0, n)
+    sweeps = 3 * max(D, 1) + (0 if P == 1 else 0)
+    got, since = jacobi_through_plan(out, ptr, nb, w, bh, x0, sweeps)
+    assert P == 1 or since == 0
+    # global Jacobi with each row's neighbours summed in the order of the part that owns it (ascending local position there)
+    x = x0.copy()
+    order_of_row = {}
+    for p in range(P):
+        recs = out['recs'].reshape(P, 8, cap)[p]
+        for i in np.nonzero(kind[p] == 1)[0]:
+            order_of_row[int(gid[p][i])] = [int(recs[q][i]) for q in range(8) if recs[q][i] >= 0]
+    for _ in range(sweeps):
+        new = np.empty(n)
+        for c in range(n):
+            s = 0.0
+            for j in order_of_row[c]:
+                s = s + w[j] * x[nb[j]]
+            new[c] = bh[c] + s
+        x = new
+    assert np.array_equal(got, x)
