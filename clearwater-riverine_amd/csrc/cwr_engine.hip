@@ -345,7 +345,7 @@ struct cwr_engine {
                                      // (18 k cells: no faster than the multi-launch passes; 0 = meshes of up to 4 096 cells only)
   int32_t *d_small_send_pos = nullptr, *d_small_send_cnt = nullptr, *d_small_recv_src = nullptr, *d_small_recv_pos = nullptr, *d_small_recv_cnt = nullptr;
   double *d_small_pub = nullptr, *d_small_red = nullptr;
-  unsigned long long* d_small_arrive = nullptr;
+
   int nt_stream = 0;            // nt loads for the streamed operands (records, bhat/c2/r0): pays for wide rows only
   std::string err;
 
@@ -354,7 +354,9 @@ struct cwr_engine {
   double* bb() const { return d_scal + (size_t)3 * ACC_N * K + (size_t)3 * K; }
   size_t scal_count() const { return (size_t)3 * ACC_N * K + 3 * K + K; }
   // allocated / cleared size of d_scal (scalars + 8 counters + the precondition flag), a multiple of 256 bytes: ONE fill kernel per memset
-  size_t scal_alloc() const { return (scal_count() + 5 + 31) & ~(size_t)31; }
+  size_t scal_alloc() const { return (scal_count() + 5 + (size_t)K + 1 + 31) & ~(size_t)31; }
+  // (behind the flag: the K arrival counters and the abort word of k_small_jacobi's parts -- zeroed by the step's one memset)
+  unsigned long long* small_arrive() const { return reinterpret_cast<unsigned long long*>(d_scal + scal_count() + 5); }
   double* bad_flag() const { return d_scal + scal_count() + 4; }   // 1.0 when k_rhs met the zero-coefficient precondition (behind the 8 counters)
   bool ghost_bad_any = false;    // partitioned engines: some rank met it (all-reduced with the check scalars)
 };
@@ -1944,7 +1946,6 @@ int ensure_small_plan(cwr_engine* e) {
     const size_t K = (size_t)e->K;
     HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&e->d_small_pub), K * pl.P * 2 * pl.S * sizeof(double)));
     HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&e->d_small_red), K * pl.P * 2 * 4 * sizeof(double)));
-    HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&e->d_small_arrive), (K + 1) * sizeof(unsigned long long)));   // + the abort word
     HIP_TRY(e, hipMemset(e->d_small_pub, 0, K * pl.P * 2 * pl.S * sizeof(double)));
     HIP_TRY(e, hipMemset(e->d_small_red, 0, K * pl.P * 2 * 4 * sizeof(double)));
   }
@@ -1971,9 +1972,9 @@ int solve_small(cwr_engine* e, double tol2, int max_iter, bool forced, SolveStat
   SmallCoop co{};
   if (P > 1) {
     if ((long long)K * P > 128) return CWR_OK;   // a part that is not resident would be waited for: one workgroup per CU, half the chip at most
-    HIP_TRY(e, hipMemsetAsync(e->d_small_arrive, 0, ((size_t)K + 1) * sizeof(unsigned long long), e->stream));
+    // (the arrival counters and the abort word lie in the scalar block cwr_step zeroed at its start: no memset of their own)
     co = SmallCoop{P, e->small_D, e->small_S, e->small_R, e->d_small_send_pos, e->d_small_send_cnt, e->d_small_recv_src, e->d_small_recv_pos,
-                   e->d_small_recv_cnt, e->d_small_pub, e->d_small_red, e->d_small_arrive, reinterpret_cast<unsigned int*>(e->d_small_arrive + K),
+                   e->d_small_recv_cnt, e->d_small_pub, e->d_small_red, e->small_arrive(), reinterpret_cast<unsigned int*>(e->small_arrive() + K),
                    (long long)e->small_spin_ms * 100000ll};
   }
   const int limit = forced ? max_iter : std::min(max_iter, e->jacobi_limit);
@@ -2411,7 +2412,7 @@ void cwr_destroy(cwr_engine* e) {
   for (hipEvent_t ev : e->ev) hipEventDestroy(ev);
   void* ptrs[] = {e->d_f1, e->d_f2, e->d_ptr, e->d_ent_edge, e->d_ent_nb, e->d_adv, e->d_vel, e->d_vol, e->d_dif,
                   e->d_bc, e->d_rec, e->d_diag, e->d_c, e->d_r, e->d_r0, e->d_p, e->d_v, e->d_s, e->d_t, e->d_b,
-                  e->d_scal, e->d_partial, e->d_fadv, e->d_fdif, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf, e->d_ptr2, e->d_col2, e->d_row2, e->d_rec2, e->d_w, e->d_react, e->d_info, e->d_tcl_ptr, e->d_tcl_cols, e->d_loc2, e->d_w2, e->d_pair_ptr, e->d_slots, e->d_line_ptr, e->d_line_faces, e->d_ledger, e->d_mass_out, e->d_chk, e->d_face_orig, e->d_row_ghost, e->d_keep, e->d_in_rows, e->d_in_vals, e->d_face_pos, e->d_trow, e->d_vptr, e->d_meta, e->d_tile_inner, e->d_tile_outer, e->d_apply_inner, e->d_apply_outer, e->d_face_inner, e->d_face_outer, e->d_chkx, e->d_sq_fast, e->d_sched, e->d_link_ptr, e->d_link_ent, e->d_link_flux, e->d_scols, e->d_scols_io, e->sched_in.d, e->sched_out.d, e->d_small_rows, e->d_small_recs, e->d_small_offs, e->d_small_send_pos, e->d_small_send_cnt, e->d_small_recv_src, e->d_small_recv_pos, e->d_small_recv_cnt, e->d_small_pub, e->d_small_red, e->d_small_arrive};
+                  e->d_scal, e->d_partial, e->d_fadv, e->d_fdif, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf, e->d_ptr2, e->d_col2, e->d_row2, e->d_rec2, e->d_w, e->d_react, e->d_info, e->d_tcl_ptr, e->d_tcl_cols, e->d_loc2, e->d_w2, e->d_pair_ptr, e->d_slots, e->d_line_ptr, e->d_line_faces, e->d_ledger, e->d_mass_out, e->d_chk, e->d_face_orig, e->d_row_ghost, e->d_keep, e->d_in_rows, e->d_in_vals, e->d_face_pos, e->d_trow, e->d_vptr, e->d_meta, e->d_tile_inner, e->d_tile_outer, e->d_apply_inner, e->d_apply_outer, e->d_face_inner, e->d_face_outer, e->d_chkx, e->d_sq_fast, e->d_sched, e->d_link_ptr, e->d_link_ent, e->d_link_flux, e->d_scols, e->d_scols_io, e->sched_in.d, e->sched_out.d, e->d_small_rows, e->d_small_recs, e->d_small_offs, e->d_small_send_pos, e->d_small_send_cnt, e->d_small_recv_src, e->d_small_recv_pos, e->d_small_recv_cnt, e->d_small_pub, e->d_small_red};
   for (void* p : ptrs) if (p) hipFree(p);
   for (void* p : {(void*)e->d_in_f, (void*)e->d_flow_l, (void*)e->d_dist, (void*)e->d_jn, (void*)e->d_bad, (void*)e->d_wa, (void*)e->d_wb, (void*)e->d_wmax})
     if (p) hipFree(p);
