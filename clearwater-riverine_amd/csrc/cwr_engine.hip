@@ -1920,7 +1920,15 @@ int ensure_small_plan(cwr_engine* e) {
   if (e->small_planned) return CWR_OK;
   e->small_planned = true;
   host::SmallPlan pl;
-  if (!host::build_small_plan(e->n_owned, e->h_ptr, e->h_nb, SMALL_THREADS, 4, e->small_parts, e->small_depth, e->small_max_parts, pl)) {
+  // the deepest halo that fits: 12 layers on a band, fewer on a wide patch (whose breadth-first levels are long: the halo rows of
+  // 12 of them no longer fit beside a part's own) -- an exchange every 8, 6, 4 ... sweeps then (profiles/r05_mid_mesh.txt)
+  bool planned = false;
+  for (int depth : {e->small_depth, 8, 6, 4, 3, 2}) {
+    if (depth > e->small_depth) continue;
+    if (host::build_small_plan(e->n_owned, e->h_ptr, e->h_nb, SMALL_THREADS, 4, e->small_parts, depth, e->small_max_parts, pl)) { planned = true; break; }
+    if (e->n_owned <= 4 * SMALL_THREADS) break;  // (one workgroup: the depth plays no part)
+  }
+  if (!planned) {
     e->use_small = false;
     return CWR_OK;
   }

@@ -393,3 +393,64 @@ def test_meshes_without_a_plan_take_the_tiled_passes(gpu_lib, monkeypatch):
     for k in range(K):
         assert rel_err(got[:n, k], ref.constituent_dict[f'c{k}'].state[steps][:n]) <= TOL_CONC
     eng.close()
+
+
+@pytest.mark.mid_mesh_default
+def test_the_parts_exchange_correctly_while_another_engine_loads_the_chip(gpu_lib):
+    """The hand-off between the parts (sc1 stores / loads, an arrival counter) is the kind of code that passes on an idle chip and
+    fails under uneven load.  Two mid-size engines step in two threads while a 190 k-cell engine keeps every CU busy from a third:
+    their states must be the SAME BITS as when each ran alone (any stale halo value would change the Jacobi iterates)."""
+    import threading
+    import clearwater_riverine_amd as cw
+    K, steps = 4, 30
+    cases = [_mid_case(140, 70, K, steps, seed=91), _mid_case(128, 100, K, steps, seed=92)]
+    big = cw.synthetic.make_mesh(500, 400, 6, seed=8, n_merge=10000, dt=40.0, diffusion_coefficient=0.5)
+    oracle.derive_coefficients(big)
+    big_in = cw.synthetic.distinct_input_array(big, 8, seed=8)
+
+    def run(case, out, idx, stop=None):
+        mesh, inputs3 = case
+        n = mesh['nreal'] + 1
+        eng = make_engine(mesh, inputs3)
+        eng.set_state(inputs3[0, :n, :])
+        sw = []
+        for t in range(steps):
+            r = eng.step(t, tol=1e-12)
+            assert r.sweep_kernel == 7
+            sw.append(r.sweeps)
+        out[idx] = (sw, eng.get_state())
+        eng.close()
+
+    solo = {}
+    for i, c in enumerate(cases):
+        run(c, solo, i)
+    stop = threading.Event()
+    errors = []
+
+    def load():
+        try:
+            nb = big['nreal'] + 1
+            eng = make_engine(big, big_in)
+            while not stop.is_set():
+                eng.set_state(big_in[0, :nb, :])
+                for t in range(5):
+                    eng.step(t, tol=1e-12)
+            eng.close()
+        except Exception as exc:                      # pragma: no cover
+            errors.append(exc)
+
+    busy = {}
+    loader = threading.Thread(target=load)
+    loader.start()
+    try:
+        for rep in range(3):
+            th = [threading.Thread(target=run, args=(c, busy, (rep, i))) for i, c in enumerate(cases)]
+            for x in th: x.start()
+            for x in th: x.join()
+    finally:
+        stop.set(); loader.join()
+    assert not errors, errors
+    for rep in range(3):
+        for i in range(len(cases)):
+            assert busy[(rep, i)][0] == solo[i][0], (rep, i)
+            assert np.array_equal(busy[(rep, i)][1], solo[i][1], equal_nan=True), (rep, i)
