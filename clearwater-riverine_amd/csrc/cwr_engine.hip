@@ -1976,7 +1976,8 @@ int solve_small(cwr_engine* e, double tol2, int max_iter, bool forced, SolveStat
   const int rpt = e->small_rpt, P = e->small_P;
   if (!e->d_info) TRY(dev_alloc(e, &e->d_info, (size_t)5 * K));
   size_t lds = (2 * (size_t)rpt * SMALL_THREADS + 64) * sizeof(double);  // two columns + the scratch of block_reduce3 (3 x 16 wave results)
-  if (P > 1) lds = std::max(lds, (size_t)84 * 1024);                     // more than half a CU's LDS: one workgroup per CU (the hand-off's measured form)
+  if (P > 1) lds = std::max(lds + ((size_t)e->small_S + 2 * (size_t)e->small_R) * sizeof(int32_t),   // + the part's exchange lists
+                            (size_t)84 * 1024);                          // more than half a CU's LDS: one workgroup per CU (the hand-off's measured form)
   SmallCoop co{};
   if (P > 1) {
     if ((long long)K * P > 128) return CWR_OK;   // a part that is not resident would be waited for: one workgroup per CU, half the chip at most

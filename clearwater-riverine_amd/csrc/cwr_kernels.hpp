@@ -1863,6 +1863,18 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_small_jacobi(
   int dir = 0;                                   // the column holding the current iterate
   int xchg = 0;                                  // exchanges made (COOP)
   bool aborted = false;
+  // COOP: this part's exchange lists, copied into LDS once (behind the reduction scratch): an exchange then has no index load from
+  // global memory in front of its stores and loads (two dependent latencies of ~0.7 us each out of ~4 us per exchange)
+  int32_t* const s_send = reinterpret_cast<int32_t*>(s_red + 64);
+  int32_t* const s_rsrc = s_send + (COOP ? co.S : 0);
+  int32_t* const s_rpos = s_rsrc + (COOP ? co.R : 0);
+  if constexpr (COOP) {
+    for (int i = tid; i < co.send_cnt[part]; i += SMALL_THREADS) s_send[i] = co.send_pos[(size_t)part * co.S + i];
+    for (int i = tid; i < co.recv_cnt[part]; i += SMALL_THREADS) {
+      s_rsrc[i] = co.recv_src[(size_t)part * co.R + i];
+      s_rpos[i] = co.recv_pos[(size_t)part * co.R + i];
+    }
+  }                                              // (published by the barriers of block_sum(bb) below)
   // COOP: publish the own rows others hold as halo and this part's three numbers, wait for every part of the constituent, refresh
   // the halo rows of the current column, and combine the numbers (sum, max, max) in part order -- the same bits in every part.
   // Called by all threads, after a workgroup barrier that followed the column's last write (block_sum / block_reduce3 end in one).
@@ -1873,7 +1885,7 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_small_jacobi(
       double* mypub = co.pub + (((size_t)k * P + part) * 2 + par) * co.S;
       const int ns = co.send_cnt[part];
       for (int s2 = tid; s2 < ns; s2 += SMALL_THREADS)
-        __hip_atomic_store(mypub + s2, col[co.send_pos[(size_t)part * co.S + s2]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mypub + s2, col[s_send[s2]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (tid == 0) {
         double* myred = co.red + (((size_t)k * P + part) * 2 + par) * 4;
         __hip_atomic_store(myred + 0, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1903,7 +1915,7 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_small_jacobi(
       const int nr = co.recv_cnt[part];
       const double* kpub = co.pub + (size_t)k * P * 2 * co.S + (size_t)par * co.S;
       for (int r = tid; r < nr; r += SMALL_THREADS)
-        col[co.recv_pos[(size_t)part * co.R + r]] = __hip_atomic_load(kpub + co.recv_src[(size_t)part * co.R + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        col[s_rpos[r]] = __hip_atomic_load(kpub + s_rsrc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (wave == 0) {
         double ra = 0.0, rb = -INFINITY, rc = -INFINITY;
         if (lane < P) {
