@@ -1983,7 +1983,7 @@ int solve_small(cwr_engine* e, double tol2, int max_iter, bool forced, SolveStat
     if ((long long)K * P > 128) return CWR_OK;   // a part that is not resident would be waited for: one workgroup per CU, half the chip at most
     // (the arrival counters and the abort word lie in the scalar block cwr_step zeroed at its start: no memset of their own)
     co = SmallCoop{P, e->small_D, e->small_S, e->small_R, e->d_small_send_pos, e->d_small_send_cnt, e->d_small_recv_src, e->d_small_recv_pos,
-                   e->d_small_recv_cnt, e->d_small_pub, e->d_small_red, e->small_arrive(), reinterpret_cast<unsigned int*>(e->small_arrive() + K),
+                   e->d_small_recv_cnt, e->d_small_pub, e->d_small_red, e->small_arrive(),
                    (long long)e->small_spin_ms * 100000ll};
   }
   const int limit = forced ? max_iter : std::min(max_iter, e->jacobi_limit);
@@ -2337,7 +2337,7 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   if (const char* v = getenv("CWR_SMALL_DEPTH")) eng->small_depth = std::max(1, std::min(16, atoi(v)));
   if (const char* v = getenv("CWR_SMALL_MAX_PARTS")) eng->small_max_parts = std::max(1, std::min(16, atoi(v)));
   if (const char* v = getenv("CWR_SMALL_MAX_CELLS")) eng->small_max_cells = std::max(0, atoi(v));
-  if (const char* v = getenv("CWR_SMALL_SPIN_MS")) eng->small_spin_ms = std::max(1, atoi(v));
+  if (const char* v = getenv("CWR_SMALL_SPIN_MS")) eng->small_spin_ms = std::max(0, atoi(v));   // (0: a test's way to the abort path -- any part that has to wait at all gives up)
   if (const char* v = getenv("CWR_OUTPUT_DIRECT_MB")) eng->out_direct_limit = (size_t)std::max(0, atoi(v)) << 20;   // 0: always the copy engine
   if (const char* v = getenv("CWR_NO_FUSED_BEGIN")) eng->fused_begin = atoi(v) == 0;
   if (eng->use_note) {

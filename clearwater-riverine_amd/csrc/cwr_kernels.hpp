@@ -1757,16 +1757,16 @@ constexpr int SMALL_DEG = 8;                     // register-resident weights: r
 // agent-scope atomics), every storing wave waits vmcnt(0), workgroup barrier, ONE lane adds to the constituent's arrival counter
 // (agent scope), ONE lane polls it with sc1 loads, workgroup barrier, then the loads; one workgroup per CU (LDS request); two
 // publication buffers alternate, so a part one exchange ahead never overwrites what a neighbour still reads.  Every spin is
-// bounded: a part that waits longer than `spin_ticks` raises the abort word, every part leaves without touching x, and the
+// bounded: a part that waits longer than `spin_ticks` raises the abort bit of every counter, every part leaves without touching x, and the
 // host takes the multi-launch path (and stops using this one).
+constexpr unsigned long long SMALL_ABORT = 1ull << 62;
 struct SmallCoop {
   int P, D, S, R;
   const int32_t* send_pos; const int32_t* send_cnt;       // [P][S], [P]
   const int32_t* recv_src; const int32_t* recv_pos; const int32_t* recv_cnt;   // [P][R] (part * 2 S + slot), [P][R], [P]
   double* pub;                      // [K][P][2][S]
   double* red;                      // [K][P][2][4]
-  unsigned long long* arrive;       // [K], zero at launch
-  unsigned int* abort_word;         // zero at launch
+  unsigned long long* arrive;       // [K], zero at launch; bit 62 = abort
   long long spin_ticks;             // bound of a wait, in wall_clock64() ticks (100 MHz)
 };
 template <int RPT, bool COOP>
@@ -1898,17 +1898,17 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_small_jacobi(
         __hip_atomic_fetch_add(co.arrive + k, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long target = (unsigned long long)P * (unsigned long long)(xchg + 1);
         const long long t0 = wall_clock64();
-        double flag = 0.0;
-        for (;;) {
-          if (__hip_atomic_load(co.arrive + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
-          if (__hip_atomic_load(co.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { flag = 1.0; break; }
+        unsigned long long seen;
+        for (;;) {                                                // ONE load per poll: the abort travels in the counter's top bit
+          seen = __hip_atomic_load(co.arrive + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (seen >= target) break;
           if (wall_clock64() - t0 > co.spin_ticks) {              // a part never came (not resident?): everyone leaves
-            __hip_atomic_store(co.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            flag = 1.0; break;
+            for (int kk = 0; kk < K; ++kk) __hip_atomic_fetch_or(co.arrive + kk, SMALL_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            seen = SMALL_ABORT; break;
           }
           __builtin_amdgcn_s_sleep(1);
         }
-        s_red[56] = flag;
+        s_red[56] = seen >= SMALL_ABORT ? 1.0 : 0.0;
       }
       __syncthreads();
       if (s_red[56] != 0.0) { aborted = true; return; }

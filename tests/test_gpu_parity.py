@@ -454,3 +454,29 @@ def test_the_parts_exchange_correctly_while_another_engine_loads_the_chip(gpu_li
         for i in range(len(cases)):
             assert busy[(rep, i)][0] == solo[i][0], (rep, i)
             assert np.array_equal(busy[(rep, i)][1], solo[i][1], equal_nan=True), (rep, i)
+
+
+@pytest.mark.mid_mesh_default
+def test_a_part_that_gives_up_waiting_sends_the_engine_back_to_the_tiled_passes(gpu_lib, monkeypatch, capfd):
+    """Every wait of the one-launch solver's parts is bounded.  With the bound at zero (CWR_SMALL_SPIN_MS=0) the first part that has
+    to wait at all raises the abort bit: all parts leave without touching x, cwr_step solves the step with the tiled passes from the
+    same start, says so once on stderr, and the engine stays with them.  Same answer as the oracle."""
+    import clearwater_riverine_amd as cw
+    K, steps = 2, 3
+    mesh, inputs3 = _mid_case(140, 70, K, steps, seed=79)
+    n = mesh['nreal'] + 1
+    monkeypatch.setenv('CWR_SMALL_SPIN_MS', '0')
+    eng = make_engine(mesh, inputs3)
+    eng.set_state(inputs3[0, :n, :])
+    ref = oracle_run(mesh, inputs3, steps)
+    capfd.readouterr()
+    kernels = [eng.step(t, tol=1e-12).sweep_kernel for t in range(steps)]
+    err = capfd.readouterr().err
+    got = eng.get_state()
+    eng.close()
+    # (on an idle chip the parts may arrive so close together that nobody waits in the first exchanges of a step: the abort can
+    # come at any step -- but once it has come, every later step takes the passes)
+    assert 6 in kernels and kernels == sorted(kernels, reverse=True), kernels
+    assert err.count('did not all arrive') == 1, err
+    for k in range(K):
+        assert rel_err(got[:n, k], ref.constituent_dict[f'c{k}'].state[steps][:n]) <= TOL_CONC
