@@ -144,6 +144,8 @@ struct cwr_engine {
   // (round 5) the check scalars of a single engine reach the host without a copy and without draining the stream: k_reduce_partials
   // stores them into this page-locked buffer and publishes a sequence number behind them (ReduceNote); the host spins on it
   double* h_note = nullptr;        // [5 K] doubles + the sequence word (hipHostMalloc, mapped)
+  double* h_notex = nullptr;       // partitioned engines: the all-reduced check block [(2 + 2 world) K + 1] (hipHostMalloc, mapped)
+  double* d_notex_view = nullptr;
   double* d_note_view = nullptr;   // the device's address of h_note
   unsigned long long* h_note_seq = nullptr;
   unsigned long long* d_note_state = nullptr;   // device: [0] the sequence counter, [1] (as unsigned int) the arrival counter
@@ -618,7 +620,7 @@ bool check_by_note(const cwr_engine* e) { return e->use_note && e->h_note && (!e
 // Wait for the `note_expected`-th notification of k_reduce_partials and take the check scalars from the host buffer.  The host
 // spins on a word of page-locked memory: no copy is enqueued and the stream is not drained -- whatever was enqueued BEHIND the
 // reduction (the step's speculative tail) runs on while the host already decides and enqueues the next step.
-int wait_check_note(cwr_engine* e, double* h, size_t count = 0) {
+int wait_check_note(cwr_engine* e, double* h, size_t count = 0, const double* from = nullptr) {
   const unsigned long long want = e->note_expected;
   for (unsigned long long spin = 1;; ++spin) {
     if (__atomic_load_n(e->h_note_seq, __ATOMIC_ACQUIRE) >= want) break;
@@ -636,7 +638,7 @@ int wait_check_note(cwr_engine* e, double* h, size_t count = 0) {
       }
     }
   }
-  std::memcpy(h, e->h_note, (count ? count : 4 * (size_t)e->K) * sizeof(double));
+  std::memcpy(h, from ? from : e->h_note, (count ? count : 4 * (size_t)e->K) * sizeof(double));
   return CWR_OK;
 }
 
@@ -653,13 +655,21 @@ int gather_check(cwr_engine* e, double* h, bool noted = false) {
   // check it downloads anyway -- the step used to end with a second, blocking download of the rank's own counters, which also
   // waited for the speculative tail behind the check)
   const size_t W = (size_t)e->world, n = 2 * K + W * 2 * K + 1;
-  HIP_TRY(e, hipMemsetAsync(e->d_chkx, 0, n * sizeof(double), e->stream));
-  HIP_TRY(e, hipMemcpyAsync(e->d_chkx, e->d_chk, 2 * K * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
-  HIP_TRY(e, hipMemcpyAsync(e->d_chkx + 2 * K + (size_t)e->rank * 2 * K, e->d_chk + 2 * K, 2 * K * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
-  HIP_TRY(e, hipMemcpyAsync(e->d_chkx + n - 1, e->bad_flag(), sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+  // (round 5) one launch lays the block out (a memset and three copies before), and the all-reduced block reaches the host through
+  // page-locked memory and a sequence word, as a single engine's check does: no copy, the stream not drained -- the stand-alone
+  // rank budgets of profiles/r05_rank_budget.txt were measured that way, so a rank of a real run has to do the same
+  k_pack_check<<<1, 256, 0, e->stream>>>((int)n, (int)K, e->rank, e->d_chk, e->bad_flag(), e->d_chkx);
+  HIP_TRY(e, hipGetLastError());
   TRY(allreduce(e, e->d_chkx, n));
   std::vector<double> all(n);
-  TRY(download(e, all.data(), e->d_chkx, n));
+  if (e->use_note && e->h_notex && e->h_note_seq) {
+    k_note_out<<<1, 256, 0, e->stream>>>((int)n, e->d_chkx, e->d_notex_view, reinterpret_cast<unsigned long long*>(e->d_note_view + 5 * K), e->d_note_state);
+    HIP_TRY(e, hipGetLastError());
+    ++e->note_expected;
+    TRY(wait_check_note(e, all.data(), n, e->h_notex));
+  } else {
+    TRY(download(e, all.data(), e->d_chkx, n));
+  }
   e->ghost_bad_any = all[n - 1] > 0.0;
   for (size_t k = 0; k < 2 * K; ++k) h[k] = all[k];
   for (size_t k = 0; k < 2 * K; ++k) {
@@ -2431,6 +2441,7 @@ void cwr_destroy(cwr_engine* e) {
   if (e->ev_evict) hipEventDestroy(e->ev_evict);
   if (e->d_note_state) hipFree(e->d_note_state);
   if (e->h_note) hipHostFree(e->h_note);
+  if (e->h_notex) hipHostFree(e->h_notex);
   if (e->stream) hipStreamDestroy(e->stream);
   delete e;
 }
@@ -3399,6 +3410,17 @@ int32_t cwr_attach_comm(cwr_engine* e, int32_t rank, int32_t world, const uint8_
   TRY(upload(e, e->d_send_cells, send_cells, (size_t)n_send));
   TRY(upload(e, e->d_recv_cells, recv_cells, (size_t)n_recv));
   TRY(dev_alloc(e, &e->d_chkx, (size_t)(2 + 2 * world) * e->K + 1));
+  if (e->h_note && !e->h_notex) {                // (the check block's way to the host without a copy: gather_check)
+    void* hp = nullptr; void* dp = nullptr;
+    const size_t bytes = ((size_t)(2 + 2 * world) * e->K + 1) * sizeof(double);
+    if (hipHostMalloc(&hp, bytes, hipHostMallocMapped) == hipSuccess && hp && hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess && dp) {
+      std::memset(hp, 0, bytes);
+      e->h_notex = static_cast<double*>(hp); e->d_notex_view = static_cast<double*>(dp);
+    } else {
+      if (hp) (void)hipHostFree(hp);
+      (void)hipGetLastError();
+    }
+  }
   if (const char* v = getenv("CWR_NO_OVERLAP")) e->overlap = atoi(v) == 0;
   if (const char* v = getenv("CWR_TEST_POISON_HALO")) e->test_poison_halo = atoi(v) != 0;
   if (const char* v = getenv("CWR_OVERLAP_RESERVE")) e->overlap_reserve = std::max(0, atoi(v)) / N_XCD * N_XCD;

@@ -192,6 +192,33 @@ struct ReduceOuts { double* p[4]; };
 // (system-scope release), and the host spins on that word.  The sequence lives in device memory (dev_seq) because these launches
 // are captured into hipGraphs: a by-value argument would freeze it.  All null: no notification.
 struct ReduceNote { double* host_out; unsigned long long* host_seq; unsigned int* arrive; unsigned long long* dev_seq; };
+// Partitioned engines: the check scalars of this rank laid out for the ONE all-reduce (sum) of a check -- [rr | bb] to be added,
+// [m1 | m2] in the rank's own slot of a (world x 2K) block that is zero elsewhere, the zero-coefficient flag last -- in one launch
+// (round 5; a memset and three device-to-device copies before).
+__global__ void __launch_bounds__(256) k_pack_check(int n, int K, int rank, const double* __restrict__ chk, const double* __restrict__ flag,
+                                                    double* __restrict__ out) {
+  const int lo = 2 * K + rank * 2 * K;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    double v = 0.0;
+    if (i < 2 * K) v = chk[i];
+    else if (i >= lo && i < lo + 2 * K) v = chk[2 * K + (i - lo)];
+    else if (i == n - 1) v = *flag;
+    out[i] = v;
+  }
+}
+// ... and the all-reduced block written to page-locked host memory with a sequence word behind it: the host spins on the word
+// instead of enqueueing a copy and draining the stream (as k_reduce_partials does for a single engine).
+__global__ void __launch_bounds__(256) k_note_out(int n, const double* __restrict__ src, double* __restrict__ host_out,
+                                                  unsigned long long* __restrict__ host_seq, unsigned long long* __restrict__ dev_seq) {
+  for (int i = threadIdx.x; i < n; i += 256) host_out[i] = src[i];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long sq = *dev_seq + 1ull;
+    *dev_seq = sq;
+    __hip_atomic_store(host_seq, sq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
 constexpr int RBLOCK = 1024;
 __global__ void __launch_bounds__(RBLOCK) k_reduce_partials(int nslots, int ND, int K, const double* __restrict__ partial,
                                                           ReduceOuts outs, int max_from, ReduceNote note) {
