@@ -476,7 +476,9 @@ def test_a_part_that_gives_up_waiting_sends_the_engine_back_to_the_tiled_passes(
     eng.close()
     # (on an idle chip the parts may arrive so close together that nobody waits in the first exchanges of a step: the abort can
     # come at any step -- but once it has come, every later step takes the passes)
-    assert 6 in kernels and kernels == sorted(kernels, reverse=True), kernels
-    assert err.count('did not all arrive') == 1, err
+    assert kernels == sorted(kernels, reverse=True), kernels
+    assert err.count('did not all arrive') == (1 if 6 in kernels else 0), err
+    if 6 not in kernels:                                         # pragma: no cover  (every part arrived within one poll of the last, 60 times)
+        pytest.skip('no part ever had to wait: the abort path was not taken in this run')
     for k in range(K):
         assert rel_err(got[:n, k], ref.constituent_dict[f'c{k}'].state[steps][:n]) <= TOL_CONC
