@@ -1998,7 +1998,7 @@ int solve_small(cwr_engine* e, double tol2, int max_iter, bool forced, SolveStat
   }
   const int limit = forced ? max_iter : std::min(max_iter, e->jacobi_limit);
   // (round 5) the five numbers per constituent reach the host through the notification buffer of the sweeps' check: no download,
-  // and -- what counts at 0.35 ms per step -- no copy's round trip behind the one launch
+  // and -- what counts at 0.2-0.35 ms per step -- no copy's round trip behind the one launch
   const bool noted = check_by_note(e);
   ReduceNote note{nullptr, nullptr, nullptr, nullptr};
   if (noted) note = ReduceNote{e->d_note_view, reinterpret_cast<unsigned long long*>(e->d_note_view + 5 * (size_t)K),
