@@ -343,6 +343,7 @@ struct cwr_engine {
                                      // (profiles/r05_mid_mesh.txt: an exchange costs ~4 us, a sweep ~1.1: 10 k x 12 0.54 / 0.44 / 0.41 ms per step at 4 / 8 / 12)
   int small_max_parts = 8;           // CWR_SMALL_MAX_PARTS
   int small_spin_ms = 500;           // CWR_SMALL_SPIN_MS: bound of a part's wait for the others
+  int small_fences = 1;              // CWR_SMALL_FENCES=0: the parts' hand-off without the agent-scope release / acquire pair (sc1 accesses only)
   int small_max_cells = 16384;       // CWR_SMALL_MAX_CELLS: meshes up to this size may take the one-launch solver with several parts
                                      // (18 k cells: no faster than the multi-launch passes; 0 = meshes of up to 4 096 cells only)
   int32_t *d_small_send_pos = nullptr, *d_small_send_cnt = nullptr, *d_small_recv_src = nullptr, *d_small_recv_pos = nullptr, *d_small_recv_cnt = nullptr;
@@ -1964,8 +1965,11 @@ int ensure_small_plan(cwr_engine* e) {
     const size_t K = (size_t)e->K;
     HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&e->d_small_pub), K * pl.P * 2 * pl.S * sizeof(double)));
     HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&e->d_small_red), K * pl.P * 2 * 4 * sizeof(double)));
-    HIP_TRY(e, hipMemset(e->d_small_pub, 0, K * pl.P * 2 * pl.S * sizeof(double)));
-    HIP_TRY(e, hipMemset(e->d_small_red, 0, K * pl.P * 2 * 4 * sizeof(double)));
+    // (ON THE ENGINE'S STREAM: a hipMemset goes to the null stream, which this non-blocking stream does not wait for -- under load it
+    // ran after the first launch had begun and zeroed values between a part's store and its neighbour's load: the one failure of
+    // test_the_parts_exchange_correctly_while_another_engine_loads_the_chip, 2 runs in 14, found by that test)
+    HIP_TRY(e, hipMemsetAsync(e->d_small_pub, 0, K * pl.P * 2 * pl.S * sizeof(double), e->stream));
+    HIP_TRY(e, hipMemsetAsync(e->d_small_red, 0, K * pl.P * 2 * 4 * sizeof(double), e->stream));
   }
   return CWR_OK;
 }
@@ -1994,7 +1998,7 @@ int solve_small(cwr_engine* e, double tol2, int max_iter, bool forced, SolveStat
     // (the arrival counters and the abort word lie in the scalar block cwr_step zeroed at its start: no memset of their own)
     co = SmallCoop{P, e->small_D, e->small_S, e->small_R, e->d_small_send_pos, e->d_small_send_cnt, e->d_small_recv_src, e->d_small_recv_pos,
                    e->d_small_recv_cnt, e->d_small_pub, e->d_small_red, e->small_arrive(),
-                   (long long)e->small_spin_ms * 100000ll};
+                   (long long)e->small_spin_ms * 100000ll, e->small_fences};
   }
   const int limit = forced ? max_iter : std::min(max_iter, e->jacobi_limit);
   // (round 5) the five numbers per constituent reach the host through the notification buffer of the sweeps' check: no download,
@@ -2339,7 +2343,7 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   CREATE_TRY(dev_alloc(eng, &eng->d_diag, (size_t)n_owned));
   CREATE_TRY(dev_alloc(eng, &eng->d_w, (size_t)nnz + SQN_PAD));
   CREATE_TRY(dev_alloc(eng, &eng->d_chk, 4 * (size_t)K + 2));      // (+ ew_rel, read by k_apply MODE 4)
-  CREATE_HIP(hipMemset(eng->d_chk, 0, (4 * (size_t)K + 2) * sizeof(double)));
+  CREATE_HIP(hipMemsetAsync(eng->d_chk, 0, (4 * (size_t)K + 2) * sizeof(double), eng->stream));   // (stream-ordered: see ensure_small_plan)
   CREATE_TRY(dev_alloc(eng, &eng->d_keep, (size_t)n_cells * K));
   if (const char* v = getenv("CWR_TEST_FIXED_SWEEPS")) eng->fixed_sweeps = std::max(0, atoi(v));
   if (const char* v = getenv("CWR_NO_NOTE")) eng->use_note = atoi(v) == 0;
@@ -2347,6 +2351,7 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   if (const char* v = getenv("CWR_SMALL_DEPTH")) eng->small_depth = std::max(1, std::min(16, atoi(v)));
   if (const char* v = getenv("CWR_SMALL_MAX_PARTS")) eng->small_max_parts = std::max(1, std::min(16, atoi(v)));
   if (const char* v = getenv("CWR_SMALL_MAX_CELLS")) eng->small_max_cells = std::max(0, atoi(v));
+  if (const char* v = getenv("CWR_SMALL_FENCES")) eng->small_fences = atoi(v) != 0;
   if (const char* v = getenv("CWR_SMALL_SPIN_MS")) eng->small_spin_ms = std::max(0, atoi(v));   // (0: a test's way to the abort path -- any part that has to wait at all gives up)
   if (const char* v = getenv("CWR_OUTPUT_DIRECT_MB")) eng->out_direct_limit = (size_t)std::max(0, atoi(v)) << 20;   // 0: always the copy engine
   if (const char* v = getenv("CWR_NO_FUSED_BEGIN")) eng->fused_begin = atoi(v) == 0;
@@ -2361,7 +2366,7 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
       eng->h_note_seq = reinterpret_cast<unsigned long long*>(eng->h_note + 5 * (size_t)K);
       eng->d_note_view = static_cast<double*>(dp);                 // (the same address on this platform; asked for, not assumed)
       CREATE_TRY(dev_alloc(eng, &eng->d_note_state, 2));
-      CREATE_HIP(hipMemset(eng->d_note_state, 0, 2 * sizeof(unsigned long long)));
+      CREATE_HIP(hipMemsetAsync(eng->d_note_state, 0, 2 * sizeof(unsigned long long), eng->stream));
     } else (void)hipGetLastError();
   }
   if (const char* v = getenv("CWR_NO_ELEMENTWISE")) eng->ew_enabled = atoi(v) == 0;

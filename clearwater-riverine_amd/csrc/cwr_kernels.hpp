@@ -1820,6 +1820,7 @@ struct SmallCoop {
   double* red;                      // [K][P][2][4]
   unsigned long long* arrive;       // [K], zero at launch; bit 62 = abort
   long long spin_ticks;             // bound of a wait, in wall_clock64() ticks (100 MHz)
+  int fences;                       // 1: an agent-scope release in front of the arrival and an acquire behind the poll (see sync_exchange)
 };
 template <int RPT, bool COOP>
 __global__ void __launch_bounds__(SMALL_THREADS) k_small_jacobi(
@@ -1947,6 +1948,10 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_small_jacobi(
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave, before the barrier its signalling lane joins
       __syncthreads();
       if (tid == 0) {
+        if (co.fences) {                                        // (every wave's stores are drained: ONE lane's release covers the workgroup)
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (ROCm 7.2 can drop the fence's own wait: keep this one, in this order)
+        }
         __hip_atomic_fetch_add(co.arrive + k, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long target = (unsigned long long)P * (unsigned long long)(xchg + 1);
         const long long t0 = wall_clock64();
@@ -1959,6 +1964,10 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_small_jacobi(
             seen = SMALL_ABORT; break;
           }
           __builtin_amdgcn_s_sleep(1);
+        }
+        if (co.fences) {                                        // ONE acquire after the match, waited for before the barrier the loads follow
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         s_red[56] = seen >= SMALL_ABORT ? 1.0 : 0.0;
       }
