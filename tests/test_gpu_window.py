@@ -159,3 +159,40 @@ def test_facade_flow_window_keyword_and_automatic_choice(gpu_lib, monkeypatch):
             assert np.array_equal(models['resident'].constituent_dict[nm].total_mass_flux, models[label].constituent_dict[nm].total_mass_flux, equal_nan=True)
     for mdl in models.values():
         mdl.close_output(); mdl.engine.close()
+
+
+def test_window_refills_beside_a_busy_chip_equal_the_resident_run_bit_for_bit(gpu_lib):
+    """The ring's refills run on a stream of their own, ordered with the steps by events only -- the kind of code that holds on an
+    idle chip and breaks under load.  The 190 k-cell comparison again (one level per step through W = 8) while a second engine in
+    another thread keeps the CUs and the copy engines busy (steps + state uploads)."""
+    import threading
+    import clearwater_riverine_amd as cw
+    steps = 39
+    mesh = cw.synthetic.make_mesh(500, 400, steps, seed=8, n_merge=10000, dt=40.0, diffusion_coefficient=0.5)
+    oracle.derive_coefficients(mesh)
+    inputs3 = cw.synthetic.distinct_input_array(mesh, 4, seed=8)
+    other = cw.synthetic.make_mesh(300, 300, 4, seed=9, n_merge=2000, dt=40.0, diffusion_coefficient=0.5)
+    oracle.derive_coefficients(other)
+    other_in = cw.synthetic.distinct_input_array(other, 8, seed=9)
+    stop = threading.Event()
+    errors = []
+
+    def load():
+        try:
+            n = other['nreal'] + 1
+            eng = make_engine(other, other_in)
+            while not stop.is_set():
+                eng.set_state(other_in[0, :n, :])
+                for t in range(3):
+                    eng.step(t, tol=1e-12)
+            eng.close()
+        except Exception as exc:                      # pragma: no cover
+            errors.append(exc)
+
+    th = threading.Thread(target=load)
+    th.start()
+    try:
+        run_pair(mesh, inputs3, 8, steps, check_every=6)
+    finally:
+        stop.set(); th.join()
+    assert not errors, errors
