@@ -219,3 +219,56 @@ def test_snapshots_written_in_place_equal_those_of_the_copy_engine(gpu_lib, monk
             assert np.array_equal(a, b, equal_nan=True)
         adv, dif, tot = hist['in place'][1][nm]
         assert np.array_equal(tot[:steps], adv[:steps] + dif[:steps], equal_nan=True)
+
+
+def test_facade_histories_beside_a_busy_chip_equal_those_of_a_quiet_run(gpu_lib):
+    """The facade's per-step read-out (snapshots written in place into page-locked rows, completion by an event) and the engine's
+    copy-free convergence check (results noted to page-locked memory behind a sequence word), with another engine keeping the CUs and
+    the copy engines busy from a second thread: the same histories bit for bit as alone."""
+    import threading
+    import clearwater_riverine_amd as cw
+    from test_gpu_parity import make_engine
+    K, steps = 3, 25
+    mesh = cw.synthetic.make_mesh(109, 28, steps, seed=20100529 % 1000, n_merge=109, dx=75.0, dy=75.0, dt=3600.0, velocity=0.4, diffusion_coefficient=0.1,
+                                  period_steps=24)
+    inputs3 = cw.synthetic.boundary_input_array(mesh, K, inlet_period_s=24 * 3600.0)
+    other = cw.synthetic.make_mesh(300, 300, 4, seed=9, n_merge=2000, dt=40.0, diffusion_coefficient=0.5)
+    oracle.derive_coefficients(other)
+    other_in = cw.synthetic.distinct_input_array(other, 8, seed=9)
+
+    def history():
+        mdl = cw.ClearwaterRiverine(mesh=dict(mesh), input_arrays={f'c{k}': inputs3[:, :, k].copy() for k in range(K)})
+        for _ in range(steps):
+            mdl.update()
+        out = ([np.array(mdl.mesh[nm]) for nm in mdl.constituents],
+               [np.array(mdl.constituent_dict[nm].total_mass_flux) for nm in mdl.constituents])
+        mdl.close_output(); mdl.engine.close()
+        return out
+
+    quiet = history()
+    stop = threading.Event()
+    errors = []
+
+    def load():
+        try:
+            n = other['nreal'] + 1
+            eng = make_engine(other, other_in)
+            while not stop.is_set():
+                eng.set_state(other_in[0, :n, :])
+                for t in range(3):
+                    eng.step(t, tol=1e-12)
+                eng.get_state()
+            eng.close()
+        except Exception as exc:                      # pragma: no cover
+            errors.append(exc)
+
+    th = threading.Thread(target=load)
+    th.start()
+    try:
+        busy = [history() for _ in range(3)]
+    finally:
+        stop.set(); th.join()
+    assert not errors, errors
+    for run in busy:
+        for a, b in zip(run[0] + run[1], quiet[0] + quiet[1]):
+            assert np.array_equal(a, b, equal_nan=True)
