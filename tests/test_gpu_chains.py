@@ -333,3 +333,57 @@ def test_chained_passes_on_a_meander_follow_the_channel(gpu_lib, monkeypatch):
         sweeps[kind] = sum(r.sweeps for r in rs)
         pt.engine.close()
     assert sweeps['auto'] < sweeps['straight'], sweeps
+
+
+@pytest.mark.parametrize('K', [4, 16])
+def test_deterministic_chained_steps_beside_a_busy_chip_repeat_the_quiet_run_bit_for_bit(gpu_lib, K):
+    """A 190 k-cell engine (chained passes walked between two vectors, graph replays, the speculative tail behind the copy-free check)
+    stepping with deterministic=True while a second engine in another thread keeps the chip busy: the same sweep counts and bits as
+    alone.  (Ordering bugs between streams, events and page-locked notifications hide on an idle chip.)"""
+    import threading
+    import clearwater_riverine_amd as cw
+    from test_gpu_parity import make_engine
+    steps = 8
+    mesh = cw.synthetic.make_mesh(500, 400, steps, seed=8, n_merge=10000, dt=40.0, diffusion_coefficient=0.5)
+    oracle.derive_coefficients(mesh)
+    inputs3 = cw.synthetic.distinct_input_array(mesh, K, seed=8)
+    other = cw.synthetic.make_mesh(300, 300, 4, seed=9, n_merge=2000, dt=40.0, diffusion_coefficient=0.5)
+    oracle.derive_coefficients(other)
+    other_in = cw.synthetic.distinct_input_array(other, 8, seed=9)
+    n = mesh['nreal'] + 1
+
+    def run():
+        eng = make_engine(mesh, inputs3)
+        eng.set_state(inputs3[0, :n, :])
+        sw = [eng.step(t, tol=1e-12, deterministic=True).sweeps for t in range(steps)]
+        out = (sw, eng.get_state(), eng.get_mass_flux()[0])
+        eng.close()
+        return out
+
+    quiet = run()
+    stop = threading.Event()
+    errors = []
+
+    def load():
+        try:
+            m = other['nreal'] + 1
+            eng = make_engine(other, other_in)
+            while not stop.is_set():
+                eng.set_state(other_in[0, :m, :])
+                for t in range(3):
+                    eng.step(t, tol=1e-12)
+                eng.get_state()
+            eng.close()
+        except Exception as exc:                      # pragma: no cover
+            errors.append(exc)
+
+    th = threading.Thread(target=load)
+    th.start()
+    try:
+        busy = [run() for _ in range(2)]
+    finally:
+        stop.set(); th.join()
+    assert not errors, errors
+    for b in busy:
+        assert b[0] == quiet[0]
+        assert np.array_equal(b[1], quiet[1], equal_nan=True) and np.array_equal(b[2], quiet[2], equal_nan=True)
