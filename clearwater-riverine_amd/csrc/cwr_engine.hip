@@ -343,6 +343,8 @@ struct cwr_engine {
                                      // (profiles/r05_mid_mesh.txt: an exchange costs ~4 us, a sweep ~1.1: 10 k x 12 0.54 / 0.44 / 0.41 ms per step at 4 / 8 / 12)
   int small_max_parts = 8;           // CWR_SMALL_MAX_PARTS
   int small_spin_ms = 500;           // CWR_SMALL_SPIN_MS: bound of a part's wait for the others
+  int small_last_sweeps = 0;         // sweeps of the last step through k_small_jacobi (0: none, or it did not converge)
+  bool small_first_check = true;     // CWR_SMALL_FIRST_CHECK=0: convergence checks from the first sweeps on
   int small_fences = 1;              // CWR_SMALL_FENCES=0: the parts' hand-off without the agent-scope release / acquire pair (sc1 accesses only)
   int small_max_cells = 16384;       // CWR_SMALL_MAX_CELLS: meshes up to this size may take the one-launch solver with several parts
                                      // (18 k cells: no faster than the multi-launch passes; 0 = meshes of up to 4 096 cells only)
@@ -2007,12 +2009,16 @@ int solve_small(cwr_engine* e, double tol2, int max_iter, bool forced, SolveStat
   ReduceNote note{nullptr, nullptr, nullptr, nullptr};
   if (noted) note = ReduceNote{e->d_note_view, reinterpret_cast<unsigned long long*>(e->d_note_view + 5 * (size_t)K),
                                reinterpret_cast<unsigned int*>(e->d_note_state + 1), e->d_note_state};
+  // one workgroup per constituent: no convergence check (two barriers and a reduction each, every fourth sweep) before three
+  // quarters of the sweeps the last step took -- the step before is the best guess there is, and a step that needs fewer only
+  // sweeps on to that point (CWR_SMALL_FIRST_CHECK=0: check from the start)
+  const int first_check = (P == 1 && e->small_first_check && !forced) ? (e->small_last_sweeps * 3 / 4) / 4 * 4 : 0;
 #define CWR_SMALL(RPTv, COOPv) do {                                                                                   \
     static bool attr_done = false;                                                                                    \
     if (!attr_done) { HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_small_jacobi<RPTv, COOPv>),     \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_done = true; }        \
     k_small_jacobi<RPTv, COOPv><<<K * P, SMALL_THREADS, lds, e->stream>>>(n, K, e->d_small_rows, e->d_small_recs, e->d_small_offs, e->d_rec, \
-        e->d_diag, e->d_b, e->d_c, tol2, e->ew_enabled ? e->ew_rel : 1.0, e->ew_enabled ? e->ew_abs : 1.0, limit, 4, e->d_info, note, co); } while (0)
+        e->d_diag, e->d_b, e->d_c, tol2, e->ew_enabled ? e->ew_rel : 1.0, e->ew_enabled ? e->ew_abs : 1.0, limit, 4, e->d_info, note, co, first_check); } while (0)
   if (P == 1) {
     if (rpt == 1) CWR_SMALL(1, false);
     else if (rpt == 2) CWR_SMALL(2, false);
@@ -2052,6 +2058,7 @@ int solve_small(cwr_engine* e, double tol2, int max_iter, bool forced, SolveStat
     if (e->ew_enabled && h[5 * k + 3] > e->ew_abs * h[5 * k + 4]) ok = false;      // element-wise rule (see k_apply MODE 4)
   }
   st.sweeps += sweeps;
+  e->small_last_sweeps = ok ? sweeps : 0;
   if (!ok) {
     // sweeps exhausted: the reference's direct solve has no such outcome, so unless the caller forced the sweeps
     // BiCGSTAB continues from the current iterate (as solve_jacobi does)
@@ -2351,6 +2358,7 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   if (const char* v = getenv("CWR_SMALL_DEPTH")) eng->small_depth = std::max(1, std::min(16, atoi(v)));
   if (const char* v = getenv("CWR_SMALL_MAX_PARTS")) eng->small_max_parts = std::max(1, std::min(16, atoi(v)));
   if (const char* v = getenv("CWR_SMALL_MAX_CELLS")) eng->small_max_cells = std::max(0, atoi(v));
+  if (const char* v = getenv("CWR_SMALL_FIRST_CHECK")) eng->small_first_check = atoi(v) != 0;
   if (const char* v = getenv("CWR_SMALL_FENCES")) eng->small_fences = atoi(v) != 0;
   if (const char* v = getenv("CWR_SMALL_SPIN_MS")) eng->small_spin_ms = std::max(0, atoi(v));   // (0: a test's way to the abort path -- any part that has to wait at all gives up)
   if (const char* v = getenv("CWR_OUTPUT_DIRECT_MB")) eng->out_direct_limit = (size_t)std::max(0, atoi(v)) << 20;   // 0: always the copy engine

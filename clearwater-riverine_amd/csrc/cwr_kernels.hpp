@@ -1829,7 +1829,7 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_small_jacobi(
     const double* __restrict__ diag, const double* __restrict__ bhat, double* __restrict__ x, double tol2, double ew_rel, double ew_abs,
     int max_sweeps, int check_every, double* __restrict__ info /* [K][5]: sweeps, ||x'-x||^2, ||bhat||^2, max(|dx| - ew_rel |x'|), max |x'| */,
     ReduceNote note /* (round 5) the same five numbers per constituent into page-locked host memory + a sequence word: no download */,
-    SmallCoop co) {
+    SmallCoop co, int first_check /* no check before this sweep (the host's guess from the last step: a check is two barriers) */) {
   extern __shared__ double s_x[];                // two columns of RPT x 1024 doubles (compile-time stride: the column a sweep
   constexpr int COL = RPT * SMALL_THREADS;       // reads or writes is an immediate offset of its LDS instructions), then scratch
   double* s_red = s_x + 2 * COL;
@@ -2060,7 +2060,7 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_small_jacobi(
     sweep_once(std::false_type{}, dx2, e1, e2);
     ++sweep; ++since;
     // COOP: the halo layers carry co.D sweeps; the check rides on the exchange
-    const bool check = (COOP ? since >= co.D : (sweep % check_every == 0)) || sweep >= max_sweeps;
+    const bool check = (COOP ? since >= co.D : (sweep >= first_check && sweep % check_every == 0)) || sweep >= max_sweeps;
     if (check) {                                 // uniform
       rr = block_sum(dx2);                       // (its barriers also publish the new column)
       if constexpr (COOP) { double u = -INFINITY, v = -INFINITY; sync_exchange(rr, u, v); since = 0; if (aborted) break; }
