@@ -2060,7 +2060,8 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_small_jacobi(
     sweep_once(std::false_type{}, dx2, e1, e2);
     ++sweep; ++since;
     // COOP: the halo layers carry co.D sweeps; the check rides on the exchange
-    const bool check = (COOP ? since >= co.D : (sweep >= first_check && sweep % check_every == 0)) || sweep >= max_sweeps;
+    // (check_every is 4 wherever the kernel is launched: a mask, not a division by a run-time value every sweep)
+    const bool check = (COOP ? since >= co.D : (sweep >= first_check && (check_every == 4 ? (sweep & 3) == 0 : sweep % check_every == 0))) || sweep >= max_sweeps;
     if (check) {                                 // uniform
       rr = block_sum(dx2);                       // (its barriers also publish the new column)
       if constexpr (COOP) { double u = -INFINITY, v = -INFINITY; sync_exchange(rr, u, v); since = 0; if (aborted) break; }
