@@ -2012,7 +2012,8 @@ int solve_small(cwr_engine* e, double tol2, int max_iter, bool forced, SolveStat
   // one workgroup per constituent: no convergence check (two barriers and a reduction each, every fourth sweep) before three
   // quarters of the sweeps the last step took -- the step before is the best guess there is, and a step that needs fewer only
   // sweeps on to that point (CWR_SMALL_FIRST_CHECK=0: check from the start)
-  const int first_check = (P == 1 && e->small_first_check && !forced) ? (e->small_last_sweeps * 3 / 4) / 4 * 4 : 0;
+  // (several parts: the exchanges before that point carry the halo rows only -- no block reduction, no partial norms)
+  const int first_check = (e->small_first_check && !forced) ? (e->small_last_sweeps * 3 / 4) / 4 * 4 : 0;
 #define CWR_SMALL(RPTv, COOPv) do {                                                                                   \
     static bool attr_done = false;                                                                                    \
     if (!attr_done) { HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_small_jacobi<RPTv, COOPv>),     \

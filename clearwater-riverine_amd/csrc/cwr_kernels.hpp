@@ -1931,7 +1931,7 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_small_jacobi(
   // COOP: publish the own rows others hold as halo and this part's three numbers, wait for every part of the constituent, refresh
   // the halo rows of the current column, and combine the numbers (sum, max, max) in part order -- the same bits in every part.
   // Called by all threads, after a workgroup barrier that followed the column's last write (block_sum / block_reduce3 end in one).
-  auto sync_exchange = [&](double& a, double& b, double& c) {
+  auto sync_exchange = [&](double& a, double& b, double& c, bool numbers = true) {   // numbers == false (uniform): the halo rows only
     if constexpr (COOP) {
       const int par = xchg & 1;
       double* col = s_x + dir * COL;
@@ -1939,7 +1939,7 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_small_jacobi(
       const int ns = co.send_cnt[part];
       for (int s2 = tid; s2 < ns; s2 += SMALL_THREADS)
         __hip_atomic_store(mypub + s2, col[s_send[s2]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (tid == 0) {
+      if (tid == 0 && numbers) {
         double* myred = co.red + (((size_t)k * P + part) * 2 + par) * 4;
         __hip_atomic_store(myred + 0, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(myred + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1977,7 +1977,7 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_small_jacobi(
       const double* kpub = co.pub + (size_t)k * P * 2 * co.S + (size_t)par * co.S;
       for (int r = tid; r < nr; r += SMALL_THREADS)
         col[s_rpos[r]] = __hip_atomic_load(kpub + s_rsrc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (wave == 0) {
+      if (wave == 0 && numbers) {
         double ra = 0.0, rb = -INFINITY, rc = -INFINITY;
         if (lane < P) {
           const double* r4 = co.red + (((size_t)k * P + lane) * 2 + par) * 4;
@@ -1993,7 +1993,7 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_small_jacobi(
         if (lane == 0) { s_red[57] = ra; s_red[58] = rb; s_red[59] = rc; }
       }
       __syncthreads();                                           // the refreshed halo rows and the combined numbers, for everyone
-      a = s_red[57]; b = s_red[58]; c = s_red[59];
+      if (numbers) { a = s_red[57]; b = s_red[58]; c = s_red[59]; }
       ++xchg;
     }
   };
@@ -2063,6 +2063,15 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_small_jacobi(
     // (check_every is 4 wherever the kernel is launched: a mask, not a division by a run-time value every sweep)
     const bool check = (COOP ? since >= co.D : (sweep >= first_check && (check_every == 4 ? (sweep & 3) == 0 : sweep % check_every == 0))) || sweep >= max_sweeps;
     if (check) {                                 // uniform
+      if constexpr (COOP) {
+        if (sweep < first_check && sweep < max_sweeps) {        // too early for the norm to matter (the host's guess): the halo rows only
+          __syncthreads();                       // (the column's last writes, in front of the exchange's reads)
+          double u = 0.0, v = 0.0, w = 0.0;
+          sync_exchange(u, v, w, false); since = 0;
+          if (aborted) break;
+          continue;
+        }
+      }
       rr = block_sum(dx2);                       // (its barriers also publish the new column)
       if constexpr (COOP) { double u = -INFINITY, v = -INFINITY; sync_exchange(rr, u, v); since = 0; if (aborted) break; }
       if (!(rr == rr) || sweep >= max_sweeps) break;          // NaN, or out of sweeps
