@@ -341,13 +341,14 @@ struct cwr_engine {
   int small_parts = 0;               // CWR_SMALL_PARTS: parts per constituent (0: the fewest that fit)
   int small_depth = 12;              // CWR_SMALL_DEPTH: halo layers = sweeps between two exchanges of a plan of several parts
                                      // (profiles/r05_mid_mesh.txt: an exchange costs ~4 us, a sweep ~1.1: 10 k x 12 0.54 / 0.44 / 0.41 ms per step at 4 / 8 / 12)
-  int small_max_parts = 8;           // CWR_SMALL_MAX_PARTS
+  int small_max_parts = 12;          // CWR_SMALL_MAX_PARTS
   int small_spin_ms = 500;           // CWR_SMALL_SPIN_MS: bound of a part's wait for the others
   int small_last_sweeps = 0;         // sweeps of the last step through k_small_jacobi (0: none, or it did not converge)
   bool small_first_check = true;     // CWR_SMALL_FIRST_CHECK=0: convergence checks from the first sweeps on
   int small_fences = 1;              // CWR_SMALL_FENCES=0: the parts' hand-off without the agent-scope release / acquire pair (sc1 accesses only)
-  int small_max_cells = 16384;       // CWR_SMALL_MAX_CELLS: meshes up to this size may take the one-launch solver with several parts
-                                     // (18 k cells: no faster than the multi-launch passes; 0 = meshes of up to 4 096 cells only)
+  int small_max_cells = 24576;       // CWR_SMALL_MAX_CELLS: meshes up to this size may take the one-launch solver with several parts
+                                     // (24 k cells x 1: 0.47 against 0.56 ms with the multi-launch passes, 32-40 k: level with them; K x parts <= 128
+                                     //  workgroups, so wide state vectors on the larger meshes stay with the passes; 0 = up to 4 096 cells only)
   int32_t *d_small_send_pos = nullptr, *d_small_send_cnt = nullptr, *d_small_recv_src = nullptr, *d_small_recv_pos = nullptr, *d_small_recv_cnt = nullptr;
   double *d_small_pub = nullptr, *d_small_red = nullptr;
 

@@ -69,7 +69,7 @@ class StepResult:
     solver: int              # 0 Jacobi only, 1 BiCGSTAB only, 2 both
     max_rel_residual: float
     solve_ms: float
-    sweep_kernel: int = 0    # 4 plain sweep, 5 J^2 pass, 6 tiled J^2 pass, 7 one-launch solver (meshes of up to 16 384 cells)
+    sweep_kernel: int = 0    # 4 plain sweep, 5 J^2 pass, 6 tiled J^2 pass, 7 one-launch solver (meshes of up to 24 576 cells)
     flags: int = 0           # INFO_* bits: tolerance decisions that were not met exactly (0 in a clean step)
     exchanges: int = 0       # partitioned: halo exchanges of this step
     overlapped: int = 0      # ... of which ran beside interior tiles

@@ -308,7 +308,7 @@ class ClearwaterRiverine:
         # engine: topology, flow field and boundary values resident in HBM
         # meshes beyond one workgroup of the one-launch solver (> 4 096 cells): internal space-filling-curve numbering (ordering.py),
         # which is what keeps the 64-row tiles of the sweep kernels compact; reference ids stay at this boundary
-        # (up to 16 384 cells the engine takes the one-launch solver with several workgroups and an order of its own, derived from
+        # (up to 24 576 cells the engine takes the one-launch solver with several workgroups and an order of its own, derived from
         # the adjacency; the numbering here then only serves the step's other kernels -- and the tiled passes as the fallback)
         # (within every tile-sized window of the curve the cells are sorted by their work: ordering.balance_windows)
         # (lanes along the principal flow axis, which the engine's chained passes walk: ordering.lane_order; CWR_NO_CHAINS=1 or

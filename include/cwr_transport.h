@@ -72,7 +72,7 @@ typedef struct cwr_step_info {
   double max_rel_residual;     /* max over constituents of ||D^-1 (b - A x)||_2 / ||D^-1 b||_2 */
   double solve_ms;             /* host wall time of the step, for information only */
   int32_t sweep_kernel;        /* which Jacobi kernel ran: 4 plain sweep, 5 J^2 pass, 6 tiled J^2 pass (x tile in LDS),
-                                  7 one-launch solver of meshes up to 16 384 cells (k_small_jacobi: one workgroup per constituent up to
+                                  7 one-launch solver of meshes up to 24 576 cells (k_small_jacobi: one workgroup per constituent up to
                                   4 096 cells, several with exchanged halo layers above), 0 none (BiCGSTAB only) */
   int32_t flags;               /* CWR_INFO_* bits: tolerance decisions that were NOT met exactly (0 in a clean step) */
   int32_t exchanges;           /* partitioned engines: neighbour halo exchanges of this step (0 on one GPU) */

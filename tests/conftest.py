@@ -11,13 +11,13 @@ for p in (ROOT, os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests')):
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
-    config.addinivalue_line('markers', 'mid_mesh_default: meshes of 4 097 .. 16 384 cells take what the engine takes by default -- the one-launch '
+    config.addinivalue_line('markers', 'mid_mesh_default: meshes of 4 097 .. 24 576 cells take what the engine takes by default -- the one-launch '
                                        'solver with several workgroups per constituent (round 5) -- instead of the tiled passes')
 
 
 @pytest.fixture(autouse=True)
 def tiled_passes_for_mid_size_meshes(request, monkeypatch):
-    """Since round 5 single-GPU engines of up to 16 384 cells take the one-launch solver (k_small_jacobi, several parts).  The many
+    """Since round 5 single-GPU engines of up to 24 576 cells take the one-launch solver (k_small_jacobi, several parts).  The many
     tests written on meshes of 5-15 k cells to exercise the TILED passes (which stay the product path above that size and on
     every rank of a partition) keep doing so: CWR_SMALL_MAX_CELLS=0 unless a test is marked mid_mesh_default.  Meshes of up to
     4 096 cells are not affected."""
