@@ -1893,6 +1893,7 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
     // element-wise rule: every |x'_i - x_i| within ew_rel |x'_i| + ew_abs max|x'| (plume fronts far below the peak are
     // invisible to the 2-norm).  Folded into `worst` (a squared ratio) so that the sweep prediction serves both rules.
     double ew_ratio = 0.0;
+    const bool norm_ok = ok;                                              // (the 2-norm criterion alone)
     if (!elementwise_ok(e, h.data(), &ew_ratio)) ok = false;
     worst = std::max(worst, ew_ratio * ew_ratio);
     if (ok) {
@@ -1902,6 +1903,9 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
       if (worst > 0.0 && worst < 1.0 && e->last_rate > 0.0 && e->last_rate < 1.0)
         extra = (int)std::floor(0.5 * std::log(1.0 / worst) / -std::log(e->last_rate));
       e->last_sweeps = std::max(2, st.sweeps - extra);
+      // (six digits below the tolerance the residual has most likely reached its rounding floor, where the margin says nothing about
+      // the sweeps that were too many: come down by a quarter at least)
+      if (worst < 1.0e-12) e->last_sweeps = std::max(2, std::min(e->last_sweeps, st.sweeps * 3 / 4));
       e->tail_done = speculated;
       return CWR_OK;
     }
@@ -1914,7 +1918,13 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
     if (prev_worst <= 0.0 && e->last_rate > 0.0 && e->last_rate < 1.0 && std::isfinite(worst))
       predicted = (int)std::ceil(0.5 * std::log(worst) / -std::log(e->last_rate)) + 1;
     if (prev_worst > 0.0 && std::isfinite(worst)) {
-      const double rate = std::pow(worst / prev_worst, 0.5 / (st.sweeps - prev_sweeps));
+      double rate = std::pow(worst / prev_worst, 0.5 / (st.sweeps - prev_sweeps));
+      // ||J||_inf of the step bounds the asymptotic contraction of a sweep from above (and the passes contract faster than a sweep):
+      // a measured rate above it is two checks at the rounding floor, not slow convergence.  Unclamped, such a rate (0.9999...)
+      // sized the next batch at the sweep limit and the over-converged steps after it came down by ~240 sweeps a step only
+      // (profiles/r05_mid_mesh.txt: 18 k cells x 4 / 8 / 16 at CFL 18 through the passes: 163, 832, 593, 353, 684 ... 2002 sweeps)
+      const double rho_t = ((size_t)e->cur_t < e->jnorm.size()) ? e->jnorm[(size_t)e->cur_t] : 0.0;
+      if (rho_t > 0.0 && rho_t < 1.0 && rate > rho_t && rate < 1.0) rate = rho_t;
       if (rate > 0.0 && rate < 1.0) e->last_rate = rate;
       if (!(rate < 1.0)) {                                               // stalled or diverging
         if (forced) { predicted = 64; } else { need_bicg = true; e->last_sweeps = 0; return CWR_OK; }
@@ -1923,6 +1933,12 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
         if (!forced && st.sweeps + predicted > e->jacobi_limit) { need_bicg = true; e->last_sweeps = 0; return CWR_OK; }
       }
     }
+    // Bounds of the next batch.  (1) Only the element-wise rule is open: its measure max(|dx| - ew_rel |x'|) does not fall
+    // geometrically -- it drops through zero within a few sweeps of the norm criterion -- so log(worst) over-predicts by hundreds of
+    // sweeps (18 k cells x 4 at CFL 18: 193 -> 403 sweeps every third step): a short batch, and another check if need be.
+    // (2) In general no batch more than doubles what the step has taken: a wrong rate costs a check, not a step.
+    if (norm_ok) predicted = std::min(predicted, std::max(8, st.sweeps / 16));
+    predicted = std::min(predicted, std::max(32, st.sweeps));
     prev_worst = worst; prev_sweeps = st.sweeps;
     want = predicted;
   }
@@ -1939,7 +1955,9 @@ int ensure_small_plan(cwr_engine* e) {
   bool planned = false;
   for (int depth : {e->small_depth, 8, 6, 4, 3, 2}) {
     if (depth > e->small_depth) continue;
-    if (host::build_small_plan(e->n_owned, e->h_ptr, e->h_nb, SMALL_THREADS, 4, e->small_parts, depth, e->small_max_parts, pl)) { planned = true; break; }
+    // (K x parts <= 128 workgroups: a wide state vector gets fewer, larger parts -- 4 rows per thread where 3 would need too many)
+    const int max_parts = std::max(1, std::min(e->small_max_parts, 128 / std::max(1, e->K)));
+    if (host::build_small_plan(e->n_owned, e->h_ptr, e->h_nb, SMALL_THREADS, 4, e->small_parts, depth, max_parts, pl)) { planned = true; break; }
     if (e->n_owned <= 4 * SMALL_THREADS) break;  // (one workgroup: the depth plays no part)
   }
   if (!planned) {

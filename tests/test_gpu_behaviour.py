@@ -395,3 +395,27 @@ def test_batch_shapes_agree_and_the_one_sweep_shape_never_ends_outside_the_state
     want = np.stack([ref.constituent_dict[f'c{k}'].state[6, :n] for k in range(K)], axis=1)
     for shape in runs:
         assert rel_err(runs[shape][0], want) <= 1e-9
+
+
+@pytest.mark.parametrize('K', [4, 16])
+def test_the_passes_batch_sizes_do_not_run_away_at_cfl_18(gpu_lib, K):
+    """An 18 k-cell river band at the reference's own time step (75 m cells, dt = 3600 s, CFL ~ 18) through the tiled passes (the
+    conftest keeps mid-size meshes on them), 40 steps.  Round 5 found the batch-size prediction running away here: a check that
+    missed only the element-wise rule was extrapolated geometrically (hundreds of sweeps too many), and two checks at the rounding
+    floor measured a contraction of 0.9999 that sized the next batch at the sweep limit -- 163, 832, 593, 353 ... 2002 sweeps a step
+    where ~170 do.  With the rate clamped by ||J||_inf and the follow-up batches bounded no step takes more than 1.6 x the median."""
+    import clearwater_riverine_amd as cw
+    from clearwater_riverine_amd.distributed import PartitionedTransport
+    T = 44
+    mesh = cw.synthetic.make_mesh(300, 60, T, seed=20100529, n_merge=0, dx=75.0, dy=75.0, depth=3.0, dt=3600.0, velocity=0.3, breathing=0.0,
+                                  diffusion_coefficient=0.1, period_steps=24)
+    inputs3 = cw.synthetic.boundary_input_array(mesh, K, inlet_period_s=86400.0)
+    pt = PartitionedTransport(mesh, inputs3, 0, 1)
+    sweeps = []
+    for t in range(40):
+        r = pt.engine.step(t, tol=1e-12)
+        assert r.sweep_kernel == 6 and r.flags == 0 and r.iterations == 0 and r.max_rel_residual <= 1e-12
+        sweeps.append(r.sweeps)
+    pt.engine.close()
+    med = float(np.median(sweeps))
+    assert max(sweeps[1:]) <= 1.6 * med, sweeps
