@@ -708,7 +708,9 @@ def test_closing_sweep_runs_its_core_tiles_beside_the_exchange_with_poisoned_hal
     for a, b in zip(split, serial):
         assert a[6] == b[6]                                      # same sweeps
         for (ea, oa, ca), (eb, ob, cb) in zip(a[13], b[13]):
-            assert ea == eb and ca == cb and oa - ob == ca, (a[13], b[13])   # one closing sweep per batch (= per check): that many more overlapped exchanges
+            # one closing sweep per batch (= per check): up to that many more overlapped exchanges -- a short follow-up batch (round 5:
+            # eight sweeps behind a check that missed only the element-wise rule) may close without an exchange in front of its sweep
+            assert ea == eb and ca == cb and 0 < oa - ob <= ca, (a[13], b[13])
 
 
 def test_the_synchronous_mode_of_the_stand_in_still_works(gpu_lib, monkeypatch):

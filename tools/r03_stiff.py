@@ -8,7 +8,7 @@ from clearwater_riverine_amd.distributed import PartitionedTransport
 
 K, steps, dt = int(sys.argv[1]), int(sys.argv[2]), float(sys.argv[3])
 pairs = [(sys.argv[i], sys.argv[i + 1]) for i in range(4, len(sys.argv) - 1, 2)]
-warm = 2
+warm = 5            # (round 5: five -- a batch shape taken for the first time builds its graph, ~10 ms at 1 M cells, and with two warm-up steps that fell into the timed ones)
 mesh = cw.synthetic.bench_mesh(warm + steps + 1, dt=dt)
 inputs3 = cw.synthetic.distinct_input_array(mesh, K, seed=4)
 first = None
