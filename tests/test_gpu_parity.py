@@ -486,3 +486,19 @@ def test_a_part_that_gives_up_waiting_sends_the_engine_back_to_the_tiled_passes(
         pytest.skip('no part ever had to wait: the abort path was not taken in this run')
     for k in range(K):
         assert rel_err(got[:n, k], ref.constituent_dict[f'c{k}'].state[steps][:n]) <= TOL_CONC
+
+
+@pytest.mark.parametrize('nx,ny,K', [(1, 1, 1), (2, 1, 2), (1, 5, 3), (2, 2, 1), (3, 3, 64), (64, 1, 2), (1, 70, 1), (33, 31, 5)])
+def test_tiny_and_degenerate_meshes_match_the_oracle(gpu_lib, nx, ny, K):
+    """One cell, one row, one column, 64 constituents on nine cells: the one-launch solver's tables (a wave with a single live row,
+    empty row slots, rows without a real neighbour) against the oracle."""
+    import clearwater_riverine_amd as cw
+    mesh, inputs3 = synthetic_case(K, nx=nx, ny=ny, n_steps=4, seed=3, n_merge=0, dt=30.0, diffusion_coefficient=0.2)
+    names = [f'c{k}' for k in range(K)]
+    ref = oracle_run(mesh, inputs3, 4)
+    model = cw.ClearwaterRiverine(mesh=dict(mesh), input_arrays={nm: inputs3[:, :, k].copy() for k, nm in enumerate(names)})
+    for _ in range(4):
+        model.update()
+        assert model.last_step.max_rel_residual <= 1e-12 and model.last_step.sweep_kernel == 7
+    for nm in names[:3] + names[-1:]:
+        assert rel_err(model.mesh[nm], ref.constituent_dict[nm].state) <= TOL_CONC
