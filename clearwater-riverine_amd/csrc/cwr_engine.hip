@@ -345,6 +345,7 @@ struct cwr_engine {
   int small_max_parts = 12;          // CWR_SMALL_MAX_PARTS
   int small_spin_ms = 500;           // CWR_SMALL_SPIN_MS: bound of a part's wait for the others
   int small_last_sweeps = 0;         // sweeps of the last step through k_small_jacobi (0: none, or it did not converge)
+  double small_last_tol2 = -1.0;     // ... and the squared tolerance it ran with
   bool small_first_check = true;     // CWR_SMALL_FIRST_CHECK=0: convergence checks from the first sweeps on
   int small_fences = 1;              // CWR_SMALL_FENCES=0: the parts' hand-off without the agent-scope release / acquire pair (sc1 accesses only)
   int small_max_cells = 24576;       // CWR_SMALL_MAX_CELLS: meshes up to this size may take the one-launch solver with several parts
@@ -2039,7 +2040,9 @@ int solve_small(cwr_engine* e, double tol2, int max_iter, bool forced, SolveStat
   // quarters of the sweeps the last step took -- the step before is the best guess there is, and a step that needs fewer only
   // sweeps on to that point (CWR_SMALL_FIRST_CHECK=0: check from the start)
   // (several parts: the exchanges before that point carry the halo rows only -- no block reduction, no partial norms)
-  const int first_check = (e->small_first_check && !forced) ? (e->small_last_sweeps * 3 / 4) / 4 * 4 : 0;
+  // (only while the tolerance stays what it was: the last step's count says nothing about a looser one)
+  const int first_check = (e->small_first_check && !forced && tol2 == e->small_last_tol2) ? (e->small_last_sweeps * 3 / 4) / 4 * 4 : 0;
+  e->small_last_tol2 = tol2;
 #define CWR_SMALL(RPTv, COOPv) do {                                                                                   \
     static bool attr_done = false;                                                                                    \
     if (!attr_done) { HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_small_jacobi<RPTv, COOPv>),     \
