@@ -1032,3 +1032,60 @@ def test_partitioned_engines_hold_the_row_wise_error_factor_of_the_global_matrix
     ref = oracle_run(mesh, inputs3, steps)
     for k in range(K):
         assert rel_err(state[:, k], ref.constituent_dict[f'c{k}'].state[steps, :n]) <= 1e-9
+
+
+def _stiff_band(K):
+    import clearwater_riverine_amd as cw
+    T = 34
+    mesh = cw.synthetic.make_mesh(300, 60, T, seed=20100529, n_merge=0, dx=75.0, dy=75.0, depth=3.0, dt=3600.0, velocity=0.3, breathing=0.0,
+                                  diffusion_coefficient=0.1, period_steps=24)
+    return mesh, cw.synthetic.boundary_input_array(mesh, K, inlet_period_s=86400.0)
+
+
+def _rank_stiff(rank, world, K, steps, uid_pipe, out_queue):
+    try:
+        os.environ['CWR_RCCL_LIB'] = MOCK_LIB
+        import clearwater_riverine_amd as cw
+        from clearwater_riverine_amd.distributed import PartitionedTransport
+        if rank == 0:
+            uid = cw.TransportEngine.comm_unique_id()
+            for _ in range(world - 1):
+                uid_pipe.put(uid)
+        else:
+            uid = uid_pipe.get(timeout=120)
+        mesh, inputs3 = _stiff_band(K)
+        pt = PartitionedTransport(mesh, inputs3, rank, world, device=0, unique_id=uid)
+        info = []
+        for t in range(steps):
+            r = pt.step(t, tol=1e-12, mass_flux=True)
+            info.append((r.sweeps, r.iterations, r.flags, r.checks))
+        out_queue.put((rank, pt.owned_reference_ids(), 0, pt.owned_state(), None, None, info, None))
+        pt.engine.close()
+    except Exception as exc:
+        out_queue.put((rank, 0, 0, None, None, None, None, repr(exc)))
+
+
+def test_partitioned_ranks_at_cfl_18_keep_their_batches_in_hand(gpu_lib, monkeypatch):
+    """The run-away of the passes' batch-size prediction (round 5; test_gpu_behaviour.py) on a partition: the 18 k-cell band at the
+    reference's own time step, K = 4, 2 ranks through the stand-in, 30 steps -- every rank the same sweeps and checks (the check is
+    all-reduced), no BiCGSTAB, no step beyond 1.6 x the median, and the single engine's answer."""
+    build_mock()
+    from clearwater_riverine_amd.distributed import PartitionedTransport
+    K, steps, world = 4, 30, 2
+    results = run_ranks(world, _rank_stiff, (K, steps))
+    assert all(r[6] == results[0][6] for r in results)
+    sweeps = [i[0] for i in results[0][6]]
+    assert all(i[1] == 0 and i[2] == 0 for i in results[0][6]), results[0][6]
+    assert max(sweeps[1:]) <= 1.6 * float(np.median(sweeps)), sweeps
+    mesh, inputs3 = _stiff_band(K)
+    pt = PartitionedTransport(mesh, inputs3, 0, 1)
+    for t in range(steps):
+        pt.step(t, tol=1e-12, mass_flux=True)
+    want = pt.gather_state()
+    n = mesh['nreal'] + 1
+    got = np.full((n, K), np.nan)
+    for r in results:
+        got[r[1]] = r[3]
+    pt.engine.close()
+    assert not np.isnan(got).any()
+    assert np.max(np.abs(got - want[:n])) <= 1e-9 * np.max(np.abs(want[:n]))
