@@ -23,7 +23,10 @@ using namespace cwr;
 
 namespace {
 
-std::string g_create_error;
+// (thread_local: two threads creating engines each keep their own message -- "no global state")
+thread_local std::string g_create_error;
+// compute units of the device the process last created an engine on (0: none yet); cwr_chain_min_rows reads it
+std::atomic<int> g_n_cu{0};
 
 // ---- RCCL, resolved lazily with dlopen so that a single-GPU engine has no RCCL dependency at all ----
 struct NcclUniqueId { char internal[128]; };
@@ -124,6 +127,14 @@ struct cwr_engine {
   // memory, kernels, events) then overlap the step's passes instead of standing between two steps (profiles/r05_window.txt)
   struct PendingLoad { int t0, n; const float *ff, *ev, *vol; };
   std::vector<PendingLoad> pending_loads;
+  // (round 6) boundary values of levels that travel with the flow-field ring (cwr_boundary_window_load): noted like the loads above,
+  // copied on the flow stream into their rows of d_bc (all T_bc levels stay allocated: n_ghost x K doubles each), one event behind them
+  struct PendingBc { int t0, n; const double* v; };
+  std::vector<PendingBc> pending_bc;
+  hipEvent_t ev_bc = nullptr;              // recorded on flow_stream behind the boundary rows of a flush
+  bool bc_event_pending = false;           // ... and not yet waited for by the engine's stream (the next cwr_step does)
+  double* d_bc_stage = nullptr;            // padded constituents (K > Ku): the caller's rows land here first
+  size_t bc_stage_cap = 0;
   bool defer_loads = false;                // cwr_step in progress has decided to enqueue them behind its batch
   std::vector<char> lvl_final;             // windowed: jnorm / err_factor / bad_level of index t are final on the host
   // the Neumann vectors of refine_error_factors: ONE column (k_neumann), two of them, and the maxima of every sweep
@@ -163,12 +174,18 @@ struct cwr_engine {
   // (Jacobi's a-posteriori bound |e| <= rho/(1-rho) |x'-x|), i.e. forward error <= 1e-6 |x| + 1e-12 max|x| at tol = 1e-12
   bool ew_enabled = true;
   double ew_rel = 0.0, ew_abs = 0.0;
+  bool ew_split = true;            // round 6: only the absolute part of the rule is floored at s = 1e-3 (CWR_EW_SPLIT=0: both, as until round 5)
+  double ew_rel_floor = 1.0e-13;   // ... and the relative part at this size (CWR_EW_REL_FLOOR)
   std::vector<double> jnorm;     // per level t: ||J||_inf of step t's Jacobi iteration matrix (k_jnorm, when the flow field is loaded)
   // per level t: F_t with ||x* - x'||_inf <= F_t ||x' - x||_inf for a Jacobi sweep x -> x' of step t: what the element-wise rule
   // is scaled by.  ||J||_inf / (1 - ||J||_inf) where that is finite, and the row-wise bound of
   // refine_error_factors where that is smaller (near-dry rows, rows next to dry cells: see there)
   std::vector<double> err_factor;
   int neumann_sweeps = 128;      // sweeps refine_error_factors may spend per level (CWR_BOUND_SWEEPS; 0 = norm bound only)
+  int neumann_sweeps_max = 2048; // ... on a level that has NO bound yet (CWR_BOUND_SWEEPS_MAX)
+  bool neu_warm = true;          // the sweeps of a level start from the previous level's vector (CWR_BOUND_WARM=0: from 1, as until round 5)
+  bool neu_holds_vector = false; // d_wa / d_wb hold a usable iterate of an earlier level
+  bool neu_in_b = false;         // ... in d_wb
   int info_flags = 0;            // CWR_INFO_* bits of the step in progress
   bool ptr_exported = false;     // cwr_state_device_ptr handed the state out: the caller may rewrite it at any time
   // real-cell entries of input_array (levels >= 1): applied to the solved level before the mass fluxes
@@ -262,6 +279,9 @@ struct cwr_engine {
   bool use_tcl = true, tcl_ready = false;
   int tcl_cfg = -1, tcl_vw = 0;   // tcl_vw: constituents per lane in the tiled pass (4 = wide rows, else VW)
   int local_reps = 2;              // J^2 applications per tile and pass (1 = exact Jacobi; > 1 = block-asynchronous)
+  int tcl_power = 2;               // 2: the passes apply J^2 (c2 = bhat + J bhat); 1 (CWR_TCL_POWER=1, round 6 A/B): the SAME kernels over J's own pattern --
+                                   // a pass is one Jacobi sweep per tile-local application, the constant is bhat, no numeric J^2 and no c2 sweep per step
+  double* c2() const { return tcl_power == 1 ? d_b : d_t; }
   bool reps_auto = true;           // chained passes: chosen per step from ||J||_inf (CWR_LOCAL_REPS fixes it)
   int reps_base = 2;               // the engine's default for ping-pong passes
   int n_tcl = 0, tcl_TR = 0, tcl_ntiles = 0, tcl_max_cols = 0, tcl_stage_cap = 0, tcl_grid = 0;
@@ -344,6 +364,10 @@ struct cwr_engine {
                                      // (profiles/r05_mid_mesh.txt: an exchange costs ~4 us, a sweep ~1.1: 10 k x 12 0.54 / 0.44 / 0.41 ms per step at 4 / 8 / 12)
   int small_max_parts = 12;          // CWR_SMALL_MAX_PARTS
   int small_spin_ms = 500;           // CWR_SMALL_SPIN_MS: bound of a part's wait for the others
+  int n_cu = 256;                    // compute units of the device (cwr_create)
+  int small_wg_cap = 128;            // workgroups one launch of the several-parts solver may have: half the CUs, 128 at most (one workgroup per CU)
+  bool small_resident_checked = false;   // the occupancy query of the several-parts kernel has been made (solve_small)
+  bool small_fell_back = false;      // a part's wait ran out once: the engine left the one-launch solver for good (CWR_INFO_SMALL_FALLBACK on every step since)
   int small_last_sweeps = 0;         // sweeps of the last step through k_small_jacobi (0: none, or it did not converge)
   double small_last_tol2 = -1.0;     // ... and the squared tolerance it ran with
   bool small_first_check = true;     // CWR_SMALL_FIRST_CHECK=0: convergence checks from the first sweeps on
@@ -764,7 +788,7 @@ int check_level(cwr_engine* e, int t, bool need_next) {
   if (e->T <= 0) return fail(e, CWR_ERR_STATE, "no flow field loaded (cwr_load_flow_field / cwr_load_coefficients)");
   if (t < 0 || t + (need_next ? 1 : 0) >= e->T)
     return fail(e, CWR_ERR_STATE, "time level " + std::to_string(t) + " out of range for " + std::to_string(e->T) + " levels");
-  if (e->windowed && !e->pending_loads.empty() && !e->defer_loads) TRY(flush_window_loads(e));
+  if (e->windowed && (!e->pending_loads.empty() || !e->pending_bc.empty()) && !e->defer_loads) TRY(flush_window_loads(e));
   if (e->windowed)
     for (int q = t; q <= t + (need_next ? 1 : 0); ++q) {
       if (e->slot_level[e->slot(q)] != q)
@@ -813,6 +837,7 @@ int alloc_flow(cwr_engine* e, int T) {
   }
   e->T = T; e->W = T; e->windowed = false;
   e->prepared_t = -1;
+  e->pending_loads.clear(); e->pending_bc.clear();   // (noted for another field: stale pointers, levels of another T / W -- ADVICE r05)
   return CWR_OK;
 }
 
@@ -912,11 +937,12 @@ int sync_jnorms(cwr_engine* e) {
 // communicator attached, or where the communicator is attached to an engine that holds a flow field (cwr_attach_comm).
 constexpr int NEU_FIRST = 12, NEU_NEXT = 8;      // sweeps before the first / every later host decision
 
+int neumann_cap(const cwr_engine* e) { return std::max(e->neumann_sweeps, e->neumann_sweeps_max); }   // sweeps a level without any bound may take
 int neumann_buffers(cwr_engine* e) {
   if (e->d_wa) return CWR_OK;
   TRY(dev_alloc(e, &e->d_wa, (size_t)e->n_real));
   TRY(dev_alloc(e, &e->d_wb, (size_t)e->n_real));
-  TRY(dev_alloc(e, &e->d_wmax, (size_t)2 * (e->neumann_sweeps + NEU_FIRST + NEU_NEXT)));
+  TRY(dev_alloc(e, &e->d_wmax, (size_t)2 * (neumann_cap(e) + NEU_FIRST + NEU_NEXT)));
   return CWR_OK;
 }
 
@@ -981,15 +1007,28 @@ int refine_level(cwr_engine* e, int t) {
   TRY(neumann_buffers(e));
   const bool part = e->comm && (e->world > 1 || e->force_coll);
   const int nr = e->n_real;
-  const int cap = e->neumann_sweeps + NEU_FIRST + NEU_NEXT;
-  k_fill<<<std::max(1, std::min(cdiv(nr, BLOCK), 2048)), BLOCK, 0, e->stream>>>((int64_t)nr, 1.0, e->d_wa, e->d_wb);
-  HIP_TRY(e, hipGetLastError());
+  const int cap = neumann_cap(e) + NEU_FIRST + NEU_NEXT;
+  // (round 6) WARM START: the sweeps of a level begin from the vector the previous level's sweeps ended with instead of from 1.  The
+  // iteration w <- 1 + J w converges to w = (I - J)^-1 1 from ANY start, and the bound holds for any iterate: with e_m = w - w_m,
+  // r_m = w_{m+1} - w_m = (I - J) e_m gives |e_m| <= (I - J)^-1 |r_m| <= ||r_m||_inf w, e_{m+1} = J e_m, so
+  //     w - 1 <= (w_{m+1} - 1) + ||r_m||_inf (w - 1)   =>   max(w) - 1 <= max(w_{m+1} - 1) / (1 - ||r_m||_inf)    (||r_m||_inf = max |r_m| < 1)
+  // -- the same formula, r no longer of one sign (k_neumann folds |r|).  A flow field changes little from level to level: after the
+  // first level a batch of twelve sweeps decides most levels, where the series from 1 needs one sweep per cell of the domain's length
+  // (river band at dt = 14 400 s: none within 128 sweeps -- F = inf, CWR_INFO_ELEMENTWISE_CLAMPED on every step, profiles/r06_matrix_probe.txt).
+  // A level WITHOUT any bound so far may therefore take up to CWR_BOUND_SWEEPS_MAX sweeps (2 048); its successors start from its vector.
+  const bool warm = e->neu_warm && e->neu_holds_vector;
+  if (!warm) {
+    k_fill<<<std::max(1, std::min(cdiv(nr, BLOCK), 2048)), BLOCK, 0, e->stream>>>((int64_t)nr, 1.0, e->d_wa, e->d_wb);
+    HIP_TRY(e, hipGetLastError());
+  }
   HIP_TRY(e, hipMemsetAsync(e->d_wmax, 0, (size_t)2 * cap * sizeof(unsigned long long), e->stream));
-  double* x = e->d_wa; double* y = e->d_wb;
+  double* x = e->neu_in_b && warm ? e->d_wb : e->d_wa; double* y = x == e->d_wa ? e->d_wb : e->d_wa;
   double best = e->err_factor[(size_t)t];
-  int since_exchange = 0;                                                    // (w_0 = 1 on every row, halo rows included: exact everywhere)
+  // (w_0 = 1 on every row, halo rows included: exact everywhere.  A warm start's halo rows hold what the previous level's last
+  // exchange left: refreshed in front of the first sweep)
+  int since_exchange = warm ? e->exch_every : 0;
   int q = 0;
-  for (int done = 0; done < e->neumann_sweeps;) {
+  for (int done = 0; done < (std::isfinite(best) ? e->neumann_sweeps : neumann_cap(e));) {
     const int batch = done == 0 ? NEU_FIRST : NEU_NEXT;                      // (one host round trip decides most levels: see the stop rules below)
     for (int i = 0; i < batch; ++i, ++q) {
       if (part && since_exchange >= e->exch_every) { TRY(exchange_halo_1col(e, x, y)); since_exchange = 0; }
@@ -1003,12 +1042,13 @@ int refine_level(cwr_engine* e, int t) {
     double r = 0.0, wmax = 0.0;
     TRY(bound_check(e, q - 1, &r, &wmax));
     // r = ||w_{m+1} - w_m||_inf, wmax = max(w_{m+1}) (over the core rows of every rank)
-    if (!std::isfinite(r) || !std::isfinite(wmax)) break;                    // NaN in the field: no bound from here
+    if (!std::isfinite(r) || !std::isfinite(wmax)) { e->neu_holds_vector = false; break; }   // NaN in the field: no bound from here (and no start for the next level)
+    e->neu_holds_vector = true; e->neu_in_b = (x == e->d_wb);
     if (r < 1.0) best = std::min(best, (wmax - 1.0) / (1.0 - r));
     if (r <= 0.1 || best <= 3.0) break;                                      // within 11 % of max(w) - 1, or below what matters
     // a field whose rows are uniformly stiff gains nothing over its norm bound and would take the most sweeps to say so: where the
     // norm form is usable (s not clamped) and ||J^12 1|| is still above 0.3 (bulk row sums >= 0.9), stop (Ohio-sized band at CFL 18, 912 levels: 0.4 -> 0.1 s)
-    if (done >= NEU_FIRST && r > 0.3 && e->err_factor[(size_t)t] < 300.0) break;
+    if (!warm && done >= NEU_FIRST && r > 0.3 && e->err_factor[(size_t)t] < 300.0) break;
   }
   e->err_factor[(size_t)t] = best;
   return CWR_OK;
@@ -1103,6 +1143,8 @@ int ensure_sq_pattern(cwr_engine* e) {
   if (e->sq_pattern || e->sq_failed) return CWR_OK;
   // symbolic J^2 on the host (cwr_host_builders.hpp: also what the CPU sanitizer build exercises)
   host::SqPattern sqp;
+  if (e->tcl_power == 1) { if (!host::symbolic_j(e->n_owned, e->n_core, e->h_ptr, e->h_nb, sqp)) { e->sq_failed = true; return CWR_OK; } }
+  else
   if (!host::symbolic_sq(e->n_owned, e->n_core, e->max_degree, e->h_ptr, e->h_nb, sqp)) { e->sq_failed = true; return CWR_OK; }   // halo too shallow: plain sweeps only
   const int n = sqp.n_sq;
   e->n_sq = n;
@@ -1448,6 +1490,14 @@ int prepare_sq(cwr_engine* e, bool& active) {
   if (!e->sq_pattern) return CWR_OK;
   // (the entry weights w were written by k_prep_step)
   const bool need_rec2 = !e->tcl_ready || e->n_sq > e->n_tcl;      // the un-tiled pass reads FaceRec-format rows
+  if (e->tcl_power == 1) {
+    // (A/B, round 6) J's own entries on the merged pattern (faces between the same two cells summed in face order); the passes' constant is bhat
+    k_j_numeric<<<cdiv(e->n_sq, BLOCK), BLOCK, 0, e->stream>>>(e->n_sq, e->d_ptr, e->d_ent_nb, e->d_w, e->d_ptr2, e->d_col2, need_rec2 ? e->d_rec2 : nullptr,
+                                                          e->tcl_ready ? e->d_w2 : nullptr);
+    HIP_TRY(e, hipGetLastError());
+    active = true;
+    return CWR_OK;
+  }
 #define CWR_SQN(DEGv) k_sq_numeric<DEGv><<<cdiv(e->n_sq, SQN_THREADS), SQN_THREADS, e->sqn_lds, e->stream>>>(e->n_sq, e->d_ptr, e->d_ent_nb, \
         e->d_w, e->d_ptr2, e->d_col2, e->d_pair_ptr, e->d_slots, e->d_sq_fast, need_rec2 ? e->d_rec2 : nullptr, e->tcl_ready ? e->d_w2 : nullptr)
   if (e->sq_rowwise) { if (e->max_degree <= 4) CWR_SQN(4); else if (e->max_degree <= 6) CWR_SQN(6); else CWR_SQN(8); }
@@ -1471,7 +1521,7 @@ int launch_sq_tiled(cwr_engine* e, const double* xin, double* yout, const int32_
                     bool chained = false, const cwr_engine::SubSched* sub = nullptr) {
   const int ntiles = tile_list ? n_list : e->tcl_ntiles;
   if (sub && sub->depth <= 0) {                        // (no such tiles on this rank)
-    if (tail && e->n_sq > e->n_tcl) TRY(launch_apply<5>(e, xin, yout, nullptr, e->d_t, nullptr, nullptr, e->n_sq, e->n_tcl));
+    if (tail && e->n_sq > e->n_tcl) TRY(launch_apply<5>(e, xin, yout, nullptr, e->c2(), nullptr, nullptr, e->n_sq, e->n_tcl));
     return CWR_OK;
   }
   if (ntiles <= 0) return CWR_OK;
@@ -1491,7 +1541,7 @@ int launch_sq_tiled(cwr_engine* e, const double* xin, double* yout, const int32_
   }
 #define CWR_TILED(VWv, Q) CWR_TCL_K(VWv, Q)<<<grid, BLOCK, e->tcl_lds, e->stream>>>(e->K, e->K / VWv, e->tcl_TR, ntiles, tile_list, depth, inplace,    \
       e->d_trow, e->d_ptr2, e->d_loc2, e->d_w2, e->d_tcl_ptr, e->d_tcl_cols, e->d_vptr, e->d_meta, e->tcl_max_cols, e->tcl_stage_cap,    \
-      e->local_reps, e->tcl_seg, e->tcl_nvmax, xin, e->d_t, yout, scols, e->own_cap)
+      e->local_reps, e->tcl_seg, e->tcl_nvmax, xin, e->c2(), yout, scols, e->own_cap)
   if (e->tcl_vw == 4) { if (e->tcl_cfg == 3) CWR_TILED(4, 3); else if (e->tcl_cfg == 4) CWR_TILED(4, 4); else if (e->tcl_cfg == 5) CWR_TILED(4, 5);
                         else if (e->tcl_cfg == 6) CWR_TILED(4, 6); else if (e->tcl_cfg == 7) CWR_TILED(4, 7); else CWR_TILED(4, 8); }
   else if (e->VW == 2) { if (e->tcl_cfg == 0) CWR_TILED(2, 0); else if (e->tcl_cfg == 1) CWR_TILED(2, 1); else if (e->tcl_cfg == 9) CWR_TILED(2, 9); else CWR_TILED(2, 2); }
@@ -1500,7 +1550,7 @@ int launch_sq_tiled(cwr_engine* e, const double* xin, double* yout, const int32_
   HIP_TRY(e, hipGetLastError());
   if (e1) HIP_TRY(e, hipEventRecord(e1, e->stream));
   if (tail && e->n_sq > e->n_tcl)                     // replayed halo layers (partitioned engines): un-tiled J^2 rows
-    TRY(launch_apply<5>(e, xin, yout, nullptr, e->d_t, nullptr, nullptr, e->n_sq, e->n_tcl));
+    TRY(launch_apply<5>(e, xin, yout, nullptr, e->c2(), nullptr, nullptr, e->n_sq, e->n_tcl));
   return CWR_OK;
 }
 
@@ -1679,7 +1729,7 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
       auto launch_passes = [&](int i, int cnt) -> int {
         for (int q = 0; q < cnt; ++q) {
           if (tiled) TRY(launch_sq_tiled(e, srcb(i + q), dstb(i + q), nullptr, 0, true, walk));
-          else TRY(launch_apply<5>(e, srcb(i + q), dstb(i + q), nullptr, e->d_t, nullptr, nullptr, e->n_sq));
+          else TRY(launch_apply<5>(e, srcb(i + q), dstb(i + q), nullptr, e->c2(), nullptr, nullptr, e->n_sq));
         }
         return CWR_OK;
       };
@@ -1722,7 +1772,7 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
             for (int i = 0; i < cwr_engine::GRAPH_SWEEPS && rc == CWR_OK; ++i) {
               double* src = (i & 1) ? e->d_p : e->d_c;
               double* dst = (i & 1) ? e->d_c : e->d_p;
-              rc = tiled ? launch_sq_tiled(e, src, dst) : launch_apply<5>(e, src, dst, nullptr, e->d_t, nullptr, nullptr, e->n_sq);
+              rc = tiled ? launch_sq_tiled(e, src, dst) : launch_apply<5>(e, src, dst, nullptr, e->c2(), nullptr, nullptr, e->n_sq);
             }
             hipGraph_t g = nullptr;
             const hipError_t ec = hipStreamEndCapture(e->stream, &g);
@@ -1769,7 +1819,7 @@ int solve_jacobi(cwr_engine* e, double tol2, int max_iter, bool forced, SolveSta
             TRY(launch_sq_tiled(e, src, dst, e->d_tile_inner, e->n_tile_inner, false));
             TRY(exchange_finish(e, src, dst));
             TRY(launch_sq_tiled(e, src, dst, e->d_tile_outer, e->n_tile_outer, true));
-            if (e->n_tile_outer == 0 && e->n_sq > e->n_tcl) TRY(launch_apply<5>(e, src, dst, nullptr, e->d_t, nullptr, nullptr, e->n_sq, e->n_tcl));
+            if (e->n_tile_outer == 0 && e->n_sq > e->n_tcl) TRY(launch_apply<5>(e, src, dst, nullptr, e->c2(), nullptr, nullptr, e->n_sq, e->n_tcl));
             since_exchange = 2; ++i;
             continue;
           }
@@ -1964,7 +2014,7 @@ int ensure_small_plan(cwr_engine* e) {
   for (int depth : {e->small_depth, 8, 6, 4, 3, 2}) {
     if (depth > e->small_depth) continue;
     // (K x parts <= 128 workgroups: a wide state vector gets fewer, larger parts -- 4 rows per thread where 3 would need too many)
-    const int max_parts = std::max(1, std::min(e->small_max_parts, 128 / std::max(1, e->K)));
+    const int max_parts = std::max(1, std::min(e->small_max_parts, e->small_wg_cap / std::max(1, e->K)));
     if (host::build_small_plan(e->n_owned, e->h_ptr, e->h_nb, SMALL_THREADS, 4, e->small_parts, depth, max_parts, pl)) { planned = true; break; }
     if (e->n_owned <= 4 * SMALL_THREADS) break;  // (one workgroup: the depth plays no part)
   }
@@ -2017,13 +2067,16 @@ int solve_small(cwr_engine* e, double tol2, int max_iter, bool forced, SolveStat
   TRY(ensure_small_plan(e));
   if (!e->use_small) return CWR_OK;              // no plan (a row with more than 8 real neighbours, too many parts): the multi-launch path
   const int rpt = e->small_rpt, P = e->small_P;
-  if (!e->d_info) TRY(dev_alloc(e, &e->d_info, (size_t)5 * K));
+  if (!e->d_info) {                               // [K][5] results + the parts' sticky abort word (see the end of k_small_jacobi)
+    TRY(dev_alloc(e, &e->d_info, (size_t)5 * K + 1));
+    HIP_TRY(e, hipMemsetAsync(e->d_info, 0, ((size_t)5 * K + 1) * sizeof(double), e->stream));
+  }
   size_t lds = (2 * (size_t)rpt * SMALL_THREADS + 64) * sizeof(double);  // two columns + the scratch of block_reduce3 (3 x 16 wave results)
   if (P > 1) lds = std::max(lds + ((size_t)e->small_S + 2 * (size_t)e->small_R) * sizeof(int32_t),   // + the part's exchange lists
                             (size_t)84 * 1024);                          // more than half a CU's LDS: one workgroup per CU (the hand-off's measured form)
   SmallCoop co{};
   if (P > 1) {
-    if ((long long)K * P > 128) return CWR_OK;   // a part that is not resident would be waited for: one workgroup per CU, half the chip at most
+    if ((long long)K * P > e->small_wg_cap) return CWR_OK;   // a part that is not resident would be waited for: one workgroup per CU, half the chip at most
     // (the arrival counters and the abort word lie in the scalar block cwr_step zeroed at its start: no memset of their own)
     co = SmallCoop{P, e->small_D, e->small_S, e->small_R, e->d_small_send_pos, e->d_small_send_cnt, e->d_small_recv_src, e->d_small_recv_pos,
                    e->d_small_recv_cnt, e->d_small_pub, e->d_small_red, e->small_arrive(),
@@ -2047,6 +2100,17 @@ int solve_small(cwr_engine* e, double tol2, int max_iter, bool forced, SolveStat
     static bool attr_done = false;                                                                                    \
     if (!attr_done) { HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_small_jacobi<RPTv, COOPv>),     \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_done = true; }        \
+    if (COOPv && !e->small_resident_checked) {                                                                        \
+      /* (round 6) the parts wait for each other inside ONE ordinary launch: all K x P workgroups must be resident together.  Asked  \
+         of the runtime for THIS kernel, block size and LDS request on THIS device instead of assumed from gfx950's constants */     \
+      int pc = 0;                                                                                                     \
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, reinterpret_cast<const void*>(&k_small_jacobi<RPTv, COOPv>), SMALL_THREADS, lds) != hipSuccess) { pc = 0; (void)hipGetLastError(); } \
+      e->small_resident_checked = true;                                                                               \
+      if ((long long)pc * e->n_cu < (long long)K * P) {                                                               \
+        if (getenv("CWR_VERBOSE")) fprintf(stderr, "[cwr] one-launch solver: %d x %d workgroups, %d resident at once on %d CUs: not taken\n", K, P, pc * e->n_cu, e->n_cu); \
+        e->use_small = false; return CWR_OK;                                                                          \
+      }                                                                                                               \
+    }                                                                                                                 \
     k_small_jacobi<RPTv, COOPv><<<K * P, SMALL_THREADS, lds, e->stream>>>(n, K, e->d_small_rows, e->d_small_recs, e->d_small_offs, e->d_rec, \
         e->d_diag, e->d_b, e->d_c, tol2, e->ew_enabled ? e->ew_rel : 1.0, e->ew_enabled ? e->ew_abs : 1.0, limit, 4, e->d_info, note, co, first_check); } while (0)
   if (P == 1) {
@@ -2062,17 +2126,22 @@ int solve_small(cwr_engine* e, double tol2, int max_iter, bool forced, SolveStat
   }
 #undef CWR_SMALL
   HIP_TRY(e, hipGetLastError());
-  std::vector<double> h((size_t)5 * K);
-  if (noted) { ++e->note_expected; TRY(wait_check_note(e, h.data(), (size_t)5 * K)); }
-  else TRY(download(e, h.data(), e->d_info, (size_t)5 * K));
-  for (int k = 0; k < K; ++k)
-    if (h[5 * (size_t)k] < 0.0) {
-      // a part was waited for longer than the bound (never seen; a CU shortage would do it): nobody wrote x -- the multi-launch
-      // path takes the step from the same start, and this engine stays with it
-      fprintf(stderr, "cwr: the one-launch solver's parts did not all arrive within %d ms; this engine uses the multi-launch passes from here on\n", e->small_spin_ms);
-      e->use_small = false;
-      return CWR_OK;
-    }
+  std::vector<double> h((size_t)5 * K + 1, 0.0);
+  if (noted) { ++e->note_expected; TRY(wait_check_note(e, h.data(), (size_t)5 * K)); if (P > 1) h[(size_t)5 * K] = e->h_note[(size_t)5 * K + 1]; }
+  else TRY(download(e, h.data(), e->d_info, (size_t)5 * K + (P > 1 ? 1 : 0)));
+  bool gave_up = h[(size_t)5 * K] != 0.0;          // SOME part gave up (any part says so: the sticky word behind the numbers)
+  for (int k = 0; k < K; ++k) if (h[5 * (size_t)k] < 0.0) gave_up = true;
+  if (gave_up) {
+    // a part was waited for longer than the bound (never seen; a CU shortage would do it).  Parts that had passed their last exchange
+    // before the abort was raised may have written their rows: the state goes back to the kept copy of x_t (k_begin_step wrote it),
+    // the multi-launch path takes the step from the same start, and this engine stays with it -- said in every step's flags from here on
+    HIP_TRY(e, hipMemcpyAsync(e->d_c, e->d_keep, (size_t)e->n_owned * K * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+    if (getenv("CWR_VERBOSE")) fprintf(stderr, "[cwr] the one-launch solver's parts did not all arrive within %d ms; this engine uses the multi-launch passes from here on\n", e->small_spin_ms);
+    e->use_small = false;
+    e->small_fell_back = true;
+    e->info_flags |= CWR_INFO_SMALL_FALLBACK;
+    return CWR_OK;
+  }
   handled = true;
   st.launches += 1;
   st.sweep_kernel = 7;
@@ -2221,7 +2290,9 @@ int32_t cwr_chain_min_rows(int32_t n_constituents) {
   if (const char* v = getenv("CWR_NO_CHAINS")) if (atoi(v) != 0) return INT32_MAX;
   // (no HIP call here: the question is asked before an engine exists, also by processes that must not open the GPU -- a test runner
   // counting its processes on the card, bench.py's launcher.  gfx950 / MI355X: 256 CUs, what cwr_create finds on the device)
-  const int n_cu = 256;
+  // (a partitioned or smaller device has fewer: the count cwr_create found, once an engine exists in this process, or CWR_N_CU)
+  int n_cu = g_n_cu.load() > 0 ? g_n_cu.load() : 256;
+  if (const char* v = getenv("CWR_N_CU")) n_cu = std::max(N_XCD, atoi(v));
   int per_cu = 4;
   if (const char* v = getenv("CWR_TCL_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(8, atoi(v)));
   int grid = (n_cu * per_cu / N_XCD) * N_XCD;
@@ -2310,6 +2381,8 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   if (const char* v = getenv("CWR_CHAIN_REUSE")) eng->chain_reuse = atoi(v) != 0;
   if (const char* v = getenv("CWR_CHAIN_MIN_TILES")) eng->chain_min_tiles = std::max(1.0, atof(v));
   if (const char* v = getenv("CWR_BOUND_SWEEPS")) eng->neumann_sweeps = std::max(0, atoi(v));
+  if (const char* v = getenv("CWR_BOUND_SWEEPS_MAX")) eng->neumann_sweeps_max = std::max(0, atoi(v));
+  if (const char* v = getenv("CWR_BOUND_WARM")) eng->neu_warm = atoi(v) != 0;
   // tile-local J^2 applications per pass: each costs LDS time only (measured 15-25 us at K = 16, 4 us at K = 1 on 1 M cells)
   // and cuts the passes from 46 to 28 (x2) / 24 (x3); narrow rows gain from the third application, wide rows do not
   // two everywhere (round 1 ran three at K <= 4).  Same box, ms per step at 2 / 3 / 4 applications (profiles/r02_w_local_reps.txt):
@@ -2322,6 +2395,7 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
   eng->nt_stream = (K >= 8) ? 1 : 0;
   if (const char* v = getenv("CWR_NT_STREAM")) eng->nt_stream = atoi(v) != 0;
   if (const char* v = getenv("CWR_SQ_MIN_K")) eng->sq_min_k = std::max(1, atoi(v));
+  if (const char* v = getenv("CWR_TCL_POWER")) eng->tcl_power = atoi(v) == 1 ? 1 : 2;
   eng->U = std::max(1, std::min(4, tile_rows / eng->R));
   int TR = 0;
   for (;;) {                                                       // the records of one tile must fit the LDS staging area
@@ -2366,6 +2440,9 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
     int per_cu = 1, n_cu = 256;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+    eng->n_cu = n_cu;
+    eng->small_wg_cap = std::max(1, std::min(128, n_cu / 2));
+    g_n_cu.store(n_cu);                           // (what cwr_chain_min_rows answers with from now on: it makes no HIP call itself)
     const void* fn = (eng->VW == 2) ? reinterpret_cast<const void*>(&k_apply<2, 2>) : reinterpret_cast<const void*>(&k_apply<1, 2>);
     per_cu = resident_blocks(fn, eng->apply_lds);
     per_cu = std::min(per_cu, eng->cu_cap);
@@ -2409,6 +2486,8 @@ int32_t cwr_create(int32_t n_owned, int32_t n_halo, int32_t n_cells, int32_t n_e
     } else (void)hipGetLastError();
   }
   if (const char* v = getenv("CWR_NO_ELEMENTWISE")) eng->ew_enabled = atoi(v) == 0;
+  if (const char* v = getenv("CWR_EW_SPLIT")) eng->ew_split = atoi(v) != 0;
+  if (const char* v = getenv("CWR_EW_REL_FLOOR")) eng->ew_rel_floor = std::max(1.0e-15, atof(v));
   CREATE_TRY(dev_alloc(eng, &eng->d_c, (size_t)n_cells * K));
   CREATE_TRY(dev_alloc(eng, &eng->d_r, nK));
   CREATE_TRY(dev_alloc(eng, &eng->d_r0, nK));
@@ -2477,12 +2556,13 @@ void cwr_destroy(cwr_engine* e) {
                   e->d_bc, e->d_rec, e->d_diag, e->d_c, e->d_r, e->d_r0, e->d_p, e->d_v, e->d_s, e->d_t, e->d_b,
                   e->d_scal, e->d_partial, e->d_fadv, e->d_fdif, e->d_send_cells, e->d_sendbuf, e->d_recv_cells, e->d_recvbuf, e->d_ptr2, e->d_col2, e->d_row2, e->d_rec2, e->d_w, e->d_react, e->d_info, e->d_tcl_ptr, e->d_tcl_cols, e->d_loc2, e->d_w2, e->d_pair_ptr, e->d_slots, e->d_line_ptr, e->d_line_faces, e->d_ledger, e->d_mass_out, e->d_chk, e->d_face_orig, e->d_row_ghost, e->d_keep, e->d_in_rows, e->d_in_vals, e->d_face_pos, e->d_trow, e->d_vptr, e->d_meta, e->d_tile_inner, e->d_tile_outer, e->d_apply_inner, e->d_apply_outer, e->d_face_inner, e->d_face_outer, e->d_chkx, e->d_sq_fast, e->d_sched, e->d_link_ptr, e->d_link_ent, e->d_link_flux, e->d_scols, e->d_scols_io, e->sched_in.d, e->sched_out.d, e->d_small_rows, e->d_small_recs, e->d_small_offs, e->d_small_send_pos, e->d_small_send_cnt, e->d_small_recv_src, e->d_small_recv_pos, e->d_small_recv_cnt, e->d_small_pub, e->d_small_red};
   for (void* p : ptrs) if (p) hipFree(p);
-  for (void* p : {(void*)e->d_in_f, (void*)e->d_flow_l, (void*)e->d_dist, (void*)e->d_jn, (void*)e->d_bad, (void*)e->d_wa, (void*)e->d_wb, (void*)e->d_wmax})
+  for (void* p : {(void*)e->d_in_f, (void*)e->d_flow_l, (void*)e->d_dist, (void*)e->d_jn, (void*)e->d_bad, (void*)e->d_wa, (void*)e->d_wb, (void*)e->d_wmax, (void*)e->d_bc_stage})
     if (p) hipFree(p);
   if (e->h_lvl) hipHostFree(e->h_lvl);
   if (e->flow_stream) { hipStreamSynchronize(e->flow_stream); hipStreamDestroy(e->flow_stream); }
   for (hipEvent_t ev : e->ev_level) if (ev) hipEventDestroy(ev);
   if (e->ev_evict) hipEventDestroy(e->ev_evict);
+  if (e->ev_bc) hipEventDestroy(e->ev_bc);
   if (e->d_note_state) hipFree(e->d_note_state);
   if (e->h_note) hipHostFree(e->h_note);
   if (e->h_notex) hipHostFree(e->h_notex);
@@ -2539,6 +2619,7 @@ int32_t cwr_flow_window_open(cwr_engine* e, int32_t T, int32_t W, const double* 
   HIP_TRY(e, enter_device(e->dev));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   W = std::min(W, T);
+  e->pending_loads.clear(); e->pending_bc.clear();   // (loads noted for a previous window: ADVICE r05)
   TRY(alloc_flow(e, W));                             // (W levels of the four arrays)
   e->T = T; e->W = W; e->windowed = W < T;
   e->dt.assign(dt, dt + T);
@@ -2594,6 +2675,33 @@ int32_t cwr_flow_window_load(cwr_engine* e, int32_t t0, int32_t n_levels, const 
 
 namespace {
 int flush_window_loads(cwr_engine* e) {
+  if (!e->pending_bc.empty()) {
+    // the boundary rows first: the flow levels enqueued behind them record the events a step waits for, and ev_bc says it outright
+    HIP_TRY(e, enter_device(e->dev));
+    std::vector<cwr_engine::PendingBc> bcs;
+    bcs.swap(e->pending_bc);
+    if (!e->ev_bc) HIP_TRY(e, hipEventCreateWithFlags(&e->ev_bc, hipEventDisableTiming));
+    for (const auto& pb : bcs) {
+      const size_t rows = (size_t)pb.n * e->n_ghost;
+      double* dst = e->d_bc + (size_t)pb.t0 * e->n_ghost * e->K;
+      if (e->K == e->Ku) {
+        HIP_TRY(e, hipMemcpyAsync(dst, pb.v, rows * e->K * sizeof(double), hipMemcpyHostToDevice, e->flow_stream));
+      } else {
+        if (e->bc_stage_cap < rows * e->Ku) {
+          HIP_TRY(e, hipStreamSynchronize(e->flow_stream));
+          hipFree(e->d_bc_stage); e->d_bc_stage = nullptr; e->bc_stage_cap = 0;
+          TRY(dev_alloc(e, &e->d_bc_stage, rows * e->Ku));
+          e->bc_stage_cap = rows * e->Ku;
+        }
+        HIP_TRY(e, hipMemcpyAsync(e->d_bc_stage, pb.v, rows * e->Ku * sizeof(double), hipMemcpyHostToDevice, e->flow_stream));
+        const int64_t total = (int64_t)rows * e->K;
+        k_pad_cols<<<(int)std::max<int64_t>(1, std::min<int64_t>(cdiv(total, BLOCK), 256 * 16)), BLOCK, 0, e->flow_stream>>>(total, e->Ku, e->K, e->d_bc_stage, dst);
+        HIP_TRY(e, hipGetLastError());
+      }
+    }
+    HIP_TRY(e, hipEventRecord(e->ev_bc, e->flow_stream));
+    e->bc_event_pending = true;
+  }
   std::vector<cwr_engine::PendingLoad> todo;
   todo.swap(e->pending_loads);
   for (const auto& pl : todo) TRY(window_load_now(e, pl.t0, pl.n, pl.ff, pl.ev, pl.vol));
@@ -2711,15 +2819,44 @@ int32_t cwr_get_coefficients(cwr_engine* e, int32_t t, float* adv, double* dif) 
 
 int32_t cwr_load_boundary(cwr_engine* e, int32_t T, const double* ghost_conc) {
   if (!e) return CWR_ERR_BAD_ARG;
-  if (T < 1 || (!ghost_conc && e->n_ghost > 0)) return fail(e, CWR_ERR_BAD_ARG, "cwr_load_boundary: bad arguments");
+  if (T < 1) return fail(e, CWR_ERR_BAD_ARG, "cwr_load_boundary: bad arguments");
   HIP_TRY(e, enter_device(e->dev));
   const size_t cnt = (size_t)T * e->n_ghost * e->K;
+  e->pending_bc.clear();
   if (e->T_bc != T) {
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
     hipFree(e->d_bc); e->d_bc = nullptr; e->T_bc = 0;
     TRY(dev_alloc(e, &e->d_bc, cnt));
     e->T_bc = T;
   }
+  if (!ghost_conc) {
+    // (round 6) NULL: T levels of zeros ("no boundary value") -- the levels then arrive a few at a time (cwr_boundary_window_load,
+    // cwr_set_boundary_level): a run that streams its flow field level by level never holds all T levels of boundary values on the host
+    if (cnt > 0) HIP_TRY(e, hipMemsetAsync(e->d_bc, 0, cnt * sizeof(double), e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return CWR_OK;
+  }
   TRY(upload_cols(e, e->d_bc, ghost_conc, (size_t)T * e->n_ghost));
+  return CWR_OK;
+}
+
+// Boundary values of levels t0 .. t0 + n_levels - 1 ((n_levels, n_ghost, K) doubles; the reference's input_array[t, ghost cells],
+// constituents.py:153-164) into their rows of the array cwr_load_boundary allocated.  On a windowed engine (cwr_flow_window_open) the
+// call only NOTES the pointer, like cwr_flow_window_load: the copy runs on the engine's flow stream beside the steps, enqueued by the
+// next cwr_step in front of the flow levels noted with it, and the step that reads level t + 1 waits for it on the device.  The host
+// array stays untouched until a cwr_step that reads the levels, or cwr_synchronize, has returned.  Other engines: a blocking upload.
+int32_t cwr_boundary_window_load(cwr_engine* e, int32_t t0, int32_t n_levels, const double* ghost_conc) {
+  if (!e) return CWR_ERR_BAD_ARG;
+  if (e->T_bc <= 0) return fail(e, CWR_ERR_STATE, "cwr_boundary_window_load: cwr_load_boundary first (it allocates the levels; NULL values: zeros)");
+  if (t0 < 0 || n_levels < 1 || t0 + n_levels > e->T_bc || (!ghost_conc && e->n_ghost > 0))
+    return fail(e, CWR_ERR_BAD_ARG, "cwr_boundary_window_load: levels outside the loaded boundary array, or NULL values");
+  if (e->n_ghost == 0) return CWR_OK;
+  if (e->windowed && e->flow_stream && !getenv("CWR_WINDOW_EAGER")) {
+    e->pending_bc.push_back(cwr_engine::PendingBc{t0, n_levels, ghost_conc});
+    return CWR_OK;
+  }
+  HIP_TRY(e, enter_device(e->dev));
+  TRY(upload_cols(e, e->d_bc + (size_t)t0 * e->n_ghost * e->K, ghost_conc, (size_t)n_levels * e->n_ghost));
   return CWR_OK;
 }
 
@@ -2835,19 +2972,25 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
   cwr_step_info local; std::memset(&local, 0, sizeof(local));
   if (info) *info = local;
   e->defer_loads = false;
-  if (e->windowed && !e->pending_loads.empty()) {
+  if (e->windowed && (!e->pending_loads.empty() || !e->pending_bc.empty())) {
     // loads this step needs -- or that would replace a level it reads -- are enqueued now; all others behind the step's batch
     bool now = false;
     for (const auto& pl : e->pending_loads)
       for (int L = pl.t0; L < pl.t0 + pl.n; ++L)
         if (L == t || L == t + 1 || e->slot(L) == e->slot(t) || e->slot(L) == e->slot(t + 1)) now = true;
+    for (const auto& pb : e->pending_bc) if (pb.t0 <= t + 1 && t + 1 < pb.t0 + pb.n) now = true;   // (the boundary values this step reads)
     e->defer_loads = !now;
   }
-  struct DeferGuard { cwr_engine* e; ~DeferGuard() { if (e->defer_loads || !e->pending_loads.empty()) { e->defer_loads = false; (void)flush_window_loads(e); } } } defer_guard{e};
+  struct DeferGuard { cwr_engine* e; ~DeferGuard() { if (e->defer_loads || !e->pending_loads.empty() || !e->pending_bc.empty()) { e->defer_loads = false; (void)flush_window_loads(e); } } } defer_guard{e};
   TRY(check_level(e, t, true));
   if (e->T_bc < t + 2) return fail(e, CWR_ERR_STATE, "cwr_step: boundary values of level t+1 not loaded (cwr_load_boundary)");
   if (!(tol > 0.0) || max_iter < 1) return fail(e, CWR_ERR_BAD_ARG, "cwr_step: tol must be > 0 and max_iter >= 1");
   HIP_TRY(e, enter_device(e->dev));
+  if (e->windowed && !e->defer_loads && !e->pending_bc.empty()) TRY(flush_window_loads(e));   // (boundary rows noted without flow levels)
+  if (e->bc_event_pending) {                           // boundary rows copied on the flow stream since the last step: this step's kernels behind them
+    HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_bc, 0));
+    e->bc_event_pending = false;
+  }
   TRY(finalize_level(e, t));
   const int K = e->K;
   const double tol2 = tol * tol;
@@ -2859,7 +3002,7 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
   e->ev_used = 0;
   e->flux_valid = false;
   e->tail_done = false;
-  e->info_flags = 0;
+  e->info_flags = e->small_fell_back ? CWR_INFO_SMALL_FALLBACK : 0;
   e->cur_t = t;
   e->deterministic = (flags & CWR_STEP_DETERMINISTIC) != 0 || (e->det_walk && e->K <= e->det_default_k);   // (the same on every rank: K and the environment are)
   e->step_chained = 0;
@@ -2873,13 +3016,27 @@ int32_t cwr_step(cwr_engine* e, int32_t t, double tol, int32_t max_iter, int32_t
     // rounding of a sweep; the step then runs at s = 1e-3 and says so: CWR_INFO_ELEMENTWISE_CLAMPED.
     // (round 4: the factor rho / (1 - rho) is replaced by the row-wise bound F_t of refine_error_factors where that is smaller --
     // meshes with dry or nearly dry cells, whose worst row sum says nothing about the error of a sweep)
+    // (round 6: the two parts of the rule are floored SEPARATELY.  What rounding limits is |x' - x| against the cell's own size: a
+    // sweep sums at most nine non-negative terms (J >= 0, b >= 0 for concentrations), so a converged sweep repeats itself to a few
+    // 1e-16 |x'_i| -- the RELATIVE part may follow s = 0.3 / F down to ew_rel = 1e-13 (s = 1e-7 at tol = 1e-12: F = 3e6), seven decades
+    // below the 1e-9 it was held at.  Only the ABSOLUTE part, s tol max|x'|, is at rounding size already at s = 1e-3 (1e-15 max|x'|)
+    // and stays floored there.  The step's bound is then F (ew_rel + ew_abs) max|x'| = (0.3 * 1e6 tol + 1e-3 F tol) max|x'|, and
+    // CWR_INFO_ELEMENTWISE_CLAMPED is raised only when THAT exceeds the target (1e6 tol + tol) max|x'| -- F > 7e8 -- or F is no
+    // bound at all.  Before: every river-band mesh with a dry cell at dt = 3600 s (F = 300 ... 5000) ran clamped, VERDICT r05 weak 2;
+    // CWR_EW_SPLIT=0 restores that rule, A/B)
     double F = ((size_t)t < e->err_factor.size()) ? e->err_factor[(size_t)t] : INFINITY;
     if (!(F >= 0.0)) F = INFINITY;
+    const double R = std::min(1.0e-2, 1.0e6 * tol), A = tol;
     const double s_raw = (F > 0.0) ? 0.3 / F : 0.1;
     const double sc = std::min(0.1, std::max(1.0e-3, s_raw));
-    if (e->ew_enabled && s_raw < 1.0e-3) e->info_flags |= CWR_INFO_ELEMENTWISE_CLAMPED;
-    e->ew_rel = sc * std::min(1.0e-2, 1.0e6 * tol);
-    e->ew_abs = sc * tol;
+    bool clamped = s_raw < 1.0e-3;
+    e->ew_rel = sc * R;
+    e->ew_abs = sc * A;
+    if (e->ew_split && clamped && std::isfinite(F)) {
+      e->ew_rel = std::max(s_raw * R, std::min(1.0e-3 * R, e->ew_rel_floor));
+      clamped = F * (e->ew_rel + e->ew_abs) > R + A;
+    }
+    if (e->ew_enabled && clamped) e->info_flags |= CWR_INFO_ELEMENTWISE_CLAMPED;
   }
 
   // one GPU: the zero-coefficient precondition of level t+1 is known from the flow field (check_ghost_levels): stop before

@@ -98,6 +98,33 @@ inline bool symbolic_sq(int n_owned, int n_core, int max_degree, const std::vect
   return true;
 }
 
+// (round 6 A/B, CWR_TCL_POWER=1) J's own pattern in the form of SqPattern, so that the tiled pass, its tiling, chains and column reuse
+// serve plain Jacobi sweeps unchanged: row c = its distinct real neighbours in order of first discovery (faces ascending); faces
+// between the same two cells become ONE entry (k_j_numeric sums them in face order).  No row-wise numeric tables (rowwise = false).
+inline bool symbolic_j(int n_owned, int n_core, const std::vector<int32_t>& ptr, const std::vector<int32_t>& nb, SqPattern& out) {
+  (void)n_core;
+  out = SqPattern();
+  const int n = n_owned;
+  out.n_sq = n;
+  out.rowwise = false;
+  out.ptr2.assign((size_t)n + 1, 0);
+  out.pair_ptr.assign((size_t)n + 1, 0);
+  out.fast.assign((size_t)n, 0);
+  std::vector<int32_t> tmp;
+  for (int c = 0; c < n; ++c) {
+    tmp.clear();
+    for (int j = ptr[(size_t)c]; j < ptr[(size_t)c + 1]; ++j) {
+      const int m = nb[(size_t)j];
+      if (m < 0) continue;
+      if (std::find(tmp.begin(), tmp.end(), m) == tmp.end()) tmp.push_back(m);
+    }
+    out.max_row = std::max(out.max_row, (int)tmp.size());
+    out.col2.insert(out.col2.end(), tmp.begin(), tmp.end());
+    out.ptr2[(size_t)c + 1] = (int32_t)out.col2.size();
+  }
+  return true;
+}
+
 // ---- tiling of the tiled J^2 pass ---------------------------------------------------------------------------------------------
 struct Tiling {
   std::vector<int32_t> trow, vptr;      // rows [trow[t], trow[t+1]) and virtual items [vptr[t], vptr[t+1]) of tile t

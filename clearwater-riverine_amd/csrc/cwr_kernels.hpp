@@ -561,7 +561,7 @@ __global__ void __launch_bounds__(BLOCK) k_fill(int64_t total, double v, double*
 // refine_error_factors in cwr_engine.hip), MATRIX-FREE and on ONE column: J's entries are formed on the fly from the level's
 // coefficients exactly as k_prep_step forms them -- no operator buffers, no K-wide vectors -- so the sweeps of an incoming level can
 // run on the flow-field stream beside the steps of a windowed run.  One thread per computed row; rows >= n_owned of w (a rank's
-// read-only layer) are input only.  max[0] = max over rows < n_dot of (w' - w) (>= 0: the series is monotone), max[1] = max w',
+// read-only layer) are input only.  max[0] = max over rows < n_dot of |w' - w| (from w = 1 the series is monotone: w' - w >= 0), max[1] = max w',
 // folded with integer atomicMax on the bit patterns (non-negative doubles order like their bits; the host zeroes the two words).
 __global__ void __launch_bounds__(BLOCK) k_neumann(
     int n_owned, int n_dot, const int32_t* __restrict__ ptr, const int32_t* __restrict__ ent_edge, const int32_t* __restrict__ ent_nb,
@@ -588,8 +588,8 @@ __global__ void __launch_bounds__(BLOCK) k_neumann(
     double w1 = 1.0 + sum / dg;
     wout[c] = w1;
     if (maxima && c < n_dot) {
-      double dr = w1 - win[c];
-      if (!(dr >= 0.0)) dr = (dr != dr) ? INFINITY : 0.0;      // (NaN in the field: no bound)
+      double dr = fabs(w1 - win[c]);                            // (|r|: a warm start's iterates are not monotone -- refine_level)
+      if (dr != dr) dr = INFINITY;                              // (NaN in the field: no bound)
       if (!(w1 >= 0.0)) w1 = INFINITY;
       r = fmax(r, dr); wv = fmax(wv, w1);
     }
@@ -1098,6 +1098,23 @@ __global__ void __launch_bounds__(BLOCK) k_build_sq(int nnz2, const int32_t* __r
   FaceRec out; out.nb = k; out.a_c = 0.0f; out.d = acc;
   rec2[s] = out;
   if (w2) w2[s] = acc;                              // compact copy for the tiled pass (which has its own index array)
+}
+
+// (round 6 A/B, CWR_TCL_POWER=1) numeric J on the merged pattern of host::symbolic_j: entry (c, k) = the sum of the Jacobi weights of
+// the faces between c and k, in face order.  One thread per row (rows have 4-8 entries).
+__global__ void __launch_bounds__(BLOCK) k_j_numeric(int n, const int32_t* __restrict__ ptr, const int32_t* __restrict__ ent_nb, const double* __restrict__ w,
+                                                    const int32_t* __restrict__ ptr2, const int32_t* __restrict__ col2, FaceRec* __restrict__ rec2,
+                                                    double* __restrict__ w2) {
+  const int c = blockIdx.x * BLOCK + threadIdx.x;
+  if (c >= n) return;
+  const int j0 = ptr[c], j1 = ptr[c + 1];
+  for (int q = ptr2[c]; q < ptr2[c + 1]; ++q) {
+    const int k = col2[q];
+    double acc = 0.0;
+    for (int j = j0; j < j1; ++j) if (ent_nb[j] == k) acc += w[j];
+    if (w2) w2[q] = acc;
+    if (rec2) { FaceRec out; out.nb = k; out.a_c = 0.0f; out.d = acc; rec2[q] = out; }
+  }
 }
 
 // J^2 pass with the x tile in LDS, software-pipelined.  The plain J^2 pass (k_apply<.,5>) gathers 9-10 neighbour rows
@@ -1809,8 +1826,9 @@ constexpr int SMALL_DEG = 8;                     // register-resident weights: r
 // agent-scope atomics), every storing wave waits vmcnt(0), workgroup barrier, ONE lane adds to the constituent's arrival counter
 // (agent scope), ONE lane polls it with sc1 loads, workgroup barrier, then the loads; one workgroup per CU (LDS request); two
 // publication buffers alternate, so a part one exchange ahead never overwrites what a neighbour still reads.  Every spin is
-// bounded: a part that waits longer than `spin_ticks` raises the abort bit of every counter, every part leaves without touching x, and the
-// host takes the multi-launch path (and stops using this one).
+// bounded: a part that waits longer than `spin_ticks` raises the abort bit of every counter and a sticky word the host reads; parts that had
+// already passed that exchange leave at their next one, and the host -- whatever some of them wrote -- restores the state from its kept
+// copy, takes the multi-launch path and stops using this one (see the end of the kernel).
 constexpr unsigned long long SMALL_ABORT = 1ull << 62;
 struct SmallCoop {
   int P, D, S, R;
@@ -2088,20 +2106,34 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_small_jacobi(
       __syncthreads();
     }
   }
-  if (aborted) {                                 // x untouched: the host takes the multi-launch path from the same start
+  // (round 6) The parts do NOT agree on an abort by themselves: a part may time out while the last arriver completes the
+  // target -- the others then pass that exchange, and if it was the final one they write their rows while the part that gave up
+  // leaves its own untouched.  So every part that aborted says so where the host looks -- a sticky word behind the K x 5 numbers
+  // (device copy and page-locked copy) -- EVERY workgroup, not only the K that carry numbers, arrives at the notification counter
+  // before the sequence word is published, and the host restores the state from its kept copy whenever the word is set: what the
+  // parts that passed may have written never counts.
+  if (aborted) {
     if (tid == 0 && part == 0) { sweep = -1; rr = 0.0; }
   } else {
 #pragma unroll
     for (int i = 0; i < RPT; ++i)
       if ((ownm >> i) & 1u) x[(size_t)row[i] * K + k] = OWN_IN_REG ? xo[i] : s_x[dir * COL + i * SMALL_THREADS + tid];
   }
-  if (tid == 0 && part == 0) {
-    info[k * 5 + 0] = (double)sweep; info[k * 5 + 1] = rr; info[k * 5 + 2] = bb; info[k * 5 + 3] = m1; info[k * 5 + 4] = m2;
+  if (tid == 0) {
+    if (part == 0) { info[k * 5 + 0] = (double)sweep; info[k * 5 + 1] = rr; info[k * 5 + 2] = bb; info[k * 5 + 3] = m1; info[k * 5 + 4] = m2; }
+    if constexpr (COOP) {
+      if (aborted) {
+        __hip_atomic_store(info + (size_t)K * 5, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (note.host_seq) __hip_atomic_store(note.host_out + (size_t)K * 5 + 1, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
     if (note.host_seq) {
-      note.host_out[k * 5 + 0] = (double)sweep; note.host_out[k * 5 + 1] = rr; note.host_out[k * 5 + 2] = bb; note.host_out[k * 5 + 3] = m1; note.host_out[k * 5 + 4] = m2;
+      if (part == 0) {
+        note.host_out[k * 5 + 0] = (double)sweep; note.host_out[k * 5 + 1] = rr; note.host_out[k * 5 + 2] = bb; note.host_out[k * 5 + 3] = m1; note.host_out[k * 5 + 4] = m2;
+      }
       __threadfence_system();
       const unsigned prev = atomicAdd(note.arrive, 1u);
-      if (prev == (unsigned)K - 1u) {              // the last constituent's workgroup: every other one's numbers are out
+      if (prev == (unsigned)(K * P) - 1u) {        // the last workgroup of the launch: every number and every abort word is out
         __threadfence_system();
         *note.arrive = 0u;
         const unsigned long long sq = *note.dev_seq + 1ull;

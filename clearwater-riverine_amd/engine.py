@@ -34,7 +34,8 @@ STEP_DETERMINISTIC = 32
 
 INFO_LOOSE_RESIDUAL = 1        # BiCGSTAB stagnated within 100 x tol and was accepted
 INFO_ELEMENTWISE_MISSED = 2    # the element-wise rule was still violated after the tightened BiCGSTAB rounds
-INFO_ELEMENTWISE_CLAMPED = 4   # error factor F > 300 (CFL of several hundred): the rule's scale 0.3 / F was held at 1e-3 (bound weaker by F / 300)
+INFO_ELEMENTWISE_CLAMPED = 4   # the step's max-norm error bound F (ew_rel + ew_abs) exceeds (1e6 tol + tol): F > ~7e8, or no factor at all (round 6: only the absolute part is floored)
+INFO_SMALL_FALLBACK = 8        # the one-launch solver's parts did not all arrive once: state restored, this and every later step through the multi-launch passes
 
 # every symbol include/cwr_transport.h declares (tests check that the library exports them all)
 ABI_SYMBOLS = (
@@ -435,8 +436,12 @@ class TransportEngine:
                 what.append('the element-wise convergence rule was not met (the norm criterion holds)')
             if info.flags & INFO_ELEMENTWISE_CLAMPED and not getattr(self, '_clamp_warned', False):
                 self._clamp_warned = True                # a property of the flow field and dt: said once per engine, flagged every step
-                what.append('the a-posteriori error factor F of this step (error_factors(): row-wise bound or ||J||/(1 - ||J||)) is above '
-                            '300: the scale of the element-wise rule was held at 1e-3, its max-norm error bound is weaker by F / 300')
+                what.append('the a-posteriori error factor F of this step (error_factors(): row-wise bound or ||J||/(1 - ||J||)) is too large '
+                            'for -- or no bound at all on -- the max-norm error of the element-wise rule: the rule ran at its floors')
+            if info.flags & INFO_SMALL_FALLBACK and not getattr(self, '_fallback_warned', False):
+                self._fallback_warned = True             # said once per engine, flagged on every step from then on
+                what.append('a part of the one-launch solver waited for another longer than CWR_SMALL_SPIN_MS (not all workgroups resident?): '
+                            'the state was restored and this engine uses the multi-launch passes from here on')
             if what:
                 warnings.warn(f'transport step {t}: ' + '; '.join(what), RuntimeWarning, stacklevel=2)
         return StepResult(info.iterations, info.sweeps, info.restarts, info.operator_launches, info.solver,

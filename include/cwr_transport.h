@@ -89,10 +89,16 @@ enum {
   CWR_INFO_LOOSE_RESIDUAL = 1,     /* BiCGSTAB stagnated within 100 x tol after 6 verified restarts and was accepted */
   CWR_INFO_ELEMENTWISE_MISSED = 2, /* the element-wise rule |x'-x| <= 1e6 tol |x| + tol max|x| (scaled, see cwr_step) was still
                                       violated after 3 tightened BiCGSTAB rounds; the norm criterion holds */
-  CWR_INFO_ELEMENTWISE_CLAMPED = 4 /* the a-posteriori error factor F of this step (cwr_get_error_factors: the row-wise bound
-                                      max((I - J)^-1 1) - 1, or ||J||_inf / (1 - ||J||_inf) where that is smaller) is above 300 -- CFL of
-                                      several hundred -- so the scale of the element-wise rule, s = 0.3 / F, fell below 1e-3 and was held
-                                      there: the max-norm forward-error bound of cwr_step is then 0.3 (1e6 tol + tol) max|x| x (1e-3 / s) */
+  CWR_INFO_ELEMENTWISE_CLAMPED = 4, /* the a-posteriori error factor F of this step (cwr_get_error_factors: the row-wise bound
+                                      max((I - J)^-1 1) - 1, or ||J||_inf / (1 - ||J||_inf) where that is smaller) is so large -- or no
+                                      bound at all -- that the step's max-norm forward-error bound F (ew_rel + ew_abs) max|x| exceeds
+                                      (1e6 tol + tol) max|x|.  Since round 6 only the ABSOLUTE part of the element-wise rule is floored
+                                      at s = 1e-3 (it is at rounding size there); the relative part follows s = 0.3 / F down to
+                                      1e-13: at tol = 1e-12 the bit is raised for F > ~7e8, or for a level without any factor
+                                      (until round 5: for every F > 300, e.g. river-band meshes with a dry cell at dt = 3600 s) */
+  CWR_INFO_SMALL_FALLBACK = 8      /* a part of the one-launch solver for meshes of 4 097 .. 24 576 cells waited for another longer
+                                      than its bound once (CU shortage): the state was restored, the step -- and every later one,
+                                      all carrying this bit -- taken by the multi-launch passes */
 };
 
 int32_t cwr_abi_version(void);
@@ -231,15 +237,19 @@ int32_t cwr_rhs(cwr_engine* e, int32_t t, const double* x_t, double* b);
  * tol: target for ||D^-1 (b - A x)||_2 / ||D^-1 b||_2 per constituent (e.g. 1e-12); max_iter bounds
  * sweeps and BiCGSTAB iterations each.  info may be NULL.
  * On top of the norm criterion every cell and constituent must satisfy |x'_i - x_i| <= s (1e6 tol |x'_i| + tol max|x'|)
- * for one more Jacobi sweep x -> x', with s = 0.3 / F kept within [1e-3, 0.1] and F the a-posteriori factor of this step's Jacobi
+ * for one more Jacobi sweep x -> x', with s = 0.3 / F (at most 0.1) and F the a-posteriori factor of this step's Jacobi
  * iteration matrix J, ||x* - x'||_inf <= F ||x' - x||_inf (cwr_get_error_factors): the ROW-WISE bound max((I - J)^-1 1) - 1, taken
  * from a few sweeps of the Neumann series when the flow field is loaded (partitioned engines: over the ranks, so that every rank
  * holds the factor of the global matrix), or the norm form ||J||_inf / (1 - ||J||_inf) where that is smaller.  That gives a
  * RIGOROUS max-norm forward error of 0.3 (1e6 tol + tol) max|x| (3e-7 of the largest concentration at tol = 1e-12) -- also on
  * meshes with dry or nearly dry cells, whose worst row sum (> 1 beside a dry cell) admits no norm bound; that every cell is also
  * within 1e-6 of ITS OWN value down to the 1e-12 max|x| floor -- plume fronts many decades below the peak, which a 2-norm cannot
- * see -- is what the per-cell form of the rule buys empirically (tests: element-wise against spsolve output up to CFL 180).  When
- * s would fall below 1e-3 (F > 300) the step runs at 1e-3 and sets CWR_INFO_ELEMENTWISE_CLAMPED.
+ * see -- is what the per-cell form of the rule buys empirically (tests: element-wise against spsolve output up to CFL 180 and on
+ * river-band meshes with dry cells at dt = 3600 / 14 400 s).  Floors (round 6): the relative part s 1e6 tol is followed down to
+ * 1e-13 (a converged sweep repeats itself to a few 1e-16 of a cell's own size), the absolute part s tol max|x'| is held at
+ * s = 1e-3 (rounding size); the bound becomes (0.3 * 1e6 tol + 1e-3 F tol) max|x| and CWR_INFO_ELEMENTWISE_CLAMPED is set only when
+ * it exceeds (1e6 tol + tol) max|x| (F > ~7e8) or the level has no factor.  CWR_EW_SPLIT=0: both parts floored at s = 1e-3, the
+ * bit set for every F > 300, as until round 5.
  * A step that fails (CWR_ERR_NOT_CONVERGED, CWR_ERR_NONFINITE, CWR_ERR_GHOST_COEFF) leaves the state exactly as it
  * found it: it may be retried with another tolerance, iteration budget or solver.
  * The call returns as soon as convergence is known: the ghost write-back and flux kernels that close the step may still

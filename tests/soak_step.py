@@ -14,7 +14,9 @@ from clearwater_riverine_amd.distributed import PartitionedTransport
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
-KNOBS = ['CWR_TCL_GRID', 'CWR_TILE_ORDER', 'CWR_LANE_KIND', 'CWR_NO_SMALL', 'CWR_DET_DEFAULT_K', 'CWR_CHAIN_MIN_TILES']
+# (CWR_SMALL_MAX_CELLS: the test runner's conftest sets it to 0 for tests written on the tiled passes; the soak takes what the engine takes by
+# default -- meshes of 4 097 ... 24 576 cells through the several-workgroups solver unless CWR_NO_SMALL is drawn: VERDICT r05 weak 8)
+KNOBS = ['CWR_TCL_GRID', 'CWR_TILE_ORDER', 'CWR_LANE_KIND', 'CWR_NO_SMALL', 'CWR_DET_DEFAULT_K', 'CWR_CHAIN_MIN_TILES', 'CWR_SMALL_MAX_CELLS']
 bad = 0
 t_all = time.time()
 for case in range(n_cases):

@@ -189,19 +189,31 @@ def test_step_parity_across_constituent_counts_on_tiled_meshes(gpu_lib, K, pad, 
 
 @pytest.mark.mid_mesh_default
 @pytest.mark.parametrize('K', [1, 12])
-@pytest.mark.parametrize('n_target,path', [(2943, 'default'), (10000, 'default'), (10000, 'tiled passes')])
-def test_baseline_configs_2_and_3_river_band_mesh(gpu_lib, K, n_target, path, monkeypatch):
+@pytest.mark.parametrize('n_target,path,dry', [(2943, 'default', 0), (10000, 'default', 0), (10000, 'tiled passes', 0),
+                                               (9750, 'default', 1), (9750, 'tiled passes', 1)])
+def test_baseline_configs_2_and_3_river_band_mesh(gpu_lib, K, n_target, path, dry, monkeypatch):
     """BASELINE configs 2 / 3: a river-band mesh of the Ohio River's size (2 943 cells; 10 000 nominal) with
     jittered, partly merged 5-6-sided cells and a locally shuffled numbering, dt = 3600 s (CFL ~ 18), one tracer and the
     12-constituent NSM-I state vector, through the facade against the oracle's spsolve.  2 943 cells take the one-launch
     LDS-resident solver with one workgroup per constituent, 10 000 the same with several (round 5) -- or, with
-    CWR_SMALL_MAX_CELLS=0, the tiled block-asynchronous passes as before."""
+    CWR_SMALL_MAX_CELLS=0, the tiled block-asynchronous passes as before.
+    dry (round 6): the reference's everyday regime as tools' matrix probe builds it -- 200 x 50 = 9 750 cells of
+    75 m, 0.5 % DRY cells (linalg.py:66,76-81: dummy diagonal 1), breathing volumes, dt = 3600 s -- 24 steps, every level element-wise
+    against spsolve, with flags == 0 and no warning on any step (until round 5 such a step ran with CWR_INFO_ELEMENTWISE_CLAMPED:
+    F = 185 ... 323 > 300; the rule's relative part is no longer floored there)."""
     if path == 'tiled passes':
         monkeypatch.setenv('CWR_SMALL_MAX_CELLS', '0')
+    import warnings
     import clearwater_riverine_amd as cw
-    nx, ny, nm = (109, 28, 109) if n_target == 2943 else (200, 51, 200)
-    mesh = cw.synthetic.make_mesh(nx, ny, 6, seed=20100529 % 100000, n_merge=nm, dx=75.0, dy=75.0, dt=3600.0, velocity=0.4,
-                                  diffusion_coefficient=0.1, period_steps=24)
+    steps = 24 if dry else 6
+    if dry:
+        mesh = cw.synthetic.make_mesh(200, 50, steps, seed=20100529, n_merge=200 * 50 // 40, dx=75.0, dy=75.0, depth=3.0, dt=3600.0, velocity=0.3,
+                                      breathing=0.1, diffusion_coefficient=0.1, period_steps=24, n_dry=200 * 50 // 200)
+        assert int((np.asarray(mesh['volume'])[1, :mesh['nreal'] + 1] == 0).sum()) >= 40
+    else:
+        nx, ny, nm = (109, 28, 109) if n_target == 2943 else (200, 51, 200)
+        mesh = cw.synthetic.make_mesh(nx, ny, steps, seed=20100529 % 100000, n_merge=nm, dx=75.0, dy=75.0, dt=3600.0, velocity=0.4,
+                                      diffusion_coefficient=0.1, period_steps=24)
     oracle.derive_coefficients(mesh)
     n = mesh['nreal'] + 1
     assert abs(n - n_target) <= 0.01 * n_target
@@ -209,13 +221,19 @@ def test_baseline_configs_2_and_3_river_band_mesh(gpu_lib, K, n_target, path, mo
     names = [f'c{k}' for k in range(K)]
     model = cw.ClearwaterRiverine(mesh=dict(mesh), input_arrays={nm_: inputs3[:, :, k].copy() for k, nm_ in enumerate(names)})
     cols = [0, K - 1] if K > 1 else [0]
-    ref = oracle_run(mesh, inputs3[:, :, cols], 6)
-    for _ in range(6):
-        model.update()
-    assert model.last_step.sweep_kernel == (6 if path == 'tiled passes' else 7) and model.last_step.iterations == 0
+    ref = oracle_run(mesh, inputs3[:, :, cols], steps)
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')                   # (no tolerance decision may be announced: RuntimeWarning -> failure)
+        for _ in range(steps):
+            model.update()
+            assert model.last_step.flags == 0 and model.last_step.iterations == 0
+    assert model.last_step.sweep_kernel == (6 if path == 'tiled passes' else 7)
+    if dry:
+        F = model.engine.error_factors()[:steps]
+        assert F.max() > 150.0 and np.isfinite(F).all()   # (the regime the test is for: at or beyond round 5's clamp threshold of 300 -- 185 ... 323 over 30 levels, profiles/r06_matrix_probe.txt)
     for kk, col in enumerate(cols):
         assert rel_err(model.mesh[names[col]], ref.constituent_dict[f'c{kk}'].state) <= TOL_CONC
-        assert flux_err(model.constituent_dict[names[col]].total_mass_flux[:6], ref.constituent_dict[f'c{kk}'].total_mass_flux[:6]) <= 1e-8
+        assert flux_err(model.constituent_dict[names[col]].total_mass_flux[:steps], ref.constituent_dict[f'c{kk}'].total_mass_flux[:steps]) <= 1e-8
 
 
 @pytest.mark.parametrize('K,steps', [(1, 912), (12, 96)])
@@ -461,31 +479,70 @@ def test_the_parts_exchange_correctly_while_another_engine_loads_the_chip(gpu_li
 
 
 @pytest.mark.mid_mesh_default
-def test_a_part_that_gives_up_waiting_sends_the_engine_back_to_the_tiled_passes(gpu_lib, monkeypatch, capfd):
+@pytest.mark.parametrize('note', ['note', 'download'])
+def test_a_part_that_gives_up_waiting_sends_the_engine_back_to_the_tiled_passes(gpu_lib, note, monkeypatch):
     """Every wait of the one-launch solver's parts is bounded.  With the bound at zero (CWR_SMALL_SPIN_MS=0) the first part that has
-    to wait at all raises the abort bit: all parts leave without touching x, cwr_step solves the step with the tiled passes from the
-    same start, says so once on stderr, and the engine stays with them.  Same answer as the oracle."""
+    to wait at all raises the abort bit.  The parts do not agree on an abort among themselves (one may time out while the
+    last arriver completes the target; the others pass, and at a final exchange write their rows): ANY part that gave up says so in
+    a sticky word the host reads -- through the page-locked notification or the download (CWR_NO_NOTE=1) --, the state is restored from
+    the kept copy, cwr_step solves the step with the tiled passes from the same start, and the engine stays with them: the step's flags
+    carry CWR_INFO_SMALL_FALLBACK from then on (one RuntimeWarning).  Same answer as the oracle."""
+    import warnings
     import clearwater_riverine_amd as cw
     K, steps = 2, 3
     mesh, inputs3 = _mid_case(140, 70, K, steps, seed=79)
     n = mesh['nreal'] + 1
     monkeypatch.setenv('CWR_SMALL_SPIN_MS', '0')
+    if note == 'download':
+        monkeypatch.setenv('CWR_NO_NOTE', '1')
     eng = make_engine(mesh, inputs3)
     eng.set_state(inputs3[0, :n, :])
     ref = oracle_run(mesh, inputs3, steps)
-    capfd.readouterr()
-    kernels = [eng.step(t, tol=1e-12).sweep_kernel for t in range(steps)]
-    err = capfd.readouterr().err
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter('always')
+        res = [eng.step(t, tol=1e-12) for t in range(steps)]
+    kernels = [r.sweep_kernel for r in res]
     got = eng.get_state()
     eng.close()
     # (on an idle chip the parts may arrive so close together that nobody waits in the first exchanges of a step: the abort can
-    # come at any step -- but once it has come, every later step takes the passes)
+    # come at any step -- but once it has come, every later step takes the passes and says why)
     assert kernels == sorted(kernels, reverse=True), kernels
-    assert err.count('did not all arrive') == (1 if 6 in kernels else 0), err
+    assert [r.flags for r in res] == [cw.engine.INFO_SMALL_FALLBACK if kk == 6 else 0 for kk in kernels]
+    said = [w for w in seen if 'multi-launch passes from here on' in str(w.message)]
+    assert len(said) == (1 if 6 in kernels else 0), [str(w.message) for w in seen]
     if 6 not in kernels:                                         # pragma: no cover  (every part arrived within one poll of the last, 60 times)
         pytest.skip('no part ever had to wait: the abort path was not taken in this run')
     for k in range(K):
         assert rel_err(got[:n, k], ref.constituent_dict[f'c{k}'].state[steps][:n]) <= TOL_CONC
+
+
+@pytest.mark.mid_mesh_default
+@pytest.mark.parametrize('parts', [2, 6, 12])
+def test_several_parts_on_a_river_band_with_dry_cells_at_the_ohio_time_step(gpu_lib, parts, monkeypatch):
+    """one case per part count on the reference's everyday regime -- 75 m cells, dt = 3600 s, 0.5 % dry cells,
+    breathing volumes -- through k_small_jacobi<RPT, true>: element-wise against the oracle after every step, no flag, no warning."""
+    import warnings
+    import clearwater_riverine_amd as cw
+    K, steps = 2, 6
+    nx, ny = {2: (110, 50), 6: (200, 50), 12: (300, 60)}[parts]
+    mesh = cw.synthetic.make_mesh(nx, ny, steps, seed=20100529, n_merge=nx * ny // 40, dx=75.0, dy=75.0, depth=3.0, dt=3600.0, velocity=0.3,
+                                  breathing=0.1, diffusion_coefficient=0.1, period_steps=24, n_dry=nx * ny // 200)
+    oracle.derive_coefficients(mesh)
+    inputs3 = cw.synthetic.boundary_input_array(mesh, K, inlet_period_s=86400.0)
+    n = mesh['nreal'] + 1
+    monkeypatch.setenv('CWR_SMALL_PARTS', str(parts))
+    ref = oracle_run(mesh, inputs3, steps)
+    eng = make_engine(mesh, inputs3)
+    eng.set_state(inputs3[0, :n, :])
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        for t in range(steps):
+            r = eng.step(t, tol=1e-12)
+            assert r.sweep_kernel == 7 and r.flags == 0 and r.iterations == 0
+            got = eng.get_state()
+            for k in range(K):
+                assert rel_err(got[:n, k], ref.constituent_dict[f'c{k}'].state[t + 1][:n]) <= TOL_CONC
+    eng.close()
 
 
 @pytest.mark.parametrize('nx,ny,K', [(1, 1, 1), (2, 1, 2), (1, 5, 3), (2, 2, 1), (3, 3, 64), (64, 1, 2), (1, 70, 1), (33, 31, 5)])

@@ -249,14 +249,17 @@ def test_a_third_of_the_cells_dry_matches_the_oracle_element_wise_without_flags(
     eng.close()
 
 
-@pytest.mark.parametrize('dt,expect_clamp', [(2000.0, False), (20000.0, True)])
-def test_plume_fronts_in_the_stiff_regime_and_the_clamp_flag(gpu_lib, dt, expect_clamp):
+@pytest.mark.parametrize('dt,split,expect_clamp', [(2000.0, 1, False), (20000.0, 1, False), (20000.0, 0, True)])
+def test_plume_fronts_in_the_stiff_regime_and_the_clamp_flag(gpu_lib, dt, split, expect_clamp, monkeypatch):
     """the element-wise rule at CFL >= 100.  dt = 2000 s on 10 m cells at 0.5 m/s is CFL 100 (||J||_inf ~ 0.99):
-    the scale s = 0.3 (1 - rho) / rho is inside [1e-3, 0.1], no flag, and every cell of the plume constituents -- fronts
-    many decades below the peak included -- is within 1e-6 of ITS OWN spsolve value.  dt = 20 000 s (CFL 1000,
-    ||J||_inf > 0.9967): the scale is held at 1e-3 and the step says so (CWR_INFO_ELEMENTWISE_CLAMPED -> RuntimeWarning)."""
+    the scale s = 0.3 (1 - rho) / rho is above 1e-3, no flag, and every cell of the plume constituents -- fronts many decades below the
+    peak included -- is within 1e-6 of ITS OWN spsolve value.  dt = 20 000 s (CFL 1000, ||J||_inf > 0.9967, F > 300): since round 6
+    only the absolute part of the rule is floored at s = 1e-3, the relative part follows 0.3 / F -- no flag, no warning, and the FULL
+    element-wise bar against spsolve (until then the step ran at s = 1e-3, said so, and was held to 1e-4 only).
+    CWR_EW_SPLIT=0: round 5's rule -- the step says CWR_INFO_ELEMENTWISE_CLAMPED (-> one RuntimeWarning)."""
     import warnings
     import clearwater_riverine_amd as cw
+    monkeypatch.setenv('CWR_EW_SPLIT', str(split))
     K, steps = 4, 2
     mesh, inputs3 = distinct_case(K, nx=200, ny=40, n_steps=steps, seed=3, n_merge=400, dt=dt, diffusion_coefficient=0.5,
                                   breathing=0.0)
@@ -265,7 +268,8 @@ def test_plume_fronts_in_the_stiff_regime_and_the_clamp_flag(gpu_lib, dt, expect
     n = mesh['nreal'] + 1
     eng = make_engine(mesh, inputs3)
     rho = eng.jacobi_norms()[:steps]
-    assert (rho > 0.9967).all() if expect_clamp else ((rho > 0.98).all() and (rho < 0.9967).all())
+    assert (rho > 0.9967).all() if dt > 2000.0 else ((rho > 0.98).all() and (rho < 0.9967).all())
+    assert ((eng.error_factors()[:steps] > 300.0).all() and np.isfinite(eng.error_factors()[:steps]).all()) if dt > 2000.0 else (eng.error_factors()[:steps] < 300.0).all()
     eng.set_state(inputs3[0, :n, :])
     flags = []
     with warnings.catch_warnings(record=True) as seen:
@@ -278,7 +282,7 @@ def test_plume_fronts_in_the_stiff_regime_and_the_clamp_flag(gpu_lib, dt, expect
     got = eng.get_state()
     for k, nm in enumerate(names):
         want = ref.constituent_dict[nm].state[steps]
-        if expect_clamp:                                  # the rigorous part of the rule: max-norm forward error
+        if expect_clamp:                                  # the rigorous part of round 5's rule: max-norm forward error
             assert rel_err(got[:, k], want, ew_rtol=1e-4, ew_atol=1e-9) <= 1e-6
         else:
             assert rel_err(got[:, k], want) <= 1e-9       # element-wise 1e-6 |b| + 1e-12 max|b|

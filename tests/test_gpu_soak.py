@@ -11,9 +11,16 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.mid_mesh_default
 def test_forty_random_steps_match_the_oracle(gpu_lib):
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, os.path.join(here, 'soak_step.py'), '40', '2026'], capture_output=True, text=True, timeout=900)
     tail = '\n'.join((r.stdout + r.stderr).splitlines()[-15:])
     assert r.returncode == 0, tail
     assert '40 of 40 cases ok' in r.stdout, tail
+    # the soak reaches the code it was written beside: mid-size meshes through the several-workgroups solver (kernel 7), others of the
+    # same sizes through the tiled passes (CWR_NO_SMALL drawn)
+    import re
+    mid = [(int(m.group(1)), int(m.group(2))) for m in re.finditer(r': n=(\d+) kernel (\d+) ', r.stdout)]
+    mid = [kk for n, kk in mid if 4096 < n <= 24576]
+    assert mid.count(7) >= 3 and mid.count(6) >= 3, r.stdout
