@@ -2269,7 +2269,7 @@ int solve_bicgstab(cwr_engine* e, double tol2, int max_iter, SolveStats& st) {
 // ====================================================================================================
 extern "C" {
 
-int32_t cwr_abi_version(void) { return 6; }
+int32_t cwr_abi_version(void) { return 7; }
 
 int32_t cwr_tile_rows(int32_t n_constituents) {
   if (n_constituents < 1 || n_constituents > 256) return 0;
@@ -3526,7 +3526,7 @@ int32_t cwr_output_release(cwr_engine* e, int32_t slot) {
 int32_t cwr_synchronize(cwr_engine* e) {
   if (!e) return CWR_ERR_BAD_ARG;
   HIP_TRY(e, enter_device(e->dev));
-  if (!e->pending_loads.empty()) TRY(flush_window_loads(e));
+  if (!e->pending_loads.empty() || !e->pending_bc.empty()) TRY(flush_window_loads(e));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   if (e->flow_stream) HIP_TRY(e, hipStreamSynchronize(e->flow_stream));   // (windowed flow field: every enqueued level has arrived)
   return CWR_OK;

@@ -40,7 +40,7 @@ INFO_SMALL_FALLBACK = 8        # the one-launch solver's parts did not all arriv
 # every symbol include/cwr_transport.h declares (tests check that the library exports them all)
 ABI_SYMBOLS = (
     'cwr_abi_version', 'cwr_tile_rows', 'cwr_chain_min_rows', 'cwr_create', 'cwr_destroy', 'cwr_last_error', 'cwr_load_flow_field',
-    'cwr_load_coefficients', 'cwr_flow_window_open', 'cwr_flow_window_load', 'cwr_get_coefficients', 'cwr_load_boundary', 'cwr_set_boundary_level',
+    'cwr_load_coefficients', 'cwr_flow_window_open', 'cwr_flow_window_load', 'cwr_get_coefficients', 'cwr_load_boundary', 'cwr_set_boundary_level', 'cwr_boundary_window_load',
     'cwr_set_state', 'cwr_get_state', 'cwr_load_real_inputs', 'cwr_react_linear', 'cwr_state_device_ptr', 'cwr_state_row_stride', 'cwr_apply', 'cwr_rhs', 'cwr_step', 'cwr_get_mass_flux',
     'cwr_get_jacobi_norms', 'cwr_set_jacobi_norms', 'cwr_get_error_factors', 'cwr_tiling_info', 'cwr_set_tile_schedule', 'cwr_get_tile_schedule',
     'cwr_time_apply', 'cwr_profile_read', 'cwr_synchronize', 'cwr_apply_bytes',
@@ -116,6 +116,7 @@ def load_library(path: str | None = None) -> C.CDLL:
         'cwr_get_coefficients': [vp, i32, vp, vp],
         'cwr_load_boundary': [vp, i32, vp],
         'cwr_set_boundary_level': [vp, i32, vp],
+        'cwr_boundary_window_load': [vp, i32, i32, vp],
         'cwr_set_state': [vp, vp],
         'cwr_get_state': [vp, vp],
         'cwr_load_real_inputs': [vp, i32, vp, vp, vp],
@@ -289,6 +290,8 @@ class TransportEngine:
         self._check(self._lib.cwr_flow_window_open(self._h, int(n_times), int(window_levels), _ptr(dtv), _ptr(dist), float(diffusion_coefficient)))
         self.n_times = int(n_times)
         self._window_keep = {}
+        self._slot_latest = {}
+        self._window_W = max(2, min(int(window_levels), int(n_times)))
 
     def volume_in_engine_order(self, volume) -> np.ndarray:
         """(T, n_cells) volumes with the columns in the engine's cell numbering (what flow_window_load(..., engine_order=True) takes):
@@ -307,8 +310,15 @@ class TransportEngine:
         if self._order is not None and not engine_order:
             vol = np.ascontiguousarray(vol[:, self._cols])
         self._check(self._lib.cwr_flow_window_load(self._h, int(t0), int(n), _ptr(ff), _ptr(ev), _ptr(vol)))
-        self._window_keep[int(t0)] = (ff, ev, vol)               # (the copies are asynchronous for page-locked arrays)
-        for k in [k for k in self._window_keep if k < int(t0) - 4 * max(1, n)]:
+        # the library only NOTES the pointers (the copies are enqueued by the next cwr_step, asynchronous for page-locked arrays): the arrays
+        # stay alive here until every slot they fill has been loaded AGAIN (a correct caller does that only after the steps that read
+        # the level returned) or synchronize() has returned -- not "a few loads later" (a ring filled level by level with
+        # temporaries before the first step lost them to the garbage collector)
+        W = max(1, int(getattr(self, '_window_W', n)))
+        for L in range(int(t0), int(t0) + n):
+            self._slot_latest[L % W] = L
+        self._window_keep[int(t0)] = (n, ff, ev, vol)
+        for k in [k for k, v in self._window_keep.items() if all(self._slot_latest.get(L % W, -1) > L for L in range(k, k + v[0]))]:
             del self._window_keep[k]
 
     def get_coefficients(self, t: int):
@@ -323,6 +333,20 @@ class TransportEngine:
         # (a rank of a partitioned run may hold no boundary cell at all -- seen first at 8 ranks: numpy cannot infer -1 of an empty array)
         g = _arr(g.reshape(T, self.n_ghost, self.K if g.size == 0 else -1), np.float64, (T, self.n_ghost, self.K), 'ghost_conc')
         self._check(self._lib.cwr_load_boundary(self._h, T, _ptr(g)))
+
+    def alloc_boundary(self, n_times: int):
+        """n_times levels of zero boundary values on the device (cwr_load_boundary with NULL): the levels then arrive through
+        boundary_window_load / set_boundary_level -- a streamed run never holds all of them on the host."""
+        self._check(self._lib.cwr_load_boundary(self._h, int(n_times), None))
+
+    def boundary_window_load(self, t0: int, ghost_conc_levels):
+        """Levels t0 .. t0 + n - 1 of the boundary values, (n, n_ghost, K) float64 (cwr_boundary_window_load): on a windowed engine only
+        noted -- copied on the flow stream beside the steps; the array is kept alive here until its levels are loaded again or synchronize()."""
+        g = _arr(ghost_conc_levels, np.float64)
+        n = g.shape[0]
+        g = _arr(g.reshape(n, self.n_ghost, self.K if g.size == 0 else -1), np.float64, (n, self.n_ghost, self.K), 'ghost_conc_levels')
+        self._check(self._lib.cwr_boundary_window_load(self._h, int(t0), int(n), _ptr(g)))
+        self._bc_keep = [(a, b, arr) for (a, b, arr) in getattr(self, '_bc_keep', []) if not (int(t0) <= a and b <= int(t0) + n)] + [(int(t0), int(t0) + n, g)]
 
     def set_boundary_level(self, t: int, ghost_conc_level):
         g = _arr(ghost_conc_level, np.float64)
@@ -592,6 +616,9 @@ class TransportEngine:
 
     def synchronize(self):
         self._check(self._lib.cwr_synchronize(self._h))
+        self._bc_keep = []                           # (every noted upload has been made: see flow_window_load / boundary_window_load)
+        if getattr(self, '_window_keep', None):
+            self._window_keep.clear()
 
     # ------------------------------------------------------------------ domain decomposition
     @staticmethod

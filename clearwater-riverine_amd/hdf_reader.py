@@ -67,7 +67,10 @@ def _time_slice(stamps: np.ndarray, datetime_range) -> Tuple[Optional[int], Opti
     raise TypeError('Invalid datetime_range, must be tuple of strings or ints')          # io/hdf.py:180-183
 
 
-def read_ras_hdf(file_path: str, datetime_range: Optional[Union[Tuple[int, int], Tuple[str, str]]] = None) -> Mesh:
+def read_ras_hdf(file_path: str, datetime_range: Optional[Union[Tuple[int, int], Tuple[str, str]]] = None, lazy: bool = False) -> Mesh:
+    """lazy=True (round 6): everything but the three per-level arrays ('Face Flow', 'Face Velocity', 'Cell Volume': the (T, .) bulk of the
+    file) is read now; those are left in the file behind mesh.attrs['level_source'] (levels.HdfLevelSource: hyperslab reads by level, the
+    same datetime_range window, io/hdf.py:149-191) for a run that streams them through the engine's ring."""
     try:
         import h5py
     except ImportError as exc:                                    # the image's default interpreter has no h5py
@@ -90,10 +93,15 @@ def read_ras_hdf(file_path: str, datetime_range: Optional[Union[Tuple[int, int],
             'face_x': centers[:, 0].astype(np.float64),
             'face_y': centers[:, 1].astype(np.float64),
             'time': stamps[sl],
-            'face_flow': res['Face Flow'][sl].astype(np.float32),
-            'edge_velocity': res['Face Velocity'][sl].astype(np.float32),
-            'volume': res['Cell Volume'][sl].astype(np.float32),
         })
+        if lazy:
+            from .levels import HdfLevelSource
+            first = 0 if t0 is None else t0
+            m.attrs['level_source'] = HdfLevelSource(file_path, area, first, len(m['time']), int(faces_cells.shape[0]), int(centers.shape[0]))
+        else:
+            m['face_flow'] = res['Face Flow'][sl].astype(np.float32)
+            m['edge_velocity'] = res['Face Velocity'][sl].astype(np.float32)
+            m['volume'] = res['Cell Volume'][sl].astype(np.float32)
         m.attrs['nreal'] = int(faces_cells[:, 0].max())                                  # io/hdf.py:268-269
         # boundary lines (io/hdf.py:355-436): External Faces joined with the line attributes on 'BC Line ID', keeping of
         # every line only the faces listed in '<name> - Flow per Face'.attrs['Faces'] (the HEC-RAS bug the reference works

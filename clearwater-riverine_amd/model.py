@@ -83,6 +83,54 @@ def _page_block(shape, fill: float) -> np.ndarray:
     return arr
 
 
+class SparseInputArray:
+    """`input_array` (T, ncell) of constituents.py:78-164 without its zeros: row 0 = the initial condition of the real cells (and whatever
+    the caller puts on ghost cells there), every other row = the boundary series of the few ghost cells that have one.  What a run that
+    streams its flow field (levels.FlowWindowFeeder) holds instead of the dense array -- (T, ncell) float64 is 86 GB per constituent at
+    1 M cells x 10 801 stamps.  Zero stays the "no boundary value" sentinel (transport.py:258-264)."""
+
+    def __init__(self, n_times: int, n_cells: int, initial_row, ghost_cells, series):
+        self.shape = (int(n_times), int(n_cells))
+        self.initial_row = np.ascontiguousarray(initial_row, dtype=np.float64).reshape(self.shape[1])
+        self.ghost_cells = np.ascontiguousarray(ghost_cells, dtype=np.int64).ravel()
+        self.series = np.ascontiguousarray(series, dtype=np.float64).reshape(self.shape[0], len(self.ghost_cells))
+
+    def row(self, t: int) -> np.ndarray:
+        out = self.initial_row.copy() if t == 0 else np.zeros(self.shape[1])
+        out[self.ghost_cells] = self.series[t]
+        return out
+
+    def ghost_block(self, t0: int, t1: int, n_real: int) -> np.ndarray:
+        """(t1 - t0, ncell - n_real) dense boundary values of levels [t0, t1)."""
+        out = np.zeros((t1 - t0, self.shape[1] - n_real))
+        if t0 == 0 and t1 > 0:
+            out[0] = self.initial_row[n_real:]
+        out[:, self.ghost_cells - n_real] = self.series[t0:t1]
+        return out
+
+    def dense(self) -> np.ndarray:
+        return np.stack([self.row(t) for t in range(self.shape[0])])
+
+
+def _is_sparse(a) -> bool:
+    return hasattr(a, 'ghost_block')
+
+
+def _ghost_levels(input_array, t0: int, t1: int, n_real: int) -> np.ndarray:
+    return input_array.ghost_block(t0, t1, n_real) if _is_sparse(input_array) else input_array[t0:t1, n_real:]
+
+
+def _real_input_levels(input_array, n_real: int):
+    """Levels whose row has non-zero entries on REAL cells (the IC row; point sources at later levels only in a dense array)."""
+    if _is_sparse(input_array):
+        return [0] if np.any(input_array.initial_row[:n_real] != 0) else []
+    return [int(r) for r in np.nonzero(np.any(input_array[:, :n_real] != 0, axis=1))[0]]
+
+
+def _real_row(input_array, t: int, n_real: int) -> np.ndarray:
+    return (input_array.initial_row[:n_real] if t == 0 else np.zeros(n_real)) if _is_sparse(input_array) else input_array[t, :n_real]
+
+
 class Constituent:
     """constituents.py:17-75 over arrays: NaN-initialised (T, ncell) state, input_array with the
     initial condition in row 0 and boundary values in ghost-cell columns, three (T, E) flux arrays."""
@@ -96,8 +144,8 @@ class Constituent:
         ncell = len(mesh['face_x'])
         self.name = name
         self.units = units
-        self.input_array = np.ascontiguousarray(input_array, dtype=np.float64)
-        if self.input_array.shape != (T, ncell):
+        self.input_array = input_array if _is_sparse(input_array) else np.ascontiguousarray(input_array, dtype=np.float64)
+        if tuple(self.input_array.shape) != (T, ncell):
             raise ValueError(f'input_array of {name}: expected {(T, ncell)}, got {self.input_array.shape}')
         if store_history:
             if flux_views is not None:
@@ -110,7 +158,7 @@ class Constituent:
         else:
             self.advection_mass_flux = self.diffusion_mass_flux = self.total_mass_flux = None
             state = state_view if state_view is not None else np.full((2, ncell), np.nan)      # rolling pair of levels
-        state[0] = self.input_array[0]               # constituents.py:94-98
+        state[0] = self.input_array.row(0) if _is_sparse(self.input_array) else self.input_array[0]               # constituents.py:94-98
         mesh[name] = state
         self.max_value = None
         self.min_value = None
@@ -164,7 +212,7 @@ def boundary_series(model_time, bc_frame) -> Dict[str, np.ndarray]:
 
 
 def input_array_from_csv(mesh: Mesh, initial_conditions_csv: str, boundary_conditions_csv: str,
-                        boundary_faces) -> np.ndarray:
+                        boundary_faces, sparse: bool = False):
     """constituents.py:78-164: IC CSV (Cell_Index, Concentration) -> row 0; BC CSV (RAS2D_TS_Name, Datetime,
     Concentration) time-aligned per boundary line (boundary_series) and written at [every time index, ghost cell of
     every face of the line] in one vectorised assignment per line.  ``boundary_faces`` is mesh.attrs['boundary_data']
@@ -174,12 +222,28 @@ def input_array_from_csv(mesh: Mesh, initial_conditions_csv: str, boundary_condi
     import pandas as pd
     T = len(mesh['time'])
     ncell = len(mesh['face_x'])
-    arr = np.zeros((T, ncell))
     ic = pd.read_csv(initial_conditions_csv)
-    arr[0, ic['Cell_Index'].astype(int).to_numpy()] = ic['Concentration'].to_numpy(dtype=np.float64)
     bc = pd.read_csv(boundary_conditions_csv, parse_dates=['Datetime']).dropna(how='all')
     f2 = np.asarray(mesh[EDGES_FACE2])
     table = _boundary_face_table(boundary_faces)
+    if sparse:
+        # (sparse=True: the same array as a SparseInputArray -- row 0 + the series of the boundary lines' ghost cells; O(T x boundary cells))
+        row0 = np.zeros(ncell)
+        row0[ic['Cell_Index'].astype(int).to_numpy()] = ic['Concentration'].to_numpy(dtype=np.float64)
+        cells, cols = [], []
+        for name, vals in boundary_series(mesh['time'], bc).items():
+            faces = table.get(name)
+            if faces is None or len(faces) == 0:
+                continue
+            for g in f2[faces]:                                  # (a later line overwrites an earlier one on a shared ghost cell, as the dense assignment does)
+                if int(g) in cells:
+                    cols[cells.index(int(g))] = vals
+                else:
+                    cells.append(int(g)); cols.append(vals)
+        series = np.stack(cols, axis=1) if cols else np.zeros((T, 0))
+        return SparseInputArray(T, ncell, row0, cells, series)
+    arr = np.zeros((T, ncell))
+    arr[0, ic['Cell_Index'].astype(int).to_numpy()] = ic['Concentration'].to_numpy(dtype=np.float64)
     for name, vals in boundary_series(mesh['time'], bc).items():
         faces = table.get(name)
         if faces is None or len(faces) == 0:
@@ -250,7 +314,9 @@ class ClearwaterRiverine:
                         diffusion_coefficient_input = cfg['diffusion_coefficient']
                     flow_field_file_path = flow_field_file_path or cfg['flow_field_filepath']
                     constituent_dict = cfg['constituents']
-                mesh = read_ras_hdf(flow_field_file_path, datetime_range=datetime_range)
+                # flow_window given: the file's levels are read W / 2 at a time while the run goes (hdf_reader lazy=True, levels.FlowWindowFeeder):
+                # host memory O(W) levels instead of the whole datetime_range (io/hdf.py:149-191 reads it whole)
+                mesh = read_ras_hdf(flow_field_file_path, datetime_range=datetime_range, lazy=flow_window is not None)
             else:
                 raise TypeError('Missing a `config_filepath` or a `constituent_dict` and '
                                 '`flow_field_file_path` to run the model.')      # transport.py:121-123
@@ -274,6 +340,12 @@ class ClearwaterRiverine:
         T = len(m['time'])
         self._n, self._ncell, self._T = n, ncell, T
 
+        # a LEVEL SOURCE instead of the three (T, .) arrays (levels.py: `.read(t0, t1)` or a callable): the flow field is streamed
+        level_source = m.attrs.get('level_source')
+        if level_source is None and 'level_source' in m:
+            level_source = m.pop('level_source')
+        if level_source is not None and flow_window is None:
+            flow_window = 16
         # a-1 host part: centroid distances and dt; the rest is derived on the GPU
         m[FACE_TO_FACE_DISTANCE] = face_to_face_distance(m)
         m[CHANGE_IN_TIME] = change_in_time(m['time'])
@@ -287,7 +359,7 @@ class ClearwaterRiverine:
             if bfaces is None:
                 bfaces = m.attrs.get('boundary_faces') or {}
             input_arrays = {
-                name: input_array_from_csv(m, cfg['initial_conditions'], cfg['boundary_conditions'], bfaces)
+                name: input_array_from_csv(m, cfg['initial_conditions'], cfg['boundary_conditions'], bfaces, sparse=level_source is not None)
                 for name, cfg in constituent_dict.items()}
         self.constituents = list(input_arrays.keys())
         self.constituent_dict: Dict[str, Constituent] = {}
@@ -331,28 +403,45 @@ class ClearwaterRiverine:
             flow_window = max(4, int(limit // per_level))
         self._flow_window = None if flow_window is None else max(2, min(int(flow_window), T))
         self._win_hi = 0                                         # levels [.., _win_hi) have been handed to the engine
+        self._feeder = None
+        n_g = ncell - n
         if self._flow_window is None:
             self.engine.load_flow_field(m[FLOW_ACROSS_FACE], m[EDGE_VELOCITY], m[VOLUME], m[CHANGE_IN_TIME],
                                         m[FACE_TO_FACE_DISTANCE], m.attrs['diffusion_coefficient'])
+        elif level_source is not None:
+            # file -> two page-locked staging blocks -> ring (levels.FlowWindowFeeder): W / 2 levels per read, the boundary values of the
+            # same levels with them; nothing of length T but the stamps, dt and what the caller's input arrays hold
+            from .levels import FlowWindowFeeder, as_level_source
+            src = as_level_source(level_source, T, E, ncell)
+            self.engine.flow_window_open(T, self._flow_window, m[CHANGE_IN_TIME], m[FACE_TO_FACE_DISTANCE], m.attrs['diffusion_coefficient'])
+            self.engine.alloc_boundary(T)
+            cons = [self.constituent_dict[c] for c in self.constituents]
+
+            def boundary_levels(t0, t1, cons=cons, n=n):
+                return np.stack([_ghost_levels(c.input_array, t0, t1, n) for c in cons], axis=2)
+
+            self._feeder = FlowWindowFeeder(self.engine, src, T, self._flow_window, cell_cols=self.engine._cols if order is not None else None,
+                                            boundary=boundary_levels if n_g > 0 else None)
+            self._feeder.fill(0)
         else:
             self._flow_arrays = (np.ascontiguousarray(m[FLOW_ACROSS_FACE], dtype=np.float32), np.ascontiguousarray(m[EDGE_VELOCITY], dtype=np.float32),
                                  self.engine.volume_in_engine_order(m[VOLUME]))          # (volumes permuted to the engine's cell order once)
             self._flow_pinned = [a for a in self._flow_arrays if a.nbytes >= (1 << 20) and self.engine.host_register(a)]   # (asynchronous uploads)
             self.engine.flow_window_open(T, self._flow_window, m[CHANGE_IN_TIME], m[FACE_TO_FACE_DISTANCE], m.attrs['diffusion_coefficient'])
             self._fill_flow_window(0)
-        ghost = np.stack([self.constituent_dict[c].input_array[:, n:] for c in self.constituents], axis=2)
-        self.engine.load_boundary(ghost)
+        if self._feeder is None:
+            ghost = np.stack([_ghost_levels(self.constituent_dict[c].input_array, 0, T, n) for c in self.constituents], axis=2)
+            self.engine.load_boundary(ghost)
         # rows of input_array that carry non-zero values in REAL cells (the IC row, normally only t = 0):
         # RHS.update_values overwrites the solution with them (linalg.py:199-200)
         self._real_input_rows = set()
         for c in self.constituents:
-            rows = np.nonzero(np.any(self.constituent_dict[c].input_array[:, :n] != 0, axis=1))[0]
-            self._real_input_rows.update(int(r) for r in rows)
+            self._real_input_rows.update(_real_input_levels(self.constituent_dict[c].input_array, n))
         # levels >= 1: the reference also writes them into the SOLVED level t+1 before the mass fluxes are taken
         # (transport.py:258-264); the engine does that on the device from these sparse entries
         lv, ce, va = [], [], []
         for r in sorted(self._real_input_rows - {0}):
-            inp = np.stack([self.constituent_dict[c].input_array[r, :n] for c in self.constituents], axis=1)
+            inp = np.stack([_real_row(self.constituent_dict[c].input_array, r, n) for c in self.constituents], axis=1)
             cells = np.nonzero(np.any(inp != 0, axis=1))[0]
             lv.append(np.full(len(cells), r, dtype=np.int32)); ce.append(cells); va.append(inp[cells])
         if lv:
@@ -380,6 +469,9 @@ class ClearwaterRiverine:
         """Windowed flow field: hand the engine every level up to t + W - 1 that it does not hold yet (the slot of level L held level
         L - W, which no step from t on reads).  Enqueued on the engine's flow stream: returns at once."""
         if self._flow_window is None:
+            return
+        if self._feeder is not None:
+            self._feeder.fill(t)
             return
         hi = min(self._T, t + self._flow_window)
         if hi > self._win_hi:
@@ -423,7 +515,7 @@ class ClearwaterRiverine:
         if overridden or self._device_level != t or (t == 0 and t in self._real_input_rows):
             x = np.stack([self._row(c, t)[0:n] for c in self.constituents], axis=1)
             if t in self._real_input_rows:                       # linalg.py:199-200
-                inp = np.stack([self.constituent_dict[c].input_array[t, :n] for c in self.constituents], axis=1)
+                inp = np.stack([_real_row(self.constituent_dict[c].input_array, t, n) for c in self.constituents], axis=1)
                 x = np.where(inp != 0, inp, x)
             self.engine.set_state(x)
         if reaction_matrix is not None:
@@ -432,7 +524,7 @@ class ClearwaterRiverine:
                 # as with the host override, non-zero input_array[t] entries on real cells win over the reaction's result
                 # (linalg.py:199-200) -- at level 0 that is the whole initial condition
                 x = self.engine.get_state()[:n]
-                inp = np.stack([self.constituent_dict[c].input_array[t, :n] for c in self.constituents], axis=1)
+                inp = np.stack([_real_row(self.constituent_dict[c].input_array, t, n) for c in self.constituents], axis=1)
                 self.engine.set_state(np.where(inp != 0, inp, x))
             if self.store_history:                               # keep mesh[name][t] consistent, as the override does
                 c_now = self.engine.get_state()
@@ -511,6 +603,8 @@ class ClearwaterRiverine:
             raise IndexError('no step taken yet')
         k = self.constituents.index(constituent_name)
         m = self.mesh
+        if FLOW_ACROSS_FACE not in m:
+            raise NotImplementedError('mass_bal_global of a streamed run: the volume columns need face_flow of every level (construct without flow_window, or from arrays)')
         vols = volume_columns(m[FLOW_ACROSS_FACE], m[CHANGE_IN_TIME], self._lines)
         mass0, vol0 = self._mass_start
         mass1, vol1 = self.engine.domain_mass(self.time_step)
@@ -529,6 +623,11 @@ class ClearwaterRiverine:
         for b in getattr(self, '_pinned', []):
             self.engine.host_unregister(b)
         self._pinned = []
+        if getattr(self, '_feeder', None) is not None:
+            if self.engine._h:
+                self.engine.synchronize()
+            self._feeder.close()
+            self._feeder = None
         if getattr(self, '_flow_pinned', None):
             if self.engine._h:
                 self.engine.synchronize()

@@ -180,8 +180,17 @@ int32_t cwr_get_coefficients(cwr_engine* e, int32_t t, float* advection_coeff, d
  * ghost_conc is (T, n_ghost, K) float64 with n_ghost = n_cells - n_owned - n_halo; 0 = "no boundary
  * value" (the reference's sentinel, transport.py:258-264). */
 int32_t cwr_load_boundary(cwr_engine* e, int32_t n_times, const double* ghost_conc);
-/* One level only (streaming alternative). */
+/* (ABI 7) ghost_conc == NULL: n_times levels of zeros ("no boundary value") are allocated and the values arrive later, a few levels at
+ * a time -- a run that streams its flow field (cwr_flow_window_load) need not hold all levels of its boundary values on the host. */
+/* One level only (blocking upload). */
 int32_t cwr_set_boundary_level(cwr_engine* e, int32_t t, const double* ghost_conc_level);
+/* (ABI 7) Levels t0 .. t0 + n_levels - 1, (n_levels, n_ghost, K) float64, into their rows of the array cwr_load_boundary allocated
+ * (input_array[t, ghost cells], constituents.py:153-164; the reference holds all T levels in RAM, constituents.py:39-48).  On an engine
+ * with a flow-field window the call only NOTES the pointer, exactly as cwr_flow_window_load does: the next cwr_step enqueues the copy on
+ * the engine's flow stream (first where the step reads level t + 1 of them, otherwise behind its batch of passes) and the step that
+ * reads the rows waits for them on the device.  The host array must stay untouched until a cwr_step that reads the levels, or
+ * cwr_synchronize, has returned; page-locked arrays (cwr_host_register) make the copy asynchronous.  Other engines: a blocking upload. */
+int32_t cwr_boundary_window_load(cwr_engine* e, int32_t t0, int32_t n_levels, const double* ghost_conc);
 
 /* ---- state --------------------------------------------------------------------------------------
  * cwr_set_state: concentrations of the owned real cells at the current level, (n_owned, K).  Used for

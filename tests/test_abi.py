@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(cw.LIB_PATH)
     for name in declared_symbols():
         assert hasattr(lib, name), f'{name} missing from {cw.LIB_PATH}'
-    assert cw.load_library().cwr_abi_version() == 6
+    assert cw.load_library().cwr_abi_version() == 7
 
 
 def test_no_torch_types_in_the_abi():

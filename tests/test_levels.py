@@ -1,0 +1,203 @@
+"""File -> staging -> ring (levels.py) without a GPU: the feeder against a recording stand-in of the
+engine's window calls, which enforces the library's contract -- a noted host array is read at the NEXT step (so it must still hold its
+levels then), a step needs its two levels in the ring, a load may only replace levels no later step reads.
+
+With the reference's own 10 801-stamp fixture (plan01) the run happens in the container's h5py interpreter (a child process, as
+tests/test_hdf_reader.py does): every level crosses once, W / 2 at a time, equal to what the whole-file read returns, with the numpy heap
+bounded by the staging blocks whatever the number of stamps."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = '/root/reference/tests/data/simple_test_cases'
+H5PY_PYTHON = '/opt/conda/bin/python3.9'
+
+
+class RecordingEngine:
+    """What levels.FlowWindowFeeder calls, with the ordering rules of include/cwr_transport.h (cwr_flow_window_load,
+    cwr_boundary_window_load) turned into assertions."""
+
+    def __init__(self, n_edges, n_cells, n_ghost, K, W, truth, bc_truth=None):
+        self.n_edges, self.n_cells, self.n_ghost, self.K, self.W = n_edges, n_cells, n_ghost, K, W
+        self.truth, self.bc_truth = truth, bc_truth
+        self.ring = {}                        # slot -> level
+        self.noted = []                       # (t0, ff, ev, vol) views not yet "copied"
+        self.noted_bc = []
+        self.t_done = -1                      # last step that returned
+        self.levels_loaded = 0
+        self.syncs = 0
+
+    def host_register(self, a):
+        return True
+
+    def host_unregister(self, a):
+        pass
+
+    def synchronize(self):
+        self._copy()
+        self.syncs += 1
+
+    def flow_window_load(self, t0, ff, ev, vol, engine_order=False):
+        n = ff.shape[0]
+        assert engine_order and 1 <= n <= self.W and ev.shape[0] == n and vol.shape[0] == n
+        assert ff.flags['C_CONTIGUOUS'] and ev.flags['C_CONTIGUOUS'] and vol.flags['C_CONTIGUOUS']
+        for L in range(t0, t0 + n):
+            old = self.ring.get(L % self.W)
+            # the level that leaves must not be read by any step still to come: steps > t_done read levels >= t_done + 1
+            assert old is None or old <= self.t_done or old == L, f'level {L} evicts level {old}, which step {self.t_done + 1} may read'
+            self.ring[L % self.W] = L
+        self.noted.append((t0, ff, ev, vol))
+        self.levels_loaded += n
+
+    def boundary_window_load(self, t0, g):
+        assert g.flags['C_CONTIGUOUS'] and g.shape[1:] == (self.n_ghost, self.K)
+        self.noted_bc.append((t0, g))
+
+    def _copy(self):
+        """The upload the library makes at the next step / synchronize: the noted host arrays must hold their levels NOW."""
+        ff_t, ev_t, vol_t = self.truth
+        for t0, ff, ev, vol in self.noted:
+            n = ff.shape[0]
+            assert np.array_equal(ff, ff_t[t0:t0 + n]) and np.array_equal(ev, ev_t[t0:t0 + n]), f'staged flows of levels {t0}..{t0 + n - 1} were overwritten before their upload'
+            assert np.array_equal(vol, vol_t[t0:t0 + n]), f'staged volumes of levels {t0}..{t0 + n - 1} were overwritten before their upload'
+        for t0, g in self.noted_bc:
+            assert np.array_equal(g, self.bc_truth[t0:t0 + g.shape[0]])
+        self.noted, self.noted_bc = [], []
+
+    def step(self, t):
+        self._copy()
+        assert self.ring.get(t % self.W) == t and self.ring.get((t + 1) % self.W) == t + 1, f'step {t}: its levels are not in the ring {self.ring}'
+        self.t_done = t
+
+
+def _fields(T, E, nc, seed=0):
+    rng = np.random.default_rng(seed)
+    return (rng.random((T, E)).astype(np.float32), rng.random((T, E)).astype(np.float32), rng.random((T, nc)).astype(np.float32))
+
+
+@pytest.mark.parametrize('T,W,chunk', [(40, 16, None), (40, 5, None), (9, 2, None), (33, 8, 3), (12, 16, None), (50, 7, 7), (31, 6, 1)])
+def test_feeder_keeps_the_ring_fed_and_never_overwrites_a_pending_level(T, W, chunk):
+    from clearwater_riverine_amd.levels import ArrayLevelSource, FlowWindowFeeder
+    E, nc, ng, K = 23, 17, 4, 3
+    ff, ev, vol = _fields(T, E, nc)
+    perm = np.random.default_rng(1).permutation(nc)
+    bc = np.random.default_rng(2).random((T, ng, K))
+    eng = RecordingEngine(E, nc, ng, K, min(W, T), (ff, ev, vol[:, perm]), bc)
+    fd = FlowWindowFeeder(eng, ArrayLevelSource(ff, ev, vol), T, W, cell_cols=perm, boundary=lambda a, b: bc[a:b], chunk=chunk, pin=False)
+    fd.fill(0)
+    for t in range(T - 1):
+        fd.fill(t)
+        eng.step(t)
+    assert eng.levels_loaded == T                              # every level crossed exactly once
+    assert fd.staged_bytes <= (fd.H * (2 * E + nc) * 4 + fd.H * ng * K * 8)
+    assert fd.H <= min(W, T) + fd.C
+    # a jump back restarts the ring at the new level (the feeder drains the engine first)
+    back = max(0, T // 2 - 1)
+    eng.ring.clear(); eng.t_done = back - 1                    # (the stand-in's eviction rule is about a forward run)
+    fd.fill(back)
+    assert eng.syncs >= 1
+    for t in range(back, T - 1):
+        fd.fill(t)
+        eng.step(t)
+
+
+def test_a_rank_cuts_its_faces_and_cells_out_of_every_level():
+    from clearwater_riverine_amd.levels import CallableLevelSource, FlowWindowFeeder
+    T, E, nc = 20, 30, 25
+    ff, ev, vol = _fields(T, E, nc, seed=5)
+    edges = np.array([3, 7, 8, 20, 29]); cells = np.array([24, 0, 5, 6])
+    eng = RecordingEngine(len(edges), len(cells), 0, 2, 4, (ff[:, edges], ev[:, edges], vol[:, cells]))
+    calls = []
+
+    def src(a, b):
+        calls.append((a, b))
+        return ff[a:b], ev[a:b], vol[a:b]
+
+    fd = FlowWindowFeeder(eng, CallableLevelSource(src, T, E, nc), T, 4, cell_cols=cells, edge_idx=edges, pin=False)
+    for t in range(T - 1):
+        fd.fill(t)
+        eng.step(t)
+    assert sum(b - a for a, b in calls) == T and max(b - a for a, b in calls) == 2
+
+
+def test_sparse_input_array_is_the_dense_one():
+    from clearwater_riverine_amd.model import SparseInputArray, _ghost_levels, _real_input_levels, _real_row
+    T, ncell, n = 7, 12, 8
+    rng = np.random.default_rng(3)
+    dense = np.zeros((T, ncell))
+    dense[0, :n] = rng.random(n) + 0.5
+    dense[:, 9] = rng.random(T) + 1.0
+    dense[:, 11] = rng.random(T) + 2.0
+    sp = SparseInputArray(T, ncell, dense[0] * (np.arange(ncell) < n), [9, 11], dense[:, [9, 11]])
+    assert np.array_equal(sp.dense(), dense)
+    for a, b in [(0, T), (0, 1), (2, 5), (6, 7)]:
+        assert np.array_equal(_ghost_levels(sp, a, b, n), _ghost_levels(dense, a, b, n))
+    assert _real_input_levels(sp, n) == _real_input_levels(dense, n) == [0]
+    assert np.array_equal(_real_row(sp, 0, n), _real_row(dense, 0, n)) and np.array_equal(_real_row(sp, 3, n), _real_row(dense, 3, n))
+
+
+_CHILD = r"""
+import sys, json, tracemalloc, resource
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + '/tests')
+from clearwater_riverine_amd.hdf_reader import read_ras_hdf
+from clearwater_riverine_amd.levels import FlowWindowFeeder
+from test_levels import RecordingEngine
+path, W = sys.argv[2], int(sys.argv[3])
+full = read_ras_hdf(path)                                  # the whole window in RAM: the truth (13 MB for this fixture)
+truth = (full['face_flow'], full['edge_velocity'], full['volume'])
+T = len(full['time'])
+out = {}
+for stamps in (T, T // 8):                                 # the numpy heap of the streamed run must not depend on the length of the run
+    lazy = read_ras_hdf(path, datetime_range=(0, stamps - 1), lazy=True)
+    assert 'face_flow' not in lazy and len(lazy['time']) == stamps
+    src = lazy.attrs['level_source']
+    E, nc = len(lazy['edges_face1']), len(lazy['face_x'])
+    eng = RecordingEngine(E, nc, 0, 1, W, truth)
+    fd = FlowWindowFeeder(eng, src, stamps, W, pin=False)
+    fd.fill(0)
+    eng.step(0)                                            # (h5py's own caches are warm from here on)
+    tracemalloc.start()
+    base = tracemalloc.get_traced_memory()[0]
+    for t in range(1, stamps - 1):
+        fd.fill(t)
+        eng.step(t)
+    peak = tracemalloc.get_traced_memory()[1] - base
+    tracemalloc.stop()
+    out[str(stamps)] = dict(levels_read=src.levels_read, largest_read=src.largest_read, loaded=eng.levels_loaded, peak_bytes=int(peak),
+                            staged_bytes=int(fd.staged_bytes), level_bytes=int((2 * E + nc) * 4))
+    fd.close()
+out['T'] = T
+out['maxrss_kb'] = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+print(json.dumps(out))
+"""
+
+
+@pytest.mark.skipif(not (os.path.isdir(REF) and os.path.exists(H5PY_PYTHON)), reason='reference HDF fixtures or an interpreter with h5py not present')
+def test_plan01s_10801_stamps_stream_through_a_window_of_16_with_bounded_memory():
+    """The reference's own fixture (tests/data/simple_test_cases/plan01_10x5: 10 801 stamps) through flow_window = 16: hyperslab reads of 8 levels,
+    each level read once, every staged level equal to the whole-file read (io/hdf.py:275-310), and the numpy heap of the loop bounded by a few
+    levels -- the same for 10 801 stamps and for 1 350."""
+    import json
+    try:
+        import h5py  # noqa: F401
+        py = sys.executable
+    except ImportError:
+        py = H5PY_PYTHON
+    r = subprocess.run([py, '-c', _CHILD, ROOT, os.path.join(REF, 'plan01_10x5/clearWaterTestCases.p01.hdf'), '16'], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    T = out['T']
+    assert T == 10801
+    for stamps in (T, T // 8):
+        o = out[str(stamps)]
+        assert o['levels_read'] == stamps == o['loaded'] and o['largest_read'] == 8
+        assert o['staged_bytes'] == 16 * o['level_bytes']
+        # the loop's own allocations: one chunk read (3 arrays of 8 levels) + slack -- NOT a function of the number of stamps
+        assert o['peak_bytes'] <= 4 * 8 * o['level_bytes'] + (256 << 10), o
+    # ... and what grows with the run is bookkeeping (~18 B per level: h5py / interpreter objects), not levels: 13.4 MB of them crossed
+    assert out[str(T)]['peak_bytes'] - out[str(T // 8)]['peak_bytes'] <= 0.03 * T * out[str(T)]['level_bytes'], out
