@@ -119,6 +119,8 @@ struct cwr_engine {
   float *d_in_f = nullptr, *d_flow_l = nullptr;   // staging of ONE level: reference face order in, face flows in internal order
   double* d_dist = nullptr;                // face_to_face_dist in internal face order (kept by windowed engines)
   unsigned long long* d_jn = nullptr;      // [T] ||J||_inf bit patterns per step (windowed)
+  double* d_lvlx = nullptr;                // partitioned + windowed: [W][world][3] a slot's level scalars laid out for their all-reduce (k_pack_level)
+  std::vector<hipEvent_t> ev_lvl_local;    // [W] recorded on flow_stream when a rank's own scalars of the slot's level are packed
   int32_t* d_bad = nullptr;                // [T] zero-coefficient flags per level (windowed)
   double* d_lvl_view = nullptr;            // the device's address of h_lvl
   double* h_lvl = nullptr;                 // page-locked [T][2]: {||J||_inf of step t, flag of level t}: where flow_stream leaves them
@@ -2561,6 +2563,8 @@ void cwr_destroy(cwr_engine* e) {
   if (e->h_lvl) hipHostFree(e->h_lvl);
   if (e->flow_stream) { hipStreamSynchronize(e->flow_stream); hipStreamDestroy(e->flow_stream); }
   for (hipEvent_t ev : e->ev_level) if (ev) hipEventDestroy(ev);
+  for (hipEvent_t ev : e->ev_lvl_local) if (ev) hipEventDestroy(ev);
+  if (e->d_lvlx) hipFree(e->d_lvlx);
   if (e->ev_evict) hipEventDestroy(e->ev_evict);
   if (e->ev_bc) hipEventDestroy(e->ev_bc);
   if (e->d_note_state) hipFree(e->d_note_state);
@@ -2615,7 +2619,11 @@ int32_t cwr_load_flow_field(cwr_engine* e, int32_t T, const float* face_flow, co
 int32_t cwr_flow_window_open(cwr_engine* e, int32_t T, int32_t W, const double* dt, const double* dist, double D) {
   if (!e) return CWR_ERR_BAD_ARG;
   if (T < 2 || W < 2 || !dt || !dist) return fail(e, CWR_ERR_BAD_ARG, "cwr_flow_window_open: need >= 2 time levels, a window of >= 2 levels and non-NULL arrays");
-  if (e->comm) return fail(e, CWR_ERR_STATE, "cwr_flow_window_open: windowed residency is for single engines (a partitioned engine holds 1 / N of every level)");
+  // (round 6) partitioned engines too: every rank holds a ring of ITS slices of W levels; what a single engine leaves for the host per level
+  // (zero-coefficient flag, ||J||_inf) is all-reduced on the communication stream at the load's point -- see window_load_now.  Collective in
+  // effect: every rank opens and loads the same levels at the same steps.
+  if (e->comm && !(e->one_comm_stream && e->comm_stream))
+    return fail(e, CWR_ERR_STATE, "cwr_flow_window_open: a partitioned engine needs its communication stream for windowed residency (not with CWR_COMM_TWO_STREAMS=1)");
   HIP_TRY(e, enter_device(e->dev));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   W = std::min(W, T);
@@ -2656,6 +2664,10 @@ int32_t cwr_flow_window_open(cwr_engine* e, int32_t T, int32_t W, const double* 
   for (hipEvent_t ev : e->ev_level) hipEventDestroy(ev);
   e->ev_level.assign((size_t)W, nullptr);
   for (auto& ev : e->ev_level) HIP_TRY(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  for (hipEvent_t ev : e->ev_lvl_local) hipEventDestroy(ev);
+  e->ev_lvl_local.assign((size_t)W, nullptr);
+  for (auto& ev : e->ev_lvl_local) HIP_TRY(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  if (e->d_lvlx) { hipFree(e->d_lvlx); e->d_lvlx = nullptr; }
   e->sched_level = -1;
   return CWR_OK;
 }
@@ -2756,6 +2768,28 @@ int window_load_now(cwr_engine* e, int t0, int n_levels, const float* face_flow,
       k_jnorm<<<dim3((unsigned)std::max(1, std::min(cdiv(e->n_owned, BLOCK), 1024)), 1u), BLOCK, 0, fs>>>(e->n_owned, e->E, e->n_cells, e->d_ptr, e->d_ent_edge,
           e->d_ent_nb, e->adv_l(st), e->dif_l(st), e->vol_l(st + 1), nullptr, e->d_jn + st, e->dt[(size_t)st]);
       st_done[q] = st;
+    }
+    if (e->comm && (e->world > 1 || e->force_coll)) {
+      // partitioned: this rank's scalars into its slot of the slot's block (flow stream), ONE sum all-reduce of world x 3 doubles on the
+      // communication stream behind it, the fold over the ranks into the page-locked words, and the slot's event -- the one a step waits
+      // for -- recorded THERE: the level is complete when every rank's share of it is.  Every rank reaches this point with the same
+      // level at the same place in its sequence of communication calls (loads are noted and flushed by rules that depend on t alone).
+      if (!(e->one_comm_stream && e->comm_stream)) return fail(e, CWR_ERR_STATE, "windowed flow field on a partitioned engine: needs the communication stream (not with CWR_COMM_TWO_STREAMS=1)");
+      const size_t blk = (size_t)3 * e->world;
+      if (!e->d_lvlx) TRY(dev_alloc(e, &e->d_lvlx, (size_t)e->W * blk));
+      hipStream_t cs = e->comm_stream;
+      k_pack_level<<<1, 64, 0, fs>>>(e->world, e->rank, e->d_bad + L, st_done[0] >= 0 ? e->d_jn + st_done[0] : nullptr,
+                                    st_done[1] >= 0 ? e->d_jn + st_done[1] : nullptr, e->d_lvlx + sl * blk);
+      HIP_TRY(e, hipGetLastError());
+      HIP_TRY(e, hipEventRecord(e->ev_lvl_local[sl], fs));
+      HIP_TRY(e, hipStreamWaitEvent(cs, e->ev_lvl_local[sl], 0));
+      NCCL_TRY(e, g_rccl.AllReduce(e->d_lvlx + sl * blk, e->d_lvlx + sl * blk, blk, NCCL_FLOAT64, NCCL_SUM, e->comm, cs));
+      k_note_level_ranks<<<1, 64, 0, cs>>>(e->world, e->d_lvlx + sl * blk, e->d_lvl_view + 2 * (size_t)L + 1,
+                                          st_done[0] >= 0 ? e->d_lvl_view + 2 * (size_t)st_done[0] : nullptr,
+                                          st_done[1] >= 0 ? e->d_lvl_view + 2 * (size_t)st_done[1] : nullptr);
+      HIP_TRY(e, hipGetLastError());
+      HIP_TRY(e, hipEventRecord(e->ev_level[sl], cs));
+      continue;
     }
     k_note_level<<<1, 1, 0, fs>>>(e->d_bad + L, e->d_lvl_view + 2 * (size_t)L + 1,
                                  st_done[0] >= 0 ? e->d_jn + st_done[0] : nullptr, st_done[0] >= 0 ? e->d_lvl_view + 2 * (size_t)st_done[0] : nullptr,
@@ -3590,7 +3624,11 @@ int32_t cwr_attach_comm(cwr_engine* e, int32_t rank, int32_t world, const uint8_
       seen[recv_cells[i]] = 1;
     }
   }
-  if (e->windowed) return fail(e, CWR_ERR_STATE, "cwr_attach_comm: this engine holds a windowed flow field (single engines only)");
+  if (e->comm) return fail(e, CWR_ERR_STATE, "cwr_attach_comm: this engine has a communicator already (its buffers are sized for that world: ADVICE r05)");
+  if (e->windowed)
+    for (int lvl : e->slot_level)
+      if (lvl >= 0) return fail(e, CWR_ERR_STATE, "cwr_attach_comm: levels were loaded into the flow-field window already -- attach the communicator first "
+                                                  "(a level's norms are all-reduced where it is loaded)");
   std::string err;
   if (!g_rccl.load(err)) return fail(e, CWR_ERR_RCCL, err);
   HIP_TRY(e, enter_device(e->dev));
@@ -3660,8 +3698,10 @@ int32_t cwr_attach_comm(cwr_engine* e, int32_t rank, int32_t world, const uint8_
   HIP_TRY(e, hipEventCreateWithFlags(&e->ev_red_in, hipEventDisableTiming));
   HIP_TRY(e, hipEventCreateWithFlags(&e->ev_red_out, hipEventDisableTiming));
   if (const char* v = getenv("CWR_COMM_TWO_STREAMS")) e->one_comm_stream = atoi(v) == 0;
-  TRY(sync_jnorms(e));
-  TRY(refine_error_factors(e));                                   // (collective: the row-wise bound of the global matrix, see there)
+  if (!e->windowed) {                                            // (a windowed field: per level, where it is loaded and where its step runs)
+    TRY(sync_jnorms(e));
+    TRY(refine_error_factors(e));                                 // (collective: the row-wise bound of the global matrix, see there)
+  }
   return sync_input_levels(e);
 }
 

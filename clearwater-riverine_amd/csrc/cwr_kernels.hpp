@@ -553,6 +553,36 @@ __global__ void k_note_level(const int32_t* __restrict__ flag, double* __restric
   __threadfence_system();
 }
 
+// (round 6) ... of a PARTITIONED engine: a rank's values of an arriving level -- the zero-coefficient flag, ||J||_inf over its own rows of up
+// to two steps -- laid out for ONE sum all-reduce (every rank in a slot of its own of a world x 3 block that is zero elsewhere, as
+// gather_check lays out the convergence check), and behind the all-reduce the fold over the ranks (any flag; the largest norm; NaN from
+// any rank stays NaN) into the same page-locked words a single engine's k_note_level writes.
+__global__ void __launch_bounds__(64) k_pack_level(int world, int rank, const int32_t* __restrict__ flag, const unsigned long long* __restrict__ jn_a,
+                                                   const unsigned long long* __restrict__ jn_b, double* __restrict__ block) {
+  for (int i = threadIdx.x; i < 3 * world; i += 64) block[i] = 0.0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    block[3 * rank + 0] = flag[0] ? 1.0 : 0.0;
+    block[3 * rank + 1] = jn_a ? __longlong_as_double((long long)jn_a[0]) : 0.0;
+    block[3 * rank + 2] = jn_b ? __longlong_as_double((long long)jn_b[0]) : 0.0;
+  }
+}
+__global__ void __launch_bounds__(64) k_note_level_ranks(int world, const double* __restrict__ block, double* __restrict__ flag_out,
+                                                         double* __restrict__ out_a, double* __restrict__ out_b) {
+  if (threadIdx.x != 0) return;
+  double f = 0.0, a = 0.0, b = 0.0;
+  for (int r = 0; r < world; ++r) {
+    const double fr = block[3 * r], ar = block[3 * r + 1], br = block[3 * r + 2];
+    if (fr != 0.0) f = 1.0;
+    a = (ar != ar || a != a) ? NAN : fmax(a, ar);
+    b = (br != br || b != b) ? NAN : fmax(b, br);
+  }
+  flag_out[0] = f;
+  if (out_a) out_a[0] = a;
+  if (out_b) out_b[0] = b;
+  __threadfence_system();
+}
+
 __global__ void __launch_bounds__(BLOCK) k_fill(int64_t total, double v, double* __restrict__ a, double* __restrict__ b) {
   for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * BLOCK) { a[i] = v; if (b) b[i] = v; }
 }

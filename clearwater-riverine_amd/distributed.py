@@ -163,17 +163,17 @@ class PartitionedTransport:
         fields = slice_fields(lm, mesh, np.asarray(dist_e), ref_cells)
         self.engine = TransportEngine(lm.face1, lm.face2, lm.n_cells, self.K, n_owned=lm.n_rows,
                                       n_halo=lm.n_halo, device=device)
-        # flow_window=W (single engines): a ring of W levels on the device, refilled one level per step on the engine's flow stream
-        # (cwr_flow_window_open / _load); the rank's slices stay on the host, page-locked so that the uploads are asynchronous
+        # flow_window=W: a ring of W levels on the device, refilled one level per step on the engine's flow stream (cwr_flow_window_open / _load);
+        # the rank's slices stay on the host, page-locked so that the uploads are asynchronous.  Round 6: ranks of a partition too (each its
+        # slices; the level's norms are all-reduced where it is loaded) -- the first levels go in once the communicator is attached, below.
         self._window = None
-        if flow_window and world == 1:
+        if flow_window:
             T = len(np.asarray(dt))
             self._window = max(2, min(int(flow_window), T))
             self._fields = (fields['face_flow'], fields['edge_velocity'], fields['volume'])
             self._pinned = [a for a in self._fields if self.engine.host_register(a)]
             self._T, self._win_lo, self._win_hi = T, 0, 0
             self.engine.flow_window_open(T, self._window, dt, fields['face_to_face_dist'], float(mesh['diffusion_coefficient']))
-            self.fill_window(0)
         else:
             self.engine.load_flow_field(fields['face_flow'], fields['edge_velocity'], fields['volume'], dt,
                                         fields['face_to_face_dist'], float(mesh['diffusion_coefficient']))
@@ -217,6 +217,7 @@ class PartitionedTransport:
             self.engine.load_real_inputs(np.concatenate(lvs), np.concatenate(ces), np.concatenate(vas))
         elif world > 1 and not self.standalone:                   # (collective for partitioned engines: also with no entries)
             self.engine.load_real_inputs(np.zeros(0, np.int32), np.zeros(0, np.int64), np.zeros((0, self.K)))
+        self.fill_window(0)                                       # (windowed: the ring's first levels, behind the communicator's attachment)
 
     def fill_window(self, t: int):
         """Windowed flow field: make levels t .. t + W - 1 resident (levels below t are not read by step t or any later one).  Only

@@ -389,7 +389,14 @@ class ClearwaterRiverine:
         if renumber and n > 4096:
             from .distributed import curve_kind                  # (one rule for the facade and the partitioned engines)
             lanes = curve_kind(n, K, 1) == 'lanes'
-            curve = lane_order(m, n, tile_rows=tile_rows(K)) if lanes else hilbert_order(m['face_x'], m['face_y'], n)
+            if lanes and FLOW_ACROSS_FACE not in m:
+                # a streamed field: the lanes follow the flow of its first levels (the numbering is a performance choice only)
+                from .levels import as_level_source
+                ff0 = as_level_source(level_source, T, len(f1), ncell).read(0, min(T, 8))[0]
+                view = Mesh(m); view.attrs = m.attrs; view[FLOW_ACROSS_FACE] = np.asarray(ff0, dtype=np.float32)
+                curve = lane_order(view, n, tile_rows=tile_rows(K))
+            else:
+                curve = lane_order(m, n, tile_rows=tile_rows(K)) if lanes else hilbert_order(m['face_x'], m['face_y'], n)
         order = balance_windows(curve, f1, f2, window=tile_rows(K)) if curve is not None else None
         self.engine = TransportEngine(f1, f2, ncell, K, device=device, cell_order=order)
         # Flow field: all T levels resident in HBM, or -- flow_window=W, or by itself when T levels exceed CWR_FLOW_RESIDENT_LIMIT_MB

@@ -155,7 +155,10 @@ int32_t cwr_load_coefficients(cwr_engine* e, int32_t n_times, const float* advec
 /* Windowed residency ("time-series streaming"): the device holds a RING of window_levels levels instead of all
  * n_times (~37 MB per level at 1 M cells: a 10 801-stamp file as the reference's tests/data/simple_test_cases/plan01_10x5 does
  * not fit whole; the reference's reader windows a file by datetime_range, io/hdf.py:149-191, and derives per level,
- * utilities.py:513-541).  Single engines.
+ * utilities.py:513-541).  Single engines, and (ABI 7) the ranks of a partition: every rank opens the same window and loads the same levels
+ * (its slices of them) at the same steps; the zero-coefficient flag and ||J||_inf of an arriving level are all-reduced on the
+ * communication stream where the level is loaded (one sum all-reduce of world x 3 doubles per level, beside the steps), the row-wise
+ * error factor is taken where the step runs (collectively).  Attach the communicator BEFORE the first level is sent to the ring.
  * cwr_flow_window_open: n_times levels in the run, a ring of window_levels >= 2 of them (level t lives in slot t % window_levels);
  *   dt (n_times), face_to_face_dist (n_edges) and D as for cwr_load_flow_field.  Replaces a loaded flow field.
  * cwr_flow_window_load: levels t0 .. t0 + n_levels - 1 (face_flow, edge_velocity: (n_levels, n_edges) f32; volume: (n_levels,

@@ -71,8 +71,9 @@ def _rank_body(rank, world, K, solver, depth, uid):
     import clearwater_riverine_amd as cw
     from clearwater_riverine_amd.distributed import PartitionedTransport
     mesh, inputs3 = make_case(K)
+    fw = int(os.environ.get('CWR_TEST_FLOW_WINDOW', '0'))     # > 0: every rank keeps a ring of this many levels of ITS slices (round 6)
     pt = PartitionedTransport(mesh, inputs3, rank, world, device=0, unique_id=uid, halo_depth=depth,
-                              renumber='hilbert' if depth >= 4 else None)
+                              renumber='hilbert' if depth >= 4 else None, flow_window=fw or None)
     infos, comm_counts, kinds = [], [], []
     pt.set_boundary_lines(case_lines(mesh))
     mass0 = pt.engine.domain_mass(0)
@@ -1089,3 +1090,40 @@ def test_partitioned_ranks_at_cfl_18_keep_their_batches_in_hand(gpu_lib, monkeyp
     pt.engine.close()
     assert not np.isnan(got).any()
     assert np.max(np.abs(got - want[:n])) <= 1e-9 * np.max(np.abs(want[:n]))
+
+
+@pytest.mark.parametrize('world,K,depth,W,big', [(2, 3, 4, 2, False), (4, 16, 8, 3, False), (2, 4, 8, 2, True), (4, 1, 6, 4, True)])
+def test_windowed_ranks_equal_resident_ranks_bit_for_bit(gpu_lib, world, K, depth, W, big, monkeypatch):
+    """cwr_flow_window_open / _load on PARTITIONED engines.  Every rank keeps a ring of W levels of its slices; the
+    zero-coefficient flag and ||J||_inf of an arriving level are all-reduced on the communication stream where the level is loaded, the
+    row-wise error factor is taken -- collectively -- where its step runs (the small mesh has dry cells: no norm bound).  Through the
+    stream-asynchronous stand-in, deterministic passes: states, fluxes, sweep counts and the ledger of every rank equal to the same ranks
+    with every level resident, BIT FOR BIT; the exchanges still run beside compute."""
+    build_mock()
+    monkeypatch.setenv('CWR_NO_SMALL', '1')
+    monkeypatch.setenv('CWR_TEST_DETERMINISTIC', '1')
+    monkeypatch.setenv('CWR_MOCK_ASYNC', '2')
+    if big:
+        monkeypatch.setenv('CWR_TEST_BIG', '1')
+    resident = run_ranks(world, _rank_main, (K, 'jacobi', depth))
+    monkeypatch.setenv('CWR_TEST_FLOW_WINDOW', str(W))
+    windowed = run_ranks(world, _rank_main, (K, 'jacobi', depth))
+    for a, b in zip(resident, windowed):
+        assert a[0] == b[0] and np.array_equal(a[1], b[1])
+        assert a[6] == b[6], (a[0], a[6], b[6])                                  # sweeps / iterations of every step
+        assert np.array_equal(a[3], b[3], equal_nan=True), f'rank {a[0]}: windowed state differs from the resident one'
+        assert np.array_equal(a[5], b[5], equal_nan=True)                        # total mass flux of the faces the rank reports
+        assert np.array_equal(a[8], b[8], equal_nan=True)                        # boundary-line ledger
+        assert a[13] == b[13] and b[12] == 1                                     # the same exchanges / overlaps / checks; asynchronous stand-in
+    # ... and the answer is the oracle's
+    mesh, inputs3 = make_case(K)
+    n = mesh['nreal'] + 1
+    state = np.full((n, K), np.nan)
+    for r in windowed:
+        state[r[1]] = r[3]
+    oracle.derive_coefficients(mesh)
+    ref = oracle.OracleModel(mesh, {f'c{k}': inputs3[:, :, k].copy() for k in range(K)})
+    for _ in range(3):
+        ref.update()
+    want = np.stack([ref.constituent_dict[f'c{k}'].state[3, :n] for k in range(K)], axis=1)
+    assert rel_err(state, want) <= 1e-9

@@ -196,3 +196,81 @@ def test_window_refills_beside_a_busy_chip_equal_the_resident_run_bit_for_bit(gp
     finally:
         stop.set(); th.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize('K,nx,ny,W', [(3, 120, 60, 6), (2, 40, 30, 16)])
+def test_facade_streams_a_lazy_level_source_through_the_ring_bit_for_bit(gpu_lib, tmp_path, K, nx, ny, W):
+    """file -> staging -> ring.  The three (T, .) arrays live in an .npz-backed store on disk (one .npy per array, memory-
+    mapped) behind a LEVEL SOURCE -- a callable (t0, t1) -> the levels -- and the facade (flow_window=W) pulls W / 2 levels at a time into two
+    page-locked staging blocks (levels.FlowWindowFeeder), the boundary values of the same levels with them (cwr_boundary_window_load; the input
+    arrays are SparseInputArrays: no (T, ncell) array anywhere).  Histories equal to the resident facade's BIT FOR BIT; every level read once,
+    never more than W / 2 at a time.  K = 3 is carried as 4 (the boundary rows are padded on the flow stream); 7 200 cells take the tiled
+    passes with a renumbered engine (volumes permuted in the staging block), 1 200 the one-launch solver."""
+    import clearwater_riverine_amd as cw
+    from clearwater_riverine_amd.model import SparseInputArray
+    steps = 30
+    mesh = cw.synthetic.make_mesh(nx, ny, steps, seed=5, n_merge=nx * ny // 36, dt=40.0, diffusion_coefficient=0.5)
+    inputs3 = cw.synthetic.distinct_input_array(mesh, K, seed=5)
+    T, ncell = inputs3.shape[0], inputs3.shape[1]
+    n = mesh['nreal'] + 1
+    assert not inputs3[1:, :n].any()                        # (this input family has no real-cell entries behind the initial row)
+    names = [f'c{k}' for k in range(K)]
+    res = cw.ClearwaterRiverine(mesh=dict(mesh), input_arrays={nm: inputs3[:, :, k].copy() for k, nm in enumerate(names)}, deterministic=True)
+    for _ in range(steps):
+        res.update()
+    # the store: one .npy per array, opened memory-mapped (np.load(mmap_mode='r')): reading a slice touches only its pages
+    for key in ('face_flow', 'edge_velocity', 'volume'):
+        np.save(tmp_path / f'{key}.npy', np.ascontiguousarray(mesh[key], dtype=np.float32))
+    maps = [np.load(tmp_path / f'{key}.npy', mmap_mode='r') for key in ('face_flow', 'edge_velocity', 'volume')]
+    calls = []
+
+    def source(t0, t1):
+        calls.append((t0, t1))
+        return tuple(np.asarray(m[t0:t1]) for m in maps)
+
+    lazy_mesh = {k: v for k, v in mesh.items() if k not in ('face_flow', 'edge_velocity', 'volume', 'advection_coeff', 'coeff_to_diffusion')}
+    lazy_mesh['level_source'] = source
+    ghosts = np.arange(n, ncell)
+    sparse = {nm: SparseInputArray(T, ncell, np.where(np.arange(ncell) < n, inputs3[0, :, k], 0.0), ghosts, inputs3[:, n:, k]) for k, nm in enumerate(names)}
+    win = cw.ClearwaterRiverine(mesh=lazy_mesh, input_arrays=sparse, deterministic=True, flow_window=W)
+    assert win._feeder is not None and win._flow_window == W
+    for _ in range(steps):
+        win.update()
+        assert (win.last_step.sweeps, win.last_step.flags) == (res.last_step.sweeps, res.last_step.flags) or win.time_step < steps
+    assert sum(b - a for a, b in calls) == T and max(b - a for a, b in calls) == W // 2
+    for nm in names:
+        assert np.array_equal(res.mesh[nm], win.mesh[nm], equal_nan=True), nm
+        assert np.array_equal(res.constituent_dict[nm].total_mass_flux, win.constituent_dict[nm].total_mass_flux, equal_nan=True)
+    assert np.array_equal(res.engine.jacobi_norms()[:steps], win.engine.jacobi_norms()[:steps])
+    for mdl in (res, win):
+        mdl.close_output(); mdl.engine.close()
+
+
+def test_boundary_levels_noted_without_flow_levels_and_on_resident_engines(gpu_lib):
+    """cwr_boundary_window_load on its own: (i) a windowed engine whose flow levels are all in the ring already and whose boundary values arrive
+    level by level just in time (the step flushes and waits for them), (ii) an engine with a resident flow field (a blocking upload).  Same bits
+    as the engine that was given all levels at once."""
+    mesh, inp, _ = load_plan('plan01', 0.01)
+    K = 2
+    inputs3 = multi_inputs(inp, K, seed=4)
+    n = mesh['nreal'] + 1
+    T, steps = inputs3.shape[0], 12
+    ref = make_engine(mesh, inputs3)
+    ref.set_state(inputs3[0, :n, :])
+    win, hi = windowed_engine(mesh, inputs3, T)                  # every flow level resident in a "ring" of T
+    win.alloc_boundary(T)                                        # (replaces the values windowed_engine loaded: zeros)
+    res = make_engine(mesh, inputs3)
+    res.alloc_boundary(T)
+    win.set_state(inputs3[0, :n, :]); res.set_state(inputs3[0, :n, :])
+    win.boundary_window_load(0, inputs3[0:1, n:, :]); res.boundary_window_load(0, inputs3[0:1, n:, :])
+    for t in range(steps):
+        g = np.ascontiguousarray(inputs3[t + 1:t + 2, n:, :])   # the level step t reads, handed over just before it
+        win.boundary_window_load(t + 1, g); res.boundary_window_load(t + 1, g)
+        a, b, c = ref.step(t, deterministic=True), win.step(t, deterministic=True), res.step(t, deterministic=True)
+        assert a.sweeps == b.sweeps == c.sweeps
+    sa, sb, sc = ref.get_state(), win.get_state(), res.get_state()
+    assert np.array_equal(sa, sb, equal_nan=True) and np.array_equal(sa, sc, equal_nan=True)
+    with pytest.raises((IndexError, ValueError)):
+        win.boundary_window_load(T - 1, inputs3[0:2, n:, :])     # beyond the allocated levels
+    for e in (ref, win, res):
+        e.close()
