@@ -219,12 +219,17 @@ def main():
                     help='internal cell numbering (reference ids stay at the boundary)')
     ap.add_argument('--halo-depth', type=int, default=0,
                     help='N > 1: halo layers = Jacobi sweeps between two exchanges (0: from the per-rank size, distributed.auto_halo_depth)')
+    ap.add_argument('--k-groups', type=int, default=1,
+                    help='N > 1: the N GPUs as N / G contiguous cell ranges x G groups of constituents (distributed.GroupedTransport: a group is a '
+                         'partitioned run of its constituents with a communicator of its own; groups never exchange).  1: N ranges of all constituents')
     ap.add_argument('--deterministic', action='store_true',
                     help='CWR_STEP_DETERMINISTIC: passes between two vectors, bitwise reproducible run to run (the default passes are chained in place)')
     ap.add_argument('--flow-window', type=int, default=0,
                     help='N = 1: keep only this many levels of the flow field on the device and upload one level per step beside the steps '
                          '(cwr_flow_window_open / _load; host arrays page-locked); 0: all levels resident (the headline configuration)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-rank-ceiling', action='store_true',
+                    help='N > 1: skip the stand-alone step of every rank (the compute-side ceiling in the per-rank report)')
     ap.add_argument('--no-pmc', action='store_true', help='skip the two rocprofv3 counter passes that measure roofline.traffic')
     ap.add_argument('--cpu-budget-s', type=float, default=100.0, help='wall-clock budget of the CPU baseline leg')
     ap.add_argument('--cpu-steps', type=int, default=3)
@@ -261,7 +266,7 @@ def main():
         dist.init_process_group(backend='gloo', rank=rank, world_size=world)
 
     from clearwater_riverine_amd import synthetic
-    from clearwater_riverine_amd.distributed import PartitionedTransport, broadcast_bytes
+    from clearwater_riverine_amd.distributed import GroupedTransport, PartitionedTransport, broadcast_bytes, group_layout
     from clearwater_riverine_amd.engine import TransportEngine
 
     K = args.constituents
@@ -285,11 +290,22 @@ def main():
     n = mesh['nreal'] + 1
 
     uid = None
-    if world > 1:
+    G = max(1, args.k_groups)
+    if world > 1 and G == 1:
         uid = broadcast_bytes(TransportEngine.comm_unique_id() if rank == 0 else None, 128, src=0)
-    pt = PartitionedTransport(mesh, inputs3, rank, world, device=local_rank, unique_id=uid, halo_depth=args.halo_depth,
+    if G > 1:
+        # R ranges x G constituent groups: one communicator per group, its id made by the group's range 0 and handed round over the control plane
+        g_, r_, R_, k0_, k1_ = group_layout(rank, world, G, K)
+        ids = [None] * world
+        dist.all_gather_object(ids, TransportEngine.comm_unique_id() if (r_ == 0 and R_ > 1) else None)
+        pt = GroupedTransport(mesh, inputs3, rank, world, G, device=local_rank, unique_id=ids[g_ * R_], halo_depth=args.halo_depth,
                               renumber=None if args.renumber == 'none' else args.renumber, flow_window=args.flow_window or None)
+    else:
+        pt = PartitionedTransport(mesh, inputs3, rank, world, device=local_rank, unique_id=uid, halo_depth=args.halo_depth,
+                                  renumber=None if args.renumber == 'none' else args.renumber, flow_window=args.flow_window or None)
     eng = pt.engine
+    K_loc = pt.K                                          # constituents THIS rank carries (K / G with constituent groups)
+    world_r = world // G                                  # cell ranges = ranks of one communicator
 
     def barrier():
         eng.synchronize()
@@ -333,6 +349,50 @@ def main():
     for t in range(args.warmup, args.warmup + args.steps):
         pt.step(t, tol=args.tol, mass_flux=True, profile=True, solver=args.solver, deterministic=args.deterministic)
     launches, total_us = eng.profile_read()
+    # ---- N > 1: what every rank's step consisted of, so that a scaling run explains itself ----
+    # computed / owned rows, passes x mean pass us, the exchanges (alone / beside compute) and all-reduces on the communication stream, the
+    # host's wall time inside the checks -- from the event-timed replay above -- and the COMPUTE-SIDE CEILING: the same rank stepped alone
+    # (tools/rank_step_profile.py's method: its real partition with a one-rank communicator, nothing exchanged) through the sweep count
+    # of the real run.  single-GPU step / slowest rank's stand-alone step is what N GPUs could reach if communication were free.
+    ranks_report = None
+    if world > 1:
+        cp = eng.comm_profile_read()
+        _ok, ntiles, tgrid, trows = eng.tiling_info()
+        lm = pt.local
+        sw_med = int(np.median([i['sweeps'] for i in iters])) if iters else 0
+        mine = {'rank': rank, 'cell_range': rank % world_r, 'constituent_group': rank // world_r, 'constituents': K_loc, 'owned_rows': int(lm.n_core), 'computed_rows': int(lm.n_rows), 'halo_rows': int(lm.n_halo), 'peers': int(len(lm.peers)),
+                'halo_depth': int(lm.depth), 'tiles': int(ntiles), 'tile_rows': int(trows), 'grid': int(tgrid),
+                'timed_region_ms_per_step': [round(1000.0 * w / args.steps, 3) for w in windows],
+                'passes_per_step': round(launches / args.steps, 2), 'mean_pass_us': round(total_us / launches, 2) if launches else None,
+                'sweeps_per_step_median': sw_med, 'steps_profiled': args.steps}
+        mine.update({k: (round(v, 1) if isinstance(v, float) else v) for k, v in cp.items()})
+        mine['standalone_ms_per_step'] = None
+        if not args.no_rank_ceiling:
+            dist.barrier()
+            try:
+                os.environ['CWR_TEST_FIXED_SWEEPS'] = str(max(3, sw_med | 1))
+                from clearwater_riverine_amd.distributed import ConstituentSlice
+                in_alone = inputs3 if G == 1 else (ConstituentSlice(inputs3, pt.k0, pt.k1) if hasattr(inputs3, 'ghost_columns') else inputs3[:, :, pt.k0:pt.k1])
+                alone = PartitionedTransport(mesh, in_alone, rank % world_r, world_r, device=local_rank, halo_depth=args.halo_depth,
+                                             renumber=None if args.renumber == 'none' else args.renumber, standalone=world_r > 1)
+                os.environ.pop('CWR_TEST_FIXED_SWEEPS', None)
+                for t in range(args.warmup):
+                    alone.step(t, tol=args.tol, mass_flux=True, solver=args.solver, deterministic=args.deterministic)
+                alone.engine.synchronize()
+                t0 = time.perf_counter()
+                for t in range(args.warmup, args.warmup + args.steps):
+                    alone.step(t, tol=args.tol, mass_flux=True, solver=args.solver, deterministic=args.deterministic)
+                alone.engine.synchronize()
+                mine['standalone_ms_per_step'] = round(1000.0 * (time.perf_counter() - t0) / args.steps, 4)
+                mine['standalone_sweeps'] = max(3, sw_med | 1)
+                alone.engine.close()
+            except Exception as exc:                     # (a report, not the measurement: say why and go on)
+                os.environ.pop('CWR_TEST_FIXED_SWEEPS', None)
+                mine['standalone_error'] = f'{type(exc).__name__}: {str(exc)[:160]}'
+            dist.barrier()
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        ranks_report = gathered
     if rank == 0:
         b_r, b_w = eng.apply_bytes()
         kernel_name = {4: 'k_apply<VW,4>: fused Jacobi sweep of the face-flux operator',
@@ -365,7 +425,7 @@ def main():
             E_loc = len(f2)
             E_ghost = int(np.count_nonzero(f2 >= lm.n_rows + lm.n_halo))
             n_loc = lm.n_rows
-            survey_apply = 24 * E_loc + 8 * K * n_loc + 12 * n_loc + 4 + 4 * (2 * (E_loc - E_ghost) + E_ghost)
+            survey_apply = 24 * E_loc + 8 * K_loc * n_loc + 12 * n_loc + 4 + 4 * (2 * (E_loc - E_ghost) + E_ghost)
             applies = 2 if r.sweep_kernel in (5, 6) else 1
             alg = applies * survey_apply
             achieved = alg / (avg_us * 1e-6) / 1e9
@@ -411,7 +471,8 @@ def main():
                                    f'{"distinct " if args.inputs == "distinct" and K > 1 else ""}constituents, implicit upwind '
                                    f'advection-diffusion step, dt={args.dt} s, D={args.diffusion}',
                        'cells': n, 'faces': int(len(mesh['edges_face1'])), 'constituents': K,
-                       'numbering': pt.numbering + (' + tile-balanced windows' if pt.numbering != 'reference' else ''), 'partition': f'contiguous cell ranges x{world}' + (f', halo depth {pt.local.depth}' if world > 1 else ''),
+                       'numbering': pt.numbering + (' + tile-balanced windows' if pt.numbering != 'reference' else ''),
+                       'partition': f'contiguous cell ranges x{world_r}' + (f' x {G} groups of {K_loc} constituents (no exchange between groups)' if G > 1 else '') + (f', halo depth {pt.local.depth}' if world_r > 1 else ''),
                        'tol': args.tol, 'flow_field': (f'ring of {args.flow_window} levels, one level uploaded per step beside the steps'
                                                        if args.flow_window and world == 1 else 'all levels resident in HBM')},
             'solver': {'method': ('J^2 passes of fused Jacobi sweeps, tiles chained along the flow and relaxed in place (block Gauss-Seidel '
@@ -424,6 +485,12 @@ def main():
                        'max_rel_residual': max_resid},
             'roofline': roofline, 'cpu_baseline': cpu,
         }
+        if ranks_report is not None:
+            line['ranks'] = ranks_report
+            alone_ms = [r.get('standalone_ms_per_step') for r in ranks_report]
+            if all(a for a in alone_ms):
+                line['compute_side_ceiling'] = {'slowest_rank_standalone_ms_per_step': max(alone_ms), 'measured_ms_per_step': round(1000.0 * elapsed / args.steps, 3),
+                                                'note': 'a rank stepped alone through the real run\'s sweep count (one-rank communicator, nothing exchanged): measured - standalone = what communication and waiting cost'}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -7,9 +7,9 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, 'csrc', 'cwr_engine.hip')
-DEPS = [SRC, os.path.join(HERE, 'csrc', 'cwr_kernels.hpp'),
-        os.path.join(HERE, "csrc", "cwr_host_builders.hpp"),
-        os.path.join(os.path.dirname(HERE), "include", "cwr_transport.h")]
+# (round 6: cwr_engine.hip is ONE translation unit cut along its section banners into csrc/cwr_engine_*.hpp: every header under csrc/ is a dependency)
+DEPS = [SRC, os.path.join(os.path.dirname(HERE), "include", "cwr_transport.h")] + \
+       sorted(os.path.join(HERE, 'csrc', f) for f in os.listdir(os.path.join(HERE, 'csrc')) if f.endswith('.hpp'))
 OUT = os.path.join(HERE, 'libcwr_transport.so')
 
 FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-munsafe-fp-atomics', '-fPIC', '-shared',

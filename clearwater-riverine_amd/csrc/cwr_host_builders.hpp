@@ -218,6 +218,68 @@ inline bool build_tiling(int n_t, int tr, int seg, int nvmax, int K, int n_cols,
   return true;
 }
 
+// ---- wave-sliced entry layout of the tiled pass (round 6) ---------------------------------------------------------------------
+// The tiled pass gives a row to a lane group of G lanes, so a wave relaxes rpw = 64 / G consecutive rows of the tile together and runs
+// as long as its LONGEST row: with the entries in CSR order every lane carries its own loop bounds (exec masks, a compare and ~7 scalar
+// instructions per gathered entry -- profiles/r06_pmc_detail_chained_pass_K16.txt).  Sliced layout (ELLPACK per wave): the rows
+// [s rpw, (s + 1) rpw) of a tile form slice s, padded to the slice's longest row L_s and stored entry-major -- entry k of row r of the
+// slice at  tile base + slice offset + k rpw + r  -- so the k-th gather of a wave reads rpw consecutive entries, every lane of the wave
+// makes the same number of trips (a scalar loop), and the addresses advance by a constant.  Padding entries have weight 0 and the
+// position of the row's own cell (a valid, finite x row): + 0 x, exact.  The tile-balanced numbering sorts the rows of a tile by J^2 row
+// length, so slices are nearly homogeneous (padding: a few per cent of the entries).
+struct EllLayout {
+  std::vector<int32_t> eptr;            // [ntiles + 1] first entry of every tile in the sliced arrays
+  std::vector<int32_t> sl;              // [ntiles][nsl + 1] slice offsets relative to the tile's first entry
+  std::vector<int32_t> pos;             // [nnz2] CSR entry -> its index in the sliced arrays (what the numeric kernels store through)
+  std::vector<uint16_t> loc;            // [total] position (pre-multiplied by K) of every sliced entry
+  int nsl = 0;                          // slices per tile (tile rows capacity / rpw)
+  int cap = 0;                          // most sliced entries of a tile, even
+  size_t total() const { return loc.size(); }
+};
+inline bool build_ell(const Tiling& tl, const std::vector<int32_t>& ptr2, int K, int rpw, int tile_rows_cap, EllLayout& out) {
+  out = EllLayout();
+  if (rpw < 1 || tile_rows_cap % rpw != 0) return false;
+  const int nt = tl.ntiles();
+  out.nsl = tile_rows_cap / rpw;
+  out.eptr.assign((size_t)nt + 1, 0);
+  out.sl.assign((size_t)nt * (out.nsl + 1), 0);
+  out.pos.assign((size_t)ptr2.back(), -1);
+  int cap = 2;
+  for (int t = 0; t < nt; ++t) {
+    const int c0 = tl.trow[(size_t)t], c1 = tl.trow[(size_t)t + 1];
+    if (c1 - c0 > tile_rows_cap) return false;
+    const size_t base = out.loc.size();
+    int off = 0;
+    for (int sidx = 0; sidx < out.nsl; ++sidx) {
+      out.sl[(size_t)t * (out.nsl + 1) + sidx] = off;
+      const int r0 = c0 + sidx * rpw, r1 = std::min(c1, r0 + rpw);
+      int L = 0;
+      for (int c = r0; c < r1; ++c) L = std::max(L, ptr2[(size_t)c + 1] - ptr2[(size_t)c]);
+      out.loc.resize(base + (size_t)off + (size_t)L * rpw);
+      for (int k = 0; k < L; ++k)
+        for (int r = 0; r < rpw; ++r) {
+          const int c = r0 + r;
+          const size_t idx = base + (size_t)off + (size_t)k * rpw + r;
+          if (c < r1 && k < ptr2[(size_t)c + 1] - ptr2[(size_t)c]) {
+            const size_t q = (size_t)ptr2[(size_t)c] + k;
+            out.pos[q] = (int32_t)idx;
+            out.loc[idx] = tl.loc2[q];
+          } else {
+            out.loc[idx] = (uint16_t)((c < r1 ? (c - c0) : 0) * K);     // padding: weight 0, the row's own cell (own rows come first in a tile's list)
+          }
+        }
+      off += L * rpw;
+    }
+    out.sl[(size_t)t * (out.nsl + 1) + out.nsl] = off;
+    if (off & 1) { out.loc.push_back(0); }                          // (tiles start at even entries: the 16-bit array stays 4-byte aligned per tile)
+    out.eptr[(size_t)t + 1] = (int32_t)out.loc.size();
+    cap = std::max(cap, off + (off & 1));
+    if (out.loc.size() > 2000000000u) return false;
+  }
+  out.cap = cap;
+  return true;
+}
+
 // per tile: the ptr2 entries of its rows, then the codes of its virtual items (one prefetch stream in the kernel)
 inline std::vector<int32_t> tile_meta(int n_t, const std::vector<int32_t>& ptr2, const Tiling& tl) {
   std::vector<int32_t> meta((size_t)n_t + tl.vtab.size());

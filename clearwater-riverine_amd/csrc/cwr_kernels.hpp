@@ -1018,7 +1018,8 @@ template <int DEG>
 __global__ void __launch_bounds__(SQN_THREADS) k_sq_numeric(
     int n, const int32_t* __restrict__ ptr, const int32_t* __restrict__ ent_nb, const double* __restrict__ w,
     const int32_t* __restrict__ ptr2, const int32_t* __restrict__ col2, const int32_t* __restrict__ pair_ptr,
-    const uint8_t* __restrict__ slots, const uint8_t* __restrict__ fast_ok, FaceRec* __restrict__ rec2, double* __restrict__ w2) {
+    const uint8_t* __restrict__ slots, const uint8_t* __restrict__ fast_ok, FaceRec* __restrict__ rec2, double* __restrict__ w2,
+    const int32_t* __restrict__ ell_pos = nullptr /* sliced layout of the tiled pass: CSR entry -> index in w2 (host::build_ell) */) {
   extern __shared__ double s_acc[];
   const int c0 = blockIdx.x * SQN_THREADS, c1 = min(c0 + SQN_THREADS, n);
   const int base = ptr2[c0], nloc = ptr2[c1] - base;
@@ -1100,7 +1101,7 @@ __global__ void __launch_bounds__(SQN_THREADS) k_sq_numeric(
   __syncthreads();
   for (int i = threadIdx.x; i < nloc; i += SQN_THREADS) {
     const double v = s_acc[i];
-    if (w2) w2[base + i] = v;
+    if (w2) w2[ell_pos ? ell_pos[base + i] : base + i] = v;
     if (rec2) { FaceRec out; out.nb = col2[base + i]; out.a_c = 0.0f; out.d = v; rec2[base + i] = out; }
   }
 }
@@ -1111,7 +1112,7 @@ __global__ void __launch_bounds__(SQN_THREADS) k_sq_numeric(
 __global__ void __launch_bounds__(BLOCK) k_build_sq(int nnz2, const int32_t* __restrict__ ptr, const int32_t* __restrict__ ent_nb,
                                                   const double* __restrict__ w, const int32_t* __restrict__ row2,
                                                   const int32_t* __restrict__ col2, FaceRec* __restrict__ rec2,
-                                                  double* __restrict__ w2) {
+                                                  double* __restrict__ w2, const int32_t* __restrict__ ell_pos = nullptr) {
   const int s = blockIdx.x * BLOCK + threadIdx.x;
   if (s >= nnz2) return;
   const int c = row2[s], k = col2[s];
@@ -1127,14 +1128,14 @@ __global__ void __launch_bounds__(BLOCK) k_build_sq(int nnz2, const int32_t* __r
   }
   FaceRec out; out.nb = k; out.a_c = 0.0f; out.d = acc;
   rec2[s] = out;
-  if (w2) w2[s] = acc;                              // compact copy for the tiled pass (which has its own index array)
+  if (w2) w2[ell_pos ? ell_pos[s] : s] = acc;       // compact copy for the tiled pass (which has its own index array)
 }
 
 // (round 6 A/B, CWR_TCL_POWER=1) numeric J on the merged pattern of host::symbolic_j: entry (c, k) = the sum of the Jacobi weights of
 // the faces between c and k, in face order.  One thread per row (rows have 4-8 entries).
 __global__ void __launch_bounds__(BLOCK) k_j_numeric(int n, const int32_t* __restrict__ ptr, const int32_t* __restrict__ ent_nb, const double* __restrict__ w,
                                                     const int32_t* __restrict__ ptr2, const int32_t* __restrict__ col2, FaceRec* __restrict__ rec2,
-                                                    double* __restrict__ w2) {
+                                                    double* __restrict__ w2, const int32_t* __restrict__ ell_pos = nullptr) {
   const int c = blockIdx.x * BLOCK + threadIdx.x;
   if (c >= n) return;
   const int j0 = ptr[c], j1 = ptr[c + 1];
@@ -1142,7 +1143,7 @@ __global__ void __launch_bounds__(BLOCK) k_j_numeric(int n, const int32_t* __res
     const int k = col2[q];
     double acc = 0.0;
     for (int j = j0; j < j1; ++j) if (ent_nb[j] == k) acc += w[j];
-    if (w2) w2[q] = acc;
+    if (w2) w2[ell_pos ? ell_pos[q] : q] = acc;
     if (rec2) { FaceRec out; out.nb = k; out.a_c = 0.0f; out.d = acc; rec2[q] = out; }
   }
 }
@@ -1188,7 +1189,11 @@ static_assert(TCL_SEG % CWR_FACE_BATCH == 0, "k_apply<.,5> closes a chunk only a
 #ifndef CWR_TCL_WAVES
 #define CWR_TCL_WAVES 1           // __launch_bounds__ second argument of the tiled pass (A/B builds: 5 forces <= 96 VGPRs)
 #endif
-template <int VW, int WRN, int TCL_U, int TCL_XR>
+// ELL (round 6): the tile's entries arrive in the wave-sliced layout of host::build_ell instead of CSR order -- `ptr2` is then the per-TILE
+// entry offset array (eptr), `meta` the per-tile slice offsets ((TCL_U * BLOCK / 64 + 1) per tile), and the gather loop of a wave is a scalar
+// loop over the slice's padded length with constant address increments: no per-lane bounds, no exec masking (see build_ell).  G must be a
+// power of two (a row's lanes never straddle two waves).  Same sums in the same order as the CSR form (padding adds + 0 x): bitwise equal.
+template <int VW, int WRN, int TCL_U, int TCL_XR, bool ELL = false>
 __global__ void __launch_bounds__(BLOCK, CWR_TCL_WAVES) k_sq_tiled(
     int K, int G, int TR, int ntiles, const int32_t* __restrict__ tile_list, int sched_depth, int inplace, const int32_t* __restrict__ trow,
     const int32_t* __restrict__ ptr2, const uint16_t* __restrict__ loc2,
@@ -1263,7 +1268,8 @@ __global__ void __launch_bounds__(BLOCK, CWR_TCL_WAVES) k_sq_tiled(
   // NOT part of the default build: once 256-row tiles fit without it (configuration {12, 1, 3}) it gains 1 % at K = 1 in a
   // same-box comparison, less than the tile-balanced numbering gives for free (3 %), and it costs 12 VGPRs and a barrier
   // wherever rows share a lane's loop (K = 16: 110 -> 119 us).  profiles/r02_r_k1_ab.txt
-  constexpr bool SPLIT = (VW == 1) && (CWR_WORK_ITEMS != 0);
+  constexpr bool SPLIT = (VW == 1) && (CWR_WORK_ITEMS != 0) && !ELL;
+  constexpr int NSL = TCL_U * (BLOCK / 64);          // ELL: slices of a tile (one per wave and row set)
   const bool rowlane = r < R;
   // x rows are FETCHED (global -> registers -> LDS) one whole 128-byte row per 8 lanes whatever VW is: with VW == 4 the
   // compute mapping above would fetch half rows (measured +6 us per pass)
@@ -1330,7 +1336,7 @@ __global__ void __launch_bounds__(BLOCK, CWR_TCL_WAVES) k_sq_tiled(
 #pragma unroll
     for (int u = 0; u < TCL_XR; ++u) if (cn[u] >= 0) ldv<XW>(xin + (size_t)cn[u] * K + gl * XW, xr[u]);
     const int c0 = n_c0, c1 = n_c1;
-    const int jb = ptr2[c0], je = ptr2[c1];
+    const int jb = ELL ? ptr2[t] : ptr2[c0], je = ELL ? ptr2[t + 1] : ptr2[c1];
 #pragma unroll
     for (int u = 0; u < WRN; ++u) { const int j = jb + tid + u * BLOCK; if (j < je) {
       // wide rows (the four-wide mapping): the entry stream bypasses cache retention so that the gathered x rows keep the L2
@@ -1342,7 +1348,8 @@ __global__ void __launch_bounds__(BLOCK, CWR_TCL_WAVES) k_sq_tiled(
     // issued before it).  The threads behind the tile's rows fetch the codes of its virtual items through the same load.
     // (`meta`: per tile its rows' ptr2 entries followed by the codes of its virtual items, tiles back to back -- one
     // uniform base + tid, exactly the shape of the row-pointer prefetch it replaces)
-    if (tid < (c1 - c0) + (n_v1 - n_v0)) pr = meta[c0 + n_v0 + tid];
+    if constexpr (ELL) { if (tid <= NSL) pr = meta[t * (NSL + 1) + tid]; }        // (the tile's slice offsets)
+    else if (tid < (c1 - c0) + (n_v1 - n_v0)) pr = meta[c0 + n_v0 + tid];
     if (rowlane) {
 #pragma unroll
       for (int u = 0; u < TCL_U; ++u) { const int c = c0 + r + u * R; if (c < c1) ld_row_nt(c2 + (size_t)c * K, q0[u]); }
@@ -1365,8 +1372,8 @@ __global__ void __launch_bounds__(BLOCK, CWR_TCL_WAVES) k_sq_tiled(
   for (int it = 0; t_cur >= 0; ++it) {
     const int c0 = c_c0, c1 = c_c1, NR = c1 - c0, nv = c_nv;
     const int ncol = tcl_ptr[t_cur + 1] - tcl_ptr[t_cur];
-    const int jb0 = ptr2[c0];
-    const int nent = ptr2[c1] - jb0;
+    const int jb0 = ELL ? ptr2[t_cur] : ptr2[c0];
+    const int nent = (ELL ? ptr2[t_cur + 1] : ptr2[c1]) - jb0;
     __syncthreads();                               // the previous tile's readers are done with LDS
     if (scols && loadlane) {
       // carry over the previous tile's own rows -- the results it has just computed -- from the staging area (written before the
@@ -1387,8 +1394,11 @@ __global__ void __launch_bounds__(BLOCK, CWR_TCL_WAVES) k_sq_tiled(
     for (int u = 0; u < WRN; ++u) { const int j = tid + u * BLOCK; if (j < nent) { s_w[j] = wr[u]; s_loc[j] = (uint16_t)lr[u]; } }
     // one store for both kinds: row pointers rebased to the tile, virtual-item codes as they are, behind the terminator
     // (a second, separate store for the codes cost this kernel 26 VGPRs -- a block per CU -- in hipcc's allocation)
+    if constexpr (ELL) { if (tid <= NSL) s_ptr[tid] = pr; }
+    else {
     if (tid < NR + nv) s_ptr[tid + (tid >= NR ? 1 : 0)] = pr - (tid < NR ? jb0 : 0);
     if (tid == 0) s_ptr[NR] = nent;
+    }
     double qc[TCL_U][VW];
 #pragma unroll
     for (int u = 0; u < TCL_U; ++u)
@@ -1432,7 +1442,34 @@ __global__ void __launch_bounds__(BLOCK, CWR_TCL_WAVES) k_sq_tiled(
         }
         __syncthreads();
       }
-      if constexpr (!SPLIT) {
+      if constexpr (ELL) {
+        // wave-sliced entries: every lane of a wave makes the slice's L trips (padding: weight 0 on the row's own cell), the k-th gather
+        // of the wave reads rpw consecutive entries -- a scalar loop, addresses advancing by a constant
+        const int rsh = 6 - __builtin_ctz((unsigned)G);                  // log2(rows per wave); G a power of two
+        const int r16 = (tid & 63) >> __builtin_ctz((unsigned)G);        // the lane's row within its wave's slice
+#pragma unroll
+        for (int u = 0; u < TCL_U; ++u) {
+          const int sidx = u * (BLOCK / 64) + (tid >> 6);
+          const int sb = __builtin_amdgcn_readfirstlane(s_ptr[sidx]);
+          const int L = __builtin_amdgcn_readfirstlane((s_ptr[sidx + 1] - sb) >> rsh);
+          double sum[VW];
+#pragma unroll
+          for (int w = 0; w < VW; ++w) sum[w] = 0.0;
+          const uint16_t* pl = s_loc + sb + r16;
+          const double* pw = s_w + sb + r16;
+          const int stride = 1 << rsh;
+          for (int k = 0; k < L; ++k) {
+            double xn[VW];
+            ld_row(s_xt + (int)pl[0], xn);
+            const double wj = pw[0];
+#pragma unroll
+            for (int w = 0; w < VW; ++w) sum[w] += wj * xn[w];
+            pl += stride; pw += stride;
+          }
+#pragma unroll
+          for (int w = 0; w < VW; ++w) y[u][w] = qc[u][w] + sum[w];     // (lanes behind the tile's last row: zero sums, never stored)
+        }
+      } else if constexpr (!SPLIT) {
         // one lane group per row (every item is a whole row: the host lists no virtual items for these variants)
         if (rowlane) {
 #pragma unroll

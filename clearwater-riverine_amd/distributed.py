@@ -293,3 +293,64 @@ class PartitionedTransport:
         out = np.empty_like(mine)
         out[self.order] = mine
         return out
+
+
+# ------------------------------------------------------------------ constituent groups x cell ranges (round 6)
+class ConstituentSlice:
+    """Columns [k0, k1) of an input provider (synthetic.DistinctInputs: initial_rows / ghost_columns / real_input_entries)."""
+
+    def __init__(self, inputs, k0: int, k1: int):
+        self._in, self.k0, self.k1 = inputs, int(k0), int(k1)
+        self.shape = tuple(inputs.shape[:2]) + (self.k1 - self.k0,)
+
+    def initial_rows(self, cells):
+        return np.ascontiguousarray(self._in.initial_rows(cells)[:, self.k0:self.k1])
+
+    def ghost_columns(self, ghost_cells):
+        return np.ascontiguousarray(self._in.ghost_columns(ghost_cells)[:, :, self.k0:self.k1])
+
+    def real_input_entries(self, cells):
+        lv, ce, va = self._in.real_input_entries(cells)
+        return lv, ce, np.ascontiguousarray(np.asarray(va)[:, self.k0:self.k1])
+
+
+def group_layout(rank: int, world: int, k_groups: int, K: int):
+    """world ranks as (world / k_groups) contiguous CELL RANGES x k_groups GROUPS OF CONSTITUENTS: rank -> (group, range, ranges, k0, k1).
+    Ranges vary fastest: the ranks of one group -- the only ones that ever exchange -- are neighbours in rank order."""
+    if k_groups < 1 or world % k_groups != 0 or k_groups > K:
+        raise ValueError(f'k_groups = {k_groups} must divide the world ({world}) and not exceed the constituents ({K})')
+    R = world // k_groups
+    g, r = divmod(rank, R)
+    cuts = [(K * i) // k_groups for i in range(k_groups + 1)]
+    return g, r, R, cuts[g], cuts[g + 1]
+
+
+class GroupedTransport:
+    """N GPUs as R cell ranges x G groups of K / G constituents.  The K systems of a step share A and never talk to each other (the
+    reference solves them one after the other, transport.py:231-249), so a group is a complete partitioned run of ITS constituents over R
+    ranges with a communicator of its own: no new kernel and no new collective -- groups never exchange anything.  Against N ranges of all K
+    constituents a rank owns N / R times the cells (longer tile lists, a smaller share of replayed halo rows, at most R - 1 instead of N - 1
+    peers) and moves 1 / G of the bytes per exchanged row.  A refinement of the contiguous-range partition of SURVEY 8e, not a replacement:
+    k_groups = 1 IS PartitionedTransport.  Priced in profiles/r06_rank_budget.txt (1 M cells x 16 on 8 GPUs: compute-side ceiling 2.5-2.7 x as
+    8 ranges, 2.9 x as 4 ranges x 2 groups)."""
+
+    def __init__(self, mesh: dict, inputs3, rank: int, world: int, k_groups: int = 1, device: int = 0, unique_id: bytes | None = None, **kw):
+        K = int(inputs3.shape[2])
+        self.group, self.range, self.ranges, self.k0, self.k1 = group_layout(rank, world, k_groups, K)
+        self.k_groups, self.K_all = int(k_groups), K
+        sub = ConstituentSlice(inputs3, self.k0, self.k1) if hasattr(inputs3, 'ghost_columns') else np.ascontiguousarray(inputs3[:, :, self.k0:self.k1])
+        self.part = PartitionedTransport(mesh, sub, self.range, self.ranges, device=device, unique_id=unique_id, **kw)
+        self.engine, self.local, self.K = self.part.engine, self.part.local, self.part.K
+        self.numbering, self.order = self.part.numbering, self.part.order
+
+    def step(self, t: int, **kw):
+        return self.part.step(t, **kw)
+
+    def fill_window(self, t: int):
+        return self.part.fill_window(t)
+
+    def owned_state(self):
+        return self.part.owned_state()
+
+    def owned_reference_ids(self):
+        return self.part.owned_reference_ids()

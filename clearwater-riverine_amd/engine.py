@@ -43,7 +43,7 @@ ABI_SYMBOLS = (
     'cwr_load_coefficients', 'cwr_flow_window_open', 'cwr_flow_window_load', 'cwr_get_coefficients', 'cwr_load_boundary', 'cwr_set_boundary_level', 'cwr_boundary_window_load',
     'cwr_set_state', 'cwr_get_state', 'cwr_load_real_inputs', 'cwr_react_linear', 'cwr_state_device_ptr', 'cwr_state_row_stride', 'cwr_apply', 'cwr_rhs', 'cwr_step', 'cwr_get_mass_flux',
     'cwr_get_jacobi_norms', 'cwr_set_jacobi_norms', 'cwr_get_error_factors', 'cwr_tiling_info', 'cwr_set_tile_schedule', 'cwr_get_tile_schedule',
-    'cwr_time_apply', 'cwr_profile_read', 'cwr_synchronize', 'cwr_apply_bytes',
+    'cwr_time_apply', 'cwr_profile_read', 'cwr_comm_profile_read', 'cwr_synchronize', 'cwr_apply_bytes',
     'cwr_comm_unique_id', 'cwr_attach_comm', 'cwr_comm_selftest',
     'cwr_set_boundary_lines', 'cwr_reset_mass_balance', 'cwr_get_mass_balance', 'cwr_domain_mass',
     'cwr_output_open', 'cwr_output_push', 'cwr_output_push_into', 'cwr_host_register', 'cwr_host_unregister', 'cwr_output_wait', 'cwr_output_release', 'cwr_output_close',
@@ -134,6 +134,7 @@ def load_library(path: str | None = None) -> C.CDLL:
         'cwr_get_error_factors': [vp, i32, vp],
         'cwr_time_apply': [vp, i32, i32, i32, P(f64)],
         'cwr_profile_read': [vp, P(C.c_int64), P(f64)],
+        'cwr_comm_profile_read': [vp, vp],
         'cwr_synchronize': [vp],
         'cwr_apply_bytes': [vp, P(C.c_int64), P(C.c_int64)],
         'cwr_comm_unique_id': [vp],
@@ -607,6 +608,14 @@ class TransportEngine:
         us = C.c_double(0.0)
         self._check(self._lib.cwr_profile_read(self._h, C.byref(n), C.byref(us)))
         return n.value, us.value
+
+    def comm_profile_read(self) -> dict:
+        """Communication side of the profiled steps since the last call (cwr_comm_profile_read): counts and microseconds."""
+        out = np.zeros(8)
+        self._check(self._lib.cwr_comm_profile_read(self._h, _ptr(out)))
+        return {'exchanges_alone': int(out[0]), 'exchanges_alone_us': float(out[1]), 'exchanges_beside_compute': int(out[2]),
+                'exchanges_beside_compute_us': float(out[3]), 'allreduces': int(out[4]), 'allreduces_us': float(out[5]),
+                'checks': int(out[6]), 'check_host_wait_us': float(out[7])}
 
     def apply_bytes(self):
         r = C.c_int64(0)

@@ -300,6 +300,12 @@ int32_t cwr_get_error_factors(cwr_engine* e, int32_t n_times, double* factors);
  * CWR_STEP_PROFILE since the last call: number of launches and their summed duration. */
 int32_t cwr_time_apply(cwr_engine* e, int32_t t, int32_t variant, int32_t reps, double* avg_us);
 int32_t cwr_profile_read(cwr_engine* e, int64_t* launches, double* total_us);
+/* (ABI 7) The communication side of the steps taken with CWR_STEP_PROFILE since the last call (partitioned engines; zeros otherwise):
+ * out[0..1] exchanges with nothing beside them: count, microseconds on the communication stream (grouped send / receive + unpack: a
+ * peer's lateness included); out[2..3] exchanges that ran beside compute; out[4..5] all-reduces; out[6..7] convergence checks: count,
+ * microseconds of host wall time inside them.  The reference has nothing to mirror (serial K-loop on one host, transport.py:231-249):
+ * this is what bench.py --gpus N reports per rank so that a scaling run explains itself. */
+int32_t cwr_comm_profile_read(cwr_engine* e, double out[8]);
 int32_t cwr_synchronize(cwr_engine* e);
 /* Algorithmic bytes of one operator launch (read, written), as DESIGN.md defines them. */
 int32_t cwr_apply_bytes(const cwr_engine* e, int64_t* bytes_read, int64_t* bytes_written);

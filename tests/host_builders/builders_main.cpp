@@ -94,6 +94,16 @@ int main(int argc, char** argv) {
   std::vector<int32_t> inner, outer;
   split_interior(n_core, tl, inner, outer);
   out["inner"] = inner; out["outer"] = outer;
+  // the wave-sliced entry layout of the tiled pass (round 6): params[10] = rows per wave, params[11] = row capacity of a tile (0: skip)
+  if (par.size() > 11 && par.at(10) > 0 && heavy == 0 && nvmax == 0) {
+    EllLayout ell;
+    const bool eok = build_ell(tl, sq.ptr2, K, par.at(10), par.at(11), ell);
+    out["ell_ok"] = {eok ? 1 : 0};
+    if (eok) {
+      out["ell_eptr"] = ell.eptr; out["ell_sl"] = ell.sl; out["ell_pos"] = ell.pos; out["ell_loc"] = widen(ell.loc);
+      out["ell_dims"] = {ell.nsl, ell.cap, (int32_t)ell.total()};
+    }
+  }
 
   if (seg >= (1 << 20)) {                              // fixed-size tiles: links, chains, schedules, carry-over codes
     const int nt = tl.ntiles();

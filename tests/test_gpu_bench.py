@@ -55,3 +55,33 @@ def test_bench_starts_its_own_ranks_for_gpus_2(gpu_lib):
     assert 'x2' in d['config']['partition']
     it = d['solver']['iterations_per_step']
     assert all(i['exchanges'] > 0 and i['checks'] >= 1 for i in it)
+    # the per-rank report that lets a scaling run explain itself
+    assert len(d['ranks']) == 2 and [r['rank'] for r in d['ranks']] == [0, 1]
+    for r in d['ranks']:
+        for key in ('owned_rows', 'computed_rows', 'halo_rows', 'peers', 'passes_per_step', 'mean_pass_us', 'exchanges_alone', 'exchanges_alone_us',
+                    'exchanges_beside_compute', 'exchanges_beside_compute_us', 'allreduces', 'allreduces_us', 'checks', 'check_host_wait_us',
+                    'standalone_ms_per_step', 'timed_region_ms_per_step'):
+            assert key in r, key
+        assert r['computed_rows'] >= r['owned_rows'] > 0 and r['peers'] == 1
+        assert r['exchanges_alone'] + r['exchanges_beside_compute'] > 0 and r['allreduces'] >= r['checks'] >= 3
+        assert r['exchanges_alone_us'] + r['exchanges_beside_compute_us'] > 0 and r['allreduces_us'] > 0 and r['check_host_wait_us'] > 0
+        assert r['standalone_ms_per_step'] and r['standalone_ms_per_step'] > 0, r
+    assert sum(r['owned_rows'] for r in d['ranks']) == d['config']['cells']
+    assert d['compute_side_ceiling']['slowest_rank_standalone_ms_per_step'] == max(r['standalone_ms_per_step'] for r in d['ranks'])
+
+
+def test_bench_constituent_groups_times_cell_ranges(gpu_lib):
+    """`--gpus 4 --k-groups 2`: two cell ranges x two groups of constituents (distributed.GroupedTransport) -- a group is a partitioned run
+    of its constituents with a communicator of its own, groups never exchange.  Through the stand-in on the one GPU: same contract line, the
+    per-rank report says who carried what."""
+    from test_gpu_multirank import build_mock
+    env = dict(os.environ, CWR_RCCL_LIB=build_mock(), CWR_BENCH_DEVICE='0')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    d = _line(['--gpus', '4', '--k-groups', '2', '--constituents', '8', '--nx', '300', '--ny', '300', '--steps', '3', '--warmup', '2', '--windows', '2',
+               '--no-rank-ceiling'], env=env)
+    assert d['n_gpus'] == 4 and d['value'] > 0 and d['config']['constituents'] == 8
+    assert 'x2 x 2 groups of 4 constituents' in d['config']['partition']
+    assert [(r['constituent_group'], r['cell_range'], r['constituents']) for r in d['ranks']] == [(0, 0, 4), (0, 1, 4), (1, 0, 4), (1, 1, 4)]
+    assert sum(r['owned_rows'] for r in d['ranks']) == 2 * d['config']['cells'] and all(r['peers'] == 1 for r in d['ranks'])
+    assert d['solver']['max_rel_residual'] <= 1e-12

@@ -438,3 +438,54 @@ def test_small_solver_plan_reproduces_the_global_jacobi_iteration_bit_for_bit(dr
             new[c] = bh[c] + s
         x = new
     assert np.array_equal(got, x)
+
+
+def check_ell(out, K, rpw, rows_cap):
+    """host::build_ell against its statement: slice s of a tile = its rows [s rpw, (s + 1) rpw), padded to the slice's longest row, entry-major;
+    every CSR entry appears exactly once at pos[q] with its position code; padding carries the row's own cell; tiles start at even entries."""
+    ptr2, trow, loc2 = out['ptr2'], out['trow'], out['loc2']
+    eptr, sl, pos, loc = out['ell_eptr'], out['ell_sl'], out['ell_pos'], out['ell_loc']
+    nsl, cap, total = (int(v) for v in out['ell_dims'])
+    nt = len(trow) - 1
+    assert nsl == rows_cap // rpw and len(eptr) == nt + 1 and len(sl) == nt * (nsl + 1) and total == len(loc) == eptr[nt]
+    seen = np.zeros(total, dtype=bool)
+    worst = 0
+    for t in range(nt):
+        c0, c1 = int(trow[t]), int(trow[t + 1])
+        offs = sl[t * (nsl + 1):(t + 1) * (nsl + 1)]
+        assert offs[0] == 0 and eptr[t] % 2 == 0
+        for s_ in range(nsl):
+            r0, r1 = c0 + s_ * rpw, min(c1, c0 + (s_ + 1) * rpw)
+            lens = [int(ptr2[c + 1] - ptr2[c]) for c in range(r0, r1)]
+            L = max(lens) if lens else 0
+            assert offs[s_ + 1] - offs[s_] == L * rpw, (t, s_)
+            for k in range(L):
+                for r in range(rpw):
+                    idx = int(eptr[t] + offs[s_] + k * rpw + r)
+                    c = r0 + r
+                    if c < r1 and k < lens[r]:
+                        q = int(ptr2[c]) + k
+                        assert pos[q] == idx and loc[idx] == loc2[q]
+                        assert not seen[idx]
+                        seen[idx] = True
+                    else:
+                        assert loc[idx] == ((c - c0) * K if c < r1 else 0)
+        used = int(offs[nsl])
+        assert eptr[t + 1] - eptr[t] == used + (used & 1)
+        worst = max(worst, used + (used & 1))
+    assert cap == max(worst, 2) and int(seen.sum()) == int(ptr2[trow[nt]]) and (pos[:int(ptr2[trow[nt]])] >= 0).all()
+
+
+@pytest.mark.parametrize('K,G,ut,seed', [(16, 4, 1, 1), (1, 1, 1, 2), (8, 2, 1, 3), (4, 2, 2, 4), (32, 8, 2, 5)])
+def test_wave_sliced_entry_layout_of_the_tiled_pass(driver, tmp_path, K, G, ut, seed):
+    """Round 6: the sliced (ELLPACK-per-wave) entry layout the tiled pass reads -- under ASan / UBSan, against a numpy statement -- on meshes
+    with merged 5-8-sided cells and dry cells, lane-group sizes G = 1 ... 8 (rows per wave 64 ... 8), one and two row sets per lane group."""
+    mesh = cw.synthetic.make_mesh(37, 23, 2, seed=seed, n_merge=60, n_merge4=12, n_dry=3)
+    n = mesh['nreal'] + 1
+    f1, f2 = np.asarray(mesh['edges_face1']), np.asarray(mesh['edges_face2'])
+    ptr, nb, edge = adjacency(f1, f2, n, n)
+    rpw, R = 64 // G, 256 // G
+    tr = R * ut if ut == 1 else R + R // 2                  # (two row sets: the second one part full)
+    out = run(driver, tmp_path, ptr, nb, edge, np.asarray(mesh['face_flow'])[0], n, n, n, K, tr, 64, limits=(1 << 30, 1 << 30, rpw, ut * R))
+    assert out['tiled'][0] == 1 and out['ell_ok'][0] == 1
+    check_ell(out, K, rpw, ut * R)
