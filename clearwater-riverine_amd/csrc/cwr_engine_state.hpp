@@ -270,7 +270,9 @@ struct cwr_engine {
   bool use_tcl = true, tcl_ready = false;
   int tcl_cfg = -1, tcl_vw = 0;   // tcl_vw: constituents per lane in the tiled pass (4 = wide rows, else VW)
   int local_reps = 2;              // J^2 applications per tile and pass (1 = exact Jacobi; > 1 = block-asynchronous)
-  bool tcl_ell = true;             // (round 6) wave-sliced entry layout of the tiled pass where it applies (CWR_TCL_ELL=0: CSR order, as until round 5)
+  bool tcl_ell = false;            // (round 6 A/B, CWR_TCL_ELL=1) wave-sliced entry layout of the tiled pass where it applies.  Built and measured: the pass 2 % faster
+                                   // at K = 16, the step not (numeric J^2 stores through an index, +10 % padded entries); K = 1: 64 rows per wave pad past the
+                                   // kernel's 256-row configuration -- slower.  Off by default: profiles/r06_ell_ab.txt
   bool tcl_use_ell = false;        // ... in use by this engine's tiling
   int64_t tcl_entries = 0;         // entries of the tiled pass's weight / position arrays (CSR: nnz2; sliced: with padding)
   int32_t *d_eptr = nullptr, *d_ell_pos = nullptr;   // sliced layout: per-tile entry offsets; CSR entry -> sliced index (the numeric kernels store through it)

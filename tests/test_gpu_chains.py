@@ -387,3 +387,32 @@ def test_deterministic_chained_steps_beside_a_busy_chip_repeat_the_quiet_run_bit
     for b in busy:
         assert b[0] == quiet[0]
         assert np.array_equal(b[1], quiet[1], equal_nan=True) and np.array_equal(b[2], quiet[2], equal_nan=True)
+
+
+@pytest.mark.parametrize('K', [16, 4, 1])
+def test_wave_sliced_entry_layout_gives_the_csr_passes_bit_for_bit(gpu_lib, K, monkeypatch):  # noqa: F811 (K shadows the module's default on purpose)
+    """Round 6 A/B knob CWR_TCL_ELL=1: the tiled pass reads its J^2 entries in the wave-sliced (ELLPACK per wave) layout of host::build_ell --
+    scalar loop control, constant address increments -- instead of CSR order.  Same sums in the same order (padding adds + 0 x): deterministic
+    steps equal the default layout's BIT FOR BIT, sweep counts included; oracle parity on top."""
+    import clearwater_riverine_amd as cw
+    from test_gpu_parity import make_engine
+    monkeypatch.setenv('CWR_NO_SMALL', '1')
+    steps = 3
+    mesh = cw.synthetic.make_mesh(150, 90, steps, seed=17, n_merge=400, n_merge4=60, n_dry=3, dt=40.0, diffusion_coefficient=0.5)
+    oracle.derive_coefficients(mesh)
+    inputs3 = cw.synthetic.distinct_input_array(mesh, K, seed=17)
+    n = mesh['nreal'] + 1
+    out = {}
+    for ell in ('0', '1'):
+        monkeypatch.setenv('CWR_TCL_ELL', ell)
+        eng = make_engine(mesh, inputs3)
+        eng.set_state(inputs3[0, :n, :])
+        sw = [eng.step(t, tol=1e-12, deterministic=True).sweeps for t in range(steps)]
+        out[ell] = (sw, eng.get_state(), eng.get_mass_flux())
+        eng.close()
+    assert out['0'][0] == out['1'][0]
+    assert np.array_equal(out['0'][1], out['1'][1], equal_nan=True)
+    assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(out['0'][2], out['1'][2]))
+    ref = oracle_run(mesh, inputs3, steps)
+    for k in range(K):
+        assert rel_err(out['1'][1][:n, k], ref.constituent_dict[f'c{k}'].state[steps][:n]) <= 1e-9
