@@ -121,10 +121,12 @@ class FlowWindowFeeder:
     edge_idx      : engine face -> source face (a rank's faces); None = identity
     boundary      : None, or callable (t0, t1) -> (t1 - t0, n_ghost, K) float64 boundary values of those levels (engine ghost order)
     chunk         : levels per read (default W // 2: two staging blocks)
+    on_levels     : None, or callable (t0, t1, face_flow, edge_velocity, volume) called with every chunk as read (e.g. to keep the few
+                    boundary-face flows a global mass balance needs)
     """
 
     def __init__(self, engine, source, T: int, W: int, *, cell_cols=None, edge_idx=None, boundary: Optional[Callable] = None,
-                 chunk: Optional[int] = None, pin: bool = True):
+                 chunk: Optional[int] = None, pin: bool = True, on_levels: Optional[Callable] = None):
         self.engine, self.source = engine, source
         self.T, self.W = int(T), max(2, min(int(W), int(T)))
         self.C = max(1, min(int(chunk) if chunk else self.W // 2, self.W))
@@ -136,6 +138,7 @@ class FlowWindowFeeder:
         self._ev = _page_aligned((self.H, E), np.float32)
         self._vol = _page_aligned((self.H, nc), np.float32)
         self.boundary = boundary
+        self.on_levels = on_levels                                # callable(a, b, face_flow, edge_velocity, volume) on every chunk as the source returned it
         self._bc = None
         if boundary is not None:
             self._bc = _page_aligned((self.H, max(1, engine.n_ghost), engine.K), np.float64)
@@ -151,6 +154,8 @@ class FlowWindowFeeder:
     def _stage(self, a: int, b: int):
         """Levels [a, b) (one contiguous stretch of the host ring) from the source into the staging blocks, then to the engine."""
         ff, ev, vol = self.source.read(a, b)
+        if self.on_levels is not None:
+            self.on_levels(a, b, ff, ev, vol)
         s0 = a % self.H
         s1 = s0 + (b - a)
         if self.edge_idx is None:

@@ -427,8 +427,20 @@ class ClearwaterRiverine:
             def boundary_levels(t0, t1, cons=cons, n=n):
                 return np.stack([_ghost_levels(c.input_array, t0, t1, n) for c in cons], axis=2)
 
+            # (the volume columns of _mass_bal_global, postproc_util.py:92-130, need face_flow on the boundary-line faces at every level: a few
+            # columns, kept as the chunks pass by -- (T, faces on lines) float32 instead of (T, nedge))
+            bd0 = m.attrs.get('boundary_data') if m.attrs.get('boundary_data') is not None else m.attrs.get('boundary_faces')
+            self._line_face_ids = None
+            keep_lines = None
+            if bd0 is not None and len(bd0):
+                ids = np.unique(np.concatenate([np.asarray(f, dtype=np.int64).ravel() for _, f in boundary_lines(bd0)]))
+                self._line_face_ids = ids
+                self._line_flow = np.full((T, len(ids)), np.nan, dtype=np.float32)
+
+                def keep_lines(a, b, ff, ev, vol, ids=ids):
+                    self._line_flow[a:b] = np.asarray(ff)[:, ids]
             self._feeder = FlowWindowFeeder(self.engine, src, T, self._flow_window, cell_cols=self.engine._cols if order is not None else None,
-                                            boundary=boundary_levels if n_g > 0 else None)
+                                            boundary=boundary_levels if n_g > 0 else None, on_levels=keep_lines)
             self._feeder.fill(0)
         else:
             self._flow_arrays = (np.ascontiguousarray(m[FLOW_ACROSS_FACE], dtype=np.float32), np.ascontiguousarray(m[EDGE_VELOCITY], dtype=np.float32),
@@ -611,8 +623,13 @@ class ClearwaterRiverine:
         k = self.constituents.index(constituent_name)
         m = self.mesh
         if FLOW_ACROSS_FACE not in m:
-            raise NotImplementedError('mass_bal_global of a streamed run: the volume columns need face_flow of every level (construct without flow_window, or from arrays)')
-        vols = volume_columns(m[FLOW_ACROSS_FACE], m[CHANGE_IN_TIME], self._lines)
+            # a streamed run: the boundary-line columns the feeder kept (levels not read yet are NaN and skipped, as xarray's sum skips the
+            # trailing NaN of dt: postproc_util.py:92-98 sums over the whole window -- call this when the run is over)
+            pos = {int(f): i for i, f in enumerate(self._line_face_ids)}
+            lines_local = [(nm, np.array([pos[int(f)] for f in faces], dtype=np.int64)) for nm, faces in self._lines]
+            vols = volume_columns(self._line_flow, m[CHANGE_IN_TIME], lines_local)
+        else:
+            vols = volume_columns(m[FLOW_ACROSS_FACE], m[CHANGE_IN_TIME], self._lines)
         mass0, vol0 = self._mass_start
         mass1, vol1 = self.engine.domain_mass(self.time_step)
         return assemble(self._lines, vols, self.engine.get_mass_balance()[:, :, k], vol0, float(mass0[k]), vol1, float(mass1[k]))

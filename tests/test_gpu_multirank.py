@@ -1127,3 +1127,62 @@ def test_windowed_ranks_equal_resident_ranks_bit_for_bit(gpu_lib, world, K, dept
         ref.update()
     want = np.stack([ref.constituent_dict[f'c{k}'].state[3, :n] for k in range(K)], axis=1)
     assert rel_err(state, want) <= 1e-9
+
+
+def _rank_groups(rank, world, K, G, depth, uid_pipe, out_queue):
+    """One rank of R cell ranges x G constituent groups (distributed.GroupedTransport): three steps, then its rows of its columns."""
+    try:
+        os.environ['CWR_RCCL_LIB'] = MOCK_LIB
+        import clearwater_riverine_amd as cw
+        from clearwater_riverine_amd.distributed import GroupedTransport, group_layout
+        if rank == 0:
+            ids = [cw.TransportEngine.comm_unique_id() for _ in range(G)]      # one communicator per group
+            for _ in range(world - 1):
+                uid_pipe.put(ids)
+        else:
+            ids = uid_pipe.get(timeout=120)
+        g, r, R, k0, k1 = group_layout(rank, world, G, K)
+        mesh, inputs3 = make_case(K)
+        gt = GroupedTransport(mesh, inputs3, rank, world, G, device=0, unique_id=ids[g] if R > 1 else None, halo_depth=depth,
+                              renumber='hilbert' if depth >= 4 else None)
+        infos = []
+        for t in range(3):
+            res = gt.step(t, tol=1e-12, mass_flux=True)
+            infos.append((res.sweeps, res.iterations, res.exchanges))
+        out_queue.put((rank, gt.owned_reference_ids(), (g, r, k0, k1), gt.owned_state(), None, None, infos, None, len(gt.local.peers)))
+        gt.engine.close()
+    except Exception as exc:
+        out_queue.put((rank, None, None, None, None, None, None, repr(exc), 0))
+
+
+@pytest.mark.parametrize('world,K,G,depth', [(4, 4, 2, 4), (6, 6, 3, 2), (4, 16, 4, 8), (6, 3, 1, 4)])
+def test_constituent_groups_times_cell_ranges_match_the_oracle(gpu_lib, world, K, G, depth, monkeypatch):
+    """Round 6: N ranks as N / G contiguous cell ranges x G groups of constituents.  A group is a complete partitioned
+    run of its constituents with a communicator of its own (the K systems share A and never talk to each other, transport.py:231-249):
+    the ranks of a group exchange halos among themselves and with nobody else.  Assembled from all ranks -- rows by range, columns by group --
+    the state is the oracle's; every rank of a group takes the same solver decisions; a rank's peers are ranks of its own group only
+    (G = 4 of 4 ranks: no communicator at all; G = 1: plain PartitionedTransport)."""
+    build_mock()
+    monkeypatch.setenv('CWR_NO_SMALL', '1')
+    results = run_ranks(world, _rank_groups, (K, G, depth))
+    mesh, inputs3 = make_case(K)
+    n = mesh['nreal'] + 1
+    R = world // G
+    state = np.full((n, K), np.nan)
+    for r in results:
+        g, rr, k0, k1 = r[2]
+        assert (g, rr) == divmod(r[0], R) and r[3].shape[1] == k1 - k0
+        state[np.asarray(r[1])[:, None], np.arange(k0, k1)[None, :]] = r[3]
+        assert r[8] <= R - 1                                         # peers within the group's ranges only
+        if R > 1:
+            assert all(i[2] > 0 for i in r[6])                       # ... and the group's ranks did exchange
+    assert not np.isnan(state).any()
+    for g in range(G):                                               # the ranks of one group decide together
+        grp = [r for r in results if r[2][0] == g]
+        assert all(r[6] == grp[0][6] for r in grp)
+    oracle.derive_coefficients(mesh)
+    ref = oracle.OracleModel(mesh, {f'c{k}': inputs3[:, :, k].copy() for k in range(K)})
+    for _ in range(3):
+        ref.update()
+    want = np.stack([ref.constituent_dict[f'c{k}'].state[3, :n] for k in range(K)], axis=1)
+    assert rel_err(state, want) <= 1e-9

@@ -215,7 +215,12 @@ def test_facade_streams_a_lazy_level_source_through_the_ring_bit_for_bit(gpu_lib
     n = mesh['nreal'] + 1
     assert not inputs3[1:, :n].any()                        # (this input family has no real-cell entries behind the initial row)
     names = [f'c{k}' for k in range(K)]
-    res = cw.ClearwaterRiverine(mesh=dict(mesh), input_arrays={nm: inputs3[:, :, k].copy() for k, nm in enumerate(names)}, deterministic=True)
+    # (two boundary-condition lines over the ghost faces: _mass_bal_global of the STREAMED run must equal the resident one -- the feeder keeps
+    # the lines' face flows as the chunks pass by)
+    gf = np.nonzero(np.asarray(mesh['edges_face2']) > mesh['nreal'])[0]
+    bfaces = {'US_Flow': gf[0::2], 'DS_Stage': gf[1::2]}
+    res_mesh = cw.Mesh(dict(mesh)); res_mesh.attrs['boundary_faces'] = bfaces
+    res = cw.ClearwaterRiverine(mesh=res_mesh, input_arrays={nm: inputs3[:, :, k].copy() for k, nm in enumerate(names)}, deterministic=True)
     for _ in range(steps):
         res.update()
     # the store: one .npy per array, opened memory-mapped (np.load(mmap_mode='r')): reading a slice touches only its pages
@@ -229,6 +234,7 @@ def test_facade_streams_a_lazy_level_source_through_the_ring_bit_for_bit(gpu_lib
         return tuple(np.asarray(m[t0:t1]) for m in maps)
 
     lazy_mesh = {k: v for k, v in mesh.items() if k not in ('face_flow', 'edge_velocity', 'volume', 'advection_coeff', 'coeff_to_diffusion')}
+    lazy_mesh = cw.Mesh(lazy_mesh); lazy_mesh.attrs['boundary_faces'] = bfaces
     lazy_mesh['level_source'] = source
     ghosts = np.arange(n, ncell)
     sparse = {nm: SparseInputArray(T, ncell, np.where(np.arange(ncell) < n, inputs3[0, :, k], 0.0), ghosts, inputs3[:, n:, k]) for k, nm in enumerate(names)}
@@ -242,6 +248,10 @@ def test_facade_streams_a_lazy_level_source_through_the_ring_bit_for_bit(gpu_lib
         assert np.array_equal(res.mesh[nm], win.mesh[nm], equal_nan=True), nm
         assert np.array_equal(res.constituent_dict[nm].total_mass_flux, win.constituent_dict[nm].total_mass_flux, equal_nan=True)
     assert np.array_equal(res.engine.jacobi_norms()[:steps], win.engine.jacobi_norms()[:steps])
+    a, b = res.mass_bal_global(names[0]), win.mass_bal_global(names[0])
+    assert list(a) == list(b)
+    for key in a:
+        assert (np.isnan(a[key]) and np.isnan(b[key])) or a[key] == b[key] or np.isclose(a[key], b[key], rtol=1e-12, atol=0.0), (key, a[key], b[key])
     for mdl in (res, win):
         mdl.close_output(); mdl.engine.close()
 
