@@ -347,7 +347,10 @@ class TransportEngine:
         n = g.shape[0]
         g = _arr(g.reshape(n, self.n_ghost, self.K if g.size == 0 else -1), np.float64, (n, self.n_ghost, self.K), 'ghost_conc_levels')
         self._check(self._lib.cwr_boundary_window_load(self._h, int(t0), int(n), _ptr(g)))
-        self._bc_keep = [(a, b, arr) for (a, b, arr) in getattr(self, '_bc_keep', []) if not (int(t0) <= a and b <= int(t0) + n)] + [(int(t0), int(t0) + n, g)]
+        # (kept alive until the levels are loaded again, synchronize(), or eight later loads: a correct caller reuses its staging only after the
+        # step that reads the levels has returned -- levels.FlowWindowFeeder's blocks are views of two staging arrays anyway)
+        keep = [(a, b, arr) for (a, b, arr) in getattr(self, '_bc_keep', []) if not (int(t0) <= a and b <= int(t0) + n)]
+        self._bc_keep = keep[-8:] + [(int(t0), int(t0) + n, g)]
 
     def set_boundary_level(self, t: int, ghost_conc_level):
         g = _arr(ghost_conc_level, np.float64)

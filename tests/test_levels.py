@@ -171,6 +171,19 @@ for stamps in (T, T // 8):                                 # the numpy heap of t
     out[str(stamps)] = dict(levels_read=src.levels_read, largest_read=src.largest_read, loaded=eng.levels_loaded, peak_bytes=int(peak),
                             staged_bytes=int(fd.staged_bytes), level_bytes=int((2 * E + nc) * 4))
     fd.close()
+# a window that does not start at the file's first stamp (io/hdf.py:158-183: an inclusive (int, int) pair): level t of the source is stamp first + t
+part = read_ras_hdf(path, datetime_range=(5, 20), lazy=True)
+src = part.attrs['level_source']
+assert len(part['time']) == 16 and src.n_times == 16 and src.first == 5
+got = src.read(2, 7)
+assert all(np.array_equal(g, tr[7:12]) for g, tr in zip(got, truth))
+assert np.array_equal(part['time'], full['time'][5:21])
+try:
+    src.read(10, 17)
+    raise SystemExit('a read past the window must raise')
+except IndexError:
+    pass
+src.close()
 out['T'] = T
 out['maxrss_kb'] = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
 print(json.dumps(out))
