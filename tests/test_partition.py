@@ -231,3 +231,35 @@ def test_auto_halo_depth_tracks_the_per_rank_size():
     assert [auto_halo_depth(1_000_000, w) for w in (2, 4, 8)] == [16, 16, 14]
     assert auto_halo_depth(10_000, 4) == 8 and auto_halo_depth(64_000_000, 8) == 16
     assert all(auto_halo_depth(n, w) % 2 == 0 for n in (5_000, 123_456, 9_999_999) for w in (2, 3, 8))
+
+
+def test_group_layout_and_constituent_slices():
+    """distributed.group_layout / ConstituentSlice (round 6: N GPUs as cell ranges x constituent groups): every (group, range) pair occurs once,
+    the groups' column ranges tile [0, K) in order, ranges vary fastest; a slice of an input provider is the columns of the dense array."""
+    import clearwater_riverine_amd as cw
+    from clearwater_riverine_amd.distributed import ConstituentSlice, group_layout
+    for world, G, K in [(8, 2, 16), (8, 4, 16), (8, 8, 16), (4, 2, 5), (6, 3, 7), (8, 1, 3)]:
+        seen, cols = set(), {}
+        for rank in range(world):
+            g, r, R, k0, k1 = group_layout(rank, world, G, K)
+            assert R == world // G and (g, r) == divmod(rank, R) and 0 <= k0 < k1 <= K
+            seen.add((g, r)); cols.setdefault(g, (k0, k1))
+            assert cols[g] == (k0, k1)
+        assert len(seen) == world
+        cuts = [cols[g] for g in range(G)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == K and all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+        assert max(b - a for a, b in cuts) - min(b - a for a, b in cuts) <= 1
+    for bad in [(8, 3, 16), (4, 8, 16), (4, 4, 3)]:
+        with pytest.raises(ValueError):
+            group_layout(0, *bad)
+    mesh = cw.synthetic.make_mesh(12, 8, 3, seed=2)
+    prov = cw.synthetic.DistinctInputs(mesh, 6, seed=1)
+    dense = prov.dense()
+    n = mesh['nreal'] + 1
+    sl = ConstituentSlice(prov, 2, 5)
+    assert sl.shape == dense.shape[:2] + (3,)
+    cells = np.array([0, 5, n - 1])
+    assert np.array_equal(sl.initial_rows(cells), dense[0, cells, 2:5])
+    ghosts = np.arange(n, dense.shape[1])
+    assert np.array_equal(sl.ghost_columns(ghosts), dense[:, n:, 2:5])
+    assert sl.real_input_entries(cells)[2].shape == (0, 3)
