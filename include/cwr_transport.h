@@ -393,7 +393,7 @@ int32_t cwr_output_push(cwr_engine* e, int32_t* slot);
  * copy is left between the device and mesh[name][t+1] (transport.py:252-273).  The copies are asynchronous when the
  * destination is page-locked (cwr_host_register: hipHostRegister with the engine's HIP runtime) and staged by HIP otherwise;
  * cwr_output_wait(slot) returns the two destinations once they are complete.
- * Round 5: a snapshot of up to 4 MB (CWR_OUTPUT_DIRECT_MB) whose destinations are page-locked is written in place by the snapshot
+ * Round 5: a snapshot of up to 8 MB (CWR_OUTPUT_DIRECT_MB; 4 until round 6) whose destinations are page-locked is written in place by the snapshot
  * kernels through the destinations' device aliases (no staging buffer, no copy command: at the reference's own mesh sizes the
  * copies' submission cost more than the bytes); the destinations must then stay registered until cwr_output_wait has returned
  * for the slot -- as before -- and cwr_output_close drains the engine's stream as well as the ring's. */

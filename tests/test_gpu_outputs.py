@@ -187,7 +187,7 @@ def test_output_ring_api_errors(gpu_lib):
 
 
 def test_snapshots_written_in_place_equal_those_of_the_copy_engine(gpu_lib, monkeypatch, capfd):
-    """Round 5: snapshots of up to CWR_OUTPUT_DIRECT_MB (4) are written by the snapshot kernels straight into the facade's
+    """Round 5: snapshots of up to CWR_OUTPUT_DIRECT_MB (8 since round 6) are written by the snapshot kernels straight into the facade's
     page-locked history rows (no staging buffer, no copy command); larger ones -- or CWR_OUTPUT_DIRECT_MB=0 -- go through the copy
     engine.  Same histories bit for bit, fluxes included (total = advection + diffusion formed in the one flux launch), and the
     debug counters say which way each facade's snapshots went."""
