@@ -131,6 +131,19 @@ class PartitionedTransport:
         n = int(np.asarray(mesh['edges_face1']).max()) + 1
         if halo_depth == 0:
             halo_depth = auto_halo_depth(n, world)
+        # (round 6) a LEVEL SOURCE instead of the three (T, .) arrays (levels.py: `.read(t0, t1)` or a callable (t0, t1) -> the levels of the
+        # WHOLE mesh in the reference's order): the rank streams its slices through its ring -- the feeder cuts its faces and cells out of
+        # every chunk in the staging block -- and never holds more than W levels of them
+        level_source = mesh.get('level_source') if 'level_source' in mesh else getattr(mesh, 'attrs', {}).get('level_source')
+        if level_source is not None:
+            from .levels import as_level_source
+            level_source = as_level_source(level_source, len(np.asarray(mesh['dt'] if 'dt' in mesh else mesh['time_seconds'])),
+                                           len(mesh['edges_face1']), len(mesh['face_x']))
+            if not flow_window:
+                flow_window = 16
+            if 'face_flow' not in mesh and renumber == 'hilbert' and curve_kind(n, int(inputs3.shape[2]), world) == 'lanes':
+                mesh = dict(mesh)                                # (the lanes follow the flow of the first levels: a performance choice only)
+                mesh['face_flow'] = np.asarray(level_source.read(0, min(level_source.n_times, 8))[0], dtype=np.float32)
         ncell = len(mesh['face_x'])
         self.order = None
         f1 = np.asarray(mesh['edges_face1'])
@@ -160,14 +173,22 @@ class PartitionedTransport:
         dt = mesh.get('dt')
         if dt is None:
             dt = change_in_time(mesh['time_seconds'] if 'time_seconds' in mesh else mesh['time'])
-        fields = slice_fields(lm, mesh, np.asarray(dist_e), ref_cells)
+        fields = slice_fields(lm, mesh, np.asarray(dist_e), ref_cells) if level_source is None else {'face_to_face_dist': np.ascontiguousarray(np.asarray(dist_e)[lm.edge_global])}
         self.engine = TransportEngine(lm.face1, lm.face2, lm.n_cells, self.K, n_owned=lm.n_rows,
                                       n_halo=lm.n_halo, device=device)
         # flow_window=W: a ring of W levels on the device, refilled one level per step on the engine's flow stream (cwr_flow_window_open / _load);
         # the rank's slices stay on the host, page-locked so that the uploads are asynchronous.  Round 6: ranks of a partition too (each its
         # slices; the level's norms are all-reduced where it is loaded) -- the first levels go in once the communicator is attached, below.
         self._window = None
-        if flow_window:
+        self._feeder = None
+        if flow_window and level_source is not None:
+            from .levels import FlowWindowFeeder
+            T = len(np.asarray(dt))
+            self._window = max(2, min(int(flow_window), T))
+            self._T = T
+            self.engine.flow_window_open(T, self._window, dt, fields['face_to_face_dist'], float(mesh['diffusion_coefficient']))
+            self._feeder = FlowWindowFeeder(self.engine, level_source, T, self._window, cell_cols=ref_cells, edge_idx=lm.edge_global)
+        elif flow_window:
             T = len(np.asarray(dt))
             self._window = max(2, min(int(flow_window), T))
             self._fields = (fields['face_flow'], fields['edge_velocity'], fields['volume'])
@@ -224,6 +245,9 @@ class PartitionedTransport:
         enqueued; a jump back in time reloads from level t."""
         if self._window is None:
             return
+        if self._feeder is not None:
+            self._feeder.fill(t)
+            return
         if t < self._win_lo or t >= self._win_hi:                # (first call, or a jump: nothing of the ring is of use)
             self._win_hi = t
         self._win_lo = t
@@ -237,6 +261,15 @@ class PartitionedTransport:
     def step(self, t: int, **kw):
         self.fill_window(t)
         return self.engine.step(t, **kw)
+
+    def close(self):
+        """Release the staging blocks of a streamed flow field (page locks), then the engine."""
+        if getattr(self, '_feeder', None) is not None:
+            if self.engine._h:
+                self.engine.synchronize()
+            self._feeder.close()
+            self._feeder = None
+        self.engine.close()
 
     def owned_state(self) -> np.ndarray:
         return self.engine.get_state()[: self.local.n_core]

@@ -72,6 +72,15 @@ def _rank_body(rank, world, K, solver, depth, uid):
     from clearwater_riverine_amd.distributed import PartitionedTransport
     mesh, inputs3 = make_case(K)
     fw = int(os.environ.get('CWR_TEST_FLOW_WINDOW', '0'))     # > 0: every rank keeps a ring of this many levels of ITS slices (round 6)
+    if fw and os.environ.get('CWR_TEST_LAZY'):                # ... fed from a LEVEL SOURCE over the whole mesh instead of the rank's resident slices
+        full = {k: np.asarray(mesh[k]) for k in ('face_flow', 'edge_velocity', 'volume')}
+        calls = []
+
+        def source(t0, t1):
+            calls.append((t0, t1))
+            return full['face_flow'][t0:t1], full['edge_velocity'][t0:t1], full['volume'][t0:t1]
+        mesh = {k: v for k, v in mesh.items() if k not in ('face_flow', 'edge_velocity', 'volume', 'advection_coeff', 'coeff_to_diffusion')}
+        mesh['level_source'] = source
     pt = PartitionedTransport(mesh, inputs3, rank, world, device=0, unique_id=uid, halo_depth=depth,
                               renumber='hilbert' if depth >= 4 else None, flow_window=fw or None)
     infos, comm_counts, kinds = [], [], []
@@ -106,7 +115,7 @@ def _rank_main(rank, world, K, solver, depth, uid_pipe, out_queue):
             uid = uid_pipe.get(timeout=120)
         pt, out = _rank_body(rank, world, K, solver, depth, uid)
         out_queue.put(out)
-        pt.engine.close()
+        pt.close()
     except Exception as exc:                                  # surface the failure in the parent
         out_queue.put((rank, 0, 0, None, None, None, None, repr(exc), None, None, None, 0, -1, None, False, None))
 
@@ -1092,8 +1101,9 @@ def test_partitioned_ranks_at_cfl_18_keep_their_batches_in_hand(gpu_lib, monkeyp
     assert np.max(np.abs(got - want[:n])) <= 1e-9 * np.max(np.abs(want[:n]))
 
 
-@pytest.mark.parametrize('world,K,depth,W,big', [(2, 3, 4, 2, False), (4, 16, 8, 3, False), (2, 4, 8, 2, True), (4, 1, 6, 4, True)])
-def test_windowed_ranks_equal_resident_ranks_bit_for_bit(gpu_lib, world, K, depth, W, big, monkeypatch):
+@pytest.mark.parametrize('world,K,depth,W,big,lazy', [(2, 3, 4, 2, False, False), (4, 16, 8, 3, False, False), (2, 4, 8, 2, True, False), (4, 1, 6, 4, True, False),
+                                                       (2, 3, 4, 4, False, True), (4, 4, 8, 2, True, True)])
+def test_windowed_ranks_equal_resident_ranks_bit_for_bit(gpu_lib, world, K, depth, W, big, lazy, monkeypatch):
     """cwr_flow_window_open / _load on PARTITIONED engines.  Every rank keeps a ring of W levels of its slices; the
     zero-coefficient flag and ||J||_inf of an arriving level are all-reduced on the communication stream where the level is loaded, the
     row-wise error factor is taken -- collectively -- where its step runs (the small mesh has dry cells: no norm bound).  Through the
@@ -1107,6 +1117,8 @@ def test_windowed_ranks_equal_resident_ranks_bit_for_bit(gpu_lib, world, K, dept
         monkeypatch.setenv('CWR_TEST_BIG', '1')
     resident = run_ranks(world, _rank_main, (K, 'jacobi', depth))
     monkeypatch.setenv('CWR_TEST_FLOW_WINDOW', str(W))
+    if lazy:                                                    # (the ranks cut their slices out of a level source over the whole mesh: levels.FlowWindowFeeder)
+        monkeypatch.setenv('CWR_TEST_LAZY', '1')
     windowed = run_ranks(world, _rank_main, (K, 'jacobi', depth))
     for a, b in zip(resident, windowed):
         assert a[0] == b[0] and np.array_equal(a[1], b[1])
