@@ -85,6 +85,10 @@ int flush_window_loads(cwr_engine* e) {
     std::vector<cwr_engine::PendingBc> bcs;
     bcs.swap(e->pending_bc);
     if (!e->ev_bc) HIP_TRY(e, hipEventCreateWithFlags(&e->ev_bc, hipEventDisableTiming));
+    if (e->ev_evict) {                                // (rows being REPLACED -- a level loaded again -- may still be read by what the engine's stream holds)
+      HIP_TRY(e, hipEventRecord(e->ev_evict, e->stream));
+      HIP_TRY(e, hipStreamWaitEvent(e->flow_stream, e->ev_evict, 0));
+    }
     for (const auto& pb : bcs) {
       const size_t rows = (size_t)pb.n * e->n_ghost;
       double* dst = e->d_bc + (size_t)pb.t0 * e->n_ghost * e->K;
