@@ -139,3 +139,51 @@ def test_the_pasted_binding_on_a_mesh_large_enough_to_be_renumbered(gpu_lib):
     for k in range(K):
         assert rel_err(model.mesh[f'c{k}'].values[:steps + 1], ref.constituent_dict[f'c{k}'].state[:steps + 1]) <= 1e-9
     model._gpu.close()
+
+
+def streaming_patch():
+    """The python block of INTEGRATION.md section 2a (streaming a long file), with its one file-bound line -- `src = HdfLevelSource(...)` --
+    replaced by a source over the Dataset's own arrays (h5py is not on the GPU box; levels.HdfLevelSource is tested against the reference's HDF
+    in tests/test_levels.py)."""
+    text = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    sec = text[text.index('## 2a. Streaming a long file'):]
+    block = re.search(r'```python\n(.*?)```', sec, re.S).group(1)
+    assert 'src = HdfLevelSource(' in block and 'FlowWindowFeeder(' in block and 'self._feed.fill(0)' in block
+    block = re.sub(r'^src = HdfLevelSource\(.*$', "src = ArrayLevelSource(m['face_flow'].values, m['edge_velocity'].values, m['volume'].values)", block, flags=re.M)
+    return block
+
+
+@pytest.mark.parametrize('case', ['plan01', 'renumbered'])
+def test_the_pasted_streaming_binding_equals_the_resident_binding_bit_for_bit(gpu_lib, case):
+    """INTEGRATION.md section 2a executed: after section 2's lines, the flow field is re-opened as a ring of 16 levels fed from a level source,
+    the boundary values travel with the levels (cwr_load_boundary(NULL) + cwr_boundary_window_load), `self._feed.fill(t)` precedes every step.
+    The histories equal those of the resident binding of section 2 BIT FOR BIT (deterministic passes: K <= 8)."""
+    import clearwater_riverine_amd as cw
+    from clearwater_riverine_amd.levels import ArrayLevelSource
+    from util import multi_inputs
+    if case == 'plan01':
+        mesh, inp, _ = load_plan('plan01', 0.01)
+        inputs3 = multi_inputs(inp, 3, seed=5)
+        steps = 40                                                # 64 levels through W = 16
+    else:
+        steps = 24
+        mesh = cw.synthetic.make_mesh(90, 60, steps, seed=31, n_merge=120, dt=40.0, diffusion_coefficient=0.5)
+        oracle.derive_coefficients(mesh)
+        inputs3 = cw.synthetic.distinct_input_array(mesh, 2, seed=31)
+    K = inputs3.shape[2]
+    resident, update = bind(mesh, inputs3)
+    for _ in range(steps):
+        update(resident)
+    streamed, update2 = bind(mesh, inputs3)
+    ns = {'self': streamed, 'np': np, 'm': streamed.mesh, 'names': streamed._names, 'n': int(mesh['nreal']) + 1,
+          'order': streamed._gpu._order, 'ArrayLevelSource': ArrayLevelSource}
+    exec(compile(streaming_patch(), 'INTEGRATION.md section 2a', 'exec'), ns)
+    assert streamed._feed.W == 16 or streamed._feed.W == inputs3.shape[0]
+    for _ in range(steps):
+        streamed._feed.fill(streamed.time_step)                   # ("in update(), before self._gpu.step")
+        update2(streamed)
+    for k in range(K):
+        assert np.array_equal(resident.mesh[f'c{k}'].values, streamed.mesh[f'c{k}'].values, equal_nan=True)
+        assert np.array_equal(resident.constituent_dict[f'c{k}'].total_mass_flux, streamed.constituent_dict[f'c{k}'].total_mass_flux, equal_nan=True)
+    streamed._feed.close()
+    resident._gpu.close(); streamed._gpu.close()
